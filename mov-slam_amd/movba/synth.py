@@ -1,0 +1,206 @@
+"""Seeded synthetic covisibility windows (BASELINE.md cfg 1-3, 5).
+
+The generator stands in for the graph `Optimizer::LocalBundleAdjustment` builds at
+/root/reference/src/Optimizer.cc:464-747: K free + F fixed keyframe vertices, P map
+points, one monocular edge per (point, observing keyframe), pinhole fx=fy=320,
+cx=320, cy=240 on 640x480 (Examples/Monocular/TartanAir.yaml:15-26).  All values are
+rounded to float32 and widened, mimicking the float->double casts at
+Optimizer.cc:559, 627, 650.  Edge order: point id ascending, then keyframe id
+ascending (stands in for the reference's std::map<KeyFrame*> pointer order).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+FX = FY = 320.0
+CX, CY = 320.0, 240.0
+WIDTH, HEIGHT = 640, 480
+HUBER_DELTA = float(np.sqrt(np.float32(5.0)))  # (double)sqrtf(5.0f): Optimizer.cc:616
+CHI2_GATE = 5.0                                   # static float delta, Optimizer.cc:52, 769
+
+
+@dataclass
+class Window:
+    """Flattened local-BA window in the layout the C-ABI takes (include/movba.h)."""
+    poses: np.ndarray        # (NP,7) f64  qx qy qz qw tx ty tz (Tcw), ascending keyframe id
+    pose_fixed: np.ndarray   # (NP,)  u8
+    points: np.ndarray       # (P,3)  f64
+    edge_pose: np.ndarray    # (E,)   i32
+    edge_point: np.ndarray   # (E,)   i32
+    obs: np.ndarray          # (E,2)  f64
+    inv_sigma2: np.ndarray   # (E,)   f64
+    cam: tuple = (FX, FY, CX, CY)
+    huber_delta: float = HUBER_DELTA
+    chi2_gate: float = CHI2_GATE
+    max_iters: int = 10
+    truth_poses: np.ndarray | None = None
+    truth_points: np.ndarray | None = None
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_poses(self): return int(self.poses.shape[0])
+    @property
+    def n_free(self): return int((self.pose_fixed == 0).sum())
+    @property
+    def n_points(self): return int(self.points.shape[0])
+    @property
+    def n_edges(self): return int(self.edge_pose.shape[0])
+
+
+def _f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+def quat_from_R(R):
+    """Rotation matrix -> unit quaternion (x,y,z,w), w >= 0."""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s
+        q[3] = (R[k, j] - R[j, k]) / s
+        q[j] = (R[j, i] + R[i, j]) / s
+        q[k] = (R[k, i] + R[i, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def R_from_quat(q):
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def make_window(n_free: int, n_fixed: int, n_points: int, seed: int,
+                run_lo: int = 2, run_hi: int = 10, outlier_frac: float = 0.05,
+                pix_sigma: float = 0.5, rot_sigma_deg: float = 0.5, trans_sigma: float = 0.02,
+                point_sigma: float = 0.05, min_obs: int = 2) -> Window:
+    rng = np.random.default_rng(seed)
+    NP = n_free + n_fixed
+    k = np.arange(NP, dtype=np.float64)
+    centres = np.stack([0.30 * k, 0.05 * np.sin(0.3 * k), 0.02 * k], axis=1)
+    yaw = 0.01 * k
+    Rcw = np.zeros((NP, 3, 3))
+    tcw = np.zeros((NP, 3))
+    for i in range(NP):
+        c, s = np.cos(yaw[i]), np.sin(yaw[i])
+        Rwc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])   # yaw about the camera's y axis
+        Rcw[i] = Rwc.T
+        tcw[i] = -Rcw[i] @ centres[i]
+
+    # candidate points until P of them have >= min_obs valid observations
+    pts, e_pose, e_point, e_uv = [], [], [], []
+    n_kept = 0
+    while n_kept < n_points:
+        m = max(256, (n_points - n_kept) * 2)
+        anchor = rng.integers(0, NP, size=m)
+        depth = rng.uniform(4.0, 30.0, size=m)
+        u = rng.uniform(0.0, WIDTH, size=m)
+        v = rng.uniform(0.0, HEIGHT, size=m)
+        run = rng.integers(run_lo, run_hi + 1, size=m)
+        off = rng.integers(0, run_hi + 1, size=m)
+        for j in range(m):
+            if n_kept >= n_points:
+                break
+            a = int(anchor[j])
+            Xc = np.array([(u[j] - CX) / FX * depth[j], (v[j] - CY) / FY * depth[j], depth[j]])
+            Xw = Rcw[a].T @ (Xc - tcw[a])
+            first = a - int(off[j]) % int(run[j])
+            ks = [kk for kk in range(first, first + int(run[j])) if 0 <= kk < NP]
+            uv_ok = []
+            for kk in ks:
+                Y = Rcw[kk] @ Xw + tcw[kk]
+                if Y[2] <= 0.1:
+                    continue
+                uu, vv = FX * Y[0] / Y[2] + CX, FY * Y[1] / Y[2] + CY
+                if 0 <= uu < WIDTH and 0 <= vv < HEIGHT:
+                    uv_ok.append((kk, uu, vv))
+            if len(uv_ok) < min_obs:
+                continue
+            pts.append(Xw)
+            for kk, uu, vv in uv_ok:
+                e_pose.append(kk); e_point.append(n_kept); e_uv.append((uu, vv))
+            n_kept += 1
+
+    truth_points = np.array(pts)
+    edge_pose = np.array(e_pose, dtype=np.int32)
+    edge_point = np.array(e_point, dtype=np.int32)
+    obs = np.array(e_uv, dtype=np.float64)
+    E = len(edge_pose)
+    obs = obs + rng.normal(0.0, pix_sigma, size=(E, 2))
+    is_out = rng.random(E) < outlier_frac
+    mag = rng.uniform(5.0, 30.0, size=E)
+    ang = rng.uniform(0.0, 2 * np.pi, size=E)
+    obs[is_out] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)[is_out]
+
+    truth_poses = np.zeros((NP, 7))
+    poses = np.zeros((NP, 7))
+    fixed = np.zeros(NP, dtype=np.uint8)
+    fixed[:n_fixed] = 1                                     # the F lowest-id keyframes, exact truth
+    for i in range(NP):
+        truth_poses[i, :4] = quat_from_R(Rcw[i]); truth_poses[i, 4:] = tcw[i]
+        if fixed[i]:
+            poses[i] = truth_poses[i]
+        else:
+            dR = _rodrigues(np.deg2rad(rot_sigma_deg) * rng.normal(size=3))
+            poses[i, :4] = quat_from_R(dR @ Rcw[i])
+            poses[i, 4:] = tcw[i] + trans_sigma * rng.normal(size=3)
+    points = truth_points + point_sigma * rng.normal(size=truth_points.shape)
+
+    poses = _f32(poses)
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)   # cast<double> of a unit float quat, renormalised by SE3Quat
+    return Window(poses=poses, pose_fixed=fixed, points=_f32(points), edge_pose=edge_pose,
+                  edge_point=edge_point, obs=_f32(obs), inv_sigma2=np.ones(E),
+                  truth_poses=truth_poses, truth_points=truth_points,
+                  meta=dict(seed=seed, K=n_free, F=n_fixed, P=n_points, E=E, outliers=int(is_out.sum())))
+
+
+def cfg(name: str, seed: int | None = None) -> Window:
+    """Named BASELINE.md configurations."""
+    if name == "tiny":      # golden-fixture size (3 KF x 20 points)
+        return make_window(2, 1, 20, 7 if seed is None else seed, run_lo=2, run_hi=3)
+    if name == "small":     # golden-fixture size (10 KF x 200 points)
+        return make_window(8, 2, 200, 11 if seed is None else seed, run_lo=2, run_hi=6)
+    if name == "cfg2":      # LBA 10 KF x 2k MapPoints
+        return make_window(10, 2, 2000, 1002 if seed is None else seed, run_lo=2, run_hi=6)
+    if name == "cfg3":      # LBA 50 KF x 20k MapPoints, Huber on
+        return make_window(50, 10, 20000, 1003 if seed is None else seed, run_lo=2, run_hi=10)
+    raise KeyError(name)
+
+
+def make_frame(n: int = 500, seed: int = 1001, outlier_frac: float = 0.10, pix_sigma: float = 0.5):
+    """cfg1: one Frame with n 2D-3D matches (PoseOptimization operand, Optimizer.cc:404-413)."""
+    rng = np.random.default_rng(seed)
+    depth = rng.uniform(4.0, 30.0, size=n)
+    u = rng.uniform(0, WIDTH, size=n); v = rng.uniform(0, HEIGHT, size=n)
+    Xc = np.stack([(u - CX) / FX * depth, (v - CY) / FY * depth, depth], axis=1)
+    Rcw = _rodrigues(np.array([0.02, -0.03, 0.01])); tcw = np.array([0.3, -0.1, 0.2])
+    Xw = (Xc - tcw) @ Rcw                                    # Rcw^T (Xc - t)
+    obs = np.stack([u, v], axis=1) + rng.normal(0, pix_sigma, size=(n, 2))
+    is_out = rng.random(n) < outlier_frac
+    mag = rng.uniform(10.0, 60.0, size=n); ang = rng.uniform(0, 2 * np.pi, size=n)
+    obs[is_out] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)[is_out]
+    truth = np.concatenate([quat_from_R(Rcw), tcw])
+    dR = _rodrigues(np.deg2rad(1.0) * rng.normal(size=3))
+    pose0 = np.concatenate([quat_from_R(dR @ Rcw), tcw + 0.05 * rng.normal(size=3)])
+    pose0 = _f32(pose0); pose0[:4] /= np.linalg.norm(pose0[:4])
+    return dict(Xw=_f32(Xw), obs=_f32(obs), pose0=pose0, truth=truth, is_outlier=is_out,
+                cam=(FX, FY, CX, CY))

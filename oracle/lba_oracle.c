@@ -1,0 +1,750 @@
+/*
+ * lba_oracle.c — CPU restatement of the reference's local-BA path (see lba_oracle.h:
+ * TEST INFRASTRUCTURE ONLY, PARITY UNPINNED).
+ *
+ * Each function cites the reference file:line it follows, or, for the arithmetic that
+ * the reference delegates to its un-vendored dependency g2o (master, unpinned,
+ * reference Dockerfile:154), the g2o class whose published behaviour it restates.
+ * Plain C99, no dependencies, single-threaded (g2o compiles its OpenMP pragmas out
+ * by default and the reference adds none: SURVEY.md §8d).
+ */
+#include "lba_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* SE3Quat (g2o types/slam3d/se3quat.h): unit quaternion (x,y,z,w) + t       */
+/* ------------------------------------------------------------------------- */
+
+/* Eigen QuaternionBase::toRotationMatrix */
+static void quat_to_R(const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+/* Eigen quaternion from rotation matrix (internal::quaternionbase_assign_impl) */
+static void R_to_quat(const double m[9], double q[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m[i * 3 + i] - m[j * 3 + j] - m[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (m[k * 3 + j] - m[j * 3 + k]) * t;
+        q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+        q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    }
+}
+
+/* SE3Quat::normalizeRotation: flip to w >= 0, then normalise */
+void lba_oracle_se3_normalize(double qt[7])
+{
+    if (qt[3] < 0.0) { qt[0] = -qt[0]; qt[1] = -qt[1]; qt[2] = -qt[2]; qt[3] = -qt[3]; }
+    const double n = sqrt(qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3]);
+    qt[0] /= n; qt[1] /= n; qt[2] /= n; qt[3] /= n;
+}
+
+/* Eigen QuaternionBase::_transformVector: v + w*uv + q.vec x uv, uv = 2 q.vec x v */
+static void quat_rotate(const double q[4], const double v[3], double out[3])
+{
+    double uv[3] = { q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0] };
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    out[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    out[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    out[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+
+/* SE3Quat::map(X) = _r * X + _t; the estimate is Tcw (src/Optimizer.cc:558-559) */
+void lba_oracle_se3_map(const double qt[7], const double X[3], double Xc[3])
+{
+    quat_rotate(qt, X, Xc);
+    Xc[0] += qt[4]; Xc[1] += qt[5]; Xc[2] += qt[6];
+}
+
+/* SE3Quat::operator*: r = a.r*b.r, t = a.t + a.r*b.t, then normalizeRotation */
+void lba_oracle_se3_mul(const double a[7], const double b[7], double out[7])
+{
+    double r[7];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    double rt[3];
+    quat_rotate(a, b + 4, rt);
+    r[4] = a[4] + rt[0]; r[5] = a[5] + rt[1]; r[6] = a[6] + rt[2];
+    lba_oracle_se3_normalize(r);
+    memcpy(out, r, sizeof r);
+}
+
+static void mat3_mul(const double A[9], const double B[9], double C[9])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C[i * 3 + j] = A[i * 3 + 0] * B[0 * 3 + j] + A[i * 3 + 1] * B[1 * 3 + j] + A[i * 3 + 2] * B[2 * 3 + j];
+}
+
+/* SE3Quat::exp(update), update = (omega, upsilon): rotation first */
+void lba_oracle_se3_exp(const double u[6], double out[7])
+{
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double theta = sqrt(wx * wx + wy * wy + wz * wz);
+    const double Om[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
+    double Om2[9];
+    mat3_mul(Om, Om, Om2);
+    double R[9], V[9];
+    double a, b, c, d;               /* R = I + a Om + b Om2 ; V = I + c Om + d Om2 */
+    if (theta < 0.00001) {
+        a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0;
+    } else {
+        a = sin(theta) / theta;
+        b = (1.0 - cos(theta)) / (theta * theta);
+        c = b;
+        d = (theta - sin(theta)) / pow(theta, 3);
+    }
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + a * Om[i] + b * Om2[i];
+        V[i] = I + c * Om[i] + d * Om2[i];
+    }
+    double r[7];
+    R_to_quat(R, r);
+    r[4] = V[0] * u[3] + V[1] * u[4] + V[2] * u[5];
+    r[5] = V[3] * u[3] + V[4] * u[4] + V[5] * u[5];
+    r[6] = V[6] * u[3] + V[7] * u[4] + V[8] * u[5];
+    lba_oracle_se3_normalize(r);     /* SE3Quat(q, t) constructor normalises */
+    memcpy(out, r, sizeof r);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Edge arithmetic                                                            */
+/* ------------------------------------------------------------------------- */
+
+/* EdgeSE3ProjectXYZ::computeError (include/OptimizableTypes.h:103-109) with
+ * Pinhole::project (src/CameraModels/Pinhole.cpp:36-43): obs - (fx*x/z+cx, fy*y/z+cy) */
+static inline void edge_error(const double Xc[3], const double obs[2], const double cam[4], double e[2])
+{
+    e[0] = obs[0] - (cam[0] * Xc[0] / Xc[2] + cam[2]);
+    e[1] = obs[1] - (cam[1] * Xc[1] / Xc[2] + cam[3]);
+}
+
+/* EdgeSE3ProjectXYZ::linearizeOplus (src/OptimizableTypes.cpp:158-180) with
+ * Pinhole::projectJac (src/CameraModels/Pinhole.cpp:77-88).
+ * Jp = -Jpi * R  (2x3, vertex 0 = point); Jc = -Jpi * [ -[Xc]x | I ] (2x6, vertex 1 = pose) */
+static inline void edge_jacobians(const double R[9], const double Xc[3], const double cam[4],
+                                  double Jp[6], double Jc[12])
+{
+    const double x = Xc[0], y = Xc[1], z = Xc[2];
+    /* -projectJac */
+    const double a00 = -(cam[0] / z), a02 = -(-cam[0] * x / (z * z));
+    const double a11 = -(cam[1] / z), a12 = -(-cam[1] * y / (z * z));
+    for (int j = 0; j < 3; ++j) {
+        Jp[j]     = a00 * R[0 * 3 + j] + a02 * R[2 * 3 + j];
+        Jp[3 + j] = a11 * R[1 * 3 + j] + a12 * R[2 * 3 + j];
+    }
+    /* SE3deriv = [0 z -y 1 0 0; -z 0 x 0 1 0; y -x 0 0 0 1] */
+    Jc[0] = a02 * y;             Jc[1] = a00 * z + a02 * (-x); Jc[2] = a00 * (-y);
+    Jc[3] = a00;                 Jc[4] = 0.0;                  Jc[5] = a02;
+    Jc[6] = a11 * (-z) + a12 * y; Jc[7] = a12 * (-x);          Jc[8] = a11 * x;
+    Jc[9] = 0.0;                 Jc[10] = a11;                 Jc[11] = a12;
+}
+
+void lba_oracle_edge(const double qt[7], const double X[3], const double obs[2],
+                     const double cam[4], double err[2], double Jp[6], double Jc[12])
+{
+    double Xc[3], R[9];
+    lba_oracle_se3_map(qt, X, Xc);
+    quat_to_R(qt, R);
+    edge_error(Xc, obs, cam, err);
+    edge_jacobians(R, Xc, cam, Jp, Jc);
+}
+
+/* g2o RobustKernelHuber::robustify; delta = (double)sqrtf(5.0f) at src/Optimizer.cc:616, 660-662 */
+void lba_oracle_huber(double e, double delta, double rho[3])
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) {
+        rho[0] = e; rho[1] = 1.0; rho[2] = 0.0;
+    } else {
+        const double sqrte = sqrt(e);
+        rho[0] = 2.0 * sqrte * delta - dsqr;
+        rho[1] = delta / sqrte;
+        rho[2] = -0.5 * rho[1] / e;
+    }
+}
+
+/* Plain 3x3 inverse by cofactors (Eigen's fixed-size inverse, BlockSolver::solve Dinv) */
+static void inv3(const double A[9], double B[9])
+{
+    const double c00 = A[4] * A[8] - A[5] * A[7];
+    const double c01 = A[5] * A[6] - A[3] * A[8];
+    const double c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    const double id = 1.0 / det;
+    B[0] = c00 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    B[3] = c01 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    B[6] = c02 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+/* Dense LL^T solve of the symmetric n x n system (stands in for LinearSolverCSparse at
+ * src/Optimizer.cc:535: an exact fp64 Cholesky; ordering only changes round-off).
+ * A is overwritten. Returns 0 when A is not positive definite. */
+static int chol_solve(double *A, int n, const double *b, double *x)
+{
+    for (int j = 0; j < n; ++j) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+        if (!(d > 0.0) || !isfinite(d)) return 0;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[i * n + j];
+            const double *ri = A + i * n, *rj = A + j * n;
+            for (int k = 0; k < j; ++k) s -= ri[k] * rj[k];
+            A[i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[i * n + k] * x[k];
+        x[i] = s / A[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s -= A[k * n + i] * x[k];
+        x[i] = s / A[i * n + i];
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Graph workspace (what g2o builds in initializeOptimization / buildStructure) */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    const lba_oracle_problem *pb;
+    int nfree;                 /* free AND active poses                               */
+    int32_t *hidx;             /* pose -> hessian index or -1 (fixed or edge-less)    */
+    int32_t *pt_start;         /* CSR over points: edges of point l                   */
+    int32_t *pt_edges;
+    uint8_t *pt_active;        /* point has >= 1 edge                                 */
+    double cam[4];
+    /* state */
+    double *poses, *points;    /* current estimates                                   */
+    double *poses_bk, *points_bk;
+    double *err;               /* E x 2 stored _error                                 */
+    /* system */
+    double *Hpp, *bp;          /* nfree x 36, nfree x 6                               */
+    double *Hll, *bl;          /* P x 9, P x 3                                        */
+    double *Hpl;               /* E x 18 (6x3 row-major), valid where pose free        */
+    double *S, *bS, *xp, *xl;  /* reduced system and increments                       */
+    double *Dinv;              /* P x 9                                               */
+} ws_t;
+
+static void ws_free(ws_t *w)
+{
+    free(w->hidx); free(w->pt_start); free(w->pt_edges); free(w->pt_active);
+    free(w->poses); free(w->points); free(w->poses_bk); free(w->points_bk); free(w->err);
+    free(w->Hpp); free(w->bp); free(w->Hll); free(w->bl); free(w->Hpl);
+    free(w->S); free(w->bS); free(w->xp); free(w->xl); free(w->Dinv);
+}
+
+/* SparseOptimizer::initializeOptimization: active vertices are those with
+ * >= 1 edge; free non-marginalised vertices (poses) are indexed first in ascending id
+ * — the caller supplies poses in ascending KeyFrame::mnId — then the points. */
+static void ws_init(ws_t *w, const lba_oracle_problem *pb)
+{
+    memset(w, 0, sizeof *w);
+    w->pb = pb;
+    const int NP = pb->n_poses, P = pb->n_points, E = pb->n_edges;
+    w->cam[0] = pb->fx; w->cam[1] = pb->fy; w->cam[2] = pb->cx; w->cam[3] = pb->cy;
+    w->hidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(NP > 0 ? NP : 1));
+    uint8_t *pose_active = (uint8_t *)calloc((size_t)(NP > 0 ? NP : 1), 1);
+    w->pt_active = (uint8_t *)calloc((size_t)(P > 0 ? P : 1), 1);
+    w->pt_start = (int32_t *)calloc((size_t)P + 2, sizeof(int32_t));
+    w->pt_edges = (int32_t *)malloc(sizeof(int32_t) * (size_t)(E > 0 ? E : 1));
+    for (int e = 0; e < E; ++e) {
+        pose_active[pb->edge_pose[e]] = 1;
+        w->pt_active[pb->edge_point[e]] = 1;
+        w->pt_start[pb->edge_point[e] + 2]++;
+    }
+    for (int l = 0; l < P; ++l) w->pt_start[l + 2] += w->pt_start[l + 1];
+    for (int e = 0; e < E; ++e) w->pt_edges[w->pt_start[pb->edge_point[e] + 1]++] = e;
+    int nf = 0;
+    for (int i = 0; i < NP; ++i) w->hidx[i] = (!pb->pose_fixed[i] && pose_active[i]) ? nf++ : -1;
+    w->nfree = nf;
+    free(pose_active);
+
+    w->poses = (double *)malloc(sizeof(double) * 7 * (size_t)(NP + 1));
+    w->poses_bk = (double *)malloc(sizeof(double) * 7 * (size_t)(NP + 1));
+    w->points = (double *)malloc(sizeof(double) * 3 * (size_t)(P + 1));
+    w->points_bk = (double *)malloc(sizeof(double) * 3 * (size_t)(P + 1));
+    memcpy(w->poses, pb->poses, sizeof(double) * 7 * (size_t)NP);
+    memcpy(w->points, pb->points, sizeof(double) * 3 * (size_t)P);
+    /* g2o::SE3Quat(q, t) normalises on construction (src/Optimizer.cc:559) */
+    for (int i = 0; i < NP; ++i) lba_oracle_se3_normalize(w->poses + 7 * i);
+    w->err = (double *)calloc(2 * (size_t)E + 2, sizeof(double));
+    w->Hpp = (double *)calloc(36 * (size_t)nf + 36, sizeof(double));
+    w->bp = (double *)calloc(6 * (size_t)nf + 6, sizeof(double));
+    w->Hll = (double *)calloc(9 * (size_t)P + 9, sizeof(double));
+    w->bl = (double *)calloc(3 * (size_t)P + 3, sizeof(double));
+    w->Hpl = (double *)calloc(18 * (size_t)E + 18, sizeof(double));
+    w->S = (double *)calloc((size_t)(6 * nf) * (size_t)(6 * nf) + 1, sizeof(double));
+    w->bS = (double *)calloc(6 * (size_t)nf + 6, sizeof(double));
+    w->xp = (double *)calloc(6 * (size_t)nf + 6, sizeof(double));
+    w->xl = (double *)calloc(3 * (size_t)P + 3, sizeof(double));
+    w->Dinv = (double *)calloc(9 * (size_t)P + 9, sizeof(double));
+}
+
+/* computeActiveErrors + activeRobustChi2 */
+static double ws_errors(ws_t *w)
+{
+    const lba_oracle_problem *pb = w->pb;
+    double F = 0.0;
+    for (int e = 0; e < pb->n_edges; ++e) {
+        double Xc[3];
+        lba_oracle_se3_map(w->poses + 7 * pb->edge_pose[e], w->points + 3 * pb->edge_point[e], Xc);
+        edge_error(Xc, pb->obs + 2 * e, w->cam, w->err + 2 * e);
+        const double *er = w->err + 2 * e;
+        const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1]);
+        if (pb->huber_delta > 0.0) {
+            double rho[3];
+            lba_oracle_huber(chi2, pb->huber_delta, rho);
+            F += rho[0];
+        } else {
+            F += chi2;
+        }
+    }
+    return F;
+}
+
+/* BlockSolver<6,3>::buildSystem: per edge linearizeOplus + constructQuadraticForm
+ * (g2o BaseBinaryEdge), sequential in edge order. */
+static void ws_build(ws_t *w)
+{
+    const lba_oracle_problem *pb = w->pb;
+    const int nf = w->nfree, P = pb->n_points;
+    memset(w->Hpp, 0, sizeof(double) * 36 * (size_t)nf);
+    memset(w->bp, 0, sizeof(double) * 6 * (size_t)nf);
+    memset(w->Hll, 0, sizeof(double) * 9 * (size_t)P);
+    memset(w->bl, 0, sizeof(double) * 3 * (size_t)P);
+    for (int e = 0; e < pb->n_edges; ++e) {
+        const int ip = pb->edge_pose[e], l = pb->edge_point[e];
+        const double *qt = w->poses + 7 * ip;
+        double Xc[3], R[9], A[6], B[12];
+        lba_oracle_se3_map(qt, w->points + 3 * l, Xc);
+        quat_to_R(qt, R);
+        edge_jacobians(R, Xc, w->cam, A, B);
+        const double *er = w->err + 2 * e;
+        const double om = pb->inv_sigma2[e];
+        double wgt = 1.0;
+        if (pb->huber_delta > 0.0) {
+            double rho[3];
+            lba_oracle_huber(om * (er[0] * er[0] + er[1] * er[1]), pb->huber_delta, rho);
+            wgt = rho[1];
+        }
+        const double wo = wgt * om;                      /* robustInformation = rho1 * Omega */
+        const double r0 = -om * er[0] * wgt, r1 = -om * er[1] * wgt;   /* omega_r *= rho1 */
+        /* point vertex (never fixed) */
+        double *Hl = w->Hll + 9 * l, *b_l = w->bl + 3 * l;
+        for (int a = 0; a < 3; ++a) {
+            b_l[a] += A[a] * r0 + A[3 + a] * r1;
+            for (int c = 0; c < 3; ++c) Hl[a * 3 + c] += wo * (A[a] * A[c] + A[3 + a] * A[3 + c]);
+        }
+        const int hi = w->hidx[ip];
+        if (hi >= 0) {
+            double *Hp = w->Hpp + 36 * hi, *b_p = w->bp + 6 * hi, *Hx = w->Hpl + 18 * e;
+            for (int a = 0; a < 6; ++a) {
+                b_p[a] += B[a] * r0 + B[6 + a] * r1;
+                for (int c = 0; c < 6; ++c) Hp[a * 6 + c] += wo * (B[a] * B[c] + B[6 + a] * B[6 + c]);
+                for (int c = 0; c < 3; ++c) Hx[a * 3 + c] = wo * (B[a] * A[c] + B[6 + a] * A[3 + c]);
+            }
+        }
+    }
+}
+
+/* BlockSolver::solve with Schur complement + exact reduced solve + back-substitution
+ * (SURVEY A.7). lambda is added to every diagonal scalar of Hpp and Hll (setLambda). */
+static int ws_solve(ws_t *w, double lambda, int keep_S)
+{
+    const lba_oracle_problem *pb = w->pb;
+    const int nf = w->nfree, n = 6 * nf, P = pb->n_points;
+    double *S = w->S;
+    memset(S, 0, sizeof(double) * (size_t)n * (size_t)n);
+    for (int i = 0; i < nf; ++i)
+        for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 6; ++c)
+                S[(6 * i + a) * n + 6 * i + c] = w->Hpp[36 * i + a * 6 + c] + (a == c ? lambda : 0.0);
+    double *coef = (double *)calloc((size_t)n + 1, sizeof(double));
+    for (int l = 0; l < P; ++l) {
+        if (!w->pt_active[l]) continue;
+        double D[9];
+        memcpy(D, w->Hll + 9 * l, sizeof D);
+        D[0] += lambda; D[4] += lambda; D[8] += lambda;
+        double *Di = w->Dinv + 9 * l;
+        inv3(D, Di);
+        const double *b_l = w->bl + 3 * l;
+        const double db[3] = { Di[0] * b_l[0] + Di[1] * b_l[1] + Di[2] * b_l[2],
+                               Di[3] * b_l[0] + Di[4] * b_l[1] + Di[5] * b_l[2],
+                               Di[6] * b_l[0] + Di[7] * b_l[1] + Di[8] * b_l[2] };
+        for (int s = w->pt_start[l]; s < w->pt_start[l + 1]; ++s) {
+            const int e1 = w->pt_edges[s], i1 = w->hidx[pb->edge_pose[e1]];
+            if (i1 < 0) continue;
+            const double *Bi = w->Hpl + 18 * e1;
+            double BD[18];
+            for (int a = 0; a < 6; ++a) {
+                coef[6 * i1 + a] += Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1] + Bi[a * 3 + 2] * db[2];
+                for (int c = 0; c < 3; ++c)
+                    BD[a * 3 + c] = Bi[a * 3] * Di[c] + Bi[a * 3 + 1] * Di[3 + c] + Bi[a * 3 + 2] * Di[6 + c];
+            }
+            for (int s2 = w->pt_start[l]; s2 < w->pt_start[l + 1]; ++s2) {
+                const int e2 = w->pt_edges[s2], i2 = w->hidx[pb->edge_pose[e2]];
+                if (i2 < 0) continue;
+                /* g2o fills the upper block triangle; the mirrored lower blocks here make the
+                 * dense symmetric matrix the Cholesky below factors */
+                const double *Bj = w->Hpl + 18 * e2;
+                for (int a = 0; a < 6; ++a)
+                    for (int c = 0; c < 6; ++c)
+                        S[(6 * i1 + a) * n + 6 * i2 + c] -=
+                            BD[a * 3] * Bj[c * 3] + BD[a * 3 + 1] * Bj[c * 3 + 1] + BD[a * 3 + 2] * Bj[c * 3 + 2];
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) w->bS[i] = w->bp[i] - coef[i];
+    free(coef);
+    int ok = 1;
+    if (n > 0) {
+        double *Sw = S;
+        if (keep_S) {
+            Sw = (double *)malloc(sizeof(double) * (size_t)n * (size_t)n);
+            memcpy(Sw, S, sizeof(double) * (size_t)n * (size_t)n);
+        }
+        ok = chol_solve(Sw, n, w->bS, w->xp);
+        if (keep_S) free(Sw);
+    }
+    if (!ok) return 0;
+    for (int l = 0; l < P; ++l) {
+        double *x = w->xl + 3 * l;
+        x[0] = x[1] = x[2] = 0.0;
+        if (!w->pt_active[l]) continue;
+        double c[3] = { w->bl[3 * l], w->bl[3 * l + 1], w->bl[3 * l + 2] };
+        for (int s = w->pt_start[l]; s < w->pt_start[l + 1]; ++s) {
+            const int e1 = w->pt_edges[s], i1 = w->hidx[pb->edge_pose[e1]];
+            if (i1 < 0) continue;
+            const double *Bi = w->Hpl + 18 * e1, *xpi = w->xp + 6 * i1;
+            for (int a = 0; a < 6; ++a)
+                for (int k = 0; k < 3; ++k) c[k] -= Bi[a * 3 + k] * xpi[a];
+        }
+        const double *Di = w->Dinv + 9 * l;
+        for (int k = 0; k < 3; ++k) x[k] = Di[k * 3] * c[0] + Di[k * 3 + 1] * c[1] + Di[k * 3 + 2] * c[2];
+    }
+    return 1;
+}
+
+/* SparseOptimizer::update: VertexSE3Expmap::oplusImpl  T <- exp(d) * T ;
+ * VertexPointXYZ::oplusImpl  X <- X + d   */
+static void ws_update(ws_t *w)
+{
+    const lba_oracle_problem *pb = w->pb;
+    for (int i = 0; i < pb->n_poses; ++i) {
+        const int hi = w->hidx[i];
+        if (hi < 0) continue;
+        double ex[7];
+        lba_oracle_se3_exp(w->xp + 6 * hi, ex);
+        lba_oracle_se3_mul(ex, w->poses + 7 * i, w->poses + 7 * i);
+    }
+    for (int l = 0; l < pb->n_points; ++l) {
+        if (!w->pt_active[l]) continue;
+        for (int k = 0; k < 3; ++k) w->points[3 * l + k] += w->xl[3 * l + k];
+    }
+}
+
+int lba_oracle_linearize(const lba_oracle_problem *pb, double lambda,
+                         double *Hpp, double *bp, double *Hll, double *bl,
+                         double *S, double *bS, int32_t *free_index, double *F0)
+{
+    ws_t w;
+    ws_init(&w, pb);
+    const double F = ws_errors(&w);
+    ws_build(&w);
+    ws_solve(&w, lambda, 1);
+    const int nf = w.nfree, n = 6 * nf;
+    if (Hpp) memcpy(Hpp, w.Hpp, sizeof(double) * 36 * (size_t)nf);
+    if (bp) memcpy(bp, w.bp, sizeof(double) * 6 * (size_t)nf);
+    if (Hll) memcpy(Hll, w.Hll, sizeof(double) * 9 * (size_t)pb->n_points);
+    if (bl) memcpy(bl, w.bl, sizeof(double) * 3 * (size_t)pb->n_points);
+    if (S) memcpy(S, w.S, sizeof(double) * (size_t)n * (size_t)n);
+    if (bS) memcpy(bS, w.bS, sizeof(double) * (size_t)n);
+    if (free_index) memcpy(free_index, w.hidx, sizeof(int32_t) * (size_t)pb->n_poses);
+    if (F0) *F0 = F;
+    ws_free(&w);
+    return nf;
+}
+
+static int stop_requested(const lba_oracle_problem *pb)
+{
+    return pb->stop ? (*pb->stop != 0) : 0;
+}
+
+/* optimizer.initializeOptimization(); optimizer.optimize(max_iters) (src/Optimizer.cc:754-755)
+ * with OptimizationAlgorithmLevenberg::solve restated per SURVEY A.3-A.4, followed by
+ * the outlier gate of src/Optimizer.cc:757-775. */
+int lba_oracle_solve(const lba_oracle_problem *pb, lba_oracle_result *res)
+{
+    res->iters_done = 0; res->n_solves = 0; res->n_outliers = 0; res->n_trace = 0;
+    res->lambda = 0.0; res->cost = 0.0; res->cost0 = 0.0; res->status = 0;
+    const int NP = pb->n_poses, P = pb->n_points, E = pb->n_edges;
+
+    /* early return before the solve (src/Optimizer.cc:749-751): nothing is written */
+    if (stop_requested(pb)) {
+        memcpy(res->poses, pb->poses, sizeof(double) * 7 * (size_t)NP);
+        memcpy(res->points, pb->points, sizeof(double) * 3 * (size_t)P);
+        for (int e = 0; e < E; ++e) { res->chi2[e] = 0.0; res->outlier[e] = 0; }
+        res->status = 1;
+        return 1;
+    }
+
+    ws_t w;
+    ws_init(&w, pb);
+    const int nvec_p = 6 * w.nfree;
+    double lambda = 0.0, ni = 2.0, F_cur = 0.0;
+    int ok = 1;
+    int have_system = (w.nfree > 0 || P > 0) && E > 0;   /* optimize() returns -1 on an empty index map */
+
+    if (!have_system) res->status = 3;
+    for (int it = 0; have_system && it < pb->max_iters && !stop_requested(pb) && ok; ++it) {
+        double F0 = ws_errors(&w);
+        if (it == 0) res->cost0 = F0;
+        ws_build(&w);
+        if (it == 0) {
+            /* computeLambdaInit: tau * max |H_jj| over all free active vertices, tau = 1e-5 */
+            double md = 0.0;
+            for (int i = 0; i < w.nfree; ++i)
+                for (int a = 0; a < 6; ++a) md = fmax(fabs(w.Hpp[36 * i + a * 7]), md);
+            for (int l = 0; l < P; ++l)
+                if (w.pt_active[l])
+                    for (int a = 0; a < 3; ++a) md = fmax(fabs(w.Hll[9 * l + a * 4]), md);
+            lambda = 1e-5 * md;
+            ni = 2.0;
+        }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            memcpy(w.poses_bk, w.poses, sizeof(double) * 7 * (size_t)NP);      /* push() */
+            memcpy(w.points_bk, w.points, sizeof(double) * 3 * (size_t)P);
+            const int ok2 = ws_solve(&w, lambda, 0);
+            if (ok2) ws_update(&w);
+            double F1 = ws_errors(&w);
+            if (!ok2) F1 = DBL_MAX;
+            /* computeScale: sum_j x_j (lambda x_j + b_j) over poses then points */
+            double scale = 0.0;
+            if (ok2) {
+                for (int j = 0; j < nvec_p; ++j) scale += w.xp[j] * (lambda * w.xp[j] + w.bp[j]);
+                for (int l = 0; l < P; ++l)
+                    if (w.pt_active[l])
+                        for (int k = 0; k < 3; ++k)
+                            scale += w.xl[3 * l + k] * (lambda * w.xl[3 * l + k] + w.bl[3 * l + k]);
+            }
+            scale += 1e-3;
+            rho = (F0 - F1) / scale;
+            const int tr = res->n_trace;
+            int accepted = 0, lambda_ok = 1;
+            if (tr < LBA_ORACLE_MAX_TRACE) {
+                res->tr_lambda[tr] = lambda; res->tr_f0[tr] = F0; res->tr_f1[tr] = F1; res->tr_rho[tr] = rho;
+            }
+            if (rho > 0.0 && isfinite(F1)) {
+                double alpha = 1.0 - pow(2.0 * rho - 1.0, 3);
+                alpha = fmin(alpha, 2.0 / 3.0);
+                const double factor = fmax(1.0 / 3.0, alpha);
+                lambda *= factor;
+                ni = 2.0;
+                F0 = F1;
+                accepted = 1;                                                   /* discardTop() */
+            } else {
+                lambda *= ni;
+                ni *= 2.0;
+                memcpy(w.poses, w.poses_bk, sizeof(double) * 7 * (size_t)NP);   /* pop() */
+                memcpy(w.points, w.points_bk, sizeof(double) * 3 * (size_t)P);
+                lambda_ok = isfinite(lambda);
+            }
+            if (tr < LBA_ORACLE_MAX_TRACE) { res->tr_accept[tr] = accepted; res->n_trace = tr + 1; }
+            res->n_solves++;
+            qmax++;
+            if (!lambda_ok) break;
+        } while (rho < 0.0 && qmax < 10 && !stop_requested(pb));
+        F_cur = F0;
+        res->iters_done = it + 1;
+        if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = 0;            /* Terminate */
+    }
+
+    /* A8: chi2 from the stored _error (stale after a rejected last trial, SURVEY A.4
+     * quirk) or recomputed at the final state; depth at the final estimates. */
+    if (!pb->stale_error_quirk) F_cur = ws_errors(&w);
+    memcpy(res->poses, w.poses, sizeof(double) * 7 * (size_t)NP);
+    memcpy(res->points, w.points, sizeof(double) * 3 * (size_t)P);
+    for (int e = 0; e < E; ++e) {
+        const double *er = w.err + 2 * e;
+        const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1]);
+        double Xc[3];
+        lba_oracle_se3_map(w.poses + 7 * pb->edge_pose[e], w.points + 3 * pb->edge_point[e], Xc);
+        const int out = (chi2 > pb->chi2_gate) || !(Xc[2] > 0.0);
+        res->chi2[e] = chi2;
+        res->outlier[e] = (uint8_t)out;
+        res->n_outliers += out;
+    }
+    res->lambda = lambda;
+    res->cost = F_cur;
+    ws_free(&w);
+    return res->status;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Pose-only optimisation (A9')                                               */
+/* ------------------------------------------------------------------------- */
+
+/* EdgeSE3ProjectXYZOnlyPose::linearizeOplus (src/OptimizableTypes.cpp:54-69):
+ * J = -projectJac(Xc) * [ -[Xc]x | I ]; error as include/OptimizableTypes.h:41-46 */
+static double pose_errors(const lba_oracle_pose_problem *pb, const double pose[7], const uint8_t *level1,
+                          int use_robust, double *err)
+{
+    const double cam[4] = { pb->fx, pb->fy, pb->cx, pb->cy };
+    double F = 0.0;
+    for (int i = 0; i < pb->n; ++i) {
+        if (level1[i]) continue;
+        double Xc[3];
+        lba_oracle_se3_map(pose, pb->Xw + 3 * i, Xc);
+        edge_error(Xc, pb->obs + 2 * i, cam, err + 2 * i);
+        const double chi2 = pb->inv_sigma2[i] * (err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]);
+        if (use_robust && pb->huber_delta > 0.0) {
+            double rho[3];
+            lba_oracle_huber(chi2, pb->huber_delta, rho);
+            F += rho[0];
+        } else {
+            F += chi2;
+        }
+    }
+    return F;
+}
+
+int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
+                        uint8_t *outlier, double *chi2_out)
+{
+    const int n = pb->n;
+    const double cam[4] = { pb->fx, pb->fy, pb->cx, pb->cy };
+    const double I9[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    double *err = (double *)calloc(2 * (size_t)n + 2, sizeof(double));
+    uint8_t *level1 = (uint8_t *)calloc((size_t)n + 1, 1);
+    double pose[7], pose0[7];
+    memcpy(pose0, pb->pose0, sizeof pose0);
+    lba_oracle_se3_normalize(pose0);
+    memcpy(pose, pose0, sizeof pose);
+    for (int i = 0; i < n; ++i) outlier[i] = 0;
+    int n_bad = 0;
+    for (int round = 0; round < pb->rounds; ++round) {
+        const int robust = (round <= 2) ? 1 : 0;           /* kernel dropped after round 2 */
+        memcpy(pose, pose0, sizeof pose);                  /* restart from the initial estimate */
+        int n_act = 0;
+        for (int i = 0; i < n; ++i) n_act += !level1[i];
+        double lambda = 0.0, ni = 2.0;
+        int ok = n_act > 0;
+        for (int it = 0; it < pb->its_per_round && ok; ++it) {
+            double F0 = pose_errors(pb, pose, level1, robust, err);
+            double H[36] = { 0 }, b[6] = { 0 };
+            for (int i = 0; i < n; ++i) {
+                if (level1[i]) continue;
+                double Xc[3], Jp[6], Jc[12];
+                lba_oracle_se3_map(pose, pb->Xw + 3 * i, Xc);
+                edge_jacobians(I9, Xc, cam, Jp, Jc);
+                const double om = pb->inv_sigma2[i];
+                double wgt = 1.0;
+                if (robust && pb->huber_delta > 0.0) {
+                    double rho[3];
+                    lba_oracle_huber(om * (err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]), pb->huber_delta, rho);
+                    wgt = rho[1];
+                }
+                const double wo = wgt * om, r0 = -om * err[2 * i] * wgt, r1 = -om * err[2 * i + 1] * wgt;
+                for (int a = 0; a < 6; ++a) {
+                    b[a] += Jc[a] * r0 + Jc[6 + a] * r1;
+                    for (int c = 0; c < 6; ++c) H[a * 6 + c] += wo * (Jc[a] * Jc[c] + Jc[6 + a] * Jc[6 + c]);
+                }
+            }
+            if (it == 0) {
+                double md = 0.0;
+                for (int a = 0; a < 6; ++a) md = fmax(fabs(H[a * 7]), md);
+                lambda = 1e-5 * md;
+                ni = 2.0;
+            }
+            double rho = 0.0;
+            int qmax = 0;
+            do {
+                double bk[7], Hd[36], x[6];
+                memcpy(bk, pose, sizeof bk);
+                memcpy(Hd, H, sizeof Hd);
+                for (int a = 0; a < 6; ++a) Hd[a * 7] += lambda;
+                const int ok2 = chol_solve(Hd, 6, b, x);
+                if (ok2) {
+                    double ex[7];
+                    lba_oracle_se3_exp(x, ex);
+                    lba_oracle_se3_mul(ex, pose, pose);
+                }
+                double F1 = pose_errors(pb, pose, level1, robust, err);
+                if (!ok2) F1 = DBL_MAX;
+                double scale = 0.0;
+                if (ok2) for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+                scale += 1e-3;
+                rho = (F0 - F1) / scale;
+                if (rho > 0.0 && isfinite(F1)) {
+                    double alpha = 1.0 - pow(2.0 * rho - 1.0, 3);
+                    alpha = fmin(alpha, 2.0 / 3.0);
+                    lambda *= fmax(1.0 / 3.0, alpha);
+                    ni = 2.0;
+                    F0 = F1;
+                } else {
+                    lambda *= ni;
+                    ni *= 2.0;
+                    memcpy(pose, bk, sizeof bk);
+                    if (!isfinite(lambda)) { qmax++; break; }
+                }
+                qmax++;
+            } while (rho < 0.0 && qmax < 10);
+            if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = 0;
+        }
+        /* re-classify every correspondence at the round's final pose */
+        n_bad = 0;
+        for (int i = 0; i < n; ++i) {
+            double Xc[3], e[2];
+            lba_oracle_se3_map(pose, pb->Xw + 3 * i, Xc);
+            edge_error(Xc, pb->obs + 2 * i, cam, e);
+            const double c2 = pb->inv_sigma2[i] * (e[0] * e[0] + e[1] * e[1]);
+            const int bad = (c2 > pb->chi2_gate) || !(Xc[2] > 0.0);
+            chi2_out[i] = c2;
+            outlier[i] = (uint8_t)bad;
+            level1[i] = (uint8_t)bad;
+            n_bad += bad;
+        }
+        if (n - n_bad < 10) break;
+    }
+    memcpy(pose_out, pose, sizeof pose);
+    free(err); free(level1);
+    return n - n_bad;
+}
