@@ -1,0 +1,177 @@
+/*
+ * movba.h — C-ABI of the MI355X-native local bundle adjustment (libmovba.so).
+ *
+ * Drop-in boundary for MoV-SLAM's optimizer hot path.  The reference has no FFI: the
+ * boundary is the static-method surface of class MOV_SLAM::Optimizer
+ * (/root/reference/include/Optimizer.h:45-60).  An adapter with those exact signatures
+ * (mov-slam_amd/host/Optimizer.cc) flattens the KeyFrame/MapPoint graph into the plain
+ * arrays below and calls these entry points; everything from "arrays in" to
+ * "poses / points / chi2 / outlier list out" — what the reference delegates to
+ * g2o at src/Optimizer.cc:754-755 plus the gate at :757-804 — runs in hand-written
+ * HIP kernels for gfx950.  No Eigen / Sophus / g2o / OpenCV / torch types cross this
+ * boundary: plain pointers and sizes only.
+ *
+ * Threading: a handle is bound to one device + one stream and must be used by one
+ * thread at a time; different handles are independent (LocalMapping thread and
+ * Tracking thread each own one, reference src/System.cc:128-129).
+ * Ownership: the caller owns every buffer; the library keeps no caller pointer
+ * after a call returns (the stop flag is read only during the call).
+ * Errors: int status, never throws / exits; on non-zero status nothing was written
+ * to the result buffers except `status` (reference convention of silent early
+ * returns, src/Optimizer.cc:525-529, 749-751).
+ */
+#ifndef MOVBA_H
+#define MOVBA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOVBA_VERSION 1
+
+/* status codes */
+#define MOVBA_OK              0
+#define MOVBA_STOPPED         1   /* *stop was set before the solve (Optimizer.cc:749-751)   */
+#define MOVBA_NO_FIXED        2   /* no fixed keyframe vertex (Optimizer.cc:525-529)          */
+#define MOVBA_EMPTY           3   /* nothing to optimise (no edges / no free vertex)          */
+#define MOVBA_ERR_ARG        -1
+#define MOVBA_ERR_HIP        -2   /* HIP runtime failure (no device, OOM, launch error)       */
+#define MOVBA_ERR_STATE      -3   /* call order violated (run before upload, ...)             */
+
+/* flags */
+#define MOVBA_FLAG_STALE_ERROR_QUIRK 1u  /* chi2 of a rejected last trial, as g2o leaves it */
+
+typedef struct movba_handle movba_handle;
+
+/* One flattened local-BA window.  Replaces the g2o graph the reference builds at
+ * src/Optimizer.cc:532-747 (vertices :554-584, :623-632; mono edges :646-672). */
+typedef struct {
+    int32_t n_poses;            /* K + F keyframe vertices, ascending KeyFrame::mnId          */
+    int32_t n_points;           /* P map-point vertices                                       */
+    int32_t n_edges;            /* E monocular edges, caller order = vpEdgesMono order        */
+    const double  *poses;       /* n_poses x 7: qx qy qz qw tx ty tz = Tcw (Optimizer.cc:559) */
+    const uint8_t *pose_fixed;  /* n_poses: 1 = setFixed(true) (Optimizer.cc:561, 578)        */
+    const double  *points;      /* n_points x 3 world position (Optimizer.cc:627)             */
+    const int32_t *edge_pose;   /* E: index into poses   (vertex 1 of the edge, :655)         */
+    const int32_t *edge_point;  /* E: index into points  (vertex 0 of the edge, :654)         */
+    const double  *obs;         /* E x 2: mvKeysUn[idx].pt (Optimizer.cc:648-650)             */
+    const double  *inv_sigma2;  /* E: information = inv_sigma2 * I2 (Optimizer.cc:656-657)    */
+    double fx, fy, cx, cy;      /* GeometricCamera::getParameter(0..3), float -> double       */
+    double huber_delta;         /* (double)sqrtf(5.0f) (Optimizer.cc:616); <= 0: no kernel    */
+    double chi2_gate;           /* 5.0 (Optimizer.cc:52, 769)                                 */
+    int32_t max_iters;          /* optimizer.optimize(10) (Optimizer.cc:755)                  */
+    uint32_t flags;             /* MOVBA_FLAG_*                                               */
+    const volatile uint8_t *stop; /* pbStopFlag (Optimizer.cc:544-545, 749), may be NULL      */
+} movba_lba_desc;
+
+#define MOVBA_MAX_TRACE 128
+
+typedef struct {
+    double  *poses;             /* n_poses x 7 out (fixed vertices returned unchanged)        */
+    double  *points;            /* n_points x 3 out                                           */
+    double  *chi2;              /* E out, caller edge order: e->chi2() (Optimizer.cc:769)     */
+    uint8_t *outlier;           /* E out: chi2 > gate || !isDepthPositive() (Optimizer.cc:769)*/
+    int32_t status;
+    int32_t iters_done;         /* outer LM iterations run                                    */
+    int32_t n_solves;           /* linear solves = accepted + rejected trials                 */
+    int32_t n_outliers;
+    int32_t pcg_iters;          /* total PCG iterations over all solves                       */
+    int32_t last_rejected;      /* 1 if the final trial was rejected                          */
+    double lambda;              /* final damping                                              */
+    double cost0, cost;         /* initial / final robust cost (activeRobustChi2)             */
+    int32_t n_trace;            /* per-trial trace (min(n_solves, MOVBA_MAX_TRACE) entries)   */
+    double  tr_lambda[MOVBA_MAX_TRACE];
+    double  tr_f0[MOVBA_MAX_TRACE];
+    double  tr_f1[MOVBA_MAX_TRACE];
+    double  tr_rho[MOVBA_MAX_TRACE];
+    int32_t tr_accept[MOVBA_MAX_TRACE];
+    int32_t tr_pcg_iters[MOVBA_MAX_TRACE];
+} movba_lba_result;
+
+/* Solver options (all have defaults; pass NULL to movba_create for defaults). */
+typedef struct {
+    double pcg_rel_tol;         /* stop when sqrt(r.z / r0.z0) <= tol       (default 1e-10)   */
+    int32_t pcg_max_iters;      /* per solve                                 (default 4*6K)    */
+    int32_t run_ahead;          /* trial sets the host keeps queued ahead    (default 2)       */
+    int32_t profile;            /* 1: bracket every kernel class with HIP events               */
+} movba_options;
+
+/* Per-kernel-class timing collected with HIP events on the handle's stream. */
+#define MOVBA_NKERNELS 6
+typedef struct {
+    const char *name[MOVBA_NKERNELS];
+    double      ms[MOVBA_NKERNELS];      /* summed device time                               */
+    int64_t     launches[MOVBA_NKERNELS];
+    double      upload_ms, structure_ms, download_ms;   /* host-side phases, wall clock     */
+} movba_profile;
+
+int  movba_version(void);
+const char *movba_status_string(int status);
+
+/* device: HIP device ordinal.  stream: a hipStream_t created by the caller on that device
+ * (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a private stream. */
+int  movba_create(movba_handle **out, int device, void *stream, const movba_options *opt);
+void movba_destroy(movba_handle *h);
+
+/* Optimizer::LocalBundleAdjustment's solve (Optimizer.cc:754-755 + :757-775) in one call:
+ * upload + run + download.  Also serves Optimizer::BundleAdjustment (Optimizer.cc:286-287). */
+int  movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_result *res);
+
+/* The same in three phases, for callers that keep the window resident in HBM
+ * (bench.py times movba_lba_run alone; the window can be re-run after movba_lba_reset). */
+int  movba_lba_upload(movba_handle *h, const movba_lba_desc *desc);   /* host structure + H2D */
+int  movba_lba_reset(movba_handle *h);                                /* restore uploaded state on device */
+int  movba_lba_run(movba_handle *h);                                  /* LM loop on device; returns after stream sync */
+int  movba_lba_download(movba_handle *h, movba_lba_result *res);      /* D2H + caller edge order */
+
+/* Copy the optimised poses (n_poses x 7 f64) into a caller-owned DEVICE buffer on the
+ * handle's stream — what the RCCL all-gather of independent windows sends. */
+int  movba_lba_export_poses_device(movba_handle *h, void *dst_device, int64_t capacity_bytes);
+
+int  movba_get_profile(movba_handle *h, movba_profile *out);
+int  movba_reset_profile(movba_handle *h);
+
+/* Host-only structure pass (no GPU needed): what movba_lba_upload derives from a window
+ * before any H2D copy.  Exposed for the CPU test suite. */
+typedef struct {
+    int32_t n_free;             /* free AND active pose vertices (hessian blocks)            */
+    int32_t n_pairs;            /* upper-triangle pose pairs sharing >= 1 point               */
+    int64_t n_entries;          /* sum over points of d(d+1)/2 over free observers            */
+    int32_t n_items;            /* schur work items (pair chunks)                             */
+    int32_t max_degree;         /* max edges per point                                        */
+    int32_t already_grouped;    /* 1 if caller edges were already grouped by point            */
+} movba_structure_info;
+int  movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info,
+                           int32_t *edge_perm /* E or NULL */, int32_t *free_index /* n_poses or NULL */);
+
+/* Pose-only optimisation behind Optimizer::PoseOptimization (Optimizer.cc:397-459), over the
+ * reference's EdgeSE3ProjectXYZOnlyPose (include/OptimizableTypes.h:30-58). */
+typedef struct {
+    int32_t n;                  /* 2D-3D matches (Frame::N non-null, Optimizer.cc:404-413)    */
+    const double *Xw;           /* n x 3 MapPoint::GetWorldPos                                */
+    const double *obs;          /* n x 2 mvKeys[i].pt                                         */
+    const double *inv_sigma2;   /* n or NULL (= 1)                                            */
+    double fx, fy, cx, cy;
+    double pose0[7];            /* initial Tcw                                                */
+    double huber_delta;         /* reprojection threshold in px                               */
+    double chi2_gate;           /* threshold^2                                                */
+    int32_t rounds;             /* 4                                                          */
+    int32_t its_per_round;      /* 10                                                         */
+} movba_pose_desc;
+
+typedef struct {
+    double   pose[7];
+    uint8_t *outlier;           /* n out (Frame::mvbOutlier, Optimizer.cc:452-456)            */
+    double  *chi2;              /* n out or NULL                                              */
+    int32_t  n_inliers;         /* return value of PoseOptimization (Optimizer.cc:458)        */
+    int32_t  status;
+} movba_pose_result;
+
+int  movba_pose_opt(movba_handle *h, const movba_pose_desc *desc, movba_pose_result *res);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOVBA_H */

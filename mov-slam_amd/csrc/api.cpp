@@ -1,0 +1,550 @@
+// C-ABI of libmovba.so (include/movba.h): handle, HBM arena, upload / run / download and
+// the host side of the LM loop.  The host only feeds the stream: every numerical decision
+// (gain ratio, accept/reject, lambda) is taken on the device by k_decide, which publishes
+// its progress in pinned host memory so the host can stay a bounded number of trial sets
+// ahead without a stream synchronise per trial.
+//
+// Replaces, behind Optimizer::LocalBundleAdjustment (/root/reference/src/Optimizer.cc:461-841),
+// the g2o objects set up at :532-545 and driven at :754-755, and the gate at :757-775.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "device_types.h"
+#include "kernels.h"
+#include "movba.h"
+#include "structure.h"
+
+using namespace movba;
+
+namespace {
+
+enum KernelClass { KC_SCHUR = 0, KC_PCG, KC_BACKSUB, KC_DECIDE, KC_SETUP, KC_FINALIZE };
+const char *kKernelNames[MOVBA_NKERNELS] = { "k_schur", "k_pcg", "k_point<backsub>", "k_decide", "setup(init+linearize+lambda)", "k_finalize" };
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct EventPair { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct movba_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    movba_options opt{};
+    // device arena
+    char *arena = nullptr;
+    size_t arena_cap = 0;
+    // pinned staging
+    char *stage = nullptr;
+    size_t stage_cap = 0;
+    HostStatus *hstat = nullptr;        // pinned, mapped
+    HostStatus *hstat_dev = nullptr;
+    Ctrl *ctrl_host = nullptr;          // pinned copy of the device Ctrl
+    // current window
+    bool uploaded = false, ran = false;
+    Structure st;
+    DevWindow win{};
+    size_t h2d_bytes = 0;
+    const volatile uint8_t *stop = nullptr;
+    int early_status = MOVBA_OK;
+    // pose-only scratch
+    char *pose_arena = nullptr;
+    size_t pose_cap = 0;
+    // profiling
+    std::vector<EventPair> ev_used;
+    std::vector<hipEvent_t> ev_pool;
+    movba_profile prof{};
+};
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            std::fprintf(stderr, "libmovba: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MOVBA_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    size_t off = 0;
+    template <typename T> size_t take(size_t count)
+    {
+        const size_t o = off;
+        off = align_up(off + count * sizeof(T), 256);
+        return o;
+    }
+};
+
+hipEvent_t get_event(movba_handle *h)
+{
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct ScopedEvents {
+    movba_handle *h; EventPair p{}; bool on;
+    ScopedEvents(movba_handle *h_, int cls) : h(h_), on(h_->opt.profile != 0)
+    {
+        if (!on) return;
+        p.a = get_event(h); p.b = get_event(h); p.cls = cls;
+        if (!p.a || !p.b) { on = false; return; }
+        hipEventRecord(p.a, h->stream);
+    }
+    ~ScopedEvents()
+    {
+        if (!on) return;
+        hipEventRecord(p.b, h->stream);
+        h->ev_used.push_back(p);
+    }
+};
+
+void harvest_events(movba_handle *h)
+{
+    for (const EventPair &p : h->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->prof.ms[p.cls] += ms;
+            h->prof.launches[p.cls] += 1;
+        }
+        h->ev_pool.push_back(p.a);
+        h->ev_pool.push_back(p.b);
+    }
+    h->ev_used.clear();
+}
+
+int ensure_arena(movba_handle *h, size_t bytes)
+{
+    if (bytes <= h->arena_cap) return MOVBA_OK;
+    if (h->arena) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->arena)); h->arena = nullptr; h->arena_cap = 0; }
+    const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->arena), cap));
+    h->arena_cap = cap;
+    return MOVBA_OK;
+}
+
+int ensure_stage(movba_handle *h, size_t bytes)
+{
+    if (bytes <= h->stage_cap) return MOVBA_OK;
+    if (h->stage) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipHostFree(h->stage)); h->stage = nullptr; h->stage_cap = 0; }
+    const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->stage), cap, hipHostMallocDefault));
+    h->stage_cap = cap;
+    return MOVBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int movba_version(void) { return MOVBA_VERSION; }
+
+const char *movba_status_string(int s)
+{
+    switch (s) {
+    case MOVBA_OK: return "ok";
+    case MOVBA_STOPPED: return "stopped before solve";
+    case MOVBA_NO_FIXED: return "no fixed keyframe";
+    case MOVBA_EMPTY: return "nothing to optimise";
+    case MOVBA_ERR_ARG: return "invalid argument";
+    case MOVBA_ERR_HIP: return "HIP runtime error";
+    case MOVBA_ERR_STATE: return "invalid call order";
+    default: return "unknown";
+    }
+}
+
+int movba_create(movba_handle **out, int device, void *stream, const movba_options *opt)
+{
+    if (!out) return MOVBA_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "libmovba: no HIP device available — the local-BA path has no CPU fallback\n");
+        return MOVBA_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) return MOVBA_ERR_ARG;
+    movba_handle *h = new (std::nothrow) movba_handle();
+    if (!h) return MOVBA_ERR_HIP;
+    h->device = device;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0;
+    if (opt) {
+        if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
+        if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
+        if (opt->run_ahead > 0) h->opt.run_ahead = opt->run_ahead;
+        h->opt.profile = opt->profile;
+    }
+    for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
+    if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
+    if (stream) { h->stream = static_cast<hipStream_t>(stream); }
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
+        h->own_stream = true;
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
+        configure_kernels(0) != hipSuccess) {
+        movba_destroy(h);
+        return MOVBA_ERR_HIP;
+    }
+    std::memset((void *)h->hstat, 0, sizeof(HostStatus));
+    *out = h;
+    return MOVBA_OK;
+}
+
+void movba_destroy(movba_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    harvest_events(h);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->arena) hipFree(h->arena);
+    if (h->pose_arena) hipFree(h->pose_arena);
+    if (h->stage) hipHostFree(h->stage);
+    if (h->hstat) hipHostFree((void *)h->hstat);
+    if (h->ctrl_host) hipHostFree(h->ctrl_host);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info, int32_t *edge_perm, int32_t *free_index)
+{
+    if (!desc || !info) return MOVBA_ERR_ARG;
+    Structure s;
+    const int rc = build_structure(*desc, s);
+    if (rc < 0) return rc;
+    info->n_free = s.nfree; info->n_pairs = s.npairs; info->n_entries = s.nentries; info->n_items = s.nitems;
+    info->max_degree = s.max_degree; info->already_grouped = s.already_grouped ? 1 : 0;
+    if (edge_perm) std::memcpy(edge_perm, s.perm.data(), sizeof(int32_t) * s.perm.size());
+    if (free_index) std::memcpy(free_index, s.hidx.data(), sizeof(int32_t) * s.hidx.size());
+    return rc;
+}
+
+int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
+{
+    if (!h || !d) return MOVBA_ERR_ARG;
+    HIP_TRY(hipSetDevice(h->device));
+    h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK;
+    const double t0 = now_ms();
+    const int rc = build_structure(*d, h->st);
+    if (rc < 0) return rc;
+    const Structure &s = h->st;
+    h->stop = d->stop;
+    if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
+    else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
+    const double t1 = now_ms();
+    h->prof.structure_ms += t1 - t0;
+    if (h->early_status != MOVBA_OK) { h->uploaded = true; return MOVBA_OK; }
+    if (pcg_lds_bytes(s.nfree) > 150 * 1024) {
+        std::fprintf(stderr, "libmovba: %d free keyframes exceed the single-workgroup PCG's LDS budget\n", s.nfree);
+        return MOVBA_ERR_ARG;
+    }
+    if ((size_t)(21 * s.NP + 6 * s.nfree + 4) * sizeof(double) > 150 * 1024) {
+        std::fprintf(stderr, "libmovba: %d keyframes exceed the point kernels' LDS staging budget\n", s.NP);
+        return MOVBA_ERR_ARG;
+    }
+
+    const int NP = s.NP, P = s.P, E = s.E, nf = s.nfree;
+    const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
+    // ---- carve the H2D region ----
+    Carver c;
+    const size_t o_gpose = c.take<int32_t>(E), o_gpoint = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1);
+    const size_t o_perm = c.take<int32_t>(E), o_hidx = c.take<int32_t>(NP), o_free = c.take<int32_t>(nf + 1);
+    const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
+    const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1);
+    const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
+    const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
+    const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
+    const size_t h2d = c.off;
+    // ---- device-only region ----
+    size_t o_st[2][9];
+    for (int b = 0; b < 2; ++b) {
+        o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
+        o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
+        o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);
+        o_st[b][6] = c.take<double>(2 * (size_t)E);  o_st[b][7] = c.take<double>(E);
+        o_st[b][8] = c.take<double>(nb);
+    }
+    const size_t o_part = c.take<double>((size_t)s.nitems * kPartStride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
+    const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
+    const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
+    const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
+    const size_t total = c.off;
+
+    int rc2 = ensure_arena(h, total); if (rc2) return rc2;
+    rc2 = ensure_stage(h, std::max(h2d, (size_t)(7 * NP + 3 * P + E) * sizeof(double) + E + 4096)); if (rc2) return rc2;
+    HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
+
+    // ---- pack ----
+    char *sg = h->stage;
+    std::memcpy(sg + o_gpose, s.g_pose.data(), sizeof(int32_t) * E);
+    std::memcpy(sg + o_gpoint, s.g_point.data(), sizeof(int32_t) * E);
+    std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
+    std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
+    std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
+    std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
+    {
+        double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
+        for (int g = 0; g < E; ++g) {
+            const int e = s.perm[g];
+            obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
+        }
+    }
+    std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int2) * (size_t)s.nentries);
+    std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
+    std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
+    std::memcpy(sg + o_pj, s.pair_j.data(), sizeof(int32_t) * s.npairs);
+    std::memcpy(sg + o_pis, s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
+    std::memcpy(sg + o_rowptr, s.row_ptr.data(), sizeof(int32_t) * (nf + 1));
+    std::memcpy(sg + o_rowent, s.row_ent.data(), sizeof(RowEnt) * s.row_ent.size());
+    std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
+    std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+    const double t2 = now_ms();
+    h->prof.structure_ms += t2 - t1;
+    HIP_TRY(hipMemcpyAsync(h->arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->prof.upload_ms += now_ms() - t2;
+    h->h2d_bytes = h2d;
+
+    // ---- device view ----
+    DevWindow &w = h->win;
+    char *a = h->arena;
+    w = DevWindow{};
+    w.NP = NP; w.P = P; w.E = E; w.nfree = nf; w.npairs = s.npairs; w.nitems = s.nitems; w.n_pt_blocks = nb;
+    w.max_iters = d->max_iters; w.flags = d->flags;
+    w.fx = d->fx; w.fy = d->fy; w.cx = d->cx; w.cy = d->cy; w.huber_delta = d->huber_delta; w.chi2_gate = d->chi2_gate;
+    w.g_pose = reinterpret_cast<int32_t *>(a + o_gpose); w.g_point = reinterpret_cast<int32_t *>(a + o_gpoint);
+    w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = reinterpret_cast<int32_t *>(a + o_perm);
+    w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
+    w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
+    w.entries = reinterpret_cast<Int2 *>(a + o_ent); w.items = reinterpret_cast<Item *>(a + o_items);
+    w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
+    w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
+    w.row_ent = reinterpret_cast<RowEnt *>(a + o_rowent);
+    w.pose0 = reinterpret_cast<double *>(a + o_pose0); w.point0 = reinterpret_cast<double *>(a + o_point0);
+    for (int b = 0; b < 2; ++b) {
+        DevState &S = w.st[b];
+        S.pose = reinterpret_cast<double *>(a + o_st[b][0]); S.Rt = reinterpret_cast<double *>(a + o_st[b][1]);
+        S.point = reinterpret_cast<double *>(a + o_st[b][2]); S.Hll = reinterpret_cast<double *>(a + o_st[b][3]);
+        S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.rec = reinterpret_cast<double *>(a + o_st[b][5]);
+        S.res = reinterpret_cast<double *>(a + o_st[b][6]); S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
+        S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
+    }
+    w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
+    w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
+    w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
+    w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev;
+    w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
+    h->uploaded = true;
+    return MOVBA_OK;
+}
+
+int movba_lba_reset(movba_handle *h)
+{
+    if (!h) return MOVBA_ERR_ARG;
+    if (!h->uploaded) return MOVBA_ERR_STATE;
+    h->ran = false;
+    return MOVBA_OK;
+}
+
+int movba_lba_run(movba_handle *h)
+{
+    if (!h) return MOVBA_ERR_ARG;
+    if (!h->uploaded) return MOVBA_ERR_STATE;
+    HIP_TRY(hipSetDevice(h->device));
+    h->ran = false;
+    if (h->early_status != MOVBA_OK) { h->ran = true; return h->early_status; }
+    // early return before the solve (src/Optimizer.cc:749-751)
+    if (h->stop && *h->stop) { h->early_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
+    const DevWindow &w = h->win;
+    hipStream_t s = h->stream;
+    h->hstat->trials_done = 0; h->hstat->done = 0; h->hstat->stop = 0;
+
+    {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
+        ScopedEvents ev(h, KC_SETUP);
+        HIP_TRY(launch_init(w, s));
+        HIP_TRY(hipMemcpyAsync(w.st[0].point, w.point0, sizeof(double) * 3 * (size_t)w.P, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(launch_linearize(w, s));
+        if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, s));
+        HIP_TRY(launch_lambda_init(w, s));
+    }
+    PcgParams pp;
+    pp.rel_tol = h->opt.pcg_rel_tol;
+    pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 4 * 6 * (w.nfree > 0 ? w.nfree : 1);
+    pp.lds_blocks = 0;
+
+    const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * 10;
+    const double t_start = now_ms();
+    for (int t = 0; t < max_trials; ++t) {
+        // stay at most run_ahead trial sets ahead of the device
+        while (!h->hstat->done && t - h->hstat->trials_done >= h->opt.run_ahead) {
+            if (h->stop && *h->stop) h->hstat->stop = 1;
+            if (now_ms() - t_start > 60000.0) {
+                std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
+                return MOVBA_ERR_HIP;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (h->hstat->done) break;
+        if (h->stop && *h->stop) h->hstat->stop = 1;
+        if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, s)); }
+        { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_pcg(w, pp, s)); }
+        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
+        { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
+    }
+    { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }
+    HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    harvest_events(h);
+    h->ran = true;
+    return MOVBA_OK;
+}
+
+int movba_lba_download(movba_handle *h, movba_lba_result *res)
+{
+    if (!h || !res) return MOVBA_ERR_ARG;
+    if (!h->uploaded || !h->ran) return MOVBA_ERR_STATE;
+    HIP_TRY(hipSetDevice(h->device));
+    res->status = h->early_status;
+    res->iters_done = 0; res->n_solves = 0; res->n_outliers = 0; res->pcg_iters = 0; res->last_rejected = 0;
+    res->lambda = 0; res->cost0 = 0; res->cost = 0; res->n_trace = 0;
+    if (h->early_status != MOVBA_OK) return h->early_status;
+    const double t0 = now_ms();
+    const DevWindow &w = h->win;
+    const Ctrl &c = *h->ctrl_host;
+    const int cur = c.cur;
+    const size_t nb_pose = sizeof(double) * 7 * (size_t)w.NP, nb_pt = sizeof(double) * 3 * (size_t)w.P, nb_chi = sizeof(double) * (size_t)w.E;
+    char *sg = h->stage;
+    const size_t o_pose = 0, o_pt = align_up(nb_pose, 256), o_chi = o_pt + align_up(nb_pt, 256), o_out = o_chi + align_up(nb_chi, 256);
+    if (res->poses) HIP_TRY(hipMemcpyAsync(sg + o_pose, w.st[cur].pose, nb_pose, hipMemcpyDeviceToHost, h->stream));
+    if (res->points) HIP_TRY(hipMemcpyAsync(sg + o_pt, w.st[cur].point, nb_pt, hipMemcpyDeviceToHost, h->stream));
+    if (res->chi2) HIP_TRY(hipMemcpyAsync(sg + o_chi, w.out_chi2, nb_chi, hipMemcpyDeviceToHost, h->stream));
+    if (res->outlier) HIP_TRY(hipMemcpyAsync(sg + o_out, w.out_outlier, (size_t)w.E, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (res->poses) std::memcpy(res->poses, sg + o_pose, nb_pose);
+    if (res->points) std::memcpy(res->points, sg + o_pt, nb_pt);
+    if (res->chi2) std::memcpy(res->chi2, sg + o_chi, nb_chi);
+    if (res->outlier) std::memcpy(res->outlier, sg + o_out, (size_t)w.E);
+    res->iters_done = c.iters_done; res->n_solves = c.n_solves; res->n_outliers = c.n_outliers;
+    res->pcg_iters = c.pcg_total_iters; res->last_rejected = c.last_rejected;
+    res->lambda = c.lambda; res->cost0 = c.cost0; res->cost = c.F0;
+    res->n_trace = c.n_trace;
+    for (int k = 0; k < c.n_trace && k < MOVBA_MAX_TRACE; ++k) {
+        res->tr_lambda[k] = c.tr_lambda[k]; res->tr_f0[k] = c.tr_f0[k]; res->tr_f1[k] = c.tr_f1[k];
+        res->tr_rho[k] = c.tr_rho[k]; res->tr_accept[k] = c.tr_accept[k]; res->tr_pcg_iters[k] = c.tr_pcg[k];
+    }
+    h->prof.download_ms += now_ms() - t0;
+    return MOVBA_OK;
+}
+
+int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_result *res)
+{
+    if (!h || !desc || !res) return MOVBA_ERR_ARG;
+    res->status = MOVBA_ERR_ARG;
+    int rc = movba_lba_upload(h, desc);
+    if (rc != MOVBA_OK) { res->status = rc; return rc; }
+    rc = movba_lba_run(h);
+    if (rc < 0) { res->status = rc; h->stop = nullptr; return rc; }
+    rc = movba_lba_download(h, res);
+    h->stop = nullptr;      // keep no caller pointer after the call returns
+    res->status = rc;
+    return rc;
+}
+
+int movba_lba_export_poses_device(movba_handle *h, void *dst, int64_t cap)
+{
+    if (!h || !dst) return MOVBA_ERR_ARG;
+    if (!h->uploaded || !h->ran || h->early_status != MOVBA_OK) return MOVBA_ERR_STATE;
+    const DevWindow &w = h->win;
+    const size_t nb = sizeof(double) * 7 * (size_t)w.NP;
+    if (cap < (int64_t)nb) return MOVBA_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(dst, w.st[h->ctrl_host->cur].pose, nb, hipMemcpyDeviceToDevice, h->stream));
+    return MOVBA_OK;
+}
+
+int movba_get_profile(movba_handle *h, movba_profile *out)
+{
+    if (!h || !out) return MOVBA_ERR_ARG;
+    *out = h->prof;
+    return MOVBA_OK;
+}
+
+int movba_reset_profile(movba_handle *h)
+{
+    if (!h) return MOVBA_ERR_ARG;
+    for (int k = 0; k < MOVBA_NKERNELS; ++k) { h->prof.ms[k] = 0; h->prof.launches[k] = 0; }
+    h->prof.upload_ms = h->prof.structure_ms = h->prof.download_ms = 0;
+    return MOVBA_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Optimizer::PoseOptimization (/root/reference/src/Optimizer.cc:397-459)
+// ---------------------------------------------------------------------------------------
+#include "pose_kernels.h"
+
+extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_pose_result *res)
+{
+    if (!h || !d || !res) return MOVBA_ERR_ARG;
+    res->status = MOVBA_ERR_ARG; res->n_inliers = 0;
+    const int n = d->n;
+    if (n < 0 || (n && (!d->Xw || !d->obs)) || d->rounds < 1 || d->its_per_round < 1) return MOVBA_ERR_ARG;
+    for (int k = 0; k < 7; ++k) res->pose[k] = d->pose0[k];
+    // fewer than 4 matches: the reference returns 0 without touching the frame (Optimizer.cc:415-418)
+    if (n < 4) { res->status = MOVBA_EMPTY; return MOVBA_EMPTY; }
+    HIP_TRY(hipSetDevice(h->device));
+    Carver c;
+    const size_t o_X = c.take<double>(3 * (size_t)n), o_obs = c.take<double>(2 * (size_t)n), o_is = c.take<double>(n);
+    const size_t h2d = c.off;
+    const size_t o_chi = c.take<double>(n), o_pose = c.take<double>(8), o_lvl = c.take<uint8_t>(n);
+    const size_t total = c.off;
+    if (total > h->pose_cap) {
+        if (h->pose_arena) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->pose_arena)); h->pose_arena = nullptr; h->pose_cap = 0; }
+        const size_t cap = align_up(2 * total, 1 << 16);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->pose_arena), cap));
+        h->pose_cap = cap;
+    }
+    int rc = ensure_stage(h, total); if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    char *sg = h->stage;
+    std::memcpy(sg + o_X, d->Xw, sizeof(double) * 3 * (size_t)n);
+    std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)n);
+    double *isg = reinterpret_cast<double *>(sg + o_is);
+    for (int i = 0; i < n; ++i) isg[i] = d->inv_sigma2 ? d->inv_sigma2[i] : 1.0;
+    HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
+    PoseDev p{};
+    p.n = n; p.rounds = d->rounds; p.its = d->its_per_round;
+    p.fx = d->fx; p.fy = d->fy; p.cx = d->cx; p.cy = d->cy; p.huber_delta = d->huber_delta; p.chi2_gate = d->chi2_gate;
+    for (int k = 0; k < 7; ++k) p.pose0[k] = d->pose0[k];
+    char *a = h->pose_arena;
+    p.Xw = reinterpret_cast<double *>(a + o_X); p.obs = reinterpret_cast<double *>(a + o_obs); p.isig = reinterpret_cast<double *>(a + o_is);
+    p.chi2 = reinterpret_cast<double *>(a + o_chi); p.pose_out = reinterpret_cast<double *>(a + o_pose); p.level1 = reinterpret_cast<uint8_t *>(a + o_lvl);
+    HIP_TRY(launch_pose_opt(p, h->stream));
+    HIP_TRY(hipMemcpyAsync(sg + o_chi, a + o_chi, total - o_chi, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const double *po = reinterpret_cast<const double *>(sg + o_pose);
+    for (int k = 0; k < 7; ++k) res->pose[k] = po[k];
+    res->n_inliers = (int32_t)po[7];
+    if (res->outlier) std::memcpy(res->outlier, sg + o_lvl, (size_t)n);
+    if (res->chi2) std::memcpy(res->chi2, sg + o_chi, sizeof(double) * (size_t)n);
+    res->status = MOVBA_OK;
+    return MOVBA_OK;
+}

@@ -1,0 +1,90 @@
+// Device-side view of one uploaded local-BA window (all pointers are HBM addresses).
+// Layout rationale in DESIGN.md §3: SoA fp64, edges grouped by map point, two state
+// buffers (current linearisation point / trial state) so g2o's push()/pop()
+// (OptimizationAlgorithmLevenberg::solve, called from /root/reference/src/Optimizer.cc:755)
+// becomes an index flip.
+#pragma once
+#include <cstdint>
+
+#include "structure.h"
+
+namespace movba {
+
+constexpr int kPartStride = 72;     // doubles per schur work-item partial
+// partial layout: [0,36) sum of B_i Dinv B_j^T (6x6 row-major)
+//                 [36,42) sum of B_i Dinv b_l           (diagonal pairs only)
+//                 [42,63) upper triangle of Hpp_ii      (diagonal pairs only)
+//                 [63,69) b_p,i                          (diagonal pairs only)
+constexpr int kPointGroup = 8;      // lanes cooperating on one map point
+constexpr int kPointBlock = 256;    // threads per block of the point kernels
+constexpr int kPointsPerBlock = kPointBlock / kPointGroup;
+constexpr int kMaxTrace = MOVBA_MAX_TRACE;
+
+struct DevState {
+    double *pose;    // NP x 7  (qx qy qz qw tx ty tz)
+    double *Rt;      // NP x 12 (R row-major, t)
+    double *point;   // P x 3
+    double *Hll;     // P x 6   (xx xy xz yy yz zz), undamped
+    double *bl;      // P x 3
+    double *rec;     // E x 4   (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2)
+    double *res;     // E x 2   (-w e0, -w e1)
+    double *chi2;    // E
+    double *Fpart;   // n_pt_blocks robust-cost partials of this state
+};
+
+// LM controller state, lives in HBM; every kernel reads it, k_decide/k_pcg/k_lambda_init write it.
+struct Ctrl {
+    double lambda, nu, F0, cost0;
+    double tr_lambda[kMaxTrace], tr_f0[kMaxTrace], tr_f1[kMaxTrace], tr_rho[kMaxTrace];
+    int32_t tr_accept[kMaxTrace], tr_pcg[kMaxTrace];
+    int32_t it, qmax, cur, done;
+    int32_t n_solves, last_rejected, iters_done, n_trace;
+    int32_t pcg_fail, pcg_last_iters, pcg_total_iters, n_outliers;
+};
+
+// Written by k_decide into pinned host memory so the host can keep the queue fed
+// without a stream synchronise per trial.
+struct HostStatus {
+    volatile int32_t trials_done;
+    volatile int32_t done;
+    volatile int32_t stop;      // host -> device: forceStopFlag seen by the host poll
+    int32_t pad;
+};
+
+struct DevWindow {
+    int32_t NP, P, E, nfree, npairs, nitems, n_pt_blocks, max_iters;
+    uint32_t flags;
+    int32_t pad0;
+    double fx, fy, cx, cy, huber_delta, chi2_gate;
+    // structure
+    const int32_t *g_pose, *g_point, *pt_start, *perm, *hidx, *free_pose;
+    const double *obs;      // E x 2 (grouped order)
+    const double *isig;     // E
+    const Int2 *entries;
+    const Item *items;
+    const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;
+    const RowEnt *row_ent;
+    // state
+    DevState st[2];
+    const double *pose0, *point0;   // uploaded initial state (for reset)
+    // reduced system
+    double *part;       // nitems x kPartStride
+    double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first
+    double *bp;         // 6 nfree
+    double *xp;         // 6 nfree
+    double *scale_part; // n_pt_blocks + 1
+    double *hmax_part;  // n_pt_blocks
+    Ctrl *ctrl;
+    HostStatus *hstat;  // device view of the pinned status block
+    // outputs (caller edge order)
+    double *out_chi2;
+    uint8_t *out_outlier;
+};
+
+struct PcgParams {
+    double rel_tol;
+    int32_t max_iters;
+    int32_t lds_blocks;     // how many leading S blocks are staged in LDS
+};
+
+}  // namespace movba

@@ -1,0 +1,881 @@
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64, fp64) for the local-BA hot path.
+//
+// What they replace: the work g2o does inside optimizer.optimize(10)
+// (/root/reference/src/Optimizer.cc:754-755) with the reference's own edge callbacks
+//   EdgeSE3ProjectXYZ::computeError   include/OptimizableTypes.h:103-109
+//   EdgeSE3ProjectXYZ::linearizeOplus src/OptimizableTypes.cpp:158-180
+//   Pinhole::project / projectJac     src/CameraModels/Pinhole.cpp:36-43, 77-88
+// and the outlier gate of src/Optimizer.cc:757-775.
+//
+// Kernel chain per LM trial (all on one stream, LM control stays on the device):
+//   k_schur  (one wave per pose-pair chunk)  -> partial 6x6 blocks of the reduced system
+//   k_pcg    (one workgroup)                 -> assemble S, block-Jacobi PCG, trial poses
+//   k_point<true> (8 lanes per map point)    -> back-substitution, trial points, errors and
+//                                               the linearisation (Hll, bl, weights) at the trial state
+//   k_decide (one wave)                      -> gain ratio, accept/reject, lambda schedule
+// None of this is GEMM-shaped (block-sparse 6x3 / 3x3 / 6x6 products over a point
+// graph), so there is no MFMA: the kernels are gather/stream kernels bound by HBM/L2
+// traffic and launch latency.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "device_types.h"
+#include "kernels.h"
+
+namespace movba {
+
+// --------------------------------------------------------------------------------
+// small device math
+// --------------------------------------------------------------------------------
+
+__device__ __forceinline__ void quat_to_R(const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+__device__ __forceinline__ void R_to_quat(const double m[9], double q[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        // i = argmax diagonal, written without dynamic register indexing
+        if (m[0] >= m[4] && m[0] >= m[8]) {
+            t = sqrt(m[0] - m[4] - m[8] + 1.0);
+            q[0] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+        } else if (m[4] > m[0] && m[4] >= m[8]) {
+            t = sqrt(m[4] - m[8] - m[0] + 1.0);
+            q[1] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+        } else {
+            t = sqrt(m[8] - m[0] - m[4] + 1.0);
+            q[2] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+        }
+    }
+}
+
+// SE3Quat::normalizeRotation
+__device__ __forceinline__ void quat_normalize(double q[4])
+{
+    if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+__device__ __forceinline__ void quat_rotate(const double q[4], const double v[3], double o[3])
+{
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    o[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    o[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    o[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+
+// T <- exp(u) * T   (VertexSE3Expmap::oplusImpl; u = (omega, upsilon), rotation first)
+__device__ void se3_oplus(const double u[6], const double T[7], double out[7])
+{
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double th = sqrt(th2);
+    double a, b, c, d;
+    if (th < 0.00001) { a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0; }
+    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = b; d = (th - sin(th)) / (th2 * th); }
+    // Om = [w]x ; Om2 = w w^T - th2 I
+    const double Om[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
+    const double Om2[9] = { wx * wx - th2, wx * wy, wx * wz, wy * wx, wy * wy - th2, wy * wz, wz * wx, wz * wy, wz * wz - th2 };
+    double R[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + a * Om[i] + b * Om2[i];
+        V[i] = I + c * Om[i] + d * Om2[i];
+    }
+    double e[7];
+    R_to_quat(R, e);
+    e[4] = V[0] * u[3] + V[1] * u[4] + V[2] * u[5];
+    e[5] = V[3] * u[3] + V[4] * u[4] + V[5] * u[5];
+    e[6] = V[6] * u[3] + V[7] * u[4] + V[8] * u[5];
+    quat_normalize(e);
+    // SE3Quat::operator*
+    double r[4];
+    r[3] = e[3] * T[3] - e[0] * T[0] - e[1] * T[1] - e[2] * T[2];
+    r[0] = e[3] * T[0] + e[0] * T[3] + e[1] * T[2] - e[2] * T[1];
+    r[1] = e[3] * T[1] + e[1] * T[3] + e[2] * T[0] - e[0] * T[2];
+    r[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
+    double rt[3];
+    quat_rotate(e, T + 4, rt);
+    quat_normalize(r);
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
+    out[4] = e[4] + rt[0]; out[5] = e[5] + rt[1]; out[6] = e[6] + rt[2];
+}
+
+// inverse of the symmetric 3x3 (xx xy xz yy yz zz) by cofactors
+__device__ __forceinline__ void inv3sym(const double A[6], double B[6])
+{
+    const double c00 = A[3] * A[5] - A[4] * A[4];
+    const double c01 = A[4] * A[2] - A[1] * A[5];
+    const double c02 = A[1] * A[4] - A[3] * A[2];
+    const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
+    B[3] = (A[0] * A[5] - A[2] * A[2]) * id;
+    B[4] = (A[2] * A[1] - A[0] * A[4]) * id;
+    B[5] = (A[0] * A[3] - A[1] * A[1]) * id;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// deterministic block reduction (fixed order), result valid in every thread
+template <int NWAVES, bool MAX>
+__device__ __forceinline__ double block_reduce(double v, double *red /* NWAVES doubles in LDS */)
+{
+    v = MAX ? wave_max(v) : wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < NWAVES; ++k) s = MAX ? fmax(s, red[k]) : s + red[k];
+    __syncthreads();
+    return s;
+}
+
+// upper-triangle index of a symmetric 6x6, a <= b
+__device__ __forceinline__ constexpr int ut6(int a, int b) { return a * 6 - a * (a - 1) / 2 + (b - a); }
+
+// --------------------------------------------------------------------------------
+// k_init_pose: uploaded poses -> state 0 (normalised like SE3Quat's constructor), Rt cache
+// --------------------------------------------------------------------------------
+__global__ void k_init_pose(DevWindow w)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        Ctrl *c = w.ctrl;
+        c->lambda = 0.0; c->nu = 2.0; c->F0 = 0.0; c->cost0 = 0.0;
+        c->it = 0; c->qmax = 0; c->cur = 0; c->done = (w.max_iters <= 0) ? 1 : 0;
+        c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
+        c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
+    }
+    if (i >= w.NP) return;
+    double q[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) q[k] = w.pose0[7 * i + k];
+    quat_normalize(q);
+    double R[9];
+    quat_to_R(q, R);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) w.st[0].pose[7 * i + k] = q[k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w.st[0].Rt[12 * i + k] = R[k];
+    w.st[0].Rt[12 * i + 9] = q[4]; w.st[0].Rt[12 * i + 10] = q[5]; w.st[0].Rt[12 * i + 11] = q[6];
+}
+
+// --------------------------------------------------------------------------------
+// k_point<BACKSUB>: 8 lanes per map point, edges of a point are contiguous.
+//   BACKSUB=false : evaluate errors + linearise (Hll, bl, per-edge Xc/weight) at state cur
+//   BACKSUB=true  : x_l = Dinv (b_l - sum_i B_il^T xp_i)  (BlockSolver::solve back-substitution),
+//                   trial point X + x_l, then the same evaluation at the trial state cur^1
+// Pose rotations/translations and the pose increments are staged in LDS.
+// --------------------------------------------------------------------------------
+template <bool BACKSUB>
+__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int cur = c->cur;
+    const int dst = BACKSUB ? (cur ^ 1) : cur;
+    const double lambda = c->lambda;
+    const DevState &S0 = w.st[cur];
+    const DevState &S1 = w.st[dst];
+
+    double *sRt = sm;                               // NP x 12 at dst
+    double *sR0 = sm + 12 * w.NP;                   // NP x 9 at cur   (BACKSUB)
+    double *sxp = sR0 + (BACKSUB ? 9 * w.NP : 0);   // nfree x 6       (BACKSUB)
+    double *red = sxp + (BACKSUB ? 6 * w.nfree : 0);// 4
+    for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+    if (BACKSUB) {
+        for (int k = threadIdx.x; k < 9 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[(k / 9) * 12 + (k % 9)];
+        for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
+    }
+    __syncthreads();
+
+    const int sub = threadIdx.x & (kPointGroup - 1);
+    const int l = blockIdx.x * kPointsPerBlock + (threadIdx.x / kPointGroup);
+    const bool valid = l < w.P;
+    int begin = 0, end = 0;
+    if (valid) { begin = w.pt_start[l]; end = w.pt_start[l + 1]; }
+    double X[3] = { 0, 0, 0 };
+    if (valid) { X[0] = S0.point[3 * l]; X[1] = S0.point[3 * l + 1]; X[2] = S0.point[3 * l + 2]; }
+    double scale = 0.0;
+
+    if (BACKSUB) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int g = begin + sub; g < end; g += kPointGroup) {
+            const int ip = w.g_pose[g];
+            const int h = w.hidx[ip];
+            if (h < 0) continue;
+            const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
+            const double x = rc.x, y = rc.y, z = rc.z, wg = rc.w;
+            const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
+            const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
+            const double *xp = sxp + 6 * h;
+            // t = J_c xp  (rows of -Jpi [ -[Xc]x | I ])
+            const double t0 = (a02 * y) * xp[0] + (a00 * z - a02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + a02 * xp[5];
+            const double t1 = (-a11 * z + a12 * y) * xp[0] + (-a12 * x) * xp[1] + (a11 * x) * xp[2] + a11 * xp[4] + a12 * xp[5];
+            const double g0 = wg * t0, g1 = wg * t1;
+            const double *R = sR0 + 9 * ip;
+            // J_p = -Jpi R : rows p0 = a00 R0 + a02 R2, p1 = a11 R1 + a12 R2
+            a0 += (a00 * R[0] + a02 * R[6]) * g0 + (a11 * R[3] + a12 * R[6]) * g1;
+            a1 += (a00 * R[1] + a02 * R[7]) * g0 + (a11 * R[4] + a12 * R[7]) * g1;
+            a2 += (a00 * R[2] + a02 * R[8]) * g0 + (a11 * R[5] + a12 * R[8]) * g1;
+        }
+#pragma unroll
+        for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
+            a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+        }
+        if (valid && end > begin) {
+            double H[6], D[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) H[k] = S0.Hll[6 * l + k];
+            H[0] += lambda; H[3] += lambda; H[5] += lambda;
+            inv3sym(H, D);
+            const double b0 = S0.bl[3 * l], b1 = S0.bl[3 * l + 1], b2 = S0.bl[3 * l + 2];
+            const double c0 = b0 - a0, c1 = b1 - a1, c2 = b2 - a2;
+            const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
+            const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
+            const double x2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
+            X[0] += x0; X[1] += x1; X[2] += x2;
+            if (sub == 0) scale = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+        }
+    }
+
+    // ---- evaluate at the destination state ----
+    double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, v0 = 0, v1 = 0, v2 = 0, F = 0.0;
+    const double dsqr = w.huber_delta * w.huber_delta;
+    for (int g = begin + sub; g < end; g += kPointGroup) {
+        const int ip = w.g_pose[g];
+        const double *R = sRt + 12 * ip;
+        const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
+        const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
+        const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
+        const double2 ob = *reinterpret_cast<const double2 *>(w.obs + 2 * g);
+        const double om = w.isig[g];
+        const double e0 = ob.x - (w.fx * x / z + w.cx);
+        const double e1 = ob.y - (w.fy * y / z + w.cy);
+        const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+        double rho0 = chi2, rho1 = 1.0;
+        if (w.huber_delta > 0.0 && !(chi2 <= dsqr)) {
+            const double sq = sqrt(chi2);
+            rho0 = 2.0 * sq * w.huber_delta - dsqr;
+            rho1 = w.huber_delta / sq;
+        }
+        const double wg = rho1 * om;
+        const double r0 = -wg * e0, r1 = -wg * e1;
+        *reinterpret_cast<double4 *>(S1.rec + 4 * g) = make_double4(x, y, z, wg);
+        *reinterpret_cast<double2 *>(S1.res + 2 * g) = make_double2(r0, r1);
+        S1.chi2[g] = chi2;
+        F += rho0;
+        const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
+        const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
+        const double p00 = a00 * R[0] + a02 * R[6], p01 = a00 * R[1] + a02 * R[7], p02 = a00 * R[2] + a02 * R[8];
+        const double p10 = a11 * R[3] + a12 * R[6], p11 = a11 * R[4] + a12 * R[7], p12 = a11 * R[5] + a12 * R[8];
+        h0 += wg * (p00 * p00 + p10 * p10); h1 += wg * (p00 * p01 + p10 * p11); h2 += wg * (p00 * p02 + p10 * p12);
+        h3 += wg * (p01 * p01 + p11 * p11); h4 += wg * (p01 * p02 + p11 * p12); h5 += wg * (p02 * p02 + p12 * p12);
+        v0 += p00 * r0 + p10 * r1; v1 += p01 * r0 + p11 * r1; v2 += p02 * r0 + p12 * r1;
+    }
+#pragma unroll
+    for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
+        h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
+        h3 += __shfl_xor(h3, o, 64); h4 += __shfl_xor(h4, o, 64); h5 += __shfl_xor(h5, o, 64);
+        v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64);
+    }
+    double hmax = 0.0;
+    if (valid && sub == 0) {
+        double *Hd = S1.Hll + 6 * l;
+        Hd[0] = h0; Hd[1] = h1; Hd[2] = h2; Hd[3] = h3; Hd[4] = h4; Hd[5] = h5;
+        S1.bl[3 * l] = v0; S1.bl[3 * l + 1] = v1; S1.bl[3 * l + 2] = v2;
+        if (BACKSUB) { S1.point[3 * l] = X[0]; S1.point[3 * l + 1] = X[1]; S1.point[3 * l + 2] = X[2]; }
+        if (end > begin) hmax = fmax(fabs(h0), fmax(fabs(h3), fabs(h5)));
+    }
+    const double Fsum = block_reduce<kPointBlock / 64, false>(F, red);
+    if (BACKSUB) {
+        const double ssum = block_reduce<kPointBlock / 64, false>(scale, red);
+        if (threadIdx.x == 0) w.scale_part[blockIdx.x] = ssum;
+    } else {
+        const double m = block_reduce<kPointBlock / 64, true>(hmax, red);
+        if (threadIdx.x == 0) w.hmax_part[blockIdx.x] = m;
+    }
+    if (threadIdx.x == 0) S1.Fpart[blockIdx.x] = Fsum;
+}
+
+// --------------------------------------------------------------------------------
+// k_schur: one wave per work item (a chunk of one pose pair's shared points).
+// Per entry (edge of pose i, edge of pose j, both on point l) a lane rebuilds the
+// Jacobians from the cached camera-frame point and adds
+//     B_il Dinv_l B_jl^T = w_i w_j  Jc_i^T ( Jp_i Dinv_l Jp_j^T ) Jc_j          (6x6)
+// (BlockSolver<6,3>::solve, Schur step, without ever storing the 6x3 Hpl blocks);
+// diagonal pairs also accumulate Hpp_ii, b_p,i (BaseBinaryEdge::constructQuadraticForm)
+// and B_il Dinv_l b_l.  Wave-level shuffle reduction, one 72-double partial per item.
+// mode 1 = diagonal pairs only, Hpp only (used once to seed lambda).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode)
+{
+    const Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= w.nitems) return;
+    const Item it = w.items[item];
+    if (mode == 1 && !it.diag) return;
+    const int cur = c->cur;
+    const double lambda = c->lambda;
+    const DevState &S0 = w.st[cur];
+    const int ip = w.free_pose[w.pair_i[it.pair]];
+    const int jp = w.free_pose[w.pair_j[it.pair]];
+    double Ri[9], Rj[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { Ri[k] = S0.Rt[12 * ip + k]; Rj[k] = S0.Rt[12 * jp + k]; }
+    double *out = w.part + (size_t)item * kPartStride;
+
+    if (it.diag) {
+        double sa[21], ha[21], ca[6], ba[6];
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { sa[k] = 0.0; ha[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ca[k] = 0.0; ba[k] = 0.0; }
+        for (int k = it.begin + lane; k < it.end; k += 64) {
+            const int g = w.entries[k].x;
+            const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
+            const double2 rr = *reinterpret_cast<const double2 *>(S0.res + 2 * g);
+            const double x = rc.x, y = rc.y, z = rc.z, wg = rc.w;
+            const double iz = 1.0 / z;
+            const double a00 = -w.fx * iz, a02 = w.fx * x * iz * iz, a11 = -w.fy * iz, a12 = w.fy * y * iz * iz;
+            const double C0[6] = { a02 * y, a00 * z - a02 * x, -a00 * y, a00, 0.0, a02 };
+            const double C1[6] = { -a11 * z + a12 * y, -a12 * x, a11 * x, 0.0, a11, a12 };
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                ba[a] += C0[a] * rr.x + C1[a] * rr.y;
+#pragma unroll
+                for (int b = a; b < 6; ++b) ha[ut6(a, b)] += wg * (C0[a] * C0[b] + C1[a] * C1[b]);
+            }
+            if (mode == 1) continue;
+            const int l = w.g_point[g];
+            double H[6], D[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) H[q] = S0.Hll[6 * l + q];
+            H[0] += lambda; H[3] += lambda; H[5] += lambda;
+            inv3sym(H, D);
+            const double P0[3] = { a00 * Ri[0] + a02 * Ri[6], a00 * Ri[1] + a02 * Ri[7], a00 * Ri[2] + a02 * Ri[8] };
+            const double P1[3] = { a11 * Ri[3] + a12 * Ri[6], a11 * Ri[4] + a12 * Ri[7], a11 * Ri[5] + a12 * Ri[8] };
+            const double T0[3] = { P0[0] * D[0] + P0[1] * D[1] + P0[2] * D[2], P0[0] * D[1] + P0[1] * D[3] + P0[2] * D[4], P0[0] * D[2] + P0[1] * D[4] + P0[2] * D[5] };
+            const double T1[3] = { P1[0] * D[0] + P1[1] * D[1] + P1[2] * D[2], P1[0] * D[1] + P1[1] * D[3] + P1[2] * D[4], P1[0] * D[2] + P1[1] * D[4] + P1[2] * D[5] };
+            const double w2 = wg * wg;
+            const double M00 = w2 * (T0[0] * P0[0] + T0[1] * P0[1] + T0[2] * P0[2]);
+            const double M01 = w2 * (T0[0] * P1[0] + T0[1] * P1[1] + T0[2] * P1[2]);
+            const double M11 = w2 * (T1[0] * P1[0] + T1[1] * P1[1] + T1[2] * P1[2]);
+            const double bl0 = S0.bl[3 * l], bl1 = S0.bl[3 * l + 1], bl2 = S0.bl[3 * l + 2];
+            const double pv0 = wg * (T0[0] * bl0 + T0[1] * bl1 + T0[2] * bl2);
+            const double pv1 = wg * (T1[0] * bl0 + T1[1] * bl1 + T1[2] * bl2);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double u0 = C0[a] * M00 + C1[a] * M01, u1 = C0[a] * M01 + C1[a] * M11;
+                ca[a] += C0[a] * pv0 + C1[a] * pv1;
+#pragma unroll
+                for (int b = a; b < 6; ++b) sa[ut6(a, b)] += u0 * C0[b] + u1 * C1[b];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 21; ++k) { sa[k] = wave_sum(sa[k]); ha[k] = wave_sum(ha[k]); }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ca[k] = wave_sum(ca[k]); ba[k] = wave_sum(ba[k]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) out[a * 6 + b] = sa[a <= b ? ut6(a, b) : ut6(b, a)];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { out[36 + k] = ca[k]; out[63 + k] = ba[k]; }
+#pragma unroll
+            for (int k = 0; k < 21; ++k) out[42 + k] = ha[k];
+        }
+    } else {
+        double acc[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+        for (int k = it.begin + lane; k < it.end; k += 64) {
+            const Int2 en = w.entries[k];
+            const double4 ri = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.x);
+            const double4 rj = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.y);
+            const int l = w.g_point[en.x];
+            double H[6], D[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) H[q] = S0.Hll[6 * l + q];
+            H[0] += lambda; H[3] += lambda; H[5] += lambda;
+            inv3sym(H, D);
+            const double izi = 1.0 / ri.z, izj = 1.0 / rj.z;
+            const double a00 = -w.fx * izi, a02 = w.fx * ri.x * izi * izi, a11 = -w.fy * izi, a12 = w.fy * ri.y * izi * izi;
+            const double b00 = -w.fx * izj, b02 = w.fx * rj.x * izj * izj, b11 = -w.fy * izj, b12 = w.fy * rj.y * izj * izj;
+            const double P0[3] = { a00 * Ri[0] + a02 * Ri[6], a00 * Ri[1] + a02 * Ri[7], a00 * Ri[2] + a02 * Ri[8] };
+            const double P1[3] = { a11 * Ri[3] + a12 * Ri[6], a11 * Ri[4] + a12 * Ri[7], a11 * Ri[5] + a12 * Ri[8] };
+            const double Q0[3] = { b00 * Rj[0] + b02 * Rj[6], b00 * Rj[1] + b02 * Rj[7], b00 * Rj[2] + b02 * Rj[8] };
+            const double Q1[3] = { b11 * Rj[3] + b12 * Rj[6], b11 * Rj[4] + b12 * Rj[7], b11 * Rj[5] + b12 * Rj[8] };
+            const double T0[3] = { P0[0] * D[0] + P0[1] * D[1] + P0[2] * D[2], P0[0] * D[1] + P0[1] * D[3] + P0[2] * D[4], P0[0] * D[2] + P0[1] * D[4] + P0[2] * D[5] };
+            const double T1[3] = { P1[0] * D[0] + P1[1] * D[1] + P1[2] * D[2], P1[0] * D[1] + P1[1] * D[3] + P1[2] * D[4], P1[0] * D[2] + P1[1] * D[4] + P1[2] * D[5] };
+            const double ww = ri.w * rj.w;
+            const double M00 = ww * (T0[0] * Q0[0] + T0[1] * Q0[1] + T0[2] * Q0[2]);
+            const double M01 = ww * (T0[0] * Q1[0] + T0[1] * Q1[1] + T0[2] * Q1[2]);
+            const double M10 = ww * (T1[0] * Q0[0] + T1[1] * Q0[1] + T1[2] * Q0[2]);
+            const double M11 = ww * (T1[0] * Q1[0] + T1[1] * Q1[1] + T1[2] * Q1[2]);
+            const double C0[6] = { a02 * ri.y, a00 * ri.z - a02 * ri.x, -a00 * ri.y, a00, 0.0, a02 };
+            const double C1[6] = { -a11 * ri.z + a12 * ri.y, -a12 * ri.x, a11 * ri.x, 0.0, a11, a12 };
+            const double E0[6] = { b02 * rj.y, b00 * rj.z - b02 * rj.x, -b00 * rj.y, b00, 0.0, b02 };
+            const double E1[6] = { -b11 * rj.z + b12 * rj.y, -b12 * rj.x, b11 * rj.x, 0.0, b11, b12 };
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const double u0 = C0[a] * M00 + C1[a] * M10, u1 = C0[a] * M01 + C1[a] * M11;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) acc[a * 6 + b] += u0 * E0[b] + u1 * E1[b];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 36; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 36; ++k) out[k] = acc[k];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------
+// k_lambda_init: OptimizationAlgorithmLevenberg::computeLambdaInit — tau * max |H_jj| over
+// the free pose and point diagonals (tau = 1e-5), and the initial robust cost F0.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_lambda_init(DevWindow w)
+{
+    Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int lane = threadIdx.x;
+    double m = 0.0, F = 0.0;
+    for (int k = lane; k < w.n_pt_blocks; k += 64) m = fmax(m, w.hmax_part[k]);
+    // fixed-order cost sum: lane-strided partials, then a fixed butterfly
+    for (int k = lane; k < w.n_pt_blocks; k += 64) F += w.st[0].Fpart[k];
+    for (int i = lane; i < w.nfree; i += 64) {
+        for (int a = 0; a < 6; ++a) {
+            double s = 0.0;
+            for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx)
+                s += w.part[(size_t)itx * kPartStride + 42 + ut6(a, a)];
+            m = fmax(m, fabs(s));
+        }
+    }
+    m = wave_max(m);
+    F = wave_sum(F);
+    if (lane == 0) {
+        c->lambda = 1e-5 * m;
+        c->nu = 2.0;
+        c->F0 = F;
+        c->cost0 = F;
+    }
+}
+
+// --------------------------------------------------------------------------------
+// k_pcg: single workgroup.  Assembles the upper blocks of S = Hpp + lambda I - sum B Dinv B^T
+// and b_S = b_p - sum B Dinv b_l from the work-item partials (fixed order), then solves
+// S x_p = b_S with block-Jacobi preconditioned conjugate gradients (replaces the
+// LinearSolverCSparse Cholesky selected at /root/reference/src/Optimizer.cc:535), and
+// applies VertexSE3Expmap::oplusImpl to produce the trial poses.
+// --------------------------------------------------------------------------------
+constexpr int kPcgThreads = 1024;
+constexpr int kPcgWaves = kPcgThreads / 64;
+
+__global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int tid = threadIdx.x;
+    const int nf = w.nfree, n = 6 * nf;
+    const int cur = c->cur;
+    const double lambda = c->lambda;
+    double *x = sm, *r = x + n, *z = r + n, *p = z + n, *Ap = p + n;
+    double *minv = Ap + n;                  // nf x 36
+    double *red0 = minv + 36 * nf;          // kPcgWaves
+    double *red1 = red0 + kPcgWaves;        // kPcgWaves
+    int *flags = reinterpret_cast<int *>(red1 + kPcgWaves);   // [0] = failure
+    if (tid == 0) flags[0] = 0;
+
+    // ---- assemble S blocks and right-hand side ----
+    for (int idx = tid; idx < w.npairs * 36; idx += kPcgThreads) {
+        const int pr = idx / 36, k = idx - pr * 36;
+        double s = 0.0;
+        for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
+            s += w.part[(size_t)itx * kPartStride + k];
+        double v = -s;
+        if (pr < nf) {
+            const int a = k / 6, b = k - a * 6;
+            const int u = a <= b ? ut6(a, b) : ut6(b, a);
+            double hpp = 0.0;
+            for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
+                hpp += w.part[(size_t)itx * kPartStride + 42 + u];
+            v += hpp + (a == b ? lambda : 0.0);
+        }
+        w.blocks[idx] = v;
+    }
+    for (int idx = tid; idx < n; idx += kPcgThreads) {
+        const int i = idx / 6, a = idx - i * 6;
+        double cc = 0.0, bb = 0.0;
+        for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx) {
+            cc += w.part[(size_t)itx * kPartStride + 36 + a];
+            bb += w.part[(size_t)itx * kPartStride + 63 + a];
+        }
+        w.bp[idx] = bb;
+        r[idx] = bb - cc;
+        x[idx] = 0.0;
+    }
+    __syncthreads();
+
+    // ---- block-Jacobi preconditioner: inverse of the 6x6 diagonal blocks (Cholesky) ----
+    for (int i = tid; i < nf; i += kPcgThreads) {
+        double L[36], Li[36];
+        const double *B = w.blocks + (size_t)i * 36;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) L[k] = B[k];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double d = L[j * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
+            if (!(d > 0.0)) ok = false;
+            d = sqrt(d);
+            L[j * 6 + j] = d;
+#pragma unroll
+            for (int q = j + 1; q < 6; ++q) {
+                double s = L[q * 6 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s -= L[q * 6 + k] * L[j * 6 + k];
+                L[q * 6 + j] = s / d;
+            }
+        }
+        // Li = L^-1 (lower), Minv = Li^T Li
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+#pragma unroll
+            for (int row = 0; row < 6; ++row) {
+                if (row < col) { Li[row * 6 + col] = 0.0; continue; }
+                double s = (row == col) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = col; k < row; ++k) s -= L[row * 6 + k] * Li[k * 6 + col];
+                Li[row * 6 + col] = s / L[row * 6 + row];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s += (k >= a && k >= b) ? Li[k * 6 + a] * Li[k * 6 + b] : 0.0;
+                minv[i * 36 + a * 6 + b] = s;
+            }
+        if (!ok) flags[0] = 1;
+    }
+    __syncthreads();
+
+    // z = Minv r ; p = z ; rz = r.z
+    double part = 0.0;
+    for (int idx = tid; idx < n; idx += kPcgThreads) {
+        const int i = idx / 6, a = idx - i * 6;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += minv[i * 36 + a * 6 + k] * r[i * 6 + k];
+        z[idx] = s; p[idx] = s;
+        part += r[idx] * s;
+    }
+    double rz = block_reduce<kPcgWaves, false>(part, red0);
+    const double rz0 = rz;
+    const double thresh = pp.rel_tol * pp.rel_tol * rz0;
+    int iters = 0;
+    bool fail = flags[0] != 0 || !(rz0 >= 0.0) || !isfinite(rz0);
+
+    if (!fail && rz0 > 0.0) {
+        for (iters = 1; iters <= pp.max_iters; ++iters) {
+            // ---- Ap = S p (symmetric block mat-vec over the per-row gather lists), p.Ap ----
+            double dp = 0.0;
+            for (int row = tid >> 2; row < n; row += kPcgThreads / 4) {
+                const int sub = tid & 3;
+                const int i = row / 6, a = row - i * 6;
+                double s = 0.0;
+                for (int e = w.row_ptr[i] + sub; e < w.row_ptr[i + 1]; e += 4) {
+                    const RowEnt re = w.row_ent[e];
+                    const double *B = w.blocks + (size_t)re.block * 36;
+                    const double *pv = p + 6 * re.col;
+                    if (!re.transposed) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) s += B[a * 6 + k] * pv[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) s += B[k * 6 + a] * pv[k];
+                    }
+                }
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (sub == 0) { Ap[row] = s; dp += p[row] * s; }
+            }
+            const double pAp = block_reduce<kPcgWaves, false>(dp, red0);
+            if (!(pAp > 0.0) || !isfinite(pAp)) { fail = true; break; }
+            const double alpha = rz / pAp;
+            for (int idx = tid; idx < n; idx += kPcgThreads) { x[idx] += alpha * p[idx]; r[idx] -= alpha * Ap[idx]; }
+            __syncthreads();
+            double pr2 = 0.0;
+            for (int idx = tid; idx < n; idx += kPcgThreads) {
+                const int i = idx / 6, a = idx - i * 6;
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s += minv[i * 36 + a * 6 + k] * r[i * 6 + k];
+                z[idx] = s;
+                pr2 += r[idx] * s;
+            }
+            const double rzn = block_reduce<kPcgWaves, false>(pr2, red1);
+            if (!isfinite(rzn)) { fail = true; break; }
+            if (rzn <= thresh) break;
+            const double beta = rzn / rz;
+            rz = rzn;
+            for (int idx = tid; idx < n; idx += kPcgThreads) p[idx] = z[idx] + beta * p[idx];
+            __syncthreads();
+        }
+        if (iters > pp.max_iters) iters = pp.max_iters;
+    }
+
+    // ---- outputs: increment, pose part of computeScale(), trial poses ----
+    double sc = 0.0;
+    for (int idx = tid; idx < n; idx += kPcgThreads) {
+        const double xv = fail ? 0.0 : x[idx];
+        w.xp[idx] = xv;
+        sc += xv * (lambda * xv + w.bp[idx]);
+        x[idx] = xv;
+    }
+    const double scs = block_reduce<kPcgWaves, false>(sc, red0);
+    const DevState &S0 = w.st[cur];
+    const DevState &S1 = w.st[cur ^ 1];
+    for (int i = tid; i < w.NP; i += kPcgThreads) {
+        double T[7], Tn[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) T[k] = S0.pose[7 * i + k];
+        const int h = w.hidx[i];
+        if (h >= 0) {
+            double u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] = x[6 * h + k];
+            se3_oplus(u, T, Tn);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) Tn[k] = T[k];
+        }
+        double R[9];
+        quat_to_R(Tn, R);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) S1.pose[7 * i + k] = Tn[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
+        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
+    }
+    if (tid == 0) {
+        w.scale_part[w.n_pt_blocks] = scs;
+        c->pcg_fail = fail ? 1 : 0;
+        c->pcg_last_iters = iters;
+        c->pcg_total_iters += iters;
+    }
+}
+
+// --------------------------------------------------------------------------------
+// k_decide: one wave.  The accept/reject logic and lambda schedule of
+// OptimizationAlgorithmLevenberg::solve plus the loop conditions of
+// SparseOptimizer::optimize, restated as a state machine that
+// advances by one trial per launch.  Publishes progress to pinned host memory.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_decide(DevWindow w)
+{
+    Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int lane = threadIdx.x;
+    const int cur = c->cur;
+    double F1 = 0.0, scale = 0.0;
+    for (int k = lane; k < w.n_pt_blocks; k += 64) { F1 += w.st[cur ^ 1].Fpart[k]; scale += w.scale_part[k]; }
+    F1 = wave_sum(F1);
+    scale = wave_sum(scale);
+    if (lane != 0) return;
+    scale += w.scale_part[w.n_pt_blocks];
+    if (c->pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
+    scale += 1e-3;
+    const double F0 = c->F0;
+    const double rho = (F0 - F1) / scale;
+    const int stop = __hip_atomic_load(&w.hstat->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int tr = c->n_trace;
+    if (tr < kMaxTrace) {
+        c->tr_lambda[tr] = c->lambda; c->tr_f0[tr] = F0; c->tr_f1[tr] = F1; c->tr_rho[tr] = rho;
+        c->tr_pcg[tr] = c->pcg_last_iters;
+    }
+    bool lambda_ok = true;
+    int accepted = 0;
+    if (rho > 0.0 && isfinite(F1)) {
+        double alpha = 1.0 - pow(2.0 * rho - 1.0, 3.0);
+        alpha = fmin(alpha, 2.0 / 3.0);
+        c->lambda *= fmax(1.0 / 3.0, alpha);
+        c->nu = 2.0;
+        c->F0 = F1;
+        c->cur = cur ^ 1;                    // discardTop(): the trial state becomes current
+        c->last_rejected = 0;
+        accepted = 1;
+    } else {
+        c->lambda *= c->nu;
+        c->nu *= 2.0;
+        c->last_rejected = 1;                // pop(): keep the current state
+        lambda_ok = isfinite(c->lambda);
+    }
+    if (tr < kMaxTrace) { c->tr_accept[tr] = accepted; c->n_trace = tr + 1; }
+    c->n_solves += 1;
+    c->qmax += 1;
+    const bool more_trials = lambda_ok && (rho < 0.0) && (c->qmax < 10) && !stop;
+    int done = 0;
+    if (!more_trials) {
+        c->iters_done = c->it + 1;
+        if (c->qmax == 10 || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
+        else {
+            c->it += 1;
+            c->qmax = 0;
+            if (c->it >= w.max_iters || stop) done = 1;
+        }
+    }
+    c->done = done;
+    __hip_atomic_store(&w.hstat->trials_done, c->n_solves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w.hstat->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// --------------------------------------------------------------------------------
+// k_finalize: chi2 / outlier flags in caller edge order (src/Optimizer.cc:757-775).
+// With the stale-error quirk the chi2 of a rejected last trial is reported, as g2o leaves
+// it in the edges; the depth test always uses the final estimates.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(DevWindow w)
+{
+    Ctrl *c = w.ctrl;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    int bad = 0;
+    if (g < w.E) {
+        const int cur = c->cur;
+        const int sel = ((w.flags & MOVBA_FLAG_STALE_ERROR_QUIRK) && c->last_rejected) ? (cur ^ 1) : cur;
+        const double chi2 = w.st[sel].chi2[g];
+        const double zc = w.st[cur].rec[4 * g + 2];
+        bad = (chi2 > w.chi2_gate) || !(zc > 0.0);
+        const int e = w.perm[g];
+        w.out_chi2[e] = chi2;
+        w.out_outlier[e] = (uint8_t)bad;
+    }
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c->n_outliers, __popcll(m));
+}
+
+// --------------------------------------------------------------------------------
+// launch wrappers
+// --------------------------------------------------------------------------------
+static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
+{
+    size_t d = 12 * (size_t)w.NP + (backsub ? 9 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
+    return d * sizeof(double);
+}
+
+size_t pcg_lds_bytes(int nfree)
+{
+    const size_t n = 6 * (size_t)nfree;
+    return (5 * n + 36 * (size_t)nfree + 2 * kPcgWaves) * sizeof(double) + 16;
+}
+
+hipError_t launch_init(const DevWindow &w, hipStream_t s)
+{
+    const int nb = (w.NP > 0 ? (w.NP + 63) / 64 : 1);
+    hipLaunchKernelGGL(k_init_pose, dim3(nb), dim3(64), 0, s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_point<false>, dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_schur(const DevWindow &w, int mode, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_schur, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lambda_init, dim3(1), dim3(64), 0, s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pcg, dim3(1), dim3(kPcgThreads), pcg_lds_bytes(w.nfree), s, w, pp);
+    return hipGetLastError();
+}
+
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_point<true>, dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_decide(const DevWindow &w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const DevWindow &w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize, dim3((w.E + 255) / 256), dim3(256), 0, s, w);
+    return hipGetLastError();
+}
+
+hipError_t configure_kernels(int nfree_max_lds_bytes)
+{
+    (void)nfree_max_lds_bytes;
+    // allow the PCG workgroup and the point kernels to use more than the default 64 KiB of LDS
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_point<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_point<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
+}  // namespace movba

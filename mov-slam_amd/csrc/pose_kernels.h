@@ -1,0 +1,23 @@
+// Device view + launch wrapper of the pose-only optimisation kernel (pose_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace movba {
+
+struct PoseDev {
+    int32_t n, rounds, its, pad;
+    double fx, fy, cx, cy, huber_delta, chi2_gate;
+    double pose0[7];
+    const double *Xw;       // n x 3
+    const double *obs;      // n x 2
+    const double *isig;     // n
+    double *chi2;           // n out
+    uint8_t *level1;        // n out: outlier flags
+    double *pose_out;       // 8: pose (7) + inlier count
+};
+
+hipError_t launch_pose_opt(const PoseDev &p, hipStream_t s);
+
+}  // namespace movba

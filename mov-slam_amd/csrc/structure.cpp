@@ -1,0 +1,120 @@
+#include "structure.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace movba {
+
+int build_structure(const movba_lba_desc& d, Structure& s)
+{
+    const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
+    if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
+    if ((NP && (!d.poses || !d.pose_fixed)) || (P && !d.points)) return MOVBA_ERR_ARG;
+    if (E && (!d.edge_pose || !d.edge_point || !d.obs || !d.inv_sigma2)) return MOVBA_ERR_ARG;
+    s = Structure();
+    s.NP = NP; s.P = P; s.E = E;
+
+    // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization)
+    std::vector<uint8_t> pose_active(NP, 0);
+    s.pt_start.assign(P + 2, 0);
+    for (int e = 0; e < E; ++e) {
+        const int ip = d.edge_pose[e], l = d.edge_point[e];
+        if (ip < 0 || ip >= NP || l < 0 || l >= P) return MOVBA_ERR_ARG;
+        pose_active[ip] = 1;
+        s.pt_start[l + 2]++;
+    }
+    // identity permutation iff the caller's edges are already in ascending point order
+    for (int e = 1; e < E && s.already_grouped; ++e)
+        if (d.edge_point[e] < d.edge_point[e - 1]) s.already_grouped = false;
+
+    for (int l = 0; l < P; ++l) s.pt_start[l + 2] += s.pt_start[l + 1];
+    s.perm.resize(E); s.g_pose.resize(E); s.g_point.resize(E);
+    for (int e = 0; e < E; ++e) {
+        const int pos = s.pt_start[d.edge_point[e] + 1]++;
+        s.perm[pos] = e;
+    }
+    s.pt_start.pop_back();      // now pt_start[l]..pt_start[l+1], size P+1
+    for (int g = 0; g < E; ++g) {
+        s.g_pose[g] = d.edge_pose[s.perm[g]];
+        s.g_point[g] = d.edge_point[s.perm[g]];
+    }
+
+    s.hidx.assign(NP, -1);
+    for (int i = 0; i < NP; ++i) {
+        if (d.pose_fixed[i]) { s.n_fixed++; continue; }
+        if (pose_active[i]) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); }
+    }
+    const int nf = s.nfree;
+    for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
+    if (E == 0) return MOVBA_EMPTY;
+
+    // ---- pose pairs sharing a point (block pattern of the reduced system) ----
+    std::vector<int64_t> cnt((size_t)nf * (size_t)nf, 0);      // upper triangle used
+    std::vector<std::pair<int32_t, int32_t>> fe;
+    auto free_edges_of = [&](int l) {
+        fe.clear();
+        for (int g = s.pt_start[l]; g < s.pt_start[l + 1]; ++g) {
+            const int h = s.hidx[s.g_pose[g]];
+            if (h >= 0) fe.emplace_back(h, g);
+        }
+        std::stable_sort(fe.begin(), fe.end(),
+                         [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
+    };
+    for (int l = 0; l < P; ++l) {
+        free_edges_of(l);
+        for (size_t a = 0; a < fe.size(); ++a) {
+            if (a + 1 < fe.size() && fe[a + 1].first == fe[a].first) return MOVBA_ERR_ARG;  // duplicate observation
+            for (size_t b = a; b < fe.size(); ++b) cnt[(size_t)fe[a].first * nf + fe[b].first]++;
+        }
+    }
+    // pair ids: the nf diagonal pairs first (pair k == (k,k)), then off-diagonal row-major
+    std::vector<int32_t> pid((size_t)nf * (size_t)nf, -1);
+    for (int i = 0; i < nf; ++i) { pid[(size_t)i * nf + i] = i; s.pair_i.push_back(i); s.pair_j.push_back(i); }
+    for (int i = 0; i < nf; ++i)
+        for (int j = i + 1; j < nf; ++j)
+            if (cnt[(size_t)i * nf + j] > 0) {
+                pid[(size_t)i * nf + j] = (int32_t)s.pair_i.size();
+                s.pair_i.push_back(i); s.pair_j.push_back(j);
+            }
+    s.npairs = (int)s.pair_i.size();
+    std::vector<int64_t> pair_ptr(s.npairs + 1, 0);
+    for (int p = 0; p < s.npairs; ++p) pair_ptr[p + 1] = pair_ptr[p] + cnt[(size_t)s.pair_i[p] * nf + s.pair_j[p]];
+    s.nentries = pair_ptr[s.npairs];
+    if (s.nentries > (int64_t)0x7fffffff) return MOVBA_ERR_ARG;
+    s.entries.resize((size_t)s.nentries);
+    std::vector<int64_t> cur(pair_ptr.begin(), pair_ptr.end() - 1);
+    for (int l = 0; l < P; ++l) {
+        free_edges_of(l);
+        for (size_t a = 0; a < fe.size(); ++a)
+            for (size_t b = a; b < fe.size(); ++b) {
+                const int p = pid[(size_t)fe[a].first * nf + fe[b].first];
+                s.entries[(size_t)cur[p]++] = Int2{ fe[a].second, fe[b].second };
+            }
+    }
+    // ---- work items: chunks of a pair's entries ----
+    s.pair_item_start.assign(s.npairs + 1, 0);
+    for (int p = 0; p < s.npairs; ++p) {
+        s.pair_item_start[p] = (int32_t)s.items.size();
+        for (int64_t b = pair_ptr[p]; b < pair_ptr[p + 1]; b += kSchurChunk)
+            s.items.push_back(Item{ p, (int32_t)b, (int32_t)std::min<int64_t>(b + kSchurChunk, pair_ptr[p + 1]), p < nf ? 1 : 0 });
+    }
+    s.pair_item_start[s.npairs] = (int32_t)s.items.size();
+    s.nitems = (int)s.items.size();
+
+    // ---- block-row gather lists for y = S x with S given by its upper blocks ----
+    std::vector<std::vector<RowEnt>> rows(nf);
+    for (int p = 0; p < s.npairs; ++p) {
+        const int i = s.pair_i[p], j = s.pair_j[p];
+        rows[i].push_back(RowEnt{ p, j, 0, 0 });
+        if (i != j) rows[j].push_back(RowEnt{ p, i, 1, 0 });
+    }
+    s.row_ptr.assign(nf + 1, 0);
+    for (int i = 0; i < nf; ++i) {
+        std::sort(rows[i].begin(), rows[i].end(), [](const RowEnt& a, const RowEnt& b) { return a.col < b.col; });
+        s.row_ptr[i + 1] = s.row_ptr[i] + (int32_t)rows[i].size();
+        s.row_ent.insert(s.row_ent.end(), rows[i].begin(), rows[i].end());
+    }
+    return MOVBA_OK;
+}
+
+}  // namespace movba

@@ -1,0 +1,47 @@
+// Host-side structure pass of a local-BA window: what g2o derives in
+// SparseOptimizer::initializeOptimization + BlockSolver::buildStructure (called from
+// /root/reference/src/Optimizer.cc:754), re-designed for the device kernels:
+//   * hessian index of every pose (free AND active poses, ascending caller order),
+//   * edges grouped by map point (stable), so one lane group owns a point,
+//   * the upper-triangle pose pairs (i<=j) that share >= 1 point — the block pattern of
+//     the reduced camera system — with, per pair, the list of (edge_i, edge_j) entries
+//     that contribute B_il Dinv_l B_jl^T, cut into fixed-size work items,
+//   * per block-row gather lists for the symmetric block mat-vec of the PCG.
+// Pure C++ (no HIP): unit-tested on CPU through movba_structure_probe.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "movba.h"
+
+namespace movba {
+
+struct Int2 { int32_t x, y; };
+struct Item { int32_t pair, begin, end, diag; };   // entries [begin,end) of one pair
+struct RowEnt { int32_t block, col, transposed, pad; };
+
+struct Structure {
+    int NP = 0, P = 0, E = 0, nfree = 0;
+    int npairs = 0, nitems = 0, max_degree = 0;
+    int64_t nentries = 0;
+    bool already_grouped = true;
+    int n_fixed = 0;
+    std::vector<int32_t> hidx;          // NP: hessian index or -1
+    std::vector<int32_t> free_pose;     // nfree: pose index
+    std::vector<int32_t> perm;          // E: grouped position -> caller edge
+    std::vector<int32_t> pt_start;      // P+1
+    std::vector<int32_t> g_pose, g_point;   // E (grouped order)
+    std::vector<int32_t> pair_i, pair_j;    // npairs (hessian indices, i <= j); pair k<nfree is (k,k)
+    std::vector<int32_t> pair_item_start;   // npairs+1
+    std::vector<Int2> entries;          // nentries: grouped edge indices (edge of i, edge of j)
+    std::vector<Item> items;            // nitems
+    std::vector<int32_t> row_ptr;       // nfree+1
+    std::vector<RowEnt> row_ent;        // mat-vec gather list per block row
+};
+
+constexpr int kSchurChunk = 1024;       // entries per schur work item (one wave each)
+
+// Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.
+int build_structure(const movba_lba_desc& d, Structure& s);
+
+}  // namespace movba

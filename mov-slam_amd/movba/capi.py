@@ -1,0 +1,260 @@
+"""ctypes binding of libmovba.so (include/movba.h) — the Python-side stand-in for the
+C++ adapter (mov-slam_amd/host/Optimizer.cc) used by tests/ and bench.py.
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+visible, every entry point raises (MovbaError) instead of computing anything here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmovba.so")
+
+MAX_TRACE = 128
+NKERNELS = 6
+OK, STOPPED, NO_FIXED, EMPTY, ERR_ARG, ERR_HIP, ERR_STATE = 0, 1, 2, 3, -1, -2, -3
+FLAG_STALE_ERROR_QUIRK = 1
+
+_d = C.POINTER(C.c_double)
+_i = C.POINTER(C.c_int32)
+_u = C.POINTER(C.c_uint8)
+
+
+class MovbaError(RuntimeError):
+    pass
+
+
+class LbaDesc(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("poses", _d), ("pose_fixed", _u), ("points", _d), ("edge_pose", _i), ("edge_point", _i),
+                ("obs", _d), ("inv_sigma2", _d),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
+                ("max_iters", C.c_int32), ("flags", C.c_uint32), ("stop", _u)]
+
+
+class LbaResult(C.Structure):
+    _fields_ = [("poses", _d), ("points", _d), ("chi2", _d), ("outlier", _u),
+                ("status", C.c_int32), ("iters_done", C.c_int32), ("n_solves", C.c_int32),
+                ("n_outliers", C.c_int32), ("pcg_iters", C.c_int32), ("last_rejected", C.c_int32),
+                ("lambda_", C.c_double), ("cost0", C.c_double), ("cost", C.c_double),
+                ("n_trace", C.c_int32),
+                ("tr_lambda", C.c_double * MAX_TRACE), ("tr_f0", C.c_double * MAX_TRACE),
+                ("tr_f1", C.c_double * MAX_TRACE), ("tr_rho", C.c_double * MAX_TRACE),
+                ("tr_accept", C.c_int32 * MAX_TRACE), ("tr_pcg_iters", C.c_int32 * MAX_TRACE)]
+
+
+class Options(C.Structure):
+    _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
+                ("profile", C.c_int32)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("name", C.c_char_p * NKERNELS), ("ms", C.c_double * NKERNELS), ("launches", C.c_int64 * NKERNELS),
+                ("upload_ms", C.c_double), ("structure_ms", C.c_double), ("download_ms", C.c_double)]
+
+
+class StructureInfo(C.Structure):
+    _fields_ = [("n_free", C.c_int32), ("n_pairs", C.c_int32), ("n_entries", C.c_int64), ("n_items", C.c_int32),
+                ("max_degree", C.c_int32), ("already_grouped", C.c_int32)]
+
+
+class PoseDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("Xw", _d), ("obs", _d), ("inv_sigma2", _d),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("pose0", C.c_double * 7), ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
+                ("rounds", C.c_int32), ("its_per_round", C.c_int32)]
+
+
+class PoseResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 7), ("outlier", _u), ("chi2", _d), ("n_inliers", C.c_int32), ("status", C.c_int32)]
+
+
+EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
+           "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
+           "movba_lba_export_poses_device", "movba_get_profile", "movba_reset_profile",
+           "movba_structure_probe", "movba_pose_opt"]
+
+_lib = None
+
+
+def lib():
+    """Load libmovba.so; raise loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MovbaError(f"{LIB_PATH} not found: build it with `make -C mov-slam_amd/csrc` "
+                             "(or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.movba_status_string.restype = C.c_char_p
+        L.movba_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(Options)]
+        L.movba_destroy.argtypes = [C.c_void_p]
+        L.movba_destroy.restype = None
+        for fn in ("movba_lba_upload",):
+            getattr(L, fn).argtypes = [C.c_void_p, C.POINTER(LbaDesc)]
+        L.movba_lba_solve.argtypes = [C.c_void_p, C.POINTER(LbaDesc), C.POINTER(LbaResult)]
+        L.movba_lba_run.argtypes = [C.c_void_p]
+        L.movba_lba_reset.argtypes = [C.c_void_p]
+        L.movba_lba_download.argtypes = [C.c_void_p, C.POINTER(LbaResult)]
+        L.movba_lba_export_poses_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.movba_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
+        L.movba_reset_profile.argtypes = [C.c_void_p]
+        L.movba_structure_probe.argtypes = [C.POINTER(LbaDesc), C.POINTER(StructureInfo), _i, _i]
+        L.movba_pose_opt.argtypes = [C.c_void_p, C.POINTER(PoseDesc), C.POINTER(PoseResult)]
+        _lib = L
+    return _lib
+
+
+def status_string(s: int) -> str:
+    return lib().movba_status_string(s).decode()
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def make_desc(w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None):
+    """Flattened window (movba.synth.Window or anything with the same fields) -> movba_lba_desc."""
+    keep = dict(
+        poses=np.ascontiguousarray(w.poses, np.float64), fixed=np.ascontiguousarray(w.pose_fixed, np.uint8),
+        points=np.ascontiguousarray(w.points, np.float64), ep=np.ascontiguousarray(w.edge_pose, np.int32),
+        el=np.ascontiguousarray(w.edge_point, np.int32), obs=np.ascontiguousarray(w.obs, np.float64),
+        isg=np.ascontiguousarray(w.inv_sigma2, np.float64))
+    d = LbaDesc()
+    d.n_poses, d.n_points, d.n_edges = len(keep["poses"]), len(keep["points"]), len(keep["ep"])
+    d.poses = _p(keep["poses"], _d); d.pose_fixed = _p(keep["fixed"], _u); d.points = _p(keep["points"], _d)
+    d.edge_pose = _p(keep["ep"], _i); d.edge_point = _p(keep["el"], _i)
+    d.obs = _p(keep["obs"], _d); d.inv_sigma2 = _p(keep["isg"], _d)
+    d.fx, d.fy, d.cx, d.cy = w.cam
+    d.huber_delta, d.chi2_gate = w.huber_delta, w.chi2_gate
+    d.max_iters = w.max_iters if max_iters is None else max_iters
+    d.flags = flags
+    if stop is not None:
+        keep["stop"] = stop
+        d.stop = _p(stop, _u)
+    return d, keep
+
+
+def structure_probe(w):
+    d, keep = make_desc(w)
+    info = StructureInfo()
+    perm = np.zeros(d.n_edges, np.int32); fidx = np.zeros(d.n_poses, np.int32)
+    rc = lib().movba_structure_probe(C.byref(d), C.byref(info), _p(perm, _i), _p(fidx, _i))
+    if rc < 0:
+        raise MovbaError(f"movba_structure_probe: {status_string(rc)}")
+    return dict(status=rc, n_free=info.n_free, n_pairs=info.n_pairs, n_entries=info.n_entries, n_items=info.n_items,
+                max_degree=info.max_degree, already_grouped=bool(info.already_grouped), perm=perm, free_index=fidx)
+
+
+class Solver:
+    """One handle = one device + one stream (movba_create / movba_destroy)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
+                 pcg_max_iters: int = 0, run_ahead: int = 0, profile: bool = False):
+        self._h = C.c_void_p()
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, 1 if profile else 0)
+        rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise MovbaError(f"movba_create failed: {status_string(rc)} (no CPU fallback)")
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            lib().movba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- results ---------------------------------------------------------------
+    def _alloc_result(self, d):
+        out = dict(poses=np.zeros((d.n_poses, 7)), points=np.zeros((d.n_points, 3)),
+                   chi2=np.zeros(d.n_edges), outlier=np.zeros(d.n_edges, np.uint8))
+        r = LbaResult()
+        r.poses = _p(out["poses"], _d); r.points = _p(out["points"], _d)
+        r.chi2 = _p(out["chi2"], _d); r.outlier = _p(out["outlier"], _u)
+        return r, out
+
+    @staticmethod
+    def _pack(r, out, rc):
+        n = r.n_trace
+        out.update(status=rc, iters_done=r.iters_done, n_solves=r.n_solves, n_outliers=r.n_outliers,
+                   pcg_iters=r.pcg_iters, last_rejected=r.last_rejected, lam=r.lambda_, cost0=r.cost0, cost=r.cost,
+                   trace=dict(lam=np.array(r.tr_lambda[:n]), f0=np.array(r.tr_f0[:n]), f1=np.array(r.tr_f1[:n]),
+                              rho=np.array(r.tr_rho[:n]), accept=np.array(r.tr_accept[:n]),
+                              pcg=np.array(r.tr_pcg_iters[:n])))
+        return out
+
+    def solve(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None) -> dict:
+        d, keep = make_desc(w, flags, stop, max_iters)
+        r, out = self._alloc_result(d)
+        rc = lib().movba_lba_solve(self._h, C.byref(d), C.byref(r))
+        if rc < 0:
+            raise MovbaError(f"movba_lba_solve: {status_string(rc)}")
+        if rc != OK:                       # silent early return: nothing written, echo the inputs
+            out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
+        return self._pack(r, out, rc)
+
+    def upload(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None):
+        d, keep = make_desc(w, flags, stop, max_iters)
+        rc = lib().movba_lba_upload(self._h, C.byref(d))
+        if rc < 0:
+            raise MovbaError(f"movba_lba_upload: {status_string(rc)}")
+        self._keep = (d, keep)
+        return rc
+
+    def run(self) -> int:
+        rc = lib().movba_lba_run(self._h)
+        if rc < 0:
+            raise MovbaError(f"movba_lba_run: {status_string(rc)}")
+        return rc
+
+    def download(self) -> dict:
+        d, keep = self._keep
+        r, out = self._alloc_result(d)
+        rc = lib().movba_lba_download(self._h, C.byref(r))
+        if rc < 0:
+            raise MovbaError(f"movba_lba_download: {status_string(rc)}")
+        if rc != OK:
+            out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
+        return self._pack(r, out, rc)
+
+    def export_poses_device(self, dst_ptr: int, nbytes: int):
+        rc = lib().movba_lba_export_poses_device(self._h, C.c_void_p(dst_ptr), nbytes)
+        if rc != OK:
+            raise MovbaError(f"movba_lba_export_poses_device: {status_string(rc)}")
+
+    def profile(self) -> dict:
+        p = Profile()
+        lib().movba_get_profile(self._h, C.byref(p))
+        return dict(kernels={p.name[k].decode(): dict(ms=p.ms[k], launches=p.launches[k]) for k in range(NKERNELS)},
+                    upload_ms=p.upload_ms, structure_ms=p.structure_ms, download_ms=p.download_ms)
+
+    def reset_profile(self):
+        lib().movba_reset_profile(self._h)
+
+    def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None) -> dict:
+        Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
+        n = len(Xw)
+        d = PoseDesc()
+        d.n = n; d.Xw = _p(Xw, _d); d.obs = _p(obs, _d)
+        isg = None
+        if inv_sigma2 is not None:
+            isg = np.ascontiguousarray(inv_sigma2, np.float64); d.inv_sigma2 = _p(isg, _d)
+        d.fx, d.fy, d.cx, d.cy = cam
+        d.pose0 = (C.c_double * 7)(*pose0)
+        d.huber_delta, d.chi2_gate, d.rounds, d.its_per_round = huber_delta, chi2_gate, rounds, its
+        outl = np.zeros(n, np.uint8); chi2 = np.zeros(n)
+        r = PoseResult(); r.outlier = _p(outl, _u); r.chi2 = _p(chi2, _d)
+        rc = lib().movba_pose_opt(self._h, C.byref(d), C.byref(r))
+        if rc < 0:
+            raise MovbaError(f"movba_pose_opt: {status_string(rc)}")
+        return dict(status=rc, n_inliers=r.n_inliers, pose=np.array(r.pose[:]), outlier=outl, chi2=chi2)

@@ -1,0 +1,34 @@
+"""Developer check: GPU path vs oracle on the synthetic configs (run on a GPU box)."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+from movba import synth, capi
+from oracle import oracle
+
+names = sys.argv[1:] or ["tiny", "small", "cfg2", "cfg3"]
+s = capi.Solver(profile=True)
+for name in names:
+    w = synth.cfg(name)
+    t = time.time(); ro = oracle.solve(w); t_cpu = time.time() - t
+    t = time.time(); rg = s.solve(w); t_gpu = time.time() - t
+    s.reset_profile()
+    s.upload(w)
+    ts = []
+    for _ in range(5):
+        t = time.time(); s.run(); ts.append(time.time() - t)
+    rg2 = s.download()
+    fr = w.pose_fixed == 0
+    print(f"{name}: E={w.n_edges} cpu {t_cpu*1e3:.1f} ms  gpu first {t_gpu*1e3:.1f} ms  run {min(ts)*1e3:.3f} ms  solves cpu/gpu {ro['n_solves']}/{rg['n_solves']} pcg {rg['pcg_iters']}")
+    print("   accept", ro['trace']['accept'].tolist(), rg['trace']['accept'].tolist())
+    print("   pose dq %.2e dt %.2e  point %.2e  chi2 %.2e  outl mismatch %d  lam rel %.2e cost rel %.2e" % (
+        np.abs(ro['poses'][:, :4] - rg['poses'][:, :4]).max(), np.abs(ro['poses'][:, 4:] - rg['poses'][:, 4:]).max(),
+        np.abs(ro['points'] - rg['points']).max(), np.abs(ro['chi2'] - rg['chi2']).max(),
+        int((ro['outlier'] != rg['outlier']).sum()), abs(ro['lam'] / rg['lam'] - 1), abs(ro['cost'] / rg['cost'] - 1)))
+    print("   rerun identical:", np.array_equal(rg['poses'], rg2['poses']), np.array_equal(rg['chi2'], rg2['chi2']))
+    print("   pcg per trial", rg['trace']['pcg'].tolist())
+    pr = s.profile()
+    for k, v in pr['kernels'].items():
+        if v['launches']:
+            print(f"   {k:32s} {v['ms']/5:9.3f} ms/run  {v['launches']/5:6.1f} launches  {1e3*v['ms']/v['launches']:8.1f} us each")
+    print("   structure %.2f ms upload %.2f ms download %.2f ms" % (pr['structure_ms'], pr['upload_ms'], pr['download_ms']))
