@@ -62,6 +62,7 @@ typedef struct {
     double huber_delta;         /* (double)sqrtf(5.0f) (Optimizer.cc:616); <= 0: no kernel    */
     double chi2_gate;           /* 5.0 (Optimizer.cc:52, 769)                                 */
     int32_t max_iters;          /* optimizer.optimize(10) (Optimizer.cc:755)                  */
+    int32_t max_trials;         /* g2o maxTrialsAfterFailure (default-constructed LM, :539); 0 -> 10 */
     uint32_t flags;             /* MOVBA_FLAG_*                                               */
     const volatile uint8_t *stop; /* pbStopFlag (Optimizer.cc:544-545, 749), may be NULL      */
 } movba_lba_desc;
@@ -95,7 +96,8 @@ typedef struct {
     double pcg_rel_tol;         /* stop when sqrt(r.z / r0.z0) <= tol       (default 1e-10)   */
     int32_t pcg_max_iters;      /* per solve                                 (default 4*6K)    */
     int32_t run_ahead;          /* trial sets the host keeps queued ahead    (default 2)       */
-    int32_t profile;            /* 1: bracket every kernel class with HIP events               */
+    int32_t profile;            /* bit k set: bracket launches of kernel class k (see movba_profile)
+                                 * with HIP events on the handle's stream; 0x3f = all          */
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */
@@ -132,6 +134,7 @@ int  movba_lba_export_poses_device(movba_handle *h, void *dst_device, int64_t ca
 
 int  movba_get_profile(movba_handle *h, movba_profile *out);
 int  movba_reset_profile(movba_handle *h);
+int  movba_set_profile_mask(movba_handle *h, int32_t mask);
 
 /* Host-only structure pass (no GPU needed): what movba_lba_upload derives from a window
  * before any H2D copy.  Exposed for the CPU test suite. */

@@ -98,17 +98,17 @@ hipEvent_t get_event(movba_handle *h)
 
 struct ScopedEvents {
     movba_handle *h; EventPair p{}; bool on;
-    ScopedEvents(movba_handle *h_, int cls) : h(h_), on(h_->opt.profile != 0)
+    ScopedEvents(movba_handle *h_, int cls) : h(h_), on(((h_->opt.profile >> cls) & 1) != 0)
     {
         if (!on) return;
         p.a = get_event(h); p.b = get_event(h); p.cls = cls;
         if (!p.a || !p.b) { on = false; return; }
-        hipEventRecord(p.a, h->stream);
+        (void)hipEventRecord(p.a, h->stream);
     }
     ~ScopedEvents()
     {
         if (!on) return;
-        hipEventRecord(p.b, h->stream);
+        (void)hipEventRecord(p.b, h->stream);
         h->ev_used.push_back(p);
     }
 };
@@ -209,16 +209,16 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
 void movba_destroy(movba_handle *h)
 {
     if (!h) return;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     harvest_events(h);
-    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-    if (h->arena) hipFree(h->arena);
-    if (h->pose_arena) hipFree(h->pose_arena);
-    if (h->stage) hipHostFree(h->stage);
-    if (h->hstat) hipHostFree((void *)h->hstat);
-    if (h->ctrl_host) hipHostFree(h->ctrl_host);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->pose_arena) (void)hipFree(h->pose_arena);
+    if (h->stage) (void)hipHostFree(h->stage);
+    if (h->hstat) (void)hipHostFree((void *)h->hstat);
+    if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -326,7 +326,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     char *a = h->arena;
     w = DevWindow{};
     w.NP = NP; w.P = P; w.E = E; w.nfree = nf; w.npairs = s.npairs; w.nitems = s.nitems; w.n_pt_blocks = nb;
-    w.max_iters = d->max_iters; w.flags = d->flags;
+    w.max_iters = d->max_iters; w.flags = d->flags; w.max_trials = d->max_trials > 0 ? d->max_trials : 10;
     w.fx = d->fx; w.fy = d->fy; w.cx = d->cx; w.cy = d->cy; w.huber_delta = d->huber_delta; w.chi2_gate = d->chi2_gate;
     w.g_pose = reinterpret_cast<int32_t *>(a + o_gpose); w.g_point = reinterpret_cast<int32_t *>(a + o_gpoint);
     w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = reinterpret_cast<int32_t *>(a + o_perm);
@@ -388,7 +388,7 @@ int movba_lba_run(movba_handle *h)
     pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 4 * 6 * (w.nfree > 0 ? w.nfree : 1);
     pp.lds_blocks = 0;
 
-    const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * 10;
+    const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
     const double t_start = now_ms();
     for (int t = 0; t < max_trials; ++t) {
         // stay at most run_ahead trial sets ahead of the device
@@ -483,6 +483,13 @@ int movba_get_profile(movba_handle *h, movba_profile *out)
 {
     if (!h || !out) return MOVBA_ERR_ARG;
     *out = h->prof;
+    return MOVBA_OK;
+}
+
+int movba_set_profile_mask(movba_handle *h, int32_t mask)
+{
+    if (!h) return MOVBA_ERR_ARG;
+    h->opt.profile = mask;
     return MOVBA_OK;
 }
 

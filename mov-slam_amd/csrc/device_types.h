@@ -54,7 +54,7 @@ struct HostStatus {
 struct DevWindow {
     int32_t NP, P, E, nfree, npairs, nitems, n_pt_blocks, max_iters;
     uint32_t flags;
-    int32_t pad0;
+    int32_t max_trials;
     double fx, fy, cx, cy, huber_delta, chi2_gate;
     // structure
     const int32_t *g_pose, *g_point, *pt_start, *perm, *hidx, *free_pose;

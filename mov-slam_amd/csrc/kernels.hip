@@ -763,11 +763,11 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
     if (tr < kMaxTrace) { c->tr_accept[tr] = accepted; c->n_trace = tr + 1; }
     c->n_solves += 1;
     c->qmax += 1;
-    const bool more_trials = lambda_ok && (rho < 0.0) && (c->qmax < 10) && !stop;
+    const bool more_trials = lambda_ok && (rho < 0.0) && (c->qmax < w.max_trials) && !stop;
     int done = 0;
     if (!more_trials) {
         c->iters_done = c->it + 1;
-        if (c->qmax == 10 || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
+        if (c->qmax == w.max_trials || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
         else {
             c->it += 1;
             c->qmax = 0;

@@ -34,7 +34,7 @@ class LbaDesc(C.Structure):
                 ("obs", _d), ("inv_sigma2", _d),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
-                ("max_iters", C.c_int32), ("flags", C.c_uint32), ("stop", _u)]
+                ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("flags", C.c_uint32), ("stop", _u)]
 
 
 class LbaResult(C.Structure):
@@ -77,7 +77,7 @@ class PoseResult(C.Structure):
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
            "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
            "movba_lba_export_poses_device", "movba_get_profile", "movba_reset_profile",
-           "movba_structure_probe", "movba_pose_opt"]
+           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask"]
 
 _lib = None
 
@@ -103,6 +103,7 @@ def lib():
         L.movba_lba_export_poses_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.movba_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.movba_reset_profile.argtypes = [C.c_void_p]
+        L.movba_set_profile_mask.argtypes = [C.c_void_p, C.c_int32]
         L.movba_structure_probe.argtypes = [C.POINTER(LbaDesc), C.POINTER(StructureInfo), _i, _i]
         L.movba_pose_opt.argtypes = [C.c_void_p, C.POINTER(PoseDesc), C.POINTER(PoseResult)]
         _lib = L
@@ -117,7 +118,7 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-def make_desc(w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None):
+def make_desc(w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
     """Flattened window (movba.synth.Window or anything with the same fields) -> movba_lba_desc."""
     keep = dict(
         poses=np.ascontiguousarray(w.poses, np.float64), fixed=np.ascontiguousarray(w.pose_fixed, np.uint8),
@@ -133,6 +134,7 @@ def make_desc(w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None):
     d.huber_delta, d.chi2_gate = w.huber_delta, w.chi2_gate
     d.max_iters = w.max_iters if max_iters is None else max_iters
     d.flags = flags
+    d.max_trials = max_trials
     if stop is not None:
         keep["stop"] = stop
         d.stop = _p(stop, _u)
@@ -154,9 +156,9 @@ class Solver:
     """One handle = one device + one stream (movba_create / movba_destroy)."""
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
-                 pcg_max_iters: int = 0, run_ahead: int = 0, profile: bool = False):
+                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False):
         self._h = C.c_void_p()
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, 1 if profile else 0)
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)))
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()
@@ -193,8 +195,8 @@ class Solver:
                               pcg=np.array(r.tr_pcg_iters[:n])))
         return out
 
-    def solve(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None) -> dict:
-        d, keep = make_desc(w, flags, stop, max_iters)
+    def solve(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0) -> dict:
+        d, keep = make_desc(w, flags, stop, max_iters, max_trials)
         r, out = self._alloc_result(d)
         rc = lib().movba_lba_solve(self._h, C.byref(d), C.byref(r))
         if rc < 0:
@@ -203,8 +205,8 @@ class Solver:
             out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
         return self._pack(r, out, rc)
 
-    def upload(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None):
-        d, keep = make_desc(w, flags, stop, max_iters)
+    def upload(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
+        d, keep = make_desc(w, flags, stop, max_iters, max_trials)
         rc = lib().movba_lba_upload(self._h, C.byref(d))
         if rc < 0:
             raise MovbaError(f"movba_lba_upload: {status_string(rc)}")
@@ -240,6 +242,9 @@ class Solver:
 
     def reset_profile(self):
         lib().movba_reset_profile(self._h)
+
+    def set_profile_mask(self, mask: int):
+        lib().movba_set_profile_mask(self._h, mask)
 
     def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None) -> dict:
         Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)

@@ -529,6 +529,7 @@ int lba_oracle_solve(const lba_oracle_problem *pb, lba_oracle_result *res)
     const int nvec_p = 6 * w.nfree;
     double lambda = 0.0, ni = 2.0, F_cur = 0.0;
     int ok = 1;
+    const int max_trials = pb->max_trials > 0 ? pb->max_trials : 10;   /* _maxTrialsAfterFailure */
     int have_system = (w.nfree > 0 || P > 0) && E > 0;   /* optimize() returns -1 on an empty index map */
 
     if (!have_system) res->status = 3;
@@ -591,10 +592,10 @@ int lba_oracle_solve(const lba_oracle_problem *pb, lba_oracle_result *res)
             res->n_solves++;
             qmax++;
             if (!lambda_ok) break;
-        } while (rho < 0.0 && qmax < 10 && !stop_requested(pb));
+        } while (rho < 0.0 && qmax < max_trials && !stop_requested(pb));
         F_cur = F0;
         res->iters_done = it + 1;
-        if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = 0;            /* Terminate */
+        if (qmax == max_trials || rho == 0.0 || !isfinite(lambda)) ok = 0;    /* Terminate */
     }
 
     /* A8: chi2 from the stored _error (stale after a rejected last trial, SURVEY A.4

@@ -45,6 +45,7 @@ typedef struct {
     double chi2_gate;            /* outlier gate (5.0 in the reference)            */
     int max_iters;               /* optimize(N) outer iterations (10)              */
     int stale_error_quirk;       /* 1: chi2 from the edges' stored _error (g2o)    */
+    int max_trials;              /* g2o maxTrialsAfterFailure property; 0 -> 10    */
     const volatile uint8_t *stop;/* forceStopFlag, may be NULL                     */
 } lba_oracle_problem;
 

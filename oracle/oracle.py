@@ -27,7 +27,7 @@ class _Problem(C.Structure):
                 ("edge_pose", _i), ("edge_point", _i), ("obs", _d), ("inv_sigma2", _d),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
-                ("max_iters", C.c_int), ("stale_error_quirk", C.c_int), ("stop", _u)]
+                ("max_iters", C.c_int), ("stale_error_quirk", C.c_int), ("max_trials", C.c_int), ("stop", _u)]
 
 
 class _Result(C.Structure):
@@ -71,7 +71,7 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-def _problem(w, stale_error_quirk=True, stop=None, max_iters=None):
+def _problem(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0):
     keep = dict(
         poses=np.ascontiguousarray(w.poses, np.float64), fixed=np.ascontiguousarray(w.pose_fixed, np.uint8),
         points=np.ascontiguousarray(w.points, np.float64), ep=np.ascontiguousarray(w.edge_pose, np.int32),
@@ -86,15 +86,16 @@ def _problem(w, stale_error_quirk=True, stop=None, max_iters=None):
     pb.huber_delta, pb.chi2_gate = w.huber_delta, w.chi2_gate
     pb.max_iters = w.max_iters if max_iters is None else max_iters
     pb.stale_error_quirk = 1 if stale_error_quirk else 0
+    pb.max_trials = max_trials
     if stop is not None:
         keep["stop"] = stop
         pb.stop = _p(stop, _u)
     return pb, keep
 
 
-def solve(w, stale_error_quirk=True, stop=None, max_iters=None) -> dict:
+def solve(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0) -> dict:
     """Optimizer::LocalBundleAdjustment's solve + outlier gate on a flattened window."""
-    pb, keep = _problem(w, stale_error_quirk, stop, max_iters)
+    pb, keep = _problem(w, stale_error_quirk, stop, max_iters, max_trials)
     poses = np.zeros((w.n_poses, 7)); points = np.zeros((w.n_points, 3))
     chi2 = np.zeros(w.n_edges); outlier = np.zeros(w.n_edges, np.uint8)
     res = _Result()

@@ -1,0 +1,60 @@
+"""Shared fixtures.  `-m "not gpu"`: oracle vs golden vectors, host logic, C-ABI symbols.
+`-m gpu`: parity of the HIP path (through the C-ABI) against the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
+sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    """-> (Window built from the fixture's inputs, dict of expected outputs)."""
+    from movba import synth
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    w = synth.Window(poses=g["in_poses"], pose_fixed=g["in_pose_fixed"], points=g["in_points"],
+                     edge_pose=g["in_edge_pose"], edge_point=g["in_edge_point"], obs=g["in_obs"],
+                     inv_sigma2=g["in_inv_sigma2"], cam=tuple(g["in_cam"]),
+                     huber_delta=float(g["in_huber_delta"]), chi2_gate=float(g["in_chi2_gate"]),
+                     max_iters=int(g["in_max_iters"]))
+    out = {k[4:]: g[k] for k in g.files if k.startswith("out_")}
+    return w, out
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libmovba.so must exist for every test that touches the C-ABI (cross-compiled on CPU)."""
+    from movba import capi
+    if not os.path.exists(capi.LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mov-slam_amd", "csrc"), "-s"])
+    return capi
+
+
+@pytest.fixture(scope="session")
+def solver(built_lib):
+    s = built_lib.Solver()          # raises loudly if the HIP library or the device is missing
+    yield s
+    s.close()
+
+
+def quat_angle(q1, q2):
+    """geodesic angle between unit quaternions (x,y,z,w), rows."""
+    d = np.abs(np.sum(q1 * q2, axis=-1)).clip(0, 1)
+    return 2 * np.arccos(d)

@@ -1,0 +1,156 @@
+"""Self-validation of the oracle's building blocks (SURVEY.md §8c i-iv)."""
+import numpy as np
+import pytest
+
+from movba import synth
+
+CAM = np.array([320.0, 320.0, 320.0, 240.0])
+
+
+def _rand_pose(rng):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    if q[3] < 0: q = -q
+    return np.concatenate([q, rng.normal(size=3)])
+
+
+def test_edge_jacobians_match_central_differences(oracle_mod):
+    """include/OptimizableTypes.h:103-109 error vs src/OptimizableTypes.cpp:158-180 Jacobians."""
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        T = _rand_pose(rng)
+        Xc = np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(3, 20)])
+        R = synth.R_from_quat(T[:4]); X = R.T @ (Xc - T[4:])
+        obs = rng.uniform(0, 480, size=2)
+        e0, Jp, Jc = oracle_mod.edge(T, X, obs, CAM)
+        h = 1e-6
+        for k in range(3):
+            d = np.zeros(3); d[k] = h
+            num = (oracle_mod.edge(T, X + d, obs, CAM)[0] - oracle_mod.edge(T, X - d, obs, CAM)[0]) / (2 * h)
+            np.testing.assert_allclose(Jp[:, k], num, rtol=1e-6, atol=1e-6)
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            Tp = oracle_mod.se3_mul(oracle_mod.se3_exp(d), T); Tm = oracle_mod.se3_mul(oracle_mod.se3_exp(-d), T)
+            num = (oracle_mod.edge(Tp, X, obs, CAM)[0] - oracle_mod.edge(Tm, X, obs, CAM)[0]) / (2 * h)
+            np.testing.assert_allclose(Jc[:, k], num, rtol=1e-6, atol=1e-5)
+
+
+def test_se3_exp_identities(oracle_mod):
+    rng = np.random.default_rng(1)
+    I = oracle_mod.se3_exp(np.zeros(6))
+    np.testing.assert_allclose(I, [0, 0, 0, 1, 0, 0, 0], atol=1e-15)
+    for scale in (1e-7, 1e-3, 0.5, 2.5):
+        u = scale * rng.normal(size=6)
+        a = oracle_mod.se3_exp(u); b = oracle_mod.se3_exp(-u)
+        np.testing.assert_allclose(oracle_mod.se3_mul(a, b), [0, 0, 0, 1, 0, 0, 0], atol=1e-12)
+        assert abs(np.linalg.norm(a[:4]) - 1) < 1e-15 and a[3] >= 0
+        # against scipy's matrix exponential of the twist
+        from scipy.linalg import expm
+        M = np.zeros((4, 4)); w = u[:3]
+        M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]; M[:3, 3] = u[3:]
+        Tm = expm(M)
+        np.testing.assert_allclose(synth.R_from_quat(a[:4]), Tm[:3, :3], atol=1e-12)
+        np.testing.assert_allclose(a[4:], Tm[:3, 3], atol=1e-12)
+
+
+def test_se3_small_angle_branch_is_continuous(oracle_mod):
+    d = np.array([1.0, -2.0, 0.5]); d /= np.linalg.norm(d)
+    lo = oracle_mod.se3_exp(np.concatenate([0.99999e-5 * d, [0.1, 0.2, 0.3]]))
+    hi = oracle_mod.se3_exp(np.concatenate([1.00001e-5 * d, [0.1, 0.2, 0.3]]))
+    np.testing.assert_allclose(lo, hi, atol=1e-9)
+
+
+def test_se3_map_and_mul_agree_with_matrices(oracle_mod):
+    rng = np.random.default_rng(2)
+    A, B = _rand_pose(rng), _rand_pose(rng)
+    X = rng.normal(size=3)
+    RA, RB = synth.R_from_quat(A[:4]), synth.R_from_quat(B[:4])
+    np.testing.assert_allclose(oracle_mod.se3_map(A, X), RA @ X + A[4:], atol=1e-14)
+    C = oracle_mod.se3_mul(A, B)
+    np.testing.assert_allclose(synth.R_from_quat(C[:4]), RA @ RB, atol=1e-14)
+    np.testing.assert_allclose(C[4:], RA @ B[4:] + A[4:], atol=1e-14)
+
+
+def test_huber_kernel(oracle_mod):
+    d = synth.HUBER_DELTA
+    assert d * d > 5.0                      # (float)sqrt(5) squared is above the chi2 gate
+    np.testing.assert_allclose(oracle_mod.huber(3.0, d), [3.0, 1.0, 0.0])
+    r = oracle_mod.huber(16.0, d)
+    np.testing.assert_allclose(r[:2], [2 * 4 * d - d * d, d / 4])
+    # continuity at the threshold
+    np.testing.assert_allclose(oracle_mod.huber(d * d * (1 + 1e-12), d)[0], d * d, rtol=1e-9)
+
+
+def test_schur_system_equals_full_system_elimination(oracle_mod):
+    """S, bS from the oracle vs eliminating the points from the full Hessian with numpy."""
+    w = synth.cfg("small")
+    lam = 0.37
+    L = oracle_mod.linearize(w, lam)
+    nf, P = L["nfree"], w.n_points
+    n = 6 * nf
+    # rebuild the full system from per-edge Jacobians
+    H = np.zeros((n + 3 * P, n + 3 * P)); b = np.zeros(n + 3 * P)
+    fi = L["free_index"]
+    for e in range(w.n_edges):
+        ip, l = w.edge_pose[e], w.edge_point[e]
+        err, Jp, Jc = oracle_mod.edge(w.poses[ip], w.points[l], w.obs[e], np.array(w.cam))
+        rho = oracle_mod.huber(err @ err, w.huber_delta)
+        sl = slice(n + 3 * l, n + 3 * l + 3)
+        H[sl, sl] += rho[1] * Jp.T @ Jp; b[sl] += -rho[1] * Jp.T @ err
+        if fi[ip] >= 0:
+            sp = slice(6 * fi[ip], 6 * fi[ip] + 6)
+            H[sp, sp] += rho[1] * Jc.T @ Jc; b[sp] += -rho[1] * Jc.T @ err
+            H[sp, sl] += rho[1] * Jc.T @ Jp; H[sl, sp] += rho[1] * Jp.T @ Jc
+    H += lam * np.eye(n + 3 * P)
+    Hpp, Hpl, Hll = H[:n, :n], H[:n, n:], H[n:, n:]
+    S = Hpp - Hpl @ np.linalg.solve(Hll, Hpl.T)
+    bS = b[:n] - Hpl @ np.linalg.solve(Hll, b[n:])
+    np.testing.assert_allclose(L["S"], S, rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(L["bS"], bS, rtol=1e-9, atol=1e-7)
+    assert np.allclose(L["S"], L["S"].T)
+
+
+def test_noise_free_window_converges_to_truth(oracle_mod):
+    w = synth.make_window(4, 2, 80, seed=5, run_lo=3, run_hi=6, outlier_frac=0.0, pix_sigma=0.0)
+    # float32 rounding of the observations leaves ~1e-5 px residuals
+    r = oracle_mod.solve(w)
+    fr = w.pose_fixed == 0
+    assert np.abs(r["poses"][fr, 4:] - w.truth_poses[fr, 4:]).max() < 1e-4
+    assert r["cost"] < 1e-2 and r["n_outliers"] == 0
+
+
+def test_stop_flag_before_solve_returns_without_writing(oracle_mod):
+    w = synth.cfg("tiny")
+    stop = np.ones(1, np.uint8)
+    r = oracle_mod.solve(w, stop=stop)
+    assert r["status"] == 1 and r["n_solves"] == 0
+    np.testing.assert_array_equal(r["poses"], w.poses)
+
+
+def test_stale_error_quirk_only_matters_after_a_rejected_last_trial(oracle_mod):
+    """after a rejected last trial g2o's edges keep the rejected
+    state's errors.  maxTrialsAfterFailure = 2 ends the hard fixture on its first pair of
+    consecutive rejections (g2o returns Terminate when the trial count reaches the property)."""
+    from conftest import load_golden
+    w = synth.cfg("small")
+    a = oracle_mod.solve(w, stale_error_quirk=True); b = oracle_mod.solve(w, stale_error_quirk=False)
+    assert a["trace"]["accept"][-1] == 1
+    np.testing.assert_array_equal(a["chi2"], b["chi2"])
+    wh, g = load_golden("lba_hard")
+    k = int(np.flatnonzero(g["tr_accept"] == 0)[0])
+    assert g["tr_accept"][k + 1] == 0
+    a = oracle_mod.solve(wh, stale_error_quirk=True, max_trials=2)
+    b = oracle_mod.solve(wh, stale_error_quirk=False, max_trials=2)
+    assert a["n_solves"] == k + 2 and a["trace"]["accept"][-1] == 0 and a["iters_done"] == k + 1
+    np.testing.assert_array_equal(a["poses"], b["poses"])           # estimates restored by pop()
+    assert np.abs(a["chi2"] - b["chi2"]).max() > 1e-3               # but the stored errors differ
+    assert np.isclose(b["cost"], g["tr_f0"][k], rtol=1e-9)
+
+
+def test_pose_only_oracle_recovers_pose(oracle_mod):
+    f = synth.make_frame()
+    r = oracle_mod.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], huber_delta=5.0, chi2_gate=25.0)
+    assert np.abs(r["pose"][4:] - f["truth"][4:]).max() < 0.02
+    # gross outliers (>= 10 px) are flagged, inliers (0.5 px noise) kept
+    assert (r["outlier"][f["is_outlier"]] == 1).all()
+    assert r["outlier"][~f["is_outlier"]].mean() < 0.01
+    assert r["n_inliers"] == int((r["outlier"] == 0).sum())
