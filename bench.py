@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — local-BA LM iterations/s on a 50 KF x 20k MapPoint window (BASELINE.json).
+
+A "step" is one complete local-BA solve (what Optimizer::LocalBundleAdjustment runs at
+/root/reference/src/Optimizer.cc:754-755 plus the gate at :757-775) of one synthetic
+covisibility window per rank, with the flattened window already resident in HBM
+(movba_lba_upload done before the timed region); the metric counts the linear solves
+(accepted + rejected LM trials) those steps performed.  With N > 1 every rank owns an
+independent window (BASELINE cfg5: weak scaling, no data-path collective) and the
+optimised keyframe poses are all-gathered over RCCL inside the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+KERNEL_CLASSES = ["k_schur", "k_pcg", "k_point<backsub>", "k_decide", "setup(init+linearize+lambda)", "k_finalize"]
+
+
+def algorithmic_bytes(K, F, P, E):
+    """SURVEY.md §8(d) B_iter split over the three kernels of one LM trial:
+    compulsory fp64 traffic with Jacobians recomputed, dense upper-block reduced system."""
+    S = K * (K + 1) // 2 * 288 + K * 48
+    per = {
+        "k_schur": E * 32 + P * 24 + (K + F) * 56 + S,                 # edge pass 1, writes S and rhs
+        "k_pcg": S + K * 56,                                           # reads S and rhs, writes poses
+        "k_point<backsub>": E * (32 + 8) + P * (24 + 24) + (K + F) * 56,   # edge pass 2, chi2 write
+    }
+    per["B_iter"] = sum(per.values())
+    return per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from movba import capi, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the local-BA path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload: cfg3 on rank 0 (the configuration the metric is quoted on), cfg5 seeds on the others ----
+    shape = dict(cfg2=(10, 2, 2000, 2, 6), cfg3=(50, 10, 20000, 2, 10))[args.config]
+    seed = (1003 if args.config == "cfg3" else 1002) if rank == 0 else shard.window_seed(rank)
+    w = synth.make_window(shape[0], shape[1], shape[2], seed, run_lo=shape[3], run_hi=shape[4])
+    K, F, P, E = w.n_free, w.n_poses - w.n_free, w.n_points, w.n_edges
+
+    stream = torch.cuda.current_stream(dev)
+    solver = capi.Solver(device=local_rank, stream=stream.cuda_stream)
+    solver.upload(w)                                     # window resident in HBM from here on
+    pose_buf = torch.empty((1, w.n_poses, 7), dtype=torch.float64, device=dev)
+
+    def step():
+        solver.run()                                     # whole LM loop on the device, returns after the stream drained
+        solver.export_poses_device(pose_buf.data_ptr(), pose_buf.numel() * 8)
+        return shard.gather_poses(pose_buf) if world > 1 else pose_buf
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    # untimed pass with every kernel class bracketed by HIP events: find the dominant kernel
+    solver.set_profile_mask(0x3f); solver.reset_profile()
+    step(); torch.cuda.synchronize(dev)
+    prof_all = solver.profile()["kernels"]
+    dominant = max(KERNEL_CLASSES[:3], key=lambda k: prof_all[k]["ms"])
+    solver.set_profile_mask(1 << KERNEL_CLASSES.index(dominant)); solver.reset_profile()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    res = solver.download()
+    prof = solver.profile()
+    solves_local = res["n_solves"] * args.steps
+
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    ss = torch.tensor([float(solves_local)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+    dt_max, solves_total = float(tt.item()), float(ss.item())
+
+    if rank == 0:
+        ab = algorithmic_bytes(K, F, P, E)
+        dk = prof["kernels"][dominant]
+        avg_s = dk["ms"] / max(dk["launches"], 1) * 1e-3
+        achieved = ab[dominant] / avg_s / 1e9 if avg_s > 0 else 0.0
+        chain_gbs = ab["B_iter"] * res["n_solves"] * args.steps / dt / 1e9
+        out = {
+            "metric": "local-BA iterations/sec (50 KF x 20k MapPoint window)" if args.config == "cfg3"
+                      else "local-BA iterations/sec (10 KF x 2k MapPoint window)",
+            "value": solves_total / dt_max,
+            "unit": "LM iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"LocalBundleAdjustment {K} KF + {F} fixed x {P} MapPoints, E={E} mono edges, Huber on, "
+                                   f"10 LM iterations ({args.config}, seed {seed}); one window per GPU",
+                       "lm_iterations_per_step": res["n_solves"], "pcg_iterations_per_step": res["pcg_iters"],
+                       "window_solves_per_s": world * args.steps / dt_max,
+                       "parallelism": f"{world} independent window(s), RCCL pose all-gather" if world > 1 else "1 window"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_us": avg_s * 1e6,
+                         "launches_timed": dk["launches"],
+                         "chain": {"B_iter_bytes": ab["B_iter"], "achieved": chain_gbs, "frac": chain_gbs / HBM_PEAK_GBS,
+                                   "note": "whole LM iteration (all kernels + launch gaps); latency-bound, not bandwidth-bound"},
+                         "kernel_ms_per_step_all_classes": {k: v["ms"] for k, v in prof_all.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle                       # CPU baseline leg: the oracle as the timed "port"
+            oracle.build()
+            n, solves, t_cpu0 = 0, 0, time.perf_counter()
+            while True:
+                o = oracle.solve(w)
+                n += 1; solves += o["n_solves"]
+                el = time.perf_counter() - t_cpu0
+                if el >= args.cpu_seconds or n >= 200:
+                    break
+            out["cpu_baseline"] = {"value": solves / el, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+                                   "sample": f"{n} full solves of the same window ({solves} LM iterations, {el:.1f} s), "
+                                             "single-threaded restated-g2o oracle (oracle/lba_oracle.c, -O3 -march=native)",
+                                   "host_cpus": os.cpu_count(), "ms_per_window_solve": 1e3 * el / n}
+            # parity spot-check of what was timed
+            out["config"]["parity_vs_oracle"] = {
+                "pose_max_abs": float(np.abs(res["poses"] - o["poses"]).max()),
+                "outlier_mismatches": int((res["outlier"] != o["outlier"]).sum())}
+        print(json.dumps(out), flush=True)
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
