@@ -197,7 +197,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     if (hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
-        configure_kernels(0) != hipSuccess) {
+        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess) {
         movba_destroy(h);
         return MOVBA_ERR_HIP;
     }
@@ -386,7 +386,8 @@ int movba_lba_run(movba_handle *h)
     PcgParams pp;
     pp.rel_tol = h->opt.pcg_rel_tol;
     pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 4 * 6 * (w.nfree > 0 ? w.nfree : 1);
-    pp.lds_blocks = 0;
+    const int nrowent = (int)h->st.row_ent.size();
+    const bool rows_kernel = pcg_rows_supported(w.nfree, h->st.row_ptr.data(), &pp);
 
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
     const double t_start = now_ms();
@@ -405,7 +406,7 @@ int movba_lba_run(movba_handle *h)
         if (h->hstat->done) break;
         if (h->stop && *h->stop) h->hstat->stop = 1;
         if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, s)); }
-        { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_pcg(w, pp, s)); }
+        { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, s) : launch_pcg(w, pp, s)); }
         { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
     }
@@ -413,6 +414,13 @@ int movba_lba_run(movba_handle *h)
     HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     harvest_events(h);
+#ifdef MOVBA_CLOCK_STAMP
+    std::fprintf(stderr, "libmovba[stamp]: k_pcg_rows %llu shader cycles in %llu x 10 ns -> %.3f GHz\n", h->ctrl_host->dbg_cycles,
+                 h->ctrl_host->dbg_ticks, h->ctrl_host->dbg_ticks ? 0.1 * (double)h->ctrl_host->dbg_cycles / (double)h->ctrl_host->dbg_ticks : 0.0);
+    std::fprintf(stderr, "libmovba[stamp]: per-iteration segments (wave 0, cycles):");
+    for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_seg[k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
+    std::fprintf(stderr, "\n");
+#endif
     h->ran = true;
     return MOVBA_OK;
 }

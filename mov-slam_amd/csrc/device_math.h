@@ -1,0 +1,189 @@
+// Small fp64 device helpers shared by the HIP kernels: SE3Quat arithmetic as g2o defines it
+// (normalizeRotation, operator*, exp — SURVEY.md Appendix A.8), Eigen's quaternion <-> matrix
+// conversions, the cofactor 3x3 inverse, and fixed-order wave / block reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+namespace movba {
+
+__device__ __forceinline__ void quat_to_R(const double q[4], double R[9])
+{
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
+}
+
+__device__ __forceinline__ void R_to_quat(const double m[9], double q[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t;
+        q[1] = (m[2] - m[6]) * t;
+        q[2] = (m[3] - m[1]) * t;
+    } else {
+        // i = argmax diagonal, written without dynamic register indexing
+        if (m[0] >= m[4] && m[0] >= m[8]) {
+            t = sqrt(m[0] - m[4] - m[8] + 1.0);
+            q[0] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+        } else if (m[4] > m[0] && m[4] >= m[8]) {
+            t = sqrt(m[4] - m[8] - m[0] + 1.0);
+            q[1] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+        } else {
+            t = sqrt(m[8] - m[0] - m[4] + 1.0);
+            q[2] = 0.5 * t; t = 0.5 / t;
+            q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+        }
+    }
+}
+
+// SE3Quat::normalizeRotation
+__device__ __forceinline__ void quat_normalize(double q[4])
+{
+    if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+__device__ __forceinline__ void quat_rotate(const double q[4], const double v[3], double o[3])
+{
+    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
+    ux += ux; uy += uy; uz += uz;
+    o[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    o[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    o[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+
+// T <- exp(u) * T   (VertexSE3Expmap::oplusImpl; u = (omega, upsilon), rotation first)
+__device__ inline void se3_oplus(const double u[6], const double T[7], double out[7])
+{
+    const double wx = u[0], wy = u[1], wz = u[2];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    const double th = sqrt(th2);
+    double a, b, c, d;
+    if (th < 0.00001) { a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0; }
+    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = b; d = (th - sin(th)) / (th2 * th); }
+    // Om = [w]x ; Om2 = w w^T - th2 I
+    const double Om[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
+    const double Om2[9] = { wx * wx - th2, wx * wy, wx * wz, wy * wx, wy * wy - th2, wy * wz, wz * wx, wz * wy, wz * wz - th2 };
+    double R[9], V[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        R[i] = I + a * Om[i] + b * Om2[i];
+        V[i] = I + c * Om[i] + d * Om2[i];
+    }
+    double e[7];
+    R_to_quat(R, e);
+    e[4] = V[0] * u[3] + V[1] * u[4] + V[2] * u[5];
+    e[5] = V[3] * u[3] + V[4] * u[4] + V[5] * u[5];
+    e[6] = V[6] * u[3] + V[7] * u[4] + V[8] * u[5];
+    quat_normalize(e);
+    // SE3Quat::operator*
+    double r[4];
+    r[3] = e[3] * T[3] - e[0] * T[0] - e[1] * T[1] - e[2] * T[2];
+    r[0] = e[3] * T[0] + e[0] * T[3] + e[1] * T[2] - e[2] * T[1];
+    r[1] = e[3] * T[1] + e[1] * T[3] + e[2] * T[0] - e[0] * T[2];
+    r[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
+    double rt[3];
+    quat_rotate(e, T + 4, rt);
+    quat_normalize(r);
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
+    out[4] = e[4] + rt[0]; out[5] = e[5] + rt[1]; out[6] = e[6] + rt[2];
+}
+
+// inverse of the symmetric 3x3 (xx xy xz yy yz zz) by cofactors
+__device__ __forceinline__ void inv3sym(const double A[6], double B[6])
+{
+    const double c00 = A[3] * A[5] - A[4] * A[4];
+    const double c01 = A[4] * A[2] - A[1] * A[5];
+    const double c02 = A[1] * A[4] - A[3] * A[2];
+    const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
+    B[3] = (A[0] * A[5] - A[2] * A[2]) * id;
+    B[4] = (A[2] * A[1] - A[0] * A[4]) * id;
+    B[5] = (A[0] * A[3] - A[1] * A[1]) * id;
+}
+
+// ---- DPP cross-lane moves (no LDS crossbar, unlike ds_bpermute-based __shfl) ----
+// ctrl: quad_perm 0x00-0xff, row_shr:n 0x110+n, row_mirror 0x140, row_half_mirror 0x141,
+//       row_bcast:15 0x142, row_bcast:31 0x143 (gfx9 encodings)
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_mov0(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// Fixed-tree sum over the 64 lanes, result broadcast to every lane (wave-uniform).
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v += dpp_mov0<0xb1>(v);             // quad_perm [1,0,3,2]
+    v += dpp_mov0<0x4e>(v);             // quad_perm [2,3,0,1]
+    v += dpp_mov0<0x141>(v);            // row_half_mirror: sums of 8
+    v += dpp_mov0<0x140>(v);            // row_mirror: every lane holds its row-of-16 sum
+    v += dpp_mov0<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_mov0<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3
+    return readlane_f64(v, 63);
+}
+
+// Sum over aligned groups of G adjacent lanes (G = 1, 2, 4 or 8), valid in every lane of the group.
+__device__ __forceinline__ double group_sum_dpp(double v, int G)
+{
+    if (G >= 2) v += dpp_mov0<0xb1>(v);
+    if (G >= 4) v += dpp_mov0<0x4e>(v);
+    if (G >= 8) v += dpp_mov0<0x141>(v);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// deterministic block reduction (fixed order), result valid in every thread
+template <int NWAVES, bool MAX>
+__device__ __forceinline__ double block_reduce(double v, double *red /* NWAVES doubles in LDS */)
+{
+    v = MAX ? wave_max(v) : wave_sum(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < NWAVES; ++k) s = MAX ? fmax(s, red[k]) : s + red[k];
+    __syncthreads();
+    return s;
+}
+
+// upper-triangle index of a symmetric 6x6, a <= b
+__device__ __forceinline__ constexpr int ut6(int a, int b) { return a * 6 - a * (a - 1) / 2 + (b - a); }
+
+}  // namespace movba

@@ -40,6 +40,8 @@ struct Ctrl {
     int32_t it, qmax, cur, done;
     int32_t n_solves, last_rejected, iters_done, n_trace;
     int32_t pcg_fail, pcg_last_iters, pcg_total_iters, n_outliers;
+    // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
+    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8];
 };
 
 // Written by k_decide into pinned host memory so the host can keep the queue fed
@@ -84,7 +86,7 @@ struct DevWindow {
 struct PcgParams {
     double rel_tol;
     int32_t max_iters;
-    int32_t lds_blocks;     // how many leading S blocks are staged in LDS
+    int32_t wave_row0[17];      // k_pcg_rows: wave wv owns block rows [wave_row0[wv], wave_row0[wv+1])
 };
 
 }  // namespace movba

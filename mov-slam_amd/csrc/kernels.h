@@ -6,7 +6,13 @@
 
 namespace movba {
 
+constexpr int kPcgRowsThreads = 512;    // 8 waves: 2 per SIMD, 256 VGPRs per lane
+constexpr int kPcgRowsEC = 2;           // oriented 6x6 blocks per lane held in VGPRs
+
 hipError_t configure_kernels(int unused);
+hipError_t configure_pcg_rows();
+bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, hipStream_t s);
 size_t pcg_lds_bytes(int nfree);
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s);

@@ -21,154 +21,11 @@
 #include <cfloat>
 #include <cmath>
 
+#include "device_math.h"
 #include "device_types.h"
 #include "kernels.h"
 
 namespace movba {
-
-// --------------------------------------------------------------------------------
-// small device math
-// --------------------------------------------------------------------------------
-
-__device__ __forceinline__ void quat_to_R(const double q[4], double R[9])
-{
-    const double x = q[0], y = q[1], z = q[2], w = q[3];
-    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
-    const double twx = tx * w, twy = ty * w, twz = tz * w;
-    const double txx = tx * x, txy = ty * x, txz = tz * x;
-    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
-    R[0] = 1.0 - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
-    R[3] = txy + twz;         R[4] = 1.0 - (txx + tzz); R[5] = tyz - twx;
-    R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
-}
-
-__device__ __forceinline__ void R_to_quat(const double m[9], double q[4])
-{
-    double t = m[0] + m[4] + m[8];
-    if (t > 0.0) {
-        t = sqrt(t + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
-        q[0] = (m[7] - m[5]) * t;
-        q[1] = (m[2] - m[6]) * t;
-        q[2] = (m[3] - m[1]) * t;
-    } else {
-        // i = argmax diagonal, written without dynamic register indexing
-        if (m[0] >= m[4] && m[0] >= m[8]) {
-            t = sqrt(m[0] - m[4] - m[8] + 1.0);
-            q[0] = 0.5 * t; t = 0.5 / t;
-            q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
-        } else if (m[4] > m[0] && m[4] >= m[8]) {
-            t = sqrt(m[4] - m[8] - m[0] + 1.0);
-            q[1] = 0.5 * t; t = 0.5 / t;
-            q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
-        } else {
-            t = sqrt(m[8] - m[0] - m[4] + 1.0);
-            q[2] = 0.5 * t; t = 0.5 / t;
-            q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
-        }
-    }
-}
-
-// SE3Quat::normalizeRotation
-__device__ __forceinline__ void quat_normalize(double q[4])
-{
-    if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-}
-
-__device__ __forceinline__ void quat_rotate(const double q[4], const double v[3], double o[3])
-{
-    double ux = q[1] * v[2] - q[2] * v[1], uy = q[2] * v[0] - q[0] * v[2], uz = q[0] * v[1] - q[1] * v[0];
-    ux += ux; uy += uy; uz += uz;
-    o[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
-    o[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
-    o[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
-}
-
-// T <- exp(u) * T   (VertexSE3Expmap::oplusImpl; u = (omega, upsilon), rotation first)
-__device__ void se3_oplus(const double u[6], const double T[7], double out[7])
-{
-    const double wx = u[0], wy = u[1], wz = u[2];
-    const double th2 = wx * wx + wy * wy + wz * wz;
-    const double th = sqrt(th2);
-    double a, b, c, d;
-    if (th < 0.00001) { a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0; }
-    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = b; d = (th - sin(th)) / (th2 * th); }
-    // Om = [w]x ; Om2 = w w^T - th2 I
-    const double Om[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
-    const double Om2[9] = { wx * wx - th2, wx * wy, wx * wz, wy * wx, wy * wy - th2, wy * wz, wz * wx, wz * wy, wz * wz - th2 };
-    double R[9], V[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const double I = (i % 4 == 0) ? 1.0 : 0.0;
-        R[i] = I + a * Om[i] + b * Om2[i];
-        V[i] = I + c * Om[i] + d * Om2[i];
-    }
-    double e[7];
-    R_to_quat(R, e);
-    e[4] = V[0] * u[3] + V[1] * u[4] + V[2] * u[5];
-    e[5] = V[3] * u[3] + V[4] * u[4] + V[5] * u[5];
-    e[6] = V[6] * u[3] + V[7] * u[4] + V[8] * u[5];
-    quat_normalize(e);
-    // SE3Quat::operator*
-    double r[4];
-    r[3] = e[3] * T[3] - e[0] * T[0] - e[1] * T[1] - e[2] * T[2];
-    r[0] = e[3] * T[0] + e[0] * T[3] + e[1] * T[2] - e[2] * T[1];
-    r[1] = e[3] * T[1] + e[1] * T[3] + e[2] * T[0] - e[0] * T[2];
-    r[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
-    double rt[3];
-    quat_rotate(e, T + 4, rt);
-    quat_normalize(r);
-    out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
-    out[4] = e[4] + rt[0]; out[5] = e[5] + rt[1]; out[6] = e[6] + rt[2];
-}
-
-// inverse of the symmetric 3x3 (xx xy xz yy yz zz) by cofactors
-__device__ __forceinline__ void inv3sym(const double A[6], double B[6])
-{
-    const double c00 = A[3] * A[5] - A[4] * A[4];
-    const double c01 = A[4] * A[2] - A[1] * A[5];
-    const double c02 = A[1] * A[4] - A[3] * A[2];
-    const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
-    B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
-    B[3] = (A[0] * A[5] - A[2] * A[2]) * id;
-    B[4] = (A[2] * A[1] - A[0] * A[4]) * id;
-    B[5] = (A[0] * A[3] - A[1] * A[1]) * id;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// deterministic block reduction (fixed order), result valid in every thread
-template <int NWAVES, bool MAX>
-__device__ __forceinline__ double block_reduce(double v, double *red /* NWAVES doubles in LDS */)
-{
-    v = MAX ? wave_max(v) : wave_sum(v);
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
-    __syncthreads();
-    double s = red[0];
-#pragma unroll
-    for (int k = 1; k < NWAVES; ++k) s = MAX ? fmax(s, red[k]) : s + red[k];
-    __syncthreads();
-    return s;
-}
-
-// upper-triangle index of a symmetric 6x6, a <= b
-__device__ __forceinline__ constexpr int ut6(int a, int b) { return a * 6 - a * (a - 1) / 2 + (b - a); }
 
 // --------------------------------------------------------------------------------
 // k_init_pose: uploaded poses -> state 0 (normalised like SE3Quat's constructor), Rt cache
@@ -182,6 +39,8 @@ __global__ void k_init_pose(DevWindow w)
         c->it = 0; c->qmax = 0; c->cur = 0; c->done = (w.max_iters <= 0) ? 1 : 0;
         c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
+        c->dbg_cycles = 0; c->dbg_ticks = 0;
+        for (int k = 0; k < 8; ++k) c->dbg_seg[k] = 0;
     }
     if (i >= w.NP) return;
     double q[7];

@@ -1,0 +1,381 @@
+// k_pcg_rows: the reduced-system solve of one LM trial in ONE workgroup, with the whole
+// (block-sparse, symmetric) matrix S held on-chip for the duration of the solve.
+//
+// Replaces the LinearSolverCSparse Cholesky the reference selects at
+// /root/reference/src/Optimizer.cc:535 by the damped block-Jacobi PCG BASELINE.json's
+// north_star asks for.  S = Hpp + lambda I - sum_l B_il Dinv_l B_jl^T is at most a few
+// hundred KB: too big for one lane, too small to be worth a grid (a grid barrier costs more
+// than a whole CG iteration here), so the design goal is latency per CG iteration:
+//   * a wave owns a run of block rows; the 6x6 blocks of those rows (both triangles, read
+//     through the per-row gather lists) are dealt to the wave's lanes and stay in VGPRs for
+//     the whole solve (kEC oriented blocks per lane); only very large / dense windows spill
+//     the tail of a list to L2 reads;
+//   * mat-vec = one 6x6 * 6x1 product per held block (p read once per block from LDS), the
+//     six partial sums parked in a wave-private LDS strip and summed by the row's owner lane
+//     in list order: no workgroup barrier inside the mat-vec;
+//   * the 6 rows of a block live in one wave, so the block-Jacobi preconditioner needs only a
+//     wave-local LDS exchange;
+//   * per CG iteration: 3 workgroup barriers, 2 DPP wave reductions.
+// All reductions run in a fixed order: results are bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+#include "device_types.h"
+#include "kernels.h"
+
+namespace movba {
+
+#ifdef MOVBA_CLOCK_STAMP
+#define SEG_STAMP(k) do { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); seg[k] += _t - seg_last; seg_last = _t; } while (0)
+#else
+#define SEG_STAMP(k) do { } while (0)
+#endif
+
+namespace {
+
+constexpr int kT = kPcgRowsThreads;     // 512 = 8 waves, 2 per SIMD -> 256 VGPRs per lane
+constexpr int kNW = kT / 64;
+constexpr int kEC = kPcgRowsEC;         // oriented 6x6 blocks held in VGPRs per lane
+constexpr int kOwnBatch = 10;           // partial sums an owner lane loads per LDS round trip
+
+__device__ __forceinline__ double sum_fixed(const double *red)
+{
+    double s = red[0];
+#pragma unroll
+    for (int k = 1; k < kNW; ++k) s += red[k];
+    return s;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int nf = w.nfree, n = 6 * nf;
+    const int cur = c->cur;
+#ifdef MOVBA_CLOCK_STAMP
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const double lambda = c->lambda;
+
+    // LDS carve (16-byte aligned pieces)
+    double *p_lds = sm;                                   // n (+pad)
+    double *minv = p_lds + ((n + 1) & ~1);                // nf x 36 (setup only)
+    double *red0 = minv + 36 * nf;                        // kNW
+    double *red1 = red0 + kNW;                            // kNW
+    double *bS = red1 + kNW;                              // n (+pad): right-hand side (setup only)
+    double *r_lds = bS + ((n + 1) & ~1);                  // n (+pad): residual, exchanged inside a wave only
+    int &s_fail = *reinterpret_cast<int *>(r_lds + ((n + 1) & ~1));   // no static LDS: keeps the dynamic base 16-B aligned
+    double *ypart = r_lds + ((n + 1) & ~1) + 2;           // 6 doubles per gather-list entry, wave-private strips
+    if (tid == 0) s_fail = 0;
+
+    // ---- assemble the upper blocks of S (to L2) and the right-hand side: fixed-order sums of the item partials ----
+    for (int idx = tid; idx < w.npairs * 36; idx += kT) {
+        const int pr = idx / 36, k = idx - pr * 36;
+        double s = 0.0;
+        for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
+            s += w.part[(size_t)itx * kPartStride + k];
+        double v = -s;
+        if (pr < nf) {
+            const int a = k / 6, b = k - a * 6;
+            const int u = a <= b ? ut6(a, b) : ut6(b, a);
+            double hpp = 0.0;
+            for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
+                hpp += w.part[(size_t)itx * kPartStride + 42 + u];
+            v += hpp + (a == b ? lambda : 0.0);
+        }
+        w.blocks[idx] = v;
+    }
+    for (int idx = tid; idx < n; idx += kT) {
+        const int i = idx / 6, a = idx - i * 6;
+        double cc = 0.0, bb = 0.0;
+        for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx) {
+            cc += w.part[(size_t)itx * kPartStride + 36 + a];
+            bb += w.part[(size_t)itx * kPartStride + 63 + a];
+        }
+        w.bp[idx] = bb;
+        bS[idx] = bb - cc;
+    }
+    __syncthreads();
+
+    // ---- block-Jacobi preconditioner: inverse of each 6x6 diagonal block by Cholesky ----
+    for (int i = tid; i < nf; i += kT) {
+        double L[36], Li[36];
+        const double *B = w.blocks + (size_t)i * 36;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) L[k] = B[k];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double d = L[j * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
+            if (!(d > 0.0)) ok = false;
+            d = sqrt(d);
+            L[j * 6 + j] = d;
+#pragma unroll
+            for (int q = j + 1; q < 6; ++q) {
+                double s = L[q * 6 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s -= L[q * 6 + k] * L[j * 6 + k];
+                L[q * 6 + j] = s / d;
+            }
+        }
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+#pragma unroll
+            for (int row = 0; row < 6; ++row) {
+                if (row < col) { Li[row * 6 + col] = 0.0; continue; }
+                double s = (row == col) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = col; k < row; ++k) s -= L[row * 6 + k] * Li[k * 6 + col];
+                Li[row * 6 + col] = s / L[row * 6 + row];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s += (k >= a && k >= b) ? Li[k * 6 + a] * Li[k * 6 + b] : 0.0;
+                minv[i * 36 + a * 6 + b] = s;
+            }
+        if (!ok) s_fail = 1;
+    }
+    __syncthreads();
+
+    // ---- ownership: wave wv owns block rows [b0, b1); lane lr < 6*(b1-b0) owns scalar row b0*6 + lr ----
+    const int b0 = pp.wave_row0[wv], b1 = pp.wave_row0[wv + 1];
+    const int row = b0 * 6 + ln;
+    const bool owner = ln < 6 * (b1 - b0);
+    const int bi = owner ? row / 6 : 0, ba = owner ? row - bi * 6 : 0;
+    const int own_e0 = owner ? w.row_ptr[bi] : 0, own_e1 = owner ? w.row_ptr[bi + 1] : 0;
+    const int own_last = max(own_e1 - 1, 0);
+    const int nrowent = w.row_ptr[nf];
+    // the wave's gather-list entries (block row, block column) are dealt to its lanes round-robin;
+    // each lane keeps up to kEC oriented 6x6 blocks in VGPRs for the whole solve
+    const int E0 = w.row_ptr[b0], E1 = w.row_ptr[b1];
+    double Bo[kEC][36];
+    int colo[kEC], yslot[kEC];
+#pragma unroll
+    for (int k = 0; k < kEC; ++k) {
+        const int e = E0 + ln + 64 * k;
+        colo[k] = 0;
+        yslot[k] = nrowent * 6;             // dummy strip behind the last entry: lanes without a k-th block write there
+#pragma unroll
+        for (int q = 0; q < 36; ++q) Bo[k][q] = 0.0;
+        if (e < E1) {
+            const RowEnt re = w.row_ent[e];
+            const double *B = w.blocks + (size_t)re.block * 36;
+            colo[k] = re.col * 6;
+            yslot[k] = e * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = re.transposed ? B[q * 6 + a] : B[a * 6 + q];
+        }
+    }
+    double x_r = 0.0, r_r = 0.0, z_r = 0.0, p_r = 0.0;
+    if (owner) r_r = bS[row];
+    // z = Minv r: a block's six rows sit in one wave, so its residuals are exchanged through LDS
+    // without a workgroup barrier (LDS operations of one wave execute in order)
+    const double2 *mrow = reinterpret_cast<const double2 *>(minv + (owner ? bi * 36 + ba * 6 : 0));
+    const double2 *rblk = reinterpret_cast<const double2 *>(r_lds + (owner ? bi * 6 : 0));
+    auto wave_lds_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto precond = [&](double rv) {
+        if (owner) r_lds[row] = rv;
+        wave_lds_sync();
+        const double2 m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
+        const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
+        const double s = m0.x * r0.x + m0.y * r0.y + m1.x * r1.x + m1.y * r1.y + m2.x * r2.x + m2.y * r2.y;
+        return owner ? s : 0.0;
+    };
+    z_r = precond(r_r);
+    p_r = z_r;
+    {
+        const double ps = wave_sum_dpp(owner ? r_r * z_r : 0.0);
+        if (ln == 0) red1[wv] = ps;
+    }
+    if (owner) p_lds[row] = p_r;
+    __syncthreads();
+    double rz = sum_fixed(red1);
+    const double rz0 = rz;
+    const double thresh = pp.rel_tol * pp.rel_tol * rz0;
+    bool fail = s_fail != 0 || !(rz0 >= 0.0) || !isfinite(rz0);
+    int iters = 0;
+
+#ifdef MOVBA_CLOCK_STAMP
+    unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, seg_last = __builtin_amdgcn_s_memtime();
+#endif
+    if (!fail && rz0 > 0.0) {
+        for (iters = 1; iters <= pp.max_iters; ++iters) {
+            SEG_STAMP(7);
+            // ---- per entry: y = Bo * p_col, parked in the wave's private part of ypart ----
+            // (branch-free: a lane without a k-th block multiplies zeros and writes the dummy strip)
+            double2 pv[kEC][3];
+#pragma unroll
+            for (int k = 0; k < kEC; ++k) {
+                const double2 *pp2 = reinterpret_cast<const double2 *>(p_lds + colo[k]);
+                pv[k][0] = pp2[0]; pv[k][1] = pp2[1]; pv[k][2] = pp2[2];
+            }
+#pragma unroll
+            for (int k = 0; k < kEC; ++k) {
+                double y[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+                    y[a] = Bo[k][a * 6] * pv[k][0].x + Bo[k][a * 6 + 1] * pv[k][0].y + Bo[k][a * 6 + 2] * pv[k][1].x +
+                           Bo[k][a * 6 + 3] * pv[k][1].y + Bo[k][a * 6 + 4] * pv[k][2].x + Bo[k][a * 6 + 5] * pv[k][2].y;
+                double2 *yo = reinterpret_cast<double2 *>(ypart + yslot[k]);
+                yo[0] = make_double2(y[0], y[1]); yo[1] = make_double2(y[2], y[3]); yo[2] = make_double2(y[4], y[5]);
+            }
+            for (int e = E0 + ln + 64 * kEC; e < E1; e += 64) {       // overflow: blocks straight from L2
+                const RowEnt re = w.row_ent[e];
+                const double *B = w.blocks + (size_t)re.block * 36;
+                const double *pv = p_lds + re.col * 6;
+                for (int a = 0; a < 6; ++a) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) s += (re.transposed ? B[q * 6 + a] : B[a * 6 + q]) * pv[q];
+                    ypart[(size_t)e * 6 + a] = s;
+                }
+            }
+            SEG_STAMP(0);
+            wave_lds_sync();
+            // owner: sum its row's partials in list order; loads issued 8 at a time, adds in order
+            double Ap = 0.0;
+            for (int e = own_e0; e < own_e1; e += kOwnBatch) {
+                double v[kOwnBatch];
+#pragma unroll
+                for (int u = 0; u < kOwnBatch; ++u) v[u] = ypart[(size_t)min(e + u, own_last) * 6 + ba];   // unconditional, clamped
+#pragma unroll
+                for (int u = 0; u < kOwnBatch; ++u) Ap += (e + u < own_e1) ? v[u] : 0.0;
+            }
+            SEG_STAMP(1);
+            {
+                const double ps = wave_sum_dpp(owner ? p_r * Ap : 0.0);
+                if (ln == 0) red0[wv] = ps;
+            }
+            SEG_STAMP(2);
+            __syncthreads();                                  // (1) p.Ap partials visible; all reads of p done
+            SEG_STAMP(3);
+            const double pAp = sum_fixed(red0);
+            if (!(pAp > 0.0) || !isfinite(pAp)) { fail = true; break; }
+            const double alpha = rz / pAp;
+            x_r += alpha * p_r;
+            r_r -= alpha * Ap;
+            z_r = precond(r_r);
+            {
+                const double ps = wave_sum_dpp(owner ? r_r * z_r : 0.0);
+                if (ln == 0) red1[wv] = ps;
+            }
+            SEG_STAMP(4);
+            __syncthreads();                                  // (2) r.z partials visible
+            SEG_STAMP(5);
+            const double rzn = sum_fixed(red1);
+            if (!isfinite(rzn)) { fail = true; break; }
+            if (rzn <= thresh) break;
+            const double beta = rzn / rz;
+            rz = rzn;
+            p_r = z_r + beta * p_r;
+            if (owner) p_lds[row] = p_r;
+            __syncthreads();                                  // (3) new search direction visible
+            SEG_STAMP(6);
+        }
+        if (iters > pp.max_iters) iters = pp.max_iters;
+    }
+    __syncthreads();
+
+    // ---- outputs: increment, pose part of computeScale(), trial poses (VertexSE3Expmap::oplusImpl) ----
+    const double xv = (fail || !owner) ? 0.0 : x_r;
+    if (owner) { w.xp[row] = xv; p_lds[row] = xv; }
+    {
+        const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + w.bp[row]) : 0.0);
+        if (ln == 0) red0[wv] = ps;
+    }
+    __syncthreads();
+    const double scs = sum_fixed(red0);
+    const DevState &S0 = w.st[cur];
+    const DevState &S1 = w.st[cur ^ 1];
+    for (int i = tid; i < w.NP; i += kT) {
+        double T[7], Tn[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) T[k] = S0.pose[7 * i + k];
+        const int h = w.hidx[i];
+        if (h >= 0) {
+            double u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] = p_lds[6 * h + k];
+            se3_oplus(u, T, Tn);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) Tn[k] = T[k];
+        }
+        double R[9];
+        quat_to_R(Tn, R);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) S1.pose[7 * i + k] = Tn[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
+        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
+    }
+    if (tid == 0) {
+        w.scale_part[w.n_pt_blocks] = scs;
+        c->pcg_fail = fail ? 1 : 0;
+        c->pcg_last_iters = iters;
+        c->pcg_total_iters += iters;
+#ifdef MOVBA_CLOCK_STAMP
+        c->dbg_cycles += __builtin_amdgcn_s_memtime() - stamp_c0;
+        c->dbg_ticks += __builtin_amdgcn_s_memrealtime() - stamp_t0;
+        for (int k = 0; k < 8; ++k) c->dbg_seg[k] += seg[k];
+#endif
+    }
+}
+
+size_t pcg_rows_lds_bytes(int nfree, int nrowent)
+{
+    const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
+    return (3 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + 6 * ((size_t)nrowent + 1)) * sizeof(double);
+}
+
+// Deals block rows to the waves so that every wave gets about the same number of gather-list
+// entries (the mat-vec work) and at most 10 block rows (60 owner lanes).
+bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
+{
+    if (nfree <= 0 || nfree > 10 * kNW) return false;
+    const int nrowent = row_ptr[nfree];
+    if (pcg_rows_lds_bytes(nfree, nrowent) > 159 * 1024) return false;
+    int b = 0;
+    pp->wave_row0[0] = 0;
+    for (int wv = 0; wv < kNW; ++wv) {
+        const int waves_left = kNW - wv;
+        const int target = row_ptr[b] + (nrowent - row_ptr[b] + waves_left - 1) / waves_left;
+        int e = b;
+        while (e < nfree && e - b < 10 && (e == b || row_ptr[e + 1] <= target) && (nfree - (e + 1)) >= 0) ++e;
+        // never leave more rows than the remaining waves can take
+        while (nfree - e > 10 * (waves_left - 1)) ++e;
+        b = e;
+        pp->wave_row0[wv + 1] = b;
+    }
+    return pp->wave_row0[kNW] == nfree;
+}
+
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_pcg_rows, dim3(1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp);
+    return hipGetLastError();
+}
+
+hipError_t configure_pcg_rows()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
+}  // namespace movba
