@@ -1,0 +1,134 @@
+// Exercises the Optimizer adapter (Optimizer.cc) against the mock map classes: builds a map from a
+// flattened window file written by tests/test_gpu_adapter.py, calls the reference-signature entry
+// points, and dumps what the map received.  Needs a GPU at run time (no CPU fallback).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "Optimizer.h"
+
+using namespace MOV_SLAM;
+
+template <typename T> static std::vector<T> rd(FILE *f, size_t n)
+{
+    std::vector<T> v(n);
+    if (n && fread(v.data(), sizeof(T), n, f) != n) { std::fprintf(stderr, "short read\n"); std::exit(2); }
+    return v;
+}
+
+static int run_lba(const char *in, const char *out, bool global)
+{
+    FILE *f = fopen(in, "rb");
+    if (!f) return 2;
+    const std::vector<int32_t> hd = rd<int32_t>(f, 4);
+    const int NP = hd[0], P = hd[1], E = hd[2];
+    const std::vector<uint8_t> fixed = rd<uint8_t>(f, NP);
+    const std::vector<double> poses = rd<double>(f, 7 * (size_t)NP), points = rd<double>(f, 3 * (size_t)P);
+    const std::vector<int32_t> ep = rd<int32_t>(f, E), el = rd<int32_t>(f, E);
+    const std::vector<double> obs = rd<double>(f, 2 * (size_t)E);
+    fclose(f);
+
+    Map map;
+    GeometricCamera cam({320.f, 320.f, 320.f, 240.f});
+    std::vector<KeyFrame> kfs(NP);                 // contiguous: pointer order == id order == std::map order
+    std::vector<MapPoint> mps(P);
+    for (int i = 0; i < NP; ++i) {
+        KeyFrame &k = kfs[i];
+        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = &cam;
+        k.mTcw = Sophus::SE3f(Eigen::Quaternionf((float)poses[7 * i + 3], (float)poses[7 * i], (float)poses[7 * i + 1], (float)poses[7 * i + 2]),
+                              Eigen::Vector3f((float)poses[7 * i + 4], (float)poses[7 * i + 5], (float)poses[7 * i + 6]));
+        map.mvKFs.push_back(&k);
+    }
+    for (int l = 0; l < P; ++l) {
+        mps[l].mnId = 5000 + l; mps[l].mpMap = &map;
+        mps[l].mWorldPos = Eigen::Vector3f((float)points[3 * l], (float)points[3 * l + 1], (float)points[3 * l + 2]);
+        map.mvMPs.push_back(&mps[l]);
+    }
+    for (int e = 0; e < E; ++e) {
+        KeyFrame &k = kfs[ep[e]];
+        cv::KeyPoint kp; kp.pt.x = (float)obs[2 * e]; kp.pt.y = (float)obs[2 * e + 1]; kp.octave = 0;
+        const int idx = (int)k.mvKeysUn.size();
+        k.mvKeysUn.push_back(kp); k.mvuRight.push_back(-1.f); k.mvpMapPoints.push_back(&mps[el[e]]);
+        mps[el[e]].mObservations[&k] = std::make_tuple(idx, -1);
+    }
+    // the newest free keyframe is the one LocalMapping passes in; every other free keyframe is covisible
+    KeyFrame *pKF = nullptr;
+    for (int i = NP - 1; i >= 0; --i) if (!fixed[i]) { pKF = &kfs[i]; break; }
+    for (int i = 0; i < NP; ++i) if (!fixed[i] && &kfs[i] != pKF) pKF->mvCovisible.push_back(&kfs[i]);
+    // global BA fixes the init keyframe only; local BA must not see it among the local ones
+    map.mnInitKFid = global ? kfs[0].mnId : 1;
+    map.mpOriginKF = &kfs[0];
+
+    int num_fixedKF = 0, num_OptKF = 0, num_MPs = 0, num_edges = 0;
+    bool stop = false;
+    if (global) Optimizer::GlobalBundleAdjustemnt(&map, 10, &stop, kfs[0].mnId, true);
+    else Optimizer::LocalBundleAdjustment(pKF, &stop, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
+
+    std::vector<int32_t> erased;
+    for (int e = 0; e < E; ++e)
+        if (mps[el[e]].mObservations.find(&kfs[ep[e]]) == mps[el[e]].mObservations.end()) { erased.push_back(ep[e]); erased.push_back(el[e]); }
+    FILE *o = fopen(out, "wb");
+    const int32_t oh[5] = { num_fixedKF, num_OptKF, num_edges, (int32_t)(erased.size() / 2), map.mnChangeIdx };
+    fwrite(oh, sizeof(int32_t), 5, o);
+    for (int i = 0; i < NP; ++i) {
+        const Sophus::SE3f T = kfs[i].GetPose();
+        const float v[7] = { T.unit_quaternion().x(), T.unit_quaternion().y(), T.unit_quaternion().z(), T.unit_quaternion().w(),
+                             T.translation()(0), T.translation()(1), T.translation()(2) };
+        fwrite(v, sizeof(float), 7, o);
+    }
+    for (int l = 0; l < P; ++l) { const Eigen::Vector3f X = mps[l].GetWorldPos(); fwrite(X.v, sizeof(float), 3, o); }
+    fwrite(erased.data(), sizeof(int32_t), erased.size(), o);
+    int nposes = 0, nnorm = 0;
+    for (int i = 0; i < NP; ++i) nposes += kfs[i].nPoseSets;
+    for (int l = 0; l < P; ++l) nnorm += mps[l].nNormalUpdates;
+    const int32_t tail[2] = { nposes, nnorm };
+    fwrite(tail, sizeof(int32_t), 2, o);
+    fclose(o);
+    return 0;
+}
+
+static int run_pose(const char *in, const char *out)
+{
+    FILE *f = fopen(in, "rb");
+    if (!f) return 2;
+    const std::vector<int32_t> hd = rd<int32_t>(f, 2);
+    const int n = hd[0], isLost = hd[1];
+    const std::vector<double> Xw = rd<double>(f, 3 * (size_t)n), obs = rd<double>(f, 2 * (size_t)n), pose0 = rd<double>(f, 7);
+    fclose(f);
+    Map map;
+    GeometricCamera cam({320.f, 320.f, 320.f, 240.f});
+    std::vector<MapPoint> mps(n);
+    Frame fr;
+    fr.N = n + 3; fr.mpCamera = &cam;
+    fr.mvKeys.resize(fr.N); fr.mvpMapPoints.assign(fr.N, nullptr); fr.mvbOutlier.assign(fr.N, false);
+    for (int i = 0; i < n; ++i) {
+        mps[i].mWorldPos = Eigen::Vector3f((float)Xw[3 * i], (float)Xw[3 * i + 1], (float)Xw[3 * i + 2]);
+        fr.mvpMapPoints[i] = &mps[i];
+        fr.mvKeys[i].pt.x = (float)obs[2 * i]; fr.mvKeys[i].pt.y = (float)obs[2 * i + 1];
+    }
+    fr.mTcw = Sophus::SE3f(Eigen::Quaternionf((float)pose0[3], (float)pose0[0], (float)pose0[1], (float)pose0[2]),
+                           Eigen::Vector3f((float)pose0[4], (float)pose0[5], (float)pose0[6]));
+    const int ninl = Optimizer::PoseOptimization(&fr, isLost != 0);
+    FILE *o = fopen(out, "wb");
+    const int32_t oh[1] = { ninl };
+    fwrite(oh, sizeof(int32_t), 1, o);
+    const Sophus::SE3f T = fr.GetPose();
+    const float v[7] = { T.unit_quaternion().x(), T.unit_quaternion().y(), T.unit_quaternion().z(), T.unit_quaternion().w(),
+                         T.translation()(0), T.translation()(1), T.translation()(2) };
+    fwrite(v, sizeof(float), 7, o);
+    std::vector<uint8_t> ob(fr.N);
+    for (int i = 0; i < fr.N; ++i) ob[i] = fr.mvbOutlier[i] ? 1 : 0;
+    fwrite(ob.data(), 1, ob.size(), o);
+    fclose(o);
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 4) { std::fprintf(stderr, "usage: adapter_test lba|gba|pose in.bin out.bin\n"); return 2; }
+    if (!std::strcmp(argv[1], "lba")) return run_lba(argv[2], argv[3], false);
+    if (!std::strcmp(argv[1], "gba")) return run_lba(argv[2], argv[3], true);
+    if (!std::strcmp(argv[1], "pose")) return run_pose(argv[2], argv[3]);
+    return 2;
+}

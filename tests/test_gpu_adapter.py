@@ -1,0 +1,148 @@
+"""The C++ Optimizer adapter (mov-slam_amd/host/Optimizer.cc: the reference's Optimizer.h call
+surface over mock map classes) end to end on the GPU: LocalBundleAdjustment, GlobalBundleAdjustemnt
+and PoseOptimization must leave in the map what the oracle computes from the same inputs, after the
+float32 casts the reference applies on write-back (src/Optimizer.cc:827, 836)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, quat_angle
+from movba import synth
+
+pytestmark = pytest.mark.gpu
+
+HOST = os.path.join(ROOT, "mov-slam_amd", "host")
+BIN = os.path.join(HOST, "adapter_test")
+
+
+@pytest.fixture(scope="module")
+def adapter_bin(built_lib):
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    return BIN
+
+
+def _f32_pose(p):
+    """what KeyFrame::GetPose() holds: float quaternion normalised in float (Sophus), float translation."""
+    p = np.asarray(p, np.float32).copy()
+    q = p[..., :4]
+    n = np.sqrt(((q[..., 0] * q[..., 0] + q[..., 1] * q[..., 1]) + q[..., 2] * q[..., 2]) + q[..., 3] * q[..., 3])
+    p[..., :4] = q / n[..., None]
+    return p.astype(np.float64)
+
+
+def _write_window(path, w):
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", w.n_poses, w.n_points, w.n_edges, 0))
+        f.write(np.ascontiguousarray(w.pose_fixed, np.uint8).tobytes())
+        f.write(np.ascontiguousarray(w.poses, np.float64).tobytes())
+        f.write(np.ascontiguousarray(w.points, np.float64).tobytes())
+        f.write(np.ascontiguousarray(w.edge_pose, np.int32).tobytes())
+        f.write(np.ascontiguousarray(w.edge_point, np.int32).tobytes())
+        f.write(np.ascontiguousarray(w.obs, np.float64).tobytes())
+
+
+def _read_out(path, w):
+    b = open(path, "rb").read()
+    hd = struct.unpack_from("5i", b, 0); off = 20
+    poses = np.frombuffer(b, np.float32, 7 * w.n_poses, off).reshape(-1, 7); off += 28 * w.n_poses
+    points = np.frombuffer(b, np.float32, 3 * w.n_points, off).reshape(-1, 3); off += 12 * w.n_points
+    erased = np.frombuffer(b, np.int32, 2 * hd[3], off).reshape(-1, 2); off += 8 * hd[3]
+    tail = struct.unpack_from("2i", b, off)
+    return dict(num_fixedKF=hd[0], num_OptKF=hd[1], num_edges=hd[2], n_erased=hd[3], change_idx=hd[4],
+                poses=poses, points=points, erased=erased, n_pose_sets=tail[0], n_normal_updates=tail[1])
+
+
+def _check_map(out, o, w, moved):
+    assert quat_angle(out["poses"][:, :4].astype(np.float64), _f32_pose(o["poses"])[:, :4]).max() < 2e-6
+    np.testing.assert_allclose(out["poses"][:, 4:], o["poses"][:, 4:].astype(np.float32), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(out["points"], o["points"].astype(np.float32), rtol=2e-6, atol=2e-6)
+    assert out["n_pose_sets"] == moved and out["n_normal_updates"] == w.n_points
+
+
+def _local_subwindow(w):
+    """What Optimizer::LocalBundleAdjustment selects (Optimizer.cc:464-523): the map points seen by at least one
+    local (free) keyframe, and the fixed keyframes that observe those points."""
+    free = w.pose_fixed == 0
+    local_pt = np.zeros(w.n_points, bool); local_pt[w.edge_point[free[w.edge_pose]]] = True
+    keep_e = local_pt[w.edge_point]
+    used_pose = free.copy(); used_pose[w.edge_pose[keep_e]] = True
+    pmap = -np.ones(w.n_poses, int); pmap[used_pose] = np.arange(used_pose.sum())
+    lmap = -np.ones(w.n_points, int); lmap[local_pt] = np.arange(local_pt.sum())
+    sub = synth.Window(poses=w.poses[used_pose], pose_fixed=w.pose_fixed[used_pose], points=w.points[local_pt],
+                       edge_pose=pmap[w.edge_pose[keep_e]].astype(np.int32), edge_point=lmap[w.edge_point[keep_e]].astype(np.int32),
+                       obs=w.obs[keep_e], inv_sigma2=w.inv_sigma2[keep_e], cam=w.cam, huber_delta=w.huber_delta,
+                       chi2_gate=w.chi2_gate, max_iters=w.max_iters)
+    return sub, used_pose, local_pt, keep_e
+
+
+@pytest.mark.parametrize("name", ["small", "cfg2"])
+def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tmp_path, name):
+    w = synth.cfg(name)
+    w.poses = _f32_pose(w.poses)                     # the doubles the adapter derives from the float map
+    fin, fout = str(tmp_path / "w.bin"), str(tmp_path / "o.bin")
+    _write_window(fin, w)
+    subprocess.check_call([adapter_bin, "lba", fin, fout])
+    out = _read_out(fout, w)
+    sub, used_pose, local_pt, keep_e = _local_subwindow(w)
+    o = oracle_mod.solve(sub)
+    K = w.n_free
+    assert (out["num_fixedKF"], out["num_OptKF"], out["num_edges"]) == (int(used_pose.sum()) - K, K, sub.n_edges)
+    assert out["change_idx"] == 1                     # IncreaseChangeIndex (Optimizer.cc:840)
+    # expected map content: optimised values for the window, everything else untouched
+    exp_poses = w.poses.copy(); exp_poses[used_pose] = o["poses"]
+    exp_points = w.points.copy(); exp_points[local_pt] = o["points"]
+    assert quat_angle(out["poses"][:, :4].astype(np.float64), _f32_pose(exp_poses)[:, :4]).max() < 2e-6
+    np.testing.assert_allclose(out["poses"][:, 4:], exp_poses[:, 4:].astype(np.float32), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(out["points"], exp_points.astype(np.float32), rtol=2e-6, atol=2e-6)
+    assert out["n_pose_sets"] == K                    # SetPose on the local keyframes only (Optimizer.cc:822-829)
+    assert out["n_normal_updates"] == int(local_pt.sum())
+    # erased (KeyFrame, MapPoint) pairs == the oracle's outliers in edge order, up to the chi2 guard band
+    ep, el = w.edge_pose[keep_e], w.edge_point[keep_e]
+    want = set(map(tuple, np.stack([ep, el], 1)[o["outlier"] == 1]))
+    got = set(map(tuple, out["erased"]))
+    guard = {(int(a), int(b)) for a, b, c in zip(ep, el, o["chi2"]) if abs(c - 5.0) < 1e-4}
+    assert (want ^ got) <= guard
+    assert out["n_erased"] == len(got)
+
+
+def test_global_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tmp_path):
+    """Tracking::CreateInitialMapMonocular -> GlobalBundleAdjustemnt (Tracking.cc:688): only the init keyframe
+    is fixed, nothing is erased, results are written directly when nLoopKF is the origin keyframe."""
+    w = synth.cfg("small")
+    w.poses = _f32_pose(w.poses)
+    fin, fout = str(tmp_path / "w.bin"), str(tmp_path / "o.bin")
+    _write_window(fin, w)
+    subprocess.check_call([adapter_bin, "gba", fin, fout])
+    out = _read_out(fout, w)
+    wg = synth.cfg("small"); wg.poses = w.poses
+    wg.pose_fixed = np.zeros_like(w.pose_fixed); wg.pose_fixed[0] = 1
+    o = oracle_mod.solve(wg, max_iters=10)
+    _check_map(out, o, w, moved=w.n_poses)
+    assert out["n_erased"] == 0 and out["change_idx"] == 0
+
+
+@pytest.mark.parametrize("is_lost", [0, 1])
+def test_pose_optimization_through_the_adapter(adapter_bin, oracle_mod, tmp_path, is_lost):
+    f = synth.make_frame()
+    pose0 = _f32_pose(f["pose0"])
+    fin, fout = str(tmp_path / "p.bin"), str(tmp_path / "po.bin")
+    n = len(f["Xw"])
+    with open(fin, "wb") as fh:
+        fh.write(struct.pack("2i", n, is_lost))
+        fh.write(np.ascontiguousarray(f["Xw"], np.float64).tobytes())
+        fh.write(np.ascontiguousarray(f["obs"], np.float64).tobytes())
+        fh.write(np.ascontiguousarray(pose0, np.float64).tobytes())
+    subprocess.check_call([adapter_bin, "pose", fin, fout])
+    b = open(fout, "rb").read()
+    ninl = struct.unpack_from("i", b, 0)[0]
+    pose = np.frombuffer(b, np.float32, 7, 4)
+    outl = np.frombuffer(b, np.uint8, n + 3, 32)
+    rep = 8.0 if is_lost else 5.0                    # reprojectErrorLost / reprojectionError defaults (Optimizer.h:55)
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], pose0, f["cam"], rep, rep * rep, rounds=4, its=10)
+    assert ninl == o["n_inliers"]
+    assert np.abs(pose.astype(np.float64) - _f32_pose(o["pose"])).max() < 2e-6
+    assert np.array_equal(outl[:n], o["outlier"]) and (outl[n:] == 1).all()   # slots without a MapPoint stay "outlier"
