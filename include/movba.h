@@ -145,6 +145,10 @@ typedef struct {
     int32_t n_items;            /* schur work items (pair chunks)                             */
     int32_t max_degree;         /* max edges per point                                        */
     int32_t already_grouped;    /* 1 if caller edges were already grouped by point            */
+    int32_t pcg_on_chip;        /* 1: reduced matrix stays in VGPRs during the PCG (k_pcg_rows) */
+    int32_t pcg_overflow;       /* 1: some gather-list tails are read from an L2 copy          */
+    int32_t pcg_max_wave_entries; /* largest number of gather entries dealt to one wave       */
+    int32_t n_row_entries;      /* gather-list entries incl. padding                          */
 } movba_structure_info;
 int  movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info,
                            int32_t *edge_perm /* E or NULL */, int32_t *free_index /* n_poses or NULL */);

@@ -8,6 +8,7 @@
 // the g2o objects set up at :532-545 and driven at :754-755, and the gate at :757-775.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -230,6 +231,15 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
     if (rc < 0) return rc;
     info->n_free = s.nfree; info->n_pairs = s.npairs; info->n_entries = s.nentries; info->n_items = s.nitems;
     info->max_degree = s.max_degree; info->already_grouped = s.already_grouped ? 1 : 0;
+    info->pcg_on_chip = 0; info->pcg_overflow = 0; info->pcg_max_wave_entries = 0; info->n_row_entries = (int32_t)s.row_ent.size();
+    if (rc == MOVBA_OK && s.nfree > 0) {
+        PcgParams pp{};
+        if (pcg_rows_supported(s.nfree, s.row_ptr.data(), &pp)) {
+            info->pcg_on_chip = 1; info->pcg_overflow = pp.overflow;
+            for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv)
+                info->pcg_max_wave_entries = std::max(info->pcg_max_wave_entries, s.row_ptr[pp.wave_row0[wv + 1]] - s.row_ptr[pp.wave_row0[wv]]);
+        }
+    }
     if (edge_perm) std::memcpy(edge_perm, s.perm.data(), sizeof(int32_t) * s.perm.size());
     if (free_index) std::memcpy(free_index, s.hidx.data(), sizeof(int32_t) * s.hidx.size());
     return rc;

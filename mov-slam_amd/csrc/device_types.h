@@ -87,6 +87,7 @@ struct PcgParams {
     double rel_tol;
     int32_t max_iters;
     int32_t wave_row0[17];      // k_pcg_rows: wave wv owns block rows [wave_row0[wv], wave_row0[wv+1])
+    int32_t overflow;           // k_pcg_rows: some wave has more gather entries than fit in VGPRs
 };
 
 }  // namespace movba

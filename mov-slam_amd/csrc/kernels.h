@@ -7,7 +7,6 @@
 namespace movba {
 
 constexpr int kPcgRowsThreads = 512;    // 8 waves: 2 per SIMD, 256 VGPRs per lane
-constexpr int kPcgRowsEC = 2;           // oriented 6x6 blocks per lane held in VGPRs
 
 hipError_t configure_kernels(int unused);
 hipError_t configure_pcg_rows();

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp)
                 double s = 0.0;
                 for (int e = w.row_ptr[i] + sub; e < w.row_ptr[i + 1]; e += 4) {
                     const RowEnt re = w.row_ent[e];
+                    if (re.block < 0) continue;                     // padding entry
                     const double *B = w.blocks + (size_t)re.block * 36;
                     const double *pv = p + 6 * re.col;
                     if (!re.transposed) {

@@ -5,14 +5,15 @@
 // /root/reference/src/Optimizer.cc:535 by the damped block-Jacobi PCG BASELINE.json's
 // north_star asks for.  S = Hpp + lambda I - sum_l B_il Dinv_l B_jl^T is at most a few
 // hundred KB: too big for one lane, too small to be worth a grid (a grid barrier costs more
-// than a whole CG iteration here), so the design goal is latency per CG iteration:
+// than two whole CG iterations here), so the design goal is latency per CG iteration:
 //   * a wave owns a run of block rows; the 6x6 blocks of those rows (both triangles, read
-//     through the per-row gather lists) are dealt to the wave's lanes and stay in VGPRs for
-//     the whole solve (kEC oriented blocks per lane); only very large / dense windows spill
-//     the tail of a list to L2 reads;
-//   * mat-vec = one 6x6 * 6x1 product per held block (p read once per block from LDS), the
-//     six partial sums parked in a wave-private LDS strip and summed by the row's owner lane
-//     in list order: no workgroup barrier inside the mat-vec;
+//     through the per-row gather lists) are dealt to the wave's lanes in PAIRS of the same row
+//     and stay in VGPRs for the whole solve; they are assembled straight from the schur
+//     work-item partials, S is never written to memory (only dense / very large windows
+//     spill the tail of a list to an L2 copy);
+//   * mat-vec = per lane y = B0 p_c0 + B1 p_c1 (p read once per block from LDS), the six sums
+//     parked in a wave-private LDS strip and added up by the row's owner lane in list order:
+//     no workgroup barrier inside the mat-vec;
 //   * the 6 rows of a block live in one wave, so the block-Jacobi preconditioner needs only a
 //     wave-local LDS exchange;
 //   * per CG iteration: 3 workgroup barriers, 2 DPP wave reductions.
@@ -35,8 +36,7 @@ namespace {
 
 constexpr int kT = kPcgRowsThreads;     // 512 = 8 waves, 2 per SIMD -> 256 VGPRs per lane
 constexpr int kNW = kT / 64;
-constexpr int kEC = kPcgRowsEC;         // oriented 6x6 blocks held in VGPRs per lane
-constexpr int kOwnBatch = 10;           // partial sums an owner lane loads per LDS round trip
+constexpr int kOwnBatch = 10;           // pair sums an owner lane loads per LDS round trip
 
 __device__ __forceinline__ double sum_fixed(const double *red)
 {
@@ -44,6 +44,22 @@ __device__ __forceinline__ double sum_fixed(const double *red)
 #pragma unroll
     for (int k = 1; k < kNW; ++k) s += red[k];
     return s;
+}
+
+// element (r,c) of the damped reduced-matrix block `pr` (upper-triangle pair id), summed from the
+// schur work-item partials in item order
+__device__ __forceinline__ double s_block_elem(const DevWindow &w, int pr, int i0, int i1, int r, int c, double lambda, int nf)
+{
+    double s = 0.0;
+    for (int itx = i0; itx < i1; ++itx) s += w.part[(size_t)itx * kPartStride + r * 6 + c];
+    double v = -s;
+    if (pr < nf) {
+        const int u = r <= c ? ut6(r, c) : ut6(c, r);
+        double hpp = 0.0;
+        for (int itx = i0; itx < i1; ++itx) hpp += w.part[(size_t)itx * kPartStride + 42 + u];
+        v += hpp + (r == c ? lambda : 0.0);
+    }
+    return v;
 }
 
 }  // namespace
@@ -60,53 +76,109 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const double lambda = c->lambda;
+    const int npad = (n + 1) & ~1;
 
-    // LDS carve (16-byte aligned pieces)
-    double *p_lds = sm;                                   // n (+pad)
-    double *minv = p_lds + ((n + 1) & ~1);                // nf x 36 (setup only)
+    // LDS carve (16-byte aligned pieces, no static LDS in front of it)
+    double *p_lds = sm;                                   // n
+    double *r_lds = p_lds + npad;                         // n: residual, exchanged inside a wave only
+    double *minv = r_lds + npad;                          // nf x 36
     double *red0 = minv + 36 * nf;                        // kNW
     double *red1 = red0 + kNW;                            // kNW
-    double *bS = red1 + kNW;                              // n (+pad): right-hand side (setup only)
-    double *r_lds = bS + ((n + 1) & ~1);                  // n (+pad): residual, exchanged inside a wave only
-    int &s_fail = *reinterpret_cast<int *>(r_lds + ((n + 1) & ~1));   // no static LDS: keeps the dynamic base 16-B aligned
-    double *ypart = r_lds + ((n + 1) & ~1) + 2;           // 6 doubles per gather-list entry, wave-private strips
+    int &s_fail = *reinterpret_cast<int *>(red1 + kNW);
+    double *ypart = red1 + kNW + 2;                       // 6 doubles per gather-list PAIR (+ one dummy strip)
     if (tid == 0) s_fail = 0;
 
-    // ---- assemble the upper blocks of S (to L2) and the right-hand side: fixed-order sums of the item partials ----
-    for (int idx = tid; idx < w.npairs * 36; idx += kT) {
-        const int pr = idx / 36, k = idx - pr * 36;
-        double s = 0.0;
-        for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
-            s += w.part[(size_t)itx * kPartStride + k];
-        double v = -s;
-        if (pr < nf) {
-            const int a = k / 6, b = k - a * 6;
-            const int u = a <= b ? ut6(a, b) : ut6(b, a);
-            double hpp = 0.0;
-            for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
-                hpp += w.part[(size_t)itx * kPartStride + 42 + u];
-            v += hpp + (a == b ? lambda : 0.0);
+    // ---- ownership: wave wv owns block rows [b0, b1); lane ln < 6*(b1-b0) owns scalar row b0*6 + ln ----
+    const int b0 = pp.wave_row0[wv], b1 = pp.wave_row0[wv + 1];
+    const int row = b0 * 6 + ln;
+    const bool owner = ln < 6 * (b1 - b0);
+    const int bi = owner ? row / 6 : 0, ba = owner ? row - bi * 6 : 0;
+    const int nrowent = w.row_ptr[nf];
+    const int P0 = w.row_ptr[b0] >> 1, P1 = w.row_ptr[b1] >> 1;      // the wave's entry pairs
+    const int own_p0 = owner ? (w.row_ptr[bi] >> 1) : 0, own_p1 = owner ? (w.row_ptr[bi + 1] >> 1) : 0;
+    const int own_last = max(own_p1 - 1, 0);
+
+    // ---- overflow only: materialise S in L2 for the list tails that do not fit in VGPRs ----
+    if (pp.overflow) {
+        for (int idx = tid; idx < w.npairs * 36; idx += kT) {
+            const int pr = idx / 36, k = idx - pr * 36;
+            const double v = s_block_elem(w, pr, w.pair_item_start[pr], w.pair_item_start[pr + 1], k / 6, k % 6, lambda, nf);
+            w.blocks[idx] = v;
+            if (pr < nf) minv[idx] = v;                     // diagonal blocks: input of the preconditioner
         }
-        w.blocks[idx] = v;
+        __syncthreads();
     }
-    for (int idx = tid; idx < n; idx += kT) {
-        const int i = idx / 6, a = idx - i * 6;
-        double cc = 0.0, bb = 0.0;
-        for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx) {
-            cc += w.part[(size_t)itx * kPartStride + 36 + a];
-            bb += w.part[(size_t)itx * kPartStride + 63 + a];
+
+    // ---- this lane's pair of oriented blocks, assembled straight from the partials into VGPRs ----
+    double Bo[2][36];
+    int colo[2];
+    const int my_pair = P0 + ln;
+    const bool have_pair = my_pair < P1;
+    const int yslot = (have_pair ? my_pair : (nrowent >> 1)) * 6;     // lanes without a pair write the dummy strip
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        colo[k] = 0;
+        // raw = sum over the pair's work items of the 6x6 partial (wide, independent loads), then
+        // S_block = [Hpp + lambda I] - raw, oriented for this entry
+        double raw[36];
+#pragma unroll
+        for (int q = 0; q < 36; ++q) raw[q] = 0.0;
+        bool valid = false, tr = false, diag = false;
+        if (have_pair) {
+            const RowEnt re = w.row_ent[2 * my_pair + k];
+            if (re.block >= 0) {
+                valid = true; tr = re.transposed != 0; diag = re.block < nf;
+                colo[k] = re.col * 6;
+                const int i0 = w.pair_item_start[re.block], i1 = w.pair_item_start[re.block + 1];
+                for (int itx = i0; itx < i1; ++itx) {
+                    const double2 *src = reinterpret_cast<const double2 *>(w.part + (size_t)itx * kPartStride);
+#pragma unroll
+                    for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] += v.x; raw[2 * q + 1] += v.y; }
+                }
+#pragma unroll
+                for (int q = 0; q < 36; ++q) raw[q] = -raw[q];
+                if (diag) {
+                    double hpp[21];
+#pragma unroll
+                    for (int q = 0; q < 21; ++q) hpp[q] = 0.0;
+                    for (int itx = i0; itx < i1; ++itx) {
+                        const double *src = w.part + (size_t)itx * kPartStride + 42;
+#pragma unroll
+                        for (int q = 0; q < 21; ++q) hpp[q] += src[q];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) raw[a * 6 + q] += hpp[a <= q ? ut6(a, q) : ut6(q, a)] + (a == q ? lambda : 0.0);
+#pragma unroll
+                    for (int q = 0; q < 36; ++q) minv[re.block * 36 + q] = raw[q];       // S_ii: input of the preconditioner
+                }
+            }
         }
-        w.bp[idx] = bb;
-        bS[idx] = bb - cc;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = valid ? (tr ? raw[q * 6 + a] : raw[a * 6 + q]) : 0.0;
+    }
+    // right-hand side b_S = b_p - sum B Dinv b_l and b_p itself (owner lanes)
+    double r_r = 0.0, bp_r = 0.0;
+    if (owner) {
+        double cc = 0.0, bb = 0.0;
+        for (int itx = w.pair_item_start[bi]; itx < w.pair_item_start[bi + 1]; ++itx) {
+            cc += w.part[(size_t)itx * kPartStride + 36 + ba];
+            bb += w.part[(size_t)itx * kPartStride + 63 + ba];
+        }
+        bp_r = bb;
+        r_r = bb - cc;
+        w.bp[row] = bb;
     }
     __syncthreads();
 
-    // ---- block-Jacobi preconditioner: inverse of each 6x6 diagonal block by Cholesky ----
+    // ---- block-Jacobi preconditioner: invert each 6x6 diagonal block in place (Cholesky) ----
     for (int i = tid; i < nf; i += kT) {
         double L[36], Li[36];
-        const double *B = w.blocks + (size_t)i * 36;
 #pragma unroll
-        for (int k = 0; k < 36; ++k) L[k] = B[k];
+        for (int k = 0; k < 36; ++k) L[k] = minv[i * 36 + k];
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -127,12 +199,12 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
 #pragma unroll
         for (int col = 0; col < 6; ++col) {
 #pragma unroll
-            for (int row = 0; row < 6; ++row) {
-                if (row < col) { Li[row * 6 + col] = 0.0; continue; }
-                double s = (row == col) ? 1.0 : 0.0;
+            for (int rw = 0; rw < 6; ++rw) {
+                if (rw < col) { Li[rw * 6 + col] = 0.0; continue; }
+                double s = (rw == col) ? 1.0 : 0.0;
 #pragma unroll
-                for (int k = col; k < row; ++k) s -= L[row * 6 + k] * Li[k * 6 + col];
-                Li[row * 6 + col] = s / L[row * 6 + row];
+                for (int k = col; k < rw; ++k) s -= L[rw * 6 + k] * Li[k * 6 + col];
+                Li[rw * 6 + col] = s / L[rw * 6 + rw];
             }
         }
 #pragma unroll
@@ -148,39 +220,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     }
     __syncthreads();
 
-    // ---- ownership: wave wv owns block rows [b0, b1); lane lr < 6*(b1-b0) owns scalar row b0*6 + lr ----
-    const int b0 = pp.wave_row0[wv], b1 = pp.wave_row0[wv + 1];
-    const int row = b0 * 6 + ln;
-    const bool owner = ln < 6 * (b1 - b0);
-    const int bi = owner ? row / 6 : 0, ba = owner ? row - bi * 6 : 0;
-    const int own_e0 = owner ? w.row_ptr[bi] : 0, own_e1 = owner ? w.row_ptr[bi + 1] : 0;
-    const int own_last = max(own_e1 - 1, 0);
-    const int nrowent = w.row_ptr[nf];
-    // the wave's gather-list entries (block row, block column) are dealt to its lanes round-robin;
-    // each lane keeps up to kEC oriented 6x6 blocks in VGPRs for the whole solve
-    const int E0 = w.row_ptr[b0], E1 = w.row_ptr[b1];
-    double Bo[kEC][36];
-    int colo[kEC], yslot[kEC];
-#pragma unroll
-    for (int k = 0; k < kEC; ++k) {
-        const int e = E0 + ln + 64 * k;
-        colo[k] = 0;
-        yslot[k] = nrowent * 6;             // dummy strip behind the last entry: lanes without a k-th block write there
-#pragma unroll
-        for (int q = 0; q < 36; ++q) Bo[k][q] = 0.0;
-        if (e < E1) {
-            const RowEnt re = w.row_ent[e];
-            const double *B = w.blocks + (size_t)re.block * 36;
-            colo[k] = re.col * 6;
-            yslot[k] = e * 6;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = re.transposed ? B[q * 6 + a] : B[a * 6 + q];
-        }
-    }
-    double x_r = 0.0, r_r = 0.0, z_r = 0.0, p_r = 0.0;
-    if (owner) r_r = bS[row];
+    double x_r = 0.0, z_r = 0.0, p_r = 0.0;
     // z = Minv r: a block's six rows sit in one wave, so its residuals are exchanged through LDS
     // without a workgroup barrier (LDS operations of one wave execute in order)
     const double2 *mrow = reinterpret_cast<const double2 *>(minv + (owner ? bi * 36 + ba * 6 : 0));
@@ -218,45 +258,45 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     if (!fail && rz0 > 0.0) {
         for (iters = 1; iters <= pp.max_iters; ++iters) {
             SEG_STAMP(7);
-            // ---- per entry: y = Bo * p_col, parked in the wave's private part of ypart ----
-            // (branch-free: a lane without a k-th block multiplies zeros and writes the dummy strip)
-            double2 pv[kEC][3];
-#pragma unroll
-            for (int k = 0; k < kEC; ++k) {
-                const double2 *pp2 = reinterpret_cast<const double2 *>(p_lds + colo[k]);
-                pv[k][0] = pp2[0]; pv[k][1] = pp2[1]; pv[k][2] = pp2[2];
-            }
-#pragma unroll
-            for (int k = 0; k < kEC; ++k) {
+            // ---- y = B0 p_c0 + B1 p_c1 for this lane's pair, parked in the wave's strip of ypart ----
+            // (branch-free: a lane without a pair multiplies zeros and writes the dummy strip)
+            {
+                const double2 *pa = reinterpret_cast<const double2 *>(p_lds + colo[0]);
+                const double2 *pb = reinterpret_cast<const double2 *>(p_lds + colo[1]);
+                const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], c0 = pb[0], c1 = pb[1], c2 = pb[2];
                 double y[6];
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
-                    y[a] = Bo[k][a * 6] * pv[k][0].x + Bo[k][a * 6 + 1] * pv[k][0].y + Bo[k][a * 6 + 2] * pv[k][1].x +
-                           Bo[k][a * 6 + 3] * pv[k][1].y + Bo[k][a * 6 + 4] * pv[k][2].x + Bo[k][a * 6 + 5] * pv[k][2].y;
-                double2 *yo = reinterpret_cast<double2 *>(ypart + yslot[k]);
+                    y[a] = Bo[0][a * 6] * a0.x + Bo[0][a * 6 + 1] * a0.y + Bo[0][a * 6 + 2] * a1.x + Bo[0][a * 6 + 3] * a1.y +
+                           Bo[0][a * 6 + 4] * a2.x + Bo[0][a * 6 + 5] * a2.y +
+                           Bo[1][a * 6] * c0.x + Bo[1][a * 6 + 1] * c0.y + Bo[1][a * 6 + 2] * c1.x + Bo[1][a * 6 + 3] * c1.y +
+                           Bo[1][a * 6 + 4] * c2.x + Bo[1][a * 6 + 5] * c2.y;
+                double2 *yo = reinterpret_cast<double2 *>(ypart + yslot);
                 yo[0] = make_double2(y[0], y[1]); yo[1] = make_double2(y[2], y[3]); yo[2] = make_double2(y[4], y[5]);
             }
-            for (int e = E0 + ln + 64 * kEC; e < E1; e += 64) {       // overflow: blocks straight from L2
-                const RowEnt re = w.row_ent[e];
-                const double *B = w.blocks + (size_t)re.block * 36;
-                const double *pv = p_lds + re.col * 6;
-                for (int a = 0; a < 6; ++a) {
-                    double s = 0.0;
+            for (int pq = P0 + ln + 64; pq < P1; pq += 64) {          // overflow pairs: blocks from the L2 copy
+                double y[6] = { 0, 0, 0, 0, 0, 0 };
+                for (int k = 0; k < 2; ++k) {
+                    const RowEnt re = w.row_ent[2 * pq + k];
+                    if (re.block < 0) continue;
+                    const double *B = w.blocks + (size_t)re.block * 36;
+                    const double *pv = p_lds + re.col * 6;
+                    for (int a = 0; a < 6; ++a)
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) s += (re.transposed ? B[q * 6 + a] : B[a * 6 + q]) * pv[q];
-                    ypart[(size_t)e * 6 + a] = s;
+                        for (int q = 0; q < 6; ++q) y[a] += (re.transposed ? B[q * 6 + a] : B[a * 6 + q]) * pv[q];
                 }
+                for (int a = 0; a < 6; ++a) ypart[pq * 6 + a] = y[a];
             }
             SEG_STAMP(0);
             wave_lds_sync();
-            // owner: sum its row's partials in list order; loads issued 8 at a time, adds in order
+            // owner: add up its row's pair sums in list order; loads issued together, adds in order
             double Ap = 0.0;
-            for (int e = own_e0; e < own_e1; e += kOwnBatch) {
+            for (int e = own_p0; e < own_p1; e += kOwnBatch) {
                 double v[kOwnBatch];
 #pragma unroll
-                for (int u = 0; u < kOwnBatch; ++u) v[u] = ypart[(size_t)min(e + u, own_last) * 6 + ba];   // unconditional, clamped
+                for (int u = 0; u < kOwnBatch; ++u) v[u] = ypart[min(e + u, own_last) * 6 + ba];   // unconditional, clamped
 #pragma unroll
-                for (int u = 0; u < kOwnBatch; ++u) Ap += (e + u < own_e1) ? v[u] : 0.0;
+                for (int u = 0; u < kOwnBatch; ++u) Ap += (e + u < own_p1) ? v[u] : 0.0;
             }
             SEG_STAMP(1);
             {
@@ -297,7 +337,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     const double xv = (fail || !owner) ? 0.0 : x_r;
     if (owner) { w.xp[row] = xv; p_lds[row] = xv; }
     {
-        const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + w.bp[row]) : 0.0);
+        const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + bp_r) : 0.0);
         if (ln == 0) red0[wv] = ps;
     }
     __syncthreads();
@@ -342,29 +382,40 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (3 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + 6 * ((size_t)nrowent + 1)) * sizeof(double);
+    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + 6 * ((size_t)nrowent / 2 + 1)) * sizeof(double);
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list
-// entries (the mat-vec work) and at most 10 block rows (60 owner lanes).
+// entries (the mat-vec work) and at most 10 block rows (60 owner lanes).  A wave holds 64 entry
+// pairs in VGPRs; anything beyond that is flagged as overflow (read from an L2 copy of S).
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
 {
     if (nfree <= 0 || nfree > 10 * kNW) return false;
     const int nrowent = row_ptr[nfree];
     if (pcg_rows_lds_bytes(nfree, nrowent) > 159 * 1024) return false;
-    int b = 0;
-    pp->wave_row0[0] = 0;
-    for (int wv = 0; wv < kNW; ++wv) {
-        const int waves_left = kNW - wv;
-        const int target = row_ptr[b] + (nrowent - row_ptr[b] + waves_left - 1) / waves_left;
-        int e = b;
-        while (e < nfree && e - b < 10 && (e == b || row_ptr[e + 1] <= target) && (nfree - (e + 1)) >= 0) ++e;
-        // never leave more rows than the remaining waves can take
-        while (nfree - e > 10 * (waves_left - 1)) ++e;
-        b = e;
-        pp->wave_row0[wv + 1] = b;
+    // smallest per-wave entry budget for which a greedy fill (<= 10 rows per wave) needs <= kNW waves
+    auto fill = [&](int cap, int32_t *out) {
+        int b = 0, wv = 0;
+        for (; wv < kNW && b < nfree; ++wv) {
+            int e = b + 1;                                      // a wave always takes at least one row
+            while (e < nfree && e - b < 10 && row_ptr[e + 1] - row_ptr[b] <= cap) ++e;
+            if (out) out[wv + 1] = e;
+            b = e;
+        }
+        if (out) for (; wv < kNW; ++wv) out[wv + 1] = nfree;
+        return b == nfree;
+    };
+    int lo = 1, hi = nrowent > 1 ? nrowent : 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (fill(mid, nullptr)) hi = mid; else lo = mid + 1;
     }
-    return pp->wave_row0[kNW] == nfree;
+    pp->wave_row0[0] = 0;
+    if (!fill(lo, pp->wave_row0)) return false;
+    pp->overflow = 0;
+    for (int wv = 0; wv < kNW; ++wv)
+        if (row_ptr[pp->wave_row0[wv + 1]] - row_ptr[pp->wave_row0[wv]] > 128) pp->overflow = 1;
+    return true;
 }
 
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, hipStream_t s)

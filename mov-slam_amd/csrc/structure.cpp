@@ -111,6 +111,7 @@ int build_structure(const movba_lba_desc& d, Structure& s)
     s.row_ptr.assign(nf + 1, 0);
     for (int i = 0; i < nf; ++i) {
         std::sort(rows[i].begin(), rows[i].end(), [](const RowEnt& a, const RowEnt& b) { return a.col < b.col; });
+        if (rows[i].size() & 1) rows[i].push_back(RowEnt{ -1, 0, 0, 0 });      // lists are consumed in pairs; -1 = zero block
         s.row_ptr[i + 1] = s.row_ptr[i] + (int32_t)rows[i].size();
         s.row_ent.insert(s.row_ent.end(), rows[i].begin(), rows[i].end());
     }

@@ -69,6 +69,23 @@ def test_baseline_configs_full_size(solver, oracle_mod, name):
     assert np.abs(np.linalg.norm(r["poses"][:, :4], axis=1) - 1).max() < 1e-14 and (r["poses"][:, 3] >= 0).all()
 
 
+def test_dense_covisibility_window_spills_list_tails_to_l2(solver, oracle_mod, built_lib):
+    """Long tracks (10-30 keyframes per point): the reduced matrix is nearly dense, the gather lists
+    exceed what one wave keeps in VGPRs and their tails are read from the L2 copy of S."""
+    w = synth.make_window(40, 4, 3000, seed=5, run_lo=10, run_hi=30)
+    plan = built_lib.structure_probe(w)
+    assert plan["pcg_on_chip"] and plan["pcg_overflow"] and plan["max_degree"] >= 25
+    check_against(solver.solve(w), oracle_mod.solve(w), w)
+
+
+def test_large_window_takes_the_generic_pcg(solver, oracle_mod, built_lib):
+    """More free keyframes than the on-chip PCG's 8 waves x 10 block rows: generic kernel, S in L2."""
+    w = synth.make_window(90, 6, 4000, seed=9, run_lo=2, run_hi=8)
+    plan = built_lib.structure_probe(w)
+    assert not plan["pcg_on_chip"]
+    check_against(solver.solve(w), oracle_mod.solve(w), w)
+
+
 def test_runs_are_bitwise_reproducible(solver):
     w = synth.cfg("cfg2")
     a = solver.solve(w); b = solver.solve(w)
