@@ -98,6 +98,8 @@ typedef struct {
     int32_t run_ahead;          /* trial sets the host keeps queued ahead    (default 2)       */
     int32_t profile;            /* bit k set: bracket launches of kernel class k (see movba_profile)
                                  * with HIP events on the handle's stream; 0x3f = all          */
+    int32_t pcg_coarse;         /* 0 = default (two-level: block-Jacobi + aggregate coarse level),
+                                 * -1 = block-Jacobi only                                       */
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */

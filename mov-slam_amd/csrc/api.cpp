@@ -57,6 +57,10 @@ struct movba_handle {
     size_t h2d_bytes = 0;
     const volatile uint8_t *stop = nullptr;
     int early_status = MOVBA_OK;
+    PcgParams pp{};
+    bool rows_kernel = false;
+    hipStream_t side = nullptr;         // k_coarse runs here, beside the LM chain
+    std::vector<hipEvent_t> sync_ev;    // 2 per trial: schur done / coarse done
     // pose-only scratch
     char *pose_arena = nullptr;
     size_t pose_cap = 0;
@@ -181,12 +185,13 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     movba_handle *h = new (std::nothrow) movba_handle();
     if (!h) return MOVBA_ERR_HIP;
     h->device = device;
-    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1;
     if (opt) {
         if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
         if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
         if (opt->run_ahead > 0) h->opt.run_ahead = opt->run_ahead;
         h->opt.profile = opt->profile;
+        if (opt->pcg_coarse < 0) h->opt.pcg_coarse = 0;
     }
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
     if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
@@ -195,7 +200,8 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
         h->own_stream = true;
     }
-    if (hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
         configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess) {
@@ -213,7 +219,10 @@ void movba_destroy(movba_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     harvest_events(h);
+    if (h->side) (void)hipStreamSynchronize(h->side);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->sync_ev) (void)hipEventDestroy(e);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->arena) (void)hipFree(h->arena);
     if (h->pose_arena) (void)hipFree(h->pose_arena);
     if (h->stage) (void)hipHostFree(h->stage);
@@ -269,6 +278,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         return MOVBA_ERR_ARG;
     }
 
+    h->pp = PcgParams{};
+    h->rows_kernel = pcg_rows_supported(s.nfree, s.row_ptr.data(), &h->pp);
+    if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     const int NP = s.NP, P = s.P, E = s.E, nf = s.nfree;
     const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
     // ---- carve the H2D region ----
@@ -279,6 +291,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
+    const size_t ncb = s.cblk_g.size();
+    const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1);
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
     const size_t h2d = c.off;
     // ---- device-only region ----
@@ -290,7 +304,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_st[b][6] = c.take<double>(2 * (size_t)E);  o_st[b][7] = c.take<double>(E);
         o_st[b][8] = c.take<double>(nb);
     }
-    const size_t o_part = c.take<double>((size_t)s.nitems * kPartStride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
+    const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
+    const size_t o_part = c.take<double>(2 * part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
+    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(2 * 48 * 48), o_acitag = c.take<int32_t>(2), o_lamsnap = c.take<double>(2);
     const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
     const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
@@ -322,6 +338,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_pis, s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
     std::memcpy(sg + o_rowptr, s.row_ptr.data(), sizeof(int32_t) * (nf + 1));
     std::memcpy(sg + o_rowent, s.row_ent.data(), sizeof(RowEnt) * s.row_ent.size());
+    std::memcpy(sg + o_cg, s.cblk_g.data(), sizeof(int32_t) * ncb);
+    std::memcpy(sg + o_ch, s.cblk_h.data(), sizeof(int32_t) * ncb);
+    std::memcpy(sg + o_cp, s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
+    std::memcpy(sg + o_ce, s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
     std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
     std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
     const double t2 = now_ms();
@@ -346,6 +366,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
     w.row_ent = reinterpret_cast<RowEnt *>(a + o_rowent);
+    w.n_agg = s.n_agg; w.n_cblk = (int32_t)ncb;
+    w.cblk_g = reinterpret_cast<int32_t *>(a + o_cg); w.cblk_h = reinterpret_cast<int32_t *>(a + o_ch);
+    w.cblk_ptr = reinterpret_cast<int32_t *>(a + o_cp); w.cblk_ent = reinterpret_cast<int32_t *>(a + o_ce);
     w.pose0 = reinterpret_cast<double *>(a + o_pose0); w.point0 = reinterpret_cast<double *>(a + o_point0);
     for (int b = 0; b < 2; ++b) {
         DevState &S = w.st[b];
@@ -356,6 +379,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
+    w.part_stride = part_stride; w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c);
+    w.aci = reinterpret_cast<double *>(a + o_aci); w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
+    w.lam_snap = reinterpret_cast<double *>(a + o_lamsnap);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev;
@@ -390,16 +416,18 @@ int movba_lba_run(movba_handle *h)
         HIP_TRY(launch_init(w, s));
         HIP_TRY(hipMemcpyAsync(w.st[0].point, w.point0, sizeof(double) * 3 * (size_t)w.P, hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_linearize(w, s));
-        if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, s));
+        if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, 0, s));
         HIP_TRY(launch_lambda_init(w, s));
     }
-    PcgParams pp;
+    PcgParams pp = h->pp;
     pp.rel_tol = h->opt.pcg_rel_tol;
     pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 4 * 6 * (w.nfree > 0 ? w.nfree : 1);
     const int nrowent = (int)h->st.row_ent.size();
-    const bool rows_kernel = pcg_rows_supported(w.nfree, h->st.row_ptr.data(), &pp);
+    const bool rows_kernel = h->rows_kernel;
+    pp.use_coarse = (h->opt.pcg_coarse && rows_kernel) ? 1 : 0;
 
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
+    int last_coarse = -1;
     const double t_start = now_ms();
     for (int t = 0; t < max_trials; ++t) {
         // stay at most run_ahead trial sets ahead of the device
@@ -415,11 +443,26 @@ int movba_lba_run(movba_handle *h)
         }
         if (h->hstat->done) break;
         if (h->stop && *h->stop) h->hstat->stop = 1;
-        if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, s)); }
-        { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, s) : launch_pcg(w, pp, s)); }
+        if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
+        if (pp.use_coarse) {
+            // coarse level of trial t is built beside the chain and preconditions trial t+1
+            while ((int)h->sync_ev.size() < 2 * (t + 1)) {
+                hipEvent_t e = nullptr;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->sync_ev.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(h->sync_ev[2 * t], s));
+            HIP_TRY(hipStreamWaitEvent(h->side, h->sync_ev[2 * t], 0));
+            HIP_TRY(launch_coarse(w, pp, t, h->side));
+            HIP_TRY(hipEventRecord(h->sync_ev[2 * t + 1], h->side));
+            if (t > 0) HIP_TRY(hipStreamWaitEvent(s, h->sync_ev[2 * t - 1], 0));
+            last_coarse = t;
+        }
+        { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, t, s) : launch_pcg(w, pp, t, s)); }
         { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
     }
+    if (last_coarse >= 0) HIP_TRY(hipStreamWaitEvent(s, h->sync_ev[2 * last_coarse + 1], 0));   // side stream drained before the run ends
     { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }
     HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -429,6 +472,8 @@ int movba_lba_run(movba_handle *h)
                  h->ctrl_host->dbg_ticks, h->ctrl_host->dbg_ticks ? 0.1 * (double)h->ctrl_host->dbg_cycles / (double)h->ctrl_host->dbg_ticks : 0.0);
     std::fprintf(stderr, "libmovba[stamp]: per-iteration segments (wave 0, cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_seg[k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
+    std::fprintf(stderr, "\nlibmovba[stamp]: setup phases per launch (cycles):");
+    for (int k = 0; k < 6; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
     std::fprintf(stderr, "\n");
 #endif
     h->ran = true;

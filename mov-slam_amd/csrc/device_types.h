@@ -41,7 +41,7 @@ struct Ctrl {
     int32_t n_solves, last_rejected, iters_done, n_trace;
     int32_t pcg_fail, pcg_last_iters, pcg_total_iters, n_outliers;
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
-    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8];
+    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8];
 };
 
 // Written by k_decide into pinned host memory so the host can keep the queue fed
@@ -66,11 +66,19 @@ struct DevWindow {
     const Item *items;
     const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;
     const RowEnt *row_ent;
+    // coarse level of the PCG preconditioner
+    int32_t n_agg, n_cblk;
+    const int32_t *cblk_g, *cblk_h, *cblk_ptr, *cblk_ent;
     // state
     DevState st[2];
     const double *pose0, *point0;   // uploaded initial state (for reset)
     // reduced system
-    double *part;       // nitems x kPartStride
+    double *part;       // 2 x nitems x kPartStride (double-buffered by trial parity)
+    size_t part_stride; // doubles between the two buffers
+    double *blocks_c;   // npairs x 36: k_coarse's own copy of S
+    double *aci;        // 2 x 48 x 48: inverse coarse matrices (by trial parity)
+    int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable
+    double *lam_snap;   // 2: lambda of the trial (by parity), written by k_schur
     double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first
     double *bp;         // 6 nfree
     double *xp;         // 6 nfree
@@ -88,6 +96,7 @@ struct PcgParams {
     int32_t max_iters;
     int32_t wave_row0[17];      // k_pcg_rows: wave wv owns block rows [wave_row0[wv], wave_row0[wv+1])
     int32_t overflow;           // k_pcg_rows: some wave has more gather entries than fit in VGPRs
+    int32_t use_coarse;         // k_pcg_rows: add the aggregate coarse-level correction to block-Jacobi
 };
 
 }  // namespace movba

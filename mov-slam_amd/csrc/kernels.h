@@ -11,14 +11,15 @@ constexpr int kPcgRowsThreads = 512;    // 8 waves: 2 per SIMD, 256 VGPRs per la
 hipError_t configure_kernels(int unused);
 hipError_t configure_pcg_rows();
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
-hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, hipStream_t s);
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s);
 size_t pcg_lds_bytes(int nfree);
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s);
-hipError_t launch_schur(const DevWindow &w, int mode, hipStream_t s);
+hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s);
+hipError_t launch_coarse(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s);
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s);
-hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, hipStream_t s);
+hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s);
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s);
 hipError_t launch_decide(const DevWindow &w, hipStream_t s);
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s);

@@ -39,8 +39,9 @@ __global__ void k_init_pose(DevWindow w)
         c->it = 0; c->qmax = 0; c->cur = 0; c->done = (w.max_iters <= 0) ? 1 : 0;
         c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
+        w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
-        for (int k = 0; k < 8; ++k) c->dbg_seg[k] = 0;
+        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; }
     }
     if (i >= w.NP) return;
     double q[7];
@@ -195,6 +196,37 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     if (threadIdx.x == 0) S1.Fpart[blockIdx.x] = Fsum;
 }
 
+// partial-slot of each of the 54 sums of a diagonal work item (layout in device_types.h) and, for the
+// 21 upper-triangle elements of the 6x6 block, the slot of the mirrored element (-1 on the diagonal)
+__device__ __constant__ int8_t kDiagMap[54] = {0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 14, 15, 16, 17, 21, 22, 23, 28, 29, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68};
+__device__ __constant__ int8_t kDiagMirror[21] = {-1, 6, 12, 18, 24, 30, -1, 13, 19, 25, 31, -1, 20, 26, 32, -1, 27, 33, -1, 34, -1};
+
+// Fixed-order reduction of NV per-lane values over the 64 lanes of a wave: two DPP steps sum each quad,
+// the 16 quad sums of every value go through a wave-private LDS strip ([NV][16] doubles) and lane k < NV
+// adds them up in order and stores the result to out[map(k)].  ~2k cycles for NV = 54, against ~30k
+// for NV butterfly reductions built on ds_bpermute shuffles.
+template <int NV>
+__device__ __forceinline__ void wave_reduce_store(double (&v)[NV], double *strip, int lane, double *out, const int8_t *omap)
+{
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double t = v[k];
+        t += dpp_mov0<0xb1>(t);
+        t += dpp_mov0<0x4e>(t);
+        if ((lane & 3) == 0) strip[k * 16 + (lane >> 2)] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < NV) {
+        const double2 *src = reinterpret_cast<const double2 *>(strip + lane * 16);
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const double2 t = src[q]; s += t.x; s += t.y; }
+        out[omap ? omap[lane] : lane] = s;
+    }
+}
+
 // --------------------------------------------------------------------------------
 // k_schur: one wave per work item (a chunk of one pose pair's shared points).
 // Per entry (edge of pose i, edge of pose j, both on point l) a lane rebuilds the
@@ -205,7 +237,7 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
 // and B_il Dinv_l b_l.  Wave-level shuffle reduction, one 72-double partial per item.
 // mode 1 = diagonal pairs only, Hpp only (used once to seed lambda).
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode)
+__global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
 {
     const Ctrl *c = w.ctrl;
     if (c->done) return;
@@ -222,7 +254,10 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode)
     double Ri[9], Rj[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { Ri[k] = S0.Rt[12 * ip + k]; Rj[k] = S0.Rt[12 * jp + k]; }
-    double *out = w.part + (size_t)item * kPartStride;
+    double *out = w.part + (size_t)(trial & 1) * w.part_stride + (size_t)item * kPartStride;
+    if (item == 0 && lane == 0) w.lam_snap[trial & 1] = lambda;      // for k_coarse(trial), which runs beside the LM chain
+    __shared__ __attribute__((aligned(16))) double strips[4][54 * 16];
+    double *strip = strips[threadIdx.x >> 6];
 
     if (it.diag) {
         double sa[21], ha[21], ca[6], ba[6];
@@ -230,6 +265,7 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode)
         for (int k = 0; k < 21; ++k) { sa[k] = 0.0; ha[k] = 0.0; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { ca[k] = 0.0; ba[k] = 0.0; }
+#pragma unroll 2
         for (int k = it.begin + lane; k < it.end; k += 64) {
             const int g = w.entries[k].x;
             const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
@@ -271,24 +307,23 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode)
                 for (int b = a; b < 6; ++b) sa[ut6(a, b)] += u0 * C0[b] + u1 * C1[b];
             }
         }
+        // 54 sums: [0,21) upper triangle of sum B Dinv B^T, [21,27) B Dinv b_l, [27,48) upper Hpp, [48,54) b_p
+        double all[54];
 #pragma unroll
-        for (int k = 0; k < 21; ++k) { sa[k] = wave_sum(sa[k]); ha[k] = wave_sum(ha[k]); }
+        for (int k = 0; k < 21; ++k) { all[k] = sa[k]; all[27 + k] = ha[k]; }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { ca[k] = wave_sum(ca[k]); ba[k] = wave_sum(ba[k]); }
-        if (lane == 0) {
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = 0; b < 6; ++b) out[a * 6 + b] = sa[a <= b ? ut6(a, b) : ut6(b, a)];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) { out[36 + k] = ca[k]; out[63 + k] = ba[k]; }
-#pragma unroll
-            for (int k = 0; k < 21; ++k) out[42 + k] = ha[k];
+        for (int k = 0; k < 6; ++k) { all[21 + k] = ca[k]; all[48 + k] = ba[k]; }
+        // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
+        wave_reduce_store<54>(all, strip, lane, out, kDiagMap);
+        if (lane < 21) {
+            const int m = kDiagMirror[lane];
+            if (m >= 0) out[m] = out[kDiagMap[lane]];
         }
     } else {
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
+#pragma unroll 2
         for (int k = it.begin + lane; k < it.end; k += 64) {
             const Int2 en = w.entries[k];
             const double4 ri = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.x);
@@ -324,12 +359,7 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode)
                 for (int b = 0; b < 6; ++b) acc[a * 6 + b] += u0 * E0[b] + u1 * E1[b];
             }
         }
-#pragma unroll
-        for (int k = 0; k < 36; ++k) acc[k] = wave_sum(acc[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 36; ++k) out[k] = acc[k];
-        }
+        wave_reduce_store<36>(acc, strip, lane, out, nullptr);
     }
 }
 
@@ -374,7 +404,7 @@ __global__ __launch_bounds__(64) void k_lambda_init(DevWindow w)
 constexpr int kPcgThreads = 1024;
 constexpr int kPcgWaves = kPcgThreads / 64;
 
-__global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp)
+__global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp, int trial)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
@@ -383,6 +413,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp)
     const int nf = w.nfree, n = 6 * nf;
     const int cur = c->cur;
     const double lambda = c->lambda;
+    const double *partials = w.part + (size_t)(trial & 1) * w.part_stride;
     double *x = sm, *r = x + n, *z = r + n, *p = z + n, *Ap = p + n;
     double *minv = Ap + n;                  // nf x 36
     double *red0 = minv + 36 * nf;          // kPcgWaves
@@ -395,14 +426,14 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp)
         const int pr = idx / 36, k = idx - pr * 36;
         double s = 0.0;
         for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
-            s += w.part[(size_t)itx * kPartStride + k];
+            s += partials[(size_t)itx * kPartStride + k];
         double v = -s;
         if (pr < nf) {
             const int a = k / 6, b = k - a * 6;
             const int u = a <= b ? ut6(a, b) : ut6(b, a);
             double hpp = 0.0;
             for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
-                hpp += w.part[(size_t)itx * kPartStride + 42 + u];
+                hpp += partials[(size_t)itx * kPartStride + 42 + u];
             v += hpp + (a == b ? lambda : 0.0);
         }
         w.blocks[idx] = v;
@@ -411,8 +442,8 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp)
         const int i = idx / 6, a = idx - i * 6;
         double cc = 0.0, bb = 0.0;
         for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx) {
-            cc += w.part[(size_t)itx * kPartStride + 36 + a];
-            bb += w.part[(size_t)itx * kPartStride + 63 + a];
+            cc += partials[(size_t)itx * kPartStride + 36 + a];
+            bb += partials[(size_t)itx * kPartStride + 63 + a];
         }
         w.bp[idx] = bb;
         r[idx] = bb - cc;
@@ -691,9 +722,9 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_schur(const DevWindow &w, int mode, hipStream_t s)
+hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_schur, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode);
+    hipLaunchKernelGGL(k_schur, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode, trial);
     return hipGetLastError();
 }
 
@@ -703,9 +734,9 @@ hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, hipStream_t s)
+hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg, dim3(1), dim3(kPcgThreads), pcg_lds_bytes(w.nfree), s, w, pp);
+    hipLaunchKernelGGL(k_pcg, dim3(1), dim3(kPcgThreads), pcg_lds_bytes(w.nfree), s, w, pp, trial);
     return hipGetLastError();
 }
 

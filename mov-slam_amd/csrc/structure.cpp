@@ -1,6 +1,7 @@
 #include "structure.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace movba {
@@ -92,11 +93,13 @@ int build_structure(const movba_lba_desc& d, Structure& s)
             }
     }
     // ---- work items: chunks of a pair's entries ----
+    int chunk = kSchurChunk;
+    if (const char *ev = std::getenv("MOVBA_SCHUR_CHUNK")) { const int v = std::atoi(ev); if (v >= 64) chunk = v; }   // tuning knob
     s.pair_item_start.assign(s.npairs + 1, 0);
     for (int p = 0; p < s.npairs; ++p) {
         s.pair_item_start[p] = (int32_t)s.items.size();
-        for (int64_t b = pair_ptr[p]; b < pair_ptr[p + 1]; b += kSchurChunk)
-            s.items.push_back(Item{ p, (int32_t)b, (int32_t)std::min<int64_t>(b + kSchurChunk, pair_ptr[p + 1]), p < nf ? 1 : 0 });
+        for (int64_t b = pair_ptr[p]; b < pair_ptr[p + 1]; b += chunk)
+            s.items.push_back(Item{ p, (int32_t)b, (int32_t)std::min<int64_t>(b + chunk, pair_ptr[p + 1]), p < nf ? 1 : 0 });
     }
     s.pair_item_start[s.npairs] = (int32_t)s.items.size();
     s.nitems = (int)s.items.size();
@@ -116,6 +119,29 @@ int build_structure(const movba_lba_desc& d, Structure& s)
         s.row_ent.insert(s.row_ent.end(), rows[i].begin(), rows[i].end());
     }
     return MOVBA_OK;
+}
+
+void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg)
+{
+    const int nf = s.nfree, G = n_agg;
+    s.n_agg = G;
+    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ent.clear(); s.cblk_ptr.assign(1, 0);
+    std::vector<int32_t> agg_of(nf, 0);
+    for (int g = 0; g < G; ++g)
+        for (int i = agg_row0[g]; i < agg_row0[g + 1]; ++i) agg_of[i] = g;
+    std::vector<std::vector<int32_t>> lists((size_t)G * G);
+    for (int i = 0; i < nf; ++i)
+        for (int e = s.row_ptr[i]; e < s.row_ptr[i + 1]; ++e)
+            if (s.row_ent[e].block >= 0)
+                lists[(size_t)agg_of[i] * G + agg_of[s.row_ent[e].col]].push_back((s.row_ent[e].block << 1) | (s.row_ent[e].transposed ? 1 : 0));
+    for (int g = 0; g < G; ++g)
+        for (int h = 0; h < G; ++h) {
+            const std::vector<int32_t>& l = lists[(size_t)g * G + h];
+            if (l.empty()) continue;
+            s.cblk_g.push_back(g); s.cblk_h.push_back(h);
+            s.cblk_ent.insert(s.cblk_ent.end(), l.begin(), l.end());
+            s.cblk_ptr.push_back((int32_t)s.cblk_ent.size());
+        }
 }
 
 }  // namespace movba

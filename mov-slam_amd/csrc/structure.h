@@ -37,9 +37,17 @@ struct Structure {
     std::vector<Item> items;            // nitems
     std::vector<int32_t> row_ptr;       // nfree+1
     std::vector<RowEnt> row_ent;        // mat-vec gather list per block row
+    // coarse level of the two-level PCG preconditioner (build_coarse): keyframe aggregates, 6 dofs each
+    int n_agg = 0;
+    std::vector<int32_t> cblk_g, cblk_h, cblk_ptr;   // non-empty coarse blocks (g,h) and their term lists
+    std::vector<int32_t> cblk_ent;      // (pair id << 1 | transposed): fine blocks summed into the coarse block
 };
 
-constexpr int kSchurChunk = 1024;       // entries per schur work item (one wave each)
+// Aggregate g = block rows [agg_row0[g], agg_row0[g+1]): fills the coarse block term lists of
+// A_c = P^T S P (P = piecewise-constant prolongation over the aggregates).
+void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg);
+
+constexpr int kSchurChunk = 512;        // entries per schur work item (one wave each)
 
 // Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.
 int build_structure(const movba_lba_desc& d, Structure& s);

@@ -50,7 +50,7 @@ class LbaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
-                ("profile", C.c_int32)]
+                ("profile", C.c_int32), ("pcg_coarse", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -159,9 +159,9 @@ class Solver:
     """One handle = one device + one stream (movba_create / movba_destroy)."""
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
-                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False):
+                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True):
         self._h = C.c_void_p()
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)))
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()
