@@ -291,7 +291,24 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
+    std::vector<int32_t> lane_plan;
+    if (h->rows_kernel) {
+        // which two oriented blocks every lane of k_pcg_rows holds, and where their partial items are
+        lane_plan.assign((size_t)kPcgRowsThreads * 8, -1);
+        for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) {
+            const int P0 = s.row_ptr[h->pp.wave_row0[wv]] >> 1, P1 = s.row_ptr[h->pp.wave_row0[wv + 1]] >> 1;
+            for (int ln = 0; ln < 64 && P0 + ln < P1; ++ln)
+                for (int k = 0; k < 2; ++k) {
+                    const RowEnt &re = s.row_ent[2 * (P0 + ln) + k];
+                    int32_t *pl = &lane_plan[((size_t)(wv * 64 + ln) * 2 + k) * 4];
+                    if (re.block < 0) continue;
+                    pl[0] = re.block; pl[1] = (re.col * 6) | (re.transposed ? (1 << 30) : 0);
+                    pl[2] = s.pair_item_start[re.block]; pl[3] = s.pair_item_start[re.block + 1];
+                }
+        }
+    }
     const size_t ncb = s.cblk_g.size();
+    const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1);
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
     const size_t h2d = c.off;
@@ -338,6 +355,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_pis, s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
     std::memcpy(sg + o_rowptr, s.row_ptr.data(), sizeof(int32_t) * (nf + 1));
     std::memcpy(sg + o_rowent, s.row_ent.data(), sizeof(RowEnt) * s.row_ent.size());
+    if (!lane_plan.empty()) std::memcpy(sg + o_plan, lane_plan.data(), sizeof(int32_t) * lane_plan.size());
     std::memcpy(sg + o_cg, s.cblk_g.data(), sizeof(int32_t) * ncb);
     std::memcpy(sg + o_ch, s.cblk_h.data(), sizeof(int32_t) * ncb);
     std::memcpy(sg + o_cp, s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
@@ -366,6 +384,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
     w.row_ent = reinterpret_cast<RowEnt *>(a + o_rowent);
+    w.lane_plan = reinterpret_cast<int32_t *>(a + o_plan);
     w.n_agg = s.n_agg; w.n_cblk = (int32_t)ncb;
     w.cblk_g = reinterpret_cast<int32_t *>(a + o_cg); w.cblk_h = reinterpret_cast<int32_t *>(a + o_ch);
     w.cblk_ptr = reinterpret_cast<int32_t *>(a + o_cp); w.cblk_ent = reinterpret_cast<int32_t *>(a + o_ce);

@@ -66,6 +66,8 @@ struct DevWindow {
     const Item *items;
     const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;
     const RowEnt *row_ent;
+    // k_pcg_rows: per (wave, lane, slot) plan {pair id or -1, transposed, col*6, first item, end item} (host-built)
+    const int32_t *lane_plan;   // kPcgRowsThreads x 2 x 4 int32
     // coarse level of the PCG preconditioner
     int32_t n_agg, n_cblk;
     const int32_t *cblk_g, *cblk_h, *cblk_ptr, *cblk_ent;

@@ -373,9 +373,20 @@ __global__ __launch_bounds__(64) void k_lambda_init(DevWindow w)
     if (c->done) return;
     const int lane = threadIdx.x;
     double m = 0.0, F = 0.0;
-    for (int k = lane; k < w.n_pt_blocks; k += 64) m = fmax(m, w.hmax_part[k]);
-    // fixed-order cost sum: lane-strided partials, then a fixed butterfly
-    for (int k = lane; k < w.n_pt_blocks; k += 64) F += w.st[0].Fpart[k];
+    // fixed-order cost sum: lane-strided partials (loads 8 deep), then a fixed butterfly
+    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * 8) {
+        double fv[8], mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
+            fv[u] = w.st[0].Fpart[k]; mv[u] = w.hmax_part[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = k0 + 64 * u < w.n_pt_blocks;
+            F += in ? fv[u] : 0.0; m = fmax(m, in ? mv[u] : 0.0);
+        }
+    }
     for (int i = lane; i < w.nfree; i += 64) {
         for (int a = 0; a < 6; ++a) {
             double s = 0.0;
@@ -619,7 +630,20 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
     const int lane = threadIdx.x;
     const int cur = c->cur;
     double F1 = 0.0, scale = 0.0;
-    for (int k = lane; k < w.n_pt_blocks; k += 64) { F1 += w.st[cur ^ 1].Fpart[k]; scale += w.scale_part[k]; }
+    // lane-strided partial sums, loads issued 8 deep (a plain loop would pay one L2 round trip per term)
+    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * 8) {
+        double fv[8], sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
+            fv[u] = w.st[cur ^ 1].Fpart[k]; sv[u] = w.scale_part[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = k0 + 64 * u < w.n_pt_blocks;
+            F1 += in ? fv[u] : 0.0; scale += in ? sv[u] : 0.0;
+        }
+    }
     F1 = wave_sum(F1);
     scale = wave_sum(scale);
     if (lane != 0) return;

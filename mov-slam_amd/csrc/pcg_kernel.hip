@@ -35,6 +35,11 @@ namespace movba {
 #else
 #define SEG_STAMP(k) do { } while (0)
 #endif
+#ifdef MOVBA_CLOCK_STAMP
+#define SETUP_STAMP(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (tid == 0) c->dbg_seg2[k] += _t - setup_last; setup_last = _t; } while (0)
+#else
+#define SETUP_STAMP(k) do { } while (0)
+#endif
 
 namespace {
 
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int cur = c->cur;
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long setup_last = stamp_c0;
 #endif
     const double lambda = c->lambda;
     const double *part = w.part + (size_t)(trial & 1) * w.part_stride;
@@ -126,11 +132,16 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     }
 
     // ---- this lane's pair of oriented blocks, assembled straight from the partials into VGPRs ----
+    // (the host-built lane plan says which blocks and which partial items: one dependent load level)
     double Bo[2][36];
     int colo[2];
     const int my_pair = P0 + ln;
     const bool have_pair = my_pair < P1;
     const int yslot = (have_pair ? my_pair : (nrowent >> 1)) * 6;     // lanes without a pair write the dummy strip
+    const int4 *plan = reinterpret_cast<const int4 *>(w.lane_plan) + (size_t)tid * 2;
+    const int4 pl0 = plan[0], pl1 = plan[1];
+    // owner lanes: items of the diagonal pair (bi, bi) carry b_p and B Dinv b_l
+    const int oi0 = owner ? w.pair_item_start[bi] : 0, oi1 = owner ? w.pair_item_start[bi + 1] : 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         colo[k] = 0;
@@ -140,12 +151,12 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #pragma unroll
         for (int q = 0; q < 36; ++q) raw[q] = 0.0;
         bool valid = false, tr = false, diag = false;
-        if (have_pair) {
-            const RowEnt re = w.row_ent[2 * my_pair + k];
-            if (re.block >= 0) {
-                valid = true; tr = re.transposed != 0; diag = re.block < nf;
-                colo[k] = re.col * 6;
-                const int i0 = w.pair_item_start[re.block], i1 = w.pair_item_start[re.block + 1];
+        {
+            const int4 pl = k ? pl1 : pl0;
+            if (pl.x >= 0) {
+                valid = true; tr = ((pl.y >> 30) & 1) != 0; diag = pl.x < nf;
+                colo[k] = pl.y & 0x3fffffff;
+                const int i0 = pl.z, i1 = pl.w;
                 for (int itx = i0; itx < i1; ++itx) {
                     const double2 *src = reinterpret_cast<const double2 *>(part + (size_t)itx * kPartStride);
 #pragma unroll
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #pragma unroll
                         for (int q = 0; q < 6; ++q) raw[a * 6 + q] += hpp[a <= q ? ut6(a, q) : ut6(q, a)] + (a == q ? lambda : 0.0);
 #pragma unroll
-                    for (int q = 0; q < 36; ++q) minv[re.block * 36 + q] = raw[q];       // S_ii: input of the preconditioner
+                    for (int q = 0; q < 36; ++q) minv[pl.x * 36 + q] = raw[q];       // S_ii: input of the preconditioner
                 }
             }
         }
@@ -176,18 +187,26 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #pragma unroll
             for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = valid ? (tr ? raw[q * 6 + a] : raw[a * 6 + q]) : 0.0;
     }
-    // right-hand side b_S = b_p - sum B Dinv b_l and b_p itself (owner lanes)
+    SETUP_STAMP(0);
+    // right-hand side b_S = b_p - sum B Dinv b_l and b_p itself (owner lanes): loads 6 items deep
     double r_r = 0.0, bp_r = 0.0;
     if (owner) {
         double cc = 0.0, bb = 0.0;
-        for (int itx = w.pair_item_start[bi]; itx < w.pair_item_start[bi + 1]; ++itx) {
-            cc += part[(size_t)itx * kPartStride + 36 + ba];
-            bb += part[(size_t)itx * kPartStride + 63 + ba];
+        for (int i0 = oi0; i0 < oi1; i0 += 6) {
+            double cv[6], bv[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const double *src = part + (size_t)min(i0 + u, oi1 - 1) * kPartStride;
+                cv[u] = src[36 + ba]; bv[u] = src[63 + ba];
+            }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { const bool in = i0 + u < oi1; cc += in ? cv[u] : 0.0; bb += in ? bv[u] : 0.0; }
         }
         bp_r = bb;
         r_r = bb - cc;
         w.bp[row] = bb;
     }
+    SETUP_STAMP(1);
     __syncthreads();
 
     // ---- block-Jacobi preconditioner: invert each 6x6 diagonal block in place (Cholesky) ----
@@ -416,6 +435,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         c->dbg_cycles += __builtin_amdgcn_s_memtime() - stamp_c0;
         c->dbg_ticks += __builtin_amdgcn_s_memrealtime() - stamp_t0;
         for (int k = 0; k < 8; ++k) c->dbg_seg[k] += seg[k];
+        (void)setup_last;
 #endif
     }
 }
