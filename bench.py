@@ -26,6 +26,24 @@ sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+ROCPROF_NAME = {"k_schur": "movba::k_schur", "k_pcg": "movba::k_pcg_rows", "k_point<backsub>": "void movba::k_point<true>"}
+
+
+def measured_traffic(kernel_class):
+    """HBM-side bytes per launch of a kernel class from the newest committed rocprofv3 PMC summary
+    (profiles/*_pmc_traffic.json, made by scripts/profile_gpu.sh + scripts/summarise_profiles.py on the
+    same bench command: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, launches with work only).
+    Raw counter sum; FETCH_SIZE under-reports wide coalesced streams by up to 2x on gfx950."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for name, v in d["kernels"].items():
+        if name.startswith(ROCPROF_NAME.get(kernel_class, "?")):
+            return v["hbm_bytes_per_launch_raw"], os.path.basename(files[-1])
+    return None, None
+
 KERNEL_CLASSES = ["k_schur", "k_pcg", "k_point<backsub>", "k_decide", "setup(init+linearize+lambda)", "k_finalize"]
 
 
@@ -125,6 +143,7 @@ def main():
         avg_s = dk["ms"] / max(dk["launches"], 1) * 1e-3
         achieved = ab[dominant] / avg_s / 1e9 if avg_s > 0 else 0.0
         chain_gbs = ab["B_iter"] * res["n_solves"] * args.steps / dt / 1e9
+        traffic, traffic_src = measured_traffic(dominant)
         out = {
             "metric": "local-BA iterations/sec (50 KF x 20k MapPoint window)" if args.config == "cfg3"
                       else "local-BA iterations/sec (10 KF x 2k MapPoint window)",
@@ -140,7 +159,7 @@ def main():
                        "window_solves_per_s": world * args.steps / dt_max,
                        "parallelism": f"{world} independent window(s), RCCL pose all-gather" if world > 1 else "1 window"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_us": avg_s * 1e6,
                          "launches_timed": dk["launches"],
                          "chain": {"B_iter_bytes": ab["B_iter"], "achieved": chain_gbs, "frac": chain_gbs / HBM_PEAK_GBS,
