@@ -50,24 +50,33 @@ int build_structure(const movba_lba_desc& d, Structure& s)
     if (E == 0) return MOVBA_EMPTY;
 
     // ---- pose pairs sharing a point (block pattern of the reduced system) ----
-    std::vector<int64_t> cnt((size_t)nf * (size_t)nf, 0);      // upper triangle used
-    std::vector<std::pair<int32_t, int32_t>> fe;
-    auto free_edges_of = [&](int l) {
-        fe.clear();
+    // free observers of every point, flattened once: (hessian index, grouped edge), ascending hessian index
+    std::vector<int32_t> fe_start(P + 1, 0), fe_h, fe_g;
+    fe_h.reserve(E); fe_g.reserve(E);
+    for (int l = 0; l < P; ++l) {
+        const size_t base = fe_h.size();
         for (int g = s.pt_start[l]; g < s.pt_start[l + 1]; ++g) {
             const int h = s.hidx[s.g_pose[g]];
-            if (h >= 0) fe.emplace_back(h, g);
+            if (h < 0) continue;
+            // insertion keeps the (usually already ascending) list sorted and stable
+            size_t pos = fe_h.size();
+            fe_h.push_back(h); fe_g.push_back(g);
+            while (pos > base && fe_h[pos - 1] > h) {
+                fe_h[pos] = fe_h[pos - 1]; fe_g[pos] = fe_g[pos - 1];
+                --pos;
+            }
+            fe_h[pos] = h; fe_g[pos] = g;
+            if (pos > base && fe_h[pos - 1] == h) return MOVBA_ERR_ARG;          // duplicate observation
+            if (pos + 1 < fe_h.size() && fe_h[pos + 1] == h) return MOVBA_ERR_ARG;
         }
-        std::stable_sort(fe.begin(), fe.end(),
-                         [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) { return a.first < b.first; });
-    };
-    for (int l = 0; l < P; ++l) {
-        free_edges_of(l);
-        for (size_t a = 0; a < fe.size(); ++a) {
-            if (a + 1 < fe.size() && fe[a + 1].first == fe[a].first) return MOVBA_ERR_ARG;  // duplicate observation
-            for (size_t b = a; b < fe.size(); ++b) cnt[(size_t)fe[a].first * nf + fe[b].first]++;
-        }
+        fe_start[l + 1] = (int32_t)fe_h.size();
     }
+    std::vector<int32_t> cnt((size_t)nf * (size_t)nf, 0);       // upper triangle used
+    for (int l = 0; l < P; ++l)
+        for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
+            int32_t *row = &cnt[(size_t)fe_h[a] * nf];
+            for (int b = a; b < fe_start[l + 1]; ++b) row[fe_h[b]]++;
+        }
     // pair ids: the nf diagonal pairs first (pair k == (k,k)), then off-diagonal row-major
     std::vector<int32_t> pid((size_t)nf * (size_t)nf, -1);
     for (int i = 0; i < nf; ++i) { pid[(size_t)i * nf + i] = i; s.pair_i.push_back(i); s.pair_j.push_back(i); }
@@ -83,13 +92,15 @@ int build_structure(const movba_lba_desc& d, Structure& s)
     s.nentries = pair_ptr[s.npairs];
     if (s.nentries > (int64_t)0x7fffffff) return MOVBA_ERR_ARG;
     s.entries.resize((size_t)s.nentries);
-    std::vector<int64_t> cur(pair_ptr.begin(), pair_ptr.end() - 1);
-    for (int l = 0; l < P; ++l) {
-        free_edges_of(l);
-        for (size_t a = 0; a < fe.size(); ++a)
-            for (size_t b = a; b < fe.size(); ++b) {
-                const int p = pid[(size_t)fe[a].first * nf + fe[b].first];
-                s.entries[(size_t)cur[p]++] = Int2{ fe[a].second, fe[b].second };
+    {
+        std::vector<int32_t> cur(s.npairs);
+        for (int p = 0; p < s.npairs; ++p) cur[p] = (int32_t)pair_ptr[p];
+        Int2 *ent = s.entries.data();
+        for (int l = 0; l < P; ++l)
+            for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
+                const int32_t *prow = &pid[(size_t)fe_h[a] * nf];
+                const int32_t ga = fe_g[a];
+                for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int2{ ga, fe_g[b] };
             }
     }
     // ---- work items: chunks of a pair's entries ----

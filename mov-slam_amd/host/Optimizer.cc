@@ -17,7 +17,9 @@
 #include "Optimizer.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -148,6 +150,30 @@ namespace MOV_SLAM
             return nEdges;
         }
 
+        // $MOVBA_DUMP_DIR/lba_<n>.mbw: the flattened window, for replay on a GPU box without the reference's
+        // stack (layout in mov-slam_amd/movba/capture.py)
+        void dump_window(const movba_lba_desc &d)
+        {
+            const char *dir = std::getenv("MOVBA_DUMP_DIR");
+            if (!dir || !*dir) return;
+            static std::atomic<int> counter{0};
+            char path[1024];
+            std::snprintf(path, sizeof path, "%s/lba_%06d.mbw", dir, counter.fetch_add(1));
+            FILE *f = std::fopen(path, "wb");
+            if (!f) return;
+            const uint32_t ver = 1, flags = d.flags;
+            const int32_t hd[4] = {d.n_poses, d.n_points, d.n_edges, d.max_iters};
+            const double dd[6] = {d.fx, d.fy, d.cx, d.cy, d.huber_delta, d.chi2_gate};
+            const uint8_t pad[8] = {0};
+            std::fwrite("MOVBAWIN", 1, 8, f);
+            std::fwrite(&ver, 4, 1, f); std::fwrite(hd, 4, 4, f); std::fwrite(&flags, 4, 1, f); std::fwrite(dd, 8, 6, f);
+            std::fwrite(d.pose_fixed, 1, d.n_poses, f); std::fwrite(pad, 1, (8 - d.n_poses % 8) % 8, f);
+            std::fwrite(d.poses, 8, 7 * (size_t)d.n_poses, f); std::fwrite(d.points, 8, 3 * (size_t)d.n_points, f);
+            std::fwrite(d.edge_pose, 4, d.n_edges, f); std::fwrite(d.edge_point, 4, d.n_edges, f);
+            std::fwrite(d.obs, 8, 2 * (size_t)d.n_edges, f); std::fwrite(d.inv_sigma2, 8, d.n_edges, f);
+            std::fclose(f);
+        }
+
         struct Solved
         {
             std::vector<double> poses, points, chi2;
@@ -177,6 +203,7 @@ namespace MOV_SLAM
             s.chi2.resize(f.edge_pose.size()); s.outlier.resize(f.edge_pose.size());
             movba_lba_result r{};
             r.poses = s.poses.data(); r.points = s.points.data(); r.chi2 = s.chi2.data(); r.outlier = s.outlier.data();
+            dump_window(d);
             s.status = movba_lba_solve(h, &d, &r);
             return s;
         }

@@ -109,6 +109,33 @@ def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tm
     assert out["n_erased"] == len(got)
 
 
+def test_adapter_dumps_replayable_windows(adapter_bin, solver, oracle_mod, tmp_path):
+    """MOVBA_DUMP_DIR: the adapter writes the flattened window it solved; replaying the file through the
+    C-ABI gives the same result, and the keyframe-trajectory ATE of GPU and oracle solutions agree (cfg4 harness)."""
+    from movba import ate, capture
+    w = synth.cfg("small")
+    w.poses = _f32_pose(w.poses)
+    fin, fout = str(tmp_path / "w.bin"), str(tmp_path / "o.bin")
+    _write_window(fin, w)
+    env = dict(os.environ, MOVBA_DUMP_DIR=str(tmp_path))
+    subprocess.check_call([adapter_bin, "lba", fin, fout], env=env)
+    dumped = capture.load_window(str(tmp_path / "lba_000000.mbw"))
+    sub, used_pose, local_pt, keep_e = _local_subwindow(w)
+    assert dumped.n_poses == sub.n_poses and dumped.n_points == sub.n_points and dumped.n_edges == sub.n_edges
+    np.testing.assert_array_equal(dumped.poses, sub.poses)
+    # map points arrive in the adapter's first-seen order (Optimizer.cc:479-504), not by id: same multiset of edges
+    np.testing.assert_array_equal(np.sort(dumped.obs.ravel()), np.sort(sub.obs.ravel()))
+    r, o = solver.solve(dumped), oracle_mod.solve(dumped)
+    assert np.abs(r["poses"] - o["poses"]).max() < 1e-8
+    # ATE of the optimised keyframe trajectory against the generating truth: GPU within 1e-6 relative of the oracle
+    truth = np.zeros((sub.n_poses, 7)); T = w.truth_poses[used_pose]
+    rows_t = ate.kf_trajectory_rows(T, range(sub.n_poses))
+    truth[:, :3] = ate.kitti_to_tartan_xyz(rows_t[:, 1:]); truth[:, 6] = 1
+    a_gpu = ate.ate_tartanair(truth, ate.kf_trajectory_rows(r["poses"], range(sub.n_poses)))["ate"]
+    a_cpu = ate.ate_tartanair(truth, ate.kf_trajectory_rows(o["poses"], range(sub.n_poses)))["ate"]
+    assert abs(a_gpu - a_cpu) <= 1e-6 * max(a_cpu, 1e-12) + 1e-12
+
+
 def test_global_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tmp_path):
     """Tracking::CreateInitialMapMonocular -> GlobalBundleAdjustemnt (Tracking.cc:688): only the init keyframe
     is fixed, nothing is erased, results are written directly when nLoopKF is the origin keyframe."""
