@@ -65,6 +65,10 @@ typedef struct {
     int32_t max_trials;         /* g2o maxTrialsAfterFailure (default-constructed LM, :539); 0 -> 10 */
     uint32_t flags;             /* MOVBA_FLAG_*                                               */
     const volatile uint8_t *stop; /* pbStopFlag (Optimizer.cc:544-545, 749), may be NULL      */
+    /* stereo observations (g2o::EdgeStereoSE3ProjectXYZ, Optimizer.cc:673-705): obs_right[e] >= 0 is
+     * mvuRight[idx] of a stereo observation (third residual u_r - (u - bf/z)); < 0 or NULL: monocular */
+    const double  *obs_right;   /* E or NULL                                                  */
+    double bf;                  /* KeyFrame::mbf (Optimizer.cc:695)                           */
 } movba_lba_desc;
 
 #define MOVBA_MAX_TRACE 128

@@ -288,6 +288,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_gpose = c.take<int32_t>(E), o_gpoint = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1);
     const size_t o_perm = c.take<int32_t>(E), o_hidx = c.take<int32_t>(NP), o_free = c.take<int32_t>(nf + 1);
     const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
+    bool stereo = false;
+    if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
+    const size_t o_obsr = c.take<double>(stereo ? E : 0);
     const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
@@ -313,13 +316,14 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
     const size_t h2d = c.off;
     // ---- device-only region ----
-    size_t o_st[2][9];
+    size_t o_st[2][10];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
         o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
         o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);
         o_st[b][6] = c.take<double>(2 * (size_t)E);  o_st[b][7] = c.take<double>(E);
         o_st[b][8] = c.take<double>(nb);
+        o_st[b][9] = c.take<double>(stereo ? E : 0);
     }
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
     const size_t o_part = c.take<double>(2 * part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
@@ -346,6 +350,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         for (int g = 0; g < E; ++g) {
             const int e = s.perm[g];
             obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
+        }
+        if (stereo) {
+            double *obr = reinterpret_cast<double *>(sg + o_obsr);
+            for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
         }
     }
     std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int2) * (size_t)s.nentries);
@@ -380,6 +388,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = reinterpret_cast<int32_t *>(a + o_perm);
     w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
+    w.obs_r = reinterpret_cast<double *>(a + o_obsr); w.bf = d->bf; w.stereo = stereo ? 1 : 0;
     w.entries = reinterpret_cast<Int2 *>(a + o_ent); w.items = reinterpret_cast<Item *>(a + o_items);
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
@@ -396,6 +405,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.rec = reinterpret_cast<double *>(a + o_st[b][5]);
         S.res = reinterpret_cast<double *>(a + o_st[b][6]); S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
+        S.res2 = reinterpret_cast<double *>(a + o_st[b][9]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
     w.part_stride = part_stride; w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c);

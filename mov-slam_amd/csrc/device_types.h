@@ -29,6 +29,7 @@ struct DevState {
     double *rec;     // E x 4   (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2)
     double *res;     // E x 2   (-w e0, -w e1)
     double *chi2;    // E
+    double *res2;    // E: -w e2 of stereo edges (stereo windows only)
     double *Fpart;   // n_pt_blocks robust-cost partials of this state
 };
 
@@ -62,6 +63,9 @@ struct DevWindow {
     const int32_t *g_pose, *g_point, *pt_start, *perm, *hidx, *free_pose;
     const double *obs;      // E x 2 (grouped order)
     const double *isig;     // E
+    const double *obs_r;    // E: right-image u of stereo observations, < 0 = monocular edge (stereo windows only)
+    double bf;              // KeyFrame::mbf
+    int32_t stereo, pad2;   // window has >= 1 stereo edge: 3-row kernels
     const Int2 *entries;
     const Item *items;
     const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;

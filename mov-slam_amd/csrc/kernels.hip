@@ -64,7 +64,7 @@ __global__ void k_init_pose(DevWindow w)
 //                   trial point X + x_l, then the same evaluation at the trial state cur^1
 // Pose rotations/translations and the pose increments are staged in LDS.
 // --------------------------------------------------------------------------------
-template <bool BACKSUB>
+template <bool BACKSUB, bool STEREO>
 __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -116,6 +116,13 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
             a0 += (a00 * R[0] + a02 * R[6]) * g0 + (a11 * R[3] + a12 * R[6]) * g1;
             a1 += (a00 * R[1] + a02 * R[7]) * g0 + (a11 * R[4] + a12 * R[7]) * g1;
             a2 += (a00 * R[2] + a02 * R[8]) * g0 + (a11 * R[5] + a12 * R[8]) * g1;
+            if (STEREO && w.obs_r[g] >= 0.0) {
+                // stereo row (g2o::EdgeStereoSE3ProjectXYZ): like row 0 with a02 -> a02 - bf/z^2
+                const double c02 = a02 - w.bf / (z * z);
+                const double t2 = (c02 * y) * xp[0] + (a00 * z - c02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + c02 * xp[5];
+                const double g2 = wg * t2;
+                a0 += (a00 * R[0] + c02 * R[6]) * g2; a1 += (a00 * R[1] + c02 * R[7]) * g2; a2 += (a00 * R[2] + c02 * R[8]) * g2;
+            }
         }
 #pragma unroll
         for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
@@ -150,7 +157,14 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         const double om = w.isig[g];
         const double e0 = ob.x - (w.fx * x / z + w.cx);
         const double e1 = ob.y - (w.fy * y / z + w.cy);
-        const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+        double chi2 = e0 * (om * e0) + e1 * (om * e1);
+        bool st = false;
+        double e2 = 0.0;
+        if (STEREO) {
+            const double ur = w.obs_r[g];
+            st = ur >= 0.0;
+            if (st) { e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
+        }
         double rho0 = chi2, rho1 = 1.0;
         if (w.huber_delta > 0.0 && !(chi2 <= dsqr)) {
             const double sq = sqrt(chi2);
@@ -170,6 +184,17 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         h0 += wg * (p00 * p00 + p10 * p10); h1 += wg * (p00 * p01 + p10 * p11); h2 += wg * (p00 * p02 + p10 * p12);
         h3 += wg * (p01 * p01 + p11 * p11); h4 += wg * (p01 * p02 + p11 * p12); h5 += wg * (p02 * p02 + p12 * p12);
         v0 += p00 * r0 + p10 * r1; v1 += p01 * r0 + p11 * r1; v2 += p02 * r0 + p12 * r1;
+        if (STEREO) {
+            const double r2 = -wg * e2;
+            S1.res2[g] = r2;
+            if (st) {
+                const double c02 = a02 - w.bf / (z * z);
+                const double p20 = a00 * R[0] + c02 * R[6], p21 = a00 * R[1] + c02 * R[7], p22 = a00 * R[2] + c02 * R[8];
+                h0 += wg * p20 * p20; h1 += wg * p20 * p21; h2 += wg * p20 * p22;
+                h3 += wg * p21 * p21; h4 += wg * p21 * p22; h5 += wg * p22 * p22;
+                v0 += p20 * r2; v1 += p21 * r2; v2 += p22 * r2;
+            }
+        }
     }
 #pragma unroll
     for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
@@ -237,6 +262,30 @@ __device__ __forceinline__ void wave_reduce_store(double (&v)[NV], double *strip
 // and B_il Dinv_l b_l.  Wave-level shuffle reduction, one 72-double partial per item.
 // mode 1 = diagonal pairs only, Hpp only (used once to seed lambda).
 // --------------------------------------------------------------------------------
+// Jacobian rows of one edge from its cached camera-frame point: P = J_point rows (-Jpi R), C = J_pose rows
+// (-Jpi [ -[Xc]x | I ]).  NR = 2: monocular edge (src/OptimizableTypes.cpp:158-180); NR = 3 adds the stereo row of
+// g2o::EdgeStereoSE3ProjectXYZ (built at src/Optimizer.cc:673-705), zeroed for the monocular edges of a mixed window.
+template <int NR>
+__device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y, double z, const double R[9], bool stereo,
+                                          double (&P)[NR][3], double (&C)[NR][6])
+{
+    const double iz = 1.0 / z;
+    const double a00 = -w.fx * iz, a02 = w.fx * x * iz * iz, a11 = -w.fy * iz, a12 = w.fy * y * iz * iz;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { P[0][q] = a00 * R[q] + a02 * R[6 + q]; P[1][q] = a11 * R[3 + q] + a12 * R[6 + q]; }
+    C[0][0] = a02 * y; C[0][1] = a00 * z - a02 * x; C[0][2] = -a00 * y; C[0][3] = a00; C[0][4] = 0.0; C[0][5] = a02;
+    C[1][0] = -a11 * z + a12 * y; C[1][1] = -a12 * x; C[1][2] = a11 * x; C[1][3] = 0.0; C[1][4] = a11; C[1][5] = a12;
+    if (NR == 3) {
+        const double m = stereo ? 1.0 : 0.0;
+        const double c00 = m * a00, c02 = m * (a02 - w.bf * iz * iz);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) P[NR - 1][q] = c00 * R[q] + c02 * R[6 + q];
+        C[NR - 1][0] = c02 * y; C[NR - 1][1] = c00 * z - c02 * x; C[NR - 1][2] = -c00 * y;
+        C[NR - 1][3] = c00; C[NR - 1][4] = 0.0; C[NR - 1][5] = c02;
+    }
+}
+
+template <int NR>
 __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
 {
     const Ctrl *c = w.ctrl;
@@ -270,16 +319,24 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
             const int g = w.entries[k].x;
             const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
             const double2 rr = *reinterpret_cast<const double2 *>(S0.res + 2 * g);
-            const double x = rc.x, y = rc.y, z = rc.z, wg = rc.w;
-            const double iz = 1.0 / z;
-            const double a00 = -w.fx * iz, a02 = w.fx * x * iz * iz, a11 = -w.fy * iz, a12 = w.fy * y * iz * iz;
-            const double C0[6] = { a02 * y, a00 * z - a02 * x, -a00 * y, a00, 0.0, a02 };
-            const double C1[6] = { -a11 * z + a12 * y, -a12 * x, a11 * x, 0.0, a11, a12 };
+            const double wg = rc.w;
+            double rv[NR];
+            rv[0] = rr.x; rv[1] = rr.y;
+            bool st = false;
+            if (NR == 3) { st = w.obs_r[g] >= 0.0; rv[NR - 1] = st ? S0.res2[g] : 0.0; }
+            double P[NR][3], C[NR][6];
+            edge_rows<NR>(w, rc.x, rc.y, rc.z, Ri, st, P, C);
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-                ba[a] += C0[a] * rr.x + C1[a] * rr.y;
 #pragma unroll
-                for (int b = a; b < 6; ++b) ha[ut6(a, b)] += wg * (C0[a] * C0[b] + C1[a] * C1[b]);
+                for (int m = 0; m < NR; ++m) ba[a] += C[m][a] * rv[m];
+#pragma unroll
+                for (int b = a; b < 6; ++b) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NR; ++m) t += C[m][a] * C[m][b];
+                    ha[ut6(a, b)] += wg * t;
+                }
             }
             if (mode == 1) continue;
             const int l = w.g_point[g];
@@ -288,23 +345,36 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
             for (int q = 0; q < 6; ++q) H[q] = S0.Hll[6 * l + q];
             H[0] += lambda; H[3] += lambda; H[5] += lambda;
             inv3sym(H, D);
-            const double P0[3] = { a00 * Ri[0] + a02 * Ri[6], a00 * Ri[1] + a02 * Ri[7], a00 * Ri[2] + a02 * Ri[8] };
-            const double P1[3] = { a11 * Ri[3] + a12 * Ri[6], a11 * Ri[4] + a12 * Ri[7], a11 * Ri[5] + a12 * Ri[8] };
-            const double T0[3] = { P0[0] * D[0] + P0[1] * D[1] + P0[2] * D[2], P0[0] * D[1] + P0[1] * D[3] + P0[2] * D[4], P0[0] * D[2] + P0[1] * D[4] + P0[2] * D[5] };
-            const double T1[3] = { P1[0] * D[0] + P1[1] * D[1] + P1[2] * D[2], P1[0] * D[1] + P1[1] * D[3] + P1[2] * D[4], P1[0] * D[2] + P1[1] * D[4] + P1[2] * D[5] };
-            const double w2 = wg * wg;
-            const double M00 = w2 * (T0[0] * P0[0] + T0[1] * P0[1] + T0[2] * P0[2]);
-            const double M01 = w2 * (T0[0] * P1[0] + T0[1] * P1[1] + T0[2] * P1[2]);
-            const double M11 = w2 * (T1[0] * P1[0] + T1[1] * P1[1] + T1[2] * P1[2]);
             const double bl0 = S0.bl[3 * l], bl1 = S0.bl[3 * l + 1], bl2 = S0.bl[3 * l + 2];
-            const double pv0 = wg * (T0[0] * bl0 + T0[1] * bl1 + T0[2] * bl2);
-            const double pv1 = wg * (T1[0] * bl0 + T1[1] * bl1 + T1[2] * bl2);
+            double T[NR][3], M[NR][NR], pv[NR];
+            const double w2 = wg * wg;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                T[m][0] = P[m][0] * D[0] + P[m][1] * D[1] + P[m][2] * D[2];
+                T[m][1] = P[m][0] * D[1] + P[m][1] * D[3] + P[m][2] * D[4];
+                T[m][2] = P[m][0] * D[2] + P[m][1] * D[4] + P[m][2] * D[5];
+                pv[m] = wg * (T[m][0] * bl0 + T[m][1] * bl1 + T[m][2] * bl2);
+            }
+#pragma unroll
+            for (int m = 0; m < NR; ++m)
+#pragma unroll
+                for (int q = 0; q < NR; ++q) M[m][q] = w2 * (T[m][0] * P[q][0] + T[m][1] * P[q][1] + T[m][2] * P[q][2]);
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-                const double u0 = C0[a] * M00 + C1[a] * M01, u1 = C0[a] * M01 + C1[a] * M11;
-                ca[a] += C0[a] * pv0 + C1[a] * pv1;
+                double u[NR];
 #pragma unroll
-                for (int b = a; b < 6; ++b) sa[ut6(a, b)] += u0 * C0[b] + u1 * C1[b];
+                for (int q = 0; q < NR; ++q) {
+                    u[q] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NR; ++m) u[q] += C[m][a] * M[m][q];
+                }
+#pragma unroll
+                for (int m = 0; m < NR; ++m) ca[a] += C[m][a] * pv[m];
+#pragma unroll
+                for (int b = a; b < 6; ++b) {
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) sa[ut6(a, b)] += u[q] * C[q][b];
+                }
             }
         }
         // 54 sums: [0,21) upper triangle of sum B Dinv B^T, [21,27) B Dinv b_l, [27,48) upper Hpp, [48,54) b_p
@@ -334,29 +404,35 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
             for (int q = 0; q < 6; ++q) H[q] = S0.Hll[6 * l + q];
             H[0] += lambda; H[3] += lambda; H[5] += lambda;
             inv3sym(H, D);
-            const double izi = 1.0 / ri.z, izj = 1.0 / rj.z;
-            const double a00 = -w.fx * izi, a02 = w.fx * ri.x * izi * izi, a11 = -w.fy * izi, a12 = w.fy * ri.y * izi * izi;
-            const double b00 = -w.fx * izj, b02 = w.fx * rj.x * izj * izj, b11 = -w.fy * izj, b12 = w.fy * rj.y * izj * izj;
-            const double P0[3] = { a00 * Ri[0] + a02 * Ri[6], a00 * Ri[1] + a02 * Ri[7], a00 * Ri[2] + a02 * Ri[8] };
-            const double P1[3] = { a11 * Ri[3] + a12 * Ri[6], a11 * Ri[4] + a12 * Ri[7], a11 * Ri[5] + a12 * Ri[8] };
-            const double Q0[3] = { b00 * Rj[0] + b02 * Rj[6], b00 * Rj[1] + b02 * Rj[7], b00 * Rj[2] + b02 * Rj[8] };
-            const double Q1[3] = { b11 * Rj[3] + b12 * Rj[6], b11 * Rj[4] + b12 * Rj[7], b11 * Rj[5] + b12 * Rj[8] };
-            const double T0[3] = { P0[0] * D[0] + P0[1] * D[1] + P0[2] * D[2], P0[0] * D[1] + P0[1] * D[3] + P0[2] * D[4], P0[0] * D[2] + P0[1] * D[4] + P0[2] * D[5] };
-            const double T1[3] = { P1[0] * D[0] + P1[1] * D[1] + P1[2] * D[2], P1[0] * D[1] + P1[1] * D[3] + P1[2] * D[4], P1[0] * D[2] + P1[1] * D[4] + P1[2] * D[5] };
+            bool sti = false, stj = false;
+            if (NR == 3) { sti = w.obs_r[en.x] >= 0.0; stj = w.obs_r[en.y] >= 0.0; }
+            double P[NR][3], C[NR][6], Q[NR][3], Ec[NR][6];
+            edge_rows<NR>(w, ri.x, ri.y, ri.z, Ri, sti, P, C);
+            edge_rows<NR>(w, rj.x, rj.y, rj.z, Rj, stj, Q, Ec);
             const double ww = ri.w * rj.w;
-            const double M00 = ww * (T0[0] * Q0[0] + T0[1] * Q0[1] + T0[2] * Q0[2]);
-            const double M01 = ww * (T0[0] * Q1[0] + T0[1] * Q1[1] + T0[2] * Q1[2]);
-            const double M10 = ww * (T1[0] * Q0[0] + T1[1] * Q0[1] + T1[2] * Q0[2]);
-            const double M11 = ww * (T1[0] * Q1[0] + T1[1] * Q1[1] + T1[2] * Q1[2]);
-            const double C0[6] = { a02 * ri.y, a00 * ri.z - a02 * ri.x, -a00 * ri.y, a00, 0.0, a02 };
-            const double C1[6] = { -a11 * ri.z + a12 * ri.y, -a12 * ri.x, a11 * ri.x, 0.0, a11, a12 };
-            const double E0[6] = { b02 * rj.y, b00 * rj.z - b02 * rj.x, -b00 * rj.y, b00, 0.0, b02 };
-            const double E1[6] = { -b11 * rj.z + b12 * rj.y, -b12 * rj.x, b11 * rj.x, 0.0, b11, b12 };
+            double M[NR][NR];
+#pragma unroll
+            for (int m = 0; m < NR; ++m) {
+                const double t0 = P[m][0] * D[0] + P[m][1] * D[1] + P[m][2] * D[2];
+                const double t1 = P[m][0] * D[1] + P[m][1] * D[3] + P[m][2] * D[4];
+                const double t2 = P[m][0] * D[2] + P[m][1] * D[4] + P[m][2] * D[5];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) M[m][q] = ww * (t0 * Q[q][0] + t1 * Q[q][1] + t2 * Q[q][2]);
+            }
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
-                const double u0 = C0[a] * M00 + C1[a] * M10, u1 = C0[a] * M01 + C1[a] * M11;
+                double u[NR];
 #pragma unroll
-                for (int b = 0; b < 6; ++b) acc[a * 6 + b] += u0 * E0[b] + u1 * E1[b];
+                for (int q = 0; q < NR; ++q) {
+                    u[q] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NR; ++m) u[q] += C[m][a] * M[m][q];
+                }
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) acc[a * 6 + b] += u[q] * Ec[q][b];
+                }
             }
         }
         wave_reduce_store<36>(acc, strip, lane, out, nullptr);
@@ -742,13 +818,15 @@ hipError_t launch_init(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_point<false>, dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    if (w.stereo) hipLaunchKernelGGL((k_point<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    else hipLaunchKernelGGL((k_point<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
     return hipGetLastError();
 }
 
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_schur, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode, trial);
+    if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode, trial);
+    else hipLaunchKernelGGL(k_schur<2>, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode, trial);
     return hipGetLastError();
 }
 
@@ -766,7 +844,8 @@ hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStr
 
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_point<true>, dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    if (w.stereo) hipLaunchKernelGGL((k_point<true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    else hipLaunchKernelGGL((k_point<true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
     return hipGetLastError();
 }
 
@@ -788,9 +867,13 @@ hipError_t configure_kernels(int nfree_max_lds_bytes)
     // allow the PCG workgroup and the point kernels to use more than the default 64 KiB of LDS
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_point<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_point<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    const void *pk[4] = { reinterpret_cast<const void *>(k_point<true, false>), reinterpret_cast<const void *>(k_point<false, false>),
+                          reinterpret_cast<const void *>(k_point<true, true>), reinterpret_cast<const void *>(k_point<false, true>) };
+    for (const void *f : pk) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace movba

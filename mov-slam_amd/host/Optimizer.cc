@@ -73,7 +73,9 @@ namespace MOV_SLAM
             std::vector<MapPoint *> edge_mp;        // vpMapPointEdgeMono
             double cam[4] = {0, 0, 0, 0};
             bool cam_set = false;
-            int skipped_stereo = 0;
+            std::vector<double> obs_right;          // mvuRight of stereo observations, -1 for monocular ones
+            bool any_stereo = false;
+            double bf = 0.0;
         };
 
         void push_pose(Flat &f, KeyFrame *pKF, bool isFixed)
@@ -123,12 +125,15 @@ namespace MOV_SLAM
                 const int leftIndex = std::get<0>(mit->second);
                 if (leftIndex == -1)
                     continue;
-                if (pKFi->mvuRight[leftIndex] >= 0)
-                {
-                    ++f.skipped_stereo;                         // stereo edges: SURVEY.md §8(f3), not built yet
-                    continue;
-                }
                 const cv::KeyPoint &kpUn = pKFi->mvKeysUn[leftIndex];
+                // stereo observation (Optimizer.cc:673-705): third measurement kp_ur = mvuRight[idx], e->bf = pKFi->mbf
+                const float kp_ur = pKFi->mvuRight[leftIndex];
+                if (kp_ur >= 0)
+                {
+                    f.any_stereo = true;
+                    f.bf = pKFi->mbf;
+                }
+                f.obs_right.push_back(kp_ur >= 0 ? (double)kp_ur : -1.0);
                 if (!f.cam_set)
                 {
                     for (int k = 0; k < 4; ++k) f.cam[k] = pKFi->mpCamera->getParameter(k);
@@ -161,7 +166,7 @@ namespace MOV_SLAM
             std::snprintf(path, sizeof path, "%s/lba_%06d.mbw", dir, counter.fetch_add(1));
             FILE *f = std::fopen(path, "wb");
             if (!f) return;
-            const uint32_t ver = 1, flags = d.flags;
+            const uint32_t ver = 1, flags = d.flags | (d.obs_right ? 0x80000000u : 0u);   // top bit: stereo trailer follows
             const int32_t hd[4] = {d.n_poses, d.n_points, d.n_edges, d.max_iters};
             const double dd[6] = {d.fx, d.fy, d.cx, d.cy, d.huber_delta, d.chi2_gate};
             const uint8_t pad[8] = {0};
@@ -171,6 +176,7 @@ namespace MOV_SLAM
             std::fwrite(d.poses, 8, 7 * (size_t)d.n_poses, f); std::fwrite(d.points, 8, 3 * (size_t)d.n_points, f);
             std::fwrite(d.edge_pose, 4, d.n_edges, f); std::fwrite(d.edge_point, 4, d.n_edges, f);
             std::fwrite(d.obs, 8, 2 * (size_t)d.n_edges, f); std::fwrite(d.inv_sigma2, 8, d.n_edges, f);
+            if (d.obs_right) { std::fwrite(&d.bf, 8, 1, f); std::fwrite(d.obs_right, 8, d.n_edges, f); }
             std::fclose(f);
         }
 
@@ -191,6 +197,8 @@ namespace MOV_SLAM
             d.poses = f.poses.data(); d.pose_fixed = f.fixed.data(); d.points = f.points.data();
             d.edge_pose = f.edge_pose.data(); d.edge_point = f.edge_point.data();
             d.obs = f.obs.data(); d.inv_sigma2 = f.inv_sigma2.data();
+            d.obs_right = f.any_stereo ? f.obs_right.data() : nullptr;
+            d.bf = f.bf;
             d.fx = f.cam[0]; d.fy = f.cam[1]; d.cx = f.cam[2]; d.cy = f.cam[3];
             const float thHuber = std::sqrt(delta);              // const float thHuberMono = sqrt(delta)  (Optimizer.cc:616)
             d.huber_delta = bRobust ? (double)thHuber : 0.0;

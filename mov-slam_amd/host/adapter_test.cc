@@ -27,6 +27,10 @@ static int run_lba(const char *in, const char *out, bool global)
     const std::vector<double> poses = rd<double>(f, 7 * (size_t)NP), points = rd<double>(f, 3 * (size_t)P);
     const std::vector<int32_t> ep = rd<int32_t>(f, E), el = rd<int32_t>(f, E);
     const std::vector<double> obs = rd<double>(f, 2 * (size_t)E);
+    // optional stereo trailer: bf, then mvuRight per edge (< 0 = monocular)
+    double bf = 0.0;
+    std::vector<double> obs_right;
+    if (fread(&bf, sizeof(double), 1, f) == 1) obs_right = rd<double>(f, E);
     fclose(f);
 
     Map map;
@@ -35,7 +39,7 @@ static int run_lba(const char *in, const char *out, bool global)
     std::vector<MapPoint> mps(P);
     for (int i = 0; i < NP; ++i) {
         KeyFrame &k = kfs[i];
-        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = &cam;
+        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = &cam; k.mbf = (float)bf;
         k.mTcw = Sophus::SE3f(Eigen::Quaternionf((float)poses[7 * i + 3], (float)poses[7 * i], (float)poses[7 * i + 1], (float)poses[7 * i + 2]),
                               Eigen::Vector3f((float)poses[7 * i + 4], (float)poses[7 * i + 5], (float)poses[7 * i + 6]));
         map.mvKFs.push_back(&k);
@@ -49,7 +53,7 @@ static int run_lba(const char *in, const char *out, bool global)
         KeyFrame &k = kfs[ep[e]];
         cv::KeyPoint kp; kp.pt.x = (float)obs[2 * e]; kp.pt.y = (float)obs[2 * e + 1]; kp.octave = 0;
         const int idx = (int)k.mvKeysUn.size();
-        k.mvKeysUn.push_back(kp); k.mvuRight.push_back(-1.f); k.mvpMapPoints.push_back(&mps[el[e]]);
+        k.mvKeysUn.push_back(kp); k.mvuRight.push_back(obs_right.empty() ? -1.f : (float)obs_right[e]); k.mvpMapPoints.push_back(&mps[el[e]]);
         mps[el[e]].mObservations[&k] = std::make_tuple(idx, -1);
     }
     // the newest free keyframe is the one LocalMapping passes in; every other free keyframe is covisible

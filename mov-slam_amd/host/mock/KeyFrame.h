@@ -1,4 +1,4 @@
-// Mock of include/KeyFrame.h (:154, :172, :198, :201, :218, :233, :254, :270-271, :293, :298, :323-324, :340, :441).
+// Mock of include/KeyFrame.h (:154, :172, :198, :201, :218, :233, :254, :270-271, :293, :298, :323-324, :340, :441; mbf :312).
 #pragma once
 #include <vector>
 #include "mock_math.h"
@@ -21,6 +21,7 @@ public:
     Sophus::SE3f mTcwGBA;
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight;
+    float mbf = 0.f;
     std::vector<float> mvInvLevelSigma2 = std::vector<float>(8, 1.0f);
     GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
     // test plumbing

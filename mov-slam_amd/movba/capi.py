@@ -34,7 +34,8 @@ class LbaDesc(C.Structure):
                 ("obs", _d), ("inv_sigma2", _d),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
-                ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("flags", C.c_uint32), ("stop", _u)]
+                ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("flags", C.c_uint32), ("stop", _u),
+                ("obs_right", _d), ("bf", C.c_double)]
 
 
 class LbaResult(C.Structure):
@@ -139,6 +140,10 @@ def make_desc(w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_tr
     if stop is not None:
         keep["stop"] = stop
         d.stop = _p(stop, _u)
+    if getattr(w, "obs_right", None) is not None:
+        keep["obs_right"] = np.ascontiguousarray(w.obs_right, np.float64)
+        d.obs_right = _p(keep["obs_right"], _d)
+        d.bf = float(w.bf)
     return d, keep
 
 

@@ -5,7 +5,8 @@ solves to $MOVBA_DUMP_DIR/lba_<n>.mbw when that variable is set, so that windows
 MoV-SLAM run can be replayed on a GPU box (scripts/replay_windows.py) without the reference's stack.
 Layout (little endian): magic 'MOVBAWIN', u32 version=1, i32 NP, P, E, max_iters, u32 flags,
 f64 cam[4], huber_delta, chi2_gate, then pose_fixed u8[NP] (padded to 8), poses f64[NP*7],
-points f64[P*3], edge_pose i32[E], edge_point i32[E], obs f64[E*2], inv_sigma2 f64[E].
+points f64[P*3], edge_pose i32[E], edge_point i32[E], obs f64[E*2], inv_sigma2 f64[E]; when the top bit of
+flags is set a stereo trailer follows: f64 bf, obs_right f64[E] (< 0 = monocular edge).
 """
 from __future__ import annotations
 
@@ -21,13 +22,16 @@ MAGIC = b"MOVBAWIN"
 def save_window(path: str, w, flags: int = 1):
     with open(path, "wb") as f:
         f.write(MAGIC)
-        f.write(struct.pack("<I4iI", 1, w.n_poses, w.n_points, w.n_edges, w.max_iters, flags))
+        stereo = getattr(w, "obs_right", None) is not None
+        f.write(struct.pack("<I4iI", 1, w.n_poses, w.n_points, w.n_edges, w.max_iters, flags | (0x80000000 if stereo else 0)))
         f.write(struct.pack("<6d", *w.cam, w.huber_delta, w.chi2_gate))
         fixed = np.ascontiguousarray(w.pose_fixed, np.uint8).tobytes()
         f.write(fixed + b"\0" * (-len(fixed) % 8))
         for arr, dt in ((w.poses, np.float64), (w.points, np.float64), (w.edge_pose, np.int32), (w.edge_point, np.int32),
                         (w.obs, np.float64), (w.inv_sigma2, np.float64)):
             f.write(np.ascontiguousarray(arr, dt).tobytes())
+        if stereo:
+            f.write(struct.pack("<d", w.bf)); f.write(np.ascontiguousarray(w.obs_right, np.float64).tobytes())
 
 
 def load_window(path: str):
@@ -47,5 +51,9 @@ def load_window(path: str):
     poses = take(np.float64, 7 * NP).reshape(NP, 7); points = take(np.float64, 3 * P).reshape(P, 3)
     ep = take(np.int32, E); el = take(np.int32, E)
     obs = take(np.float64, 2 * E).reshape(E, 2); isg = take(np.float64, E)
-    return synth.Window(poses=poses, pose_fixed=fixed, points=points, edge_pose=ep, edge_point=el, obs=obs, inv_sigma2=isg,
-                        cam=tuple(cam), huber_delta=huber, chi2_gate=gate, max_iters=max_iters, meta=dict(flags=flags))
+    w = synth.Window(poses=poses, pose_fixed=fixed, points=points, edge_pose=ep, edge_point=el, obs=obs, inv_sigma2=isg,
+                     cam=tuple(cam), huber_delta=huber, chi2_gate=gate, max_iters=max_iters, meta=dict(flags=flags & 0x7fffffff))
+    if flags & 0x80000000:
+        w.bf = struct.unpack_from("<d", b, off)[0]; off += 8
+        w.obs_right = take(np.float64, E)
+    return w

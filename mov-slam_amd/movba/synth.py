@@ -38,6 +38,8 @@ class Window:
     truth_poses: np.ndarray | None = None
     truth_points: np.ndarray | None = None
     meta: dict = field(default_factory=dict)
+    obs_right: np.ndarray | None = None   # (E,) f64: right-image u of stereo observations, < 0 = monocular edge
+    bf: float = 0.0                       # KeyFrame::mbf (baseline * fx)
 
     @property
     def n_poses(self): return int(self.poses.shape[0])
@@ -92,7 +94,7 @@ def _rodrigues(w):
 def make_window(n_free: int, n_fixed: int, n_points: int, seed: int,
                 run_lo: int = 2, run_hi: int = 10, outlier_frac: float = 0.05,
                 pix_sigma: float = 0.5, rot_sigma_deg: float = 0.5, trans_sigma: float = 0.02,
-                point_sigma: float = 0.05, min_obs: int = 2) -> Window:
+                point_sigma: float = 0.05, min_obs: int = 2, stereo_frac: float = 0.0, bf: float = 80.0) -> Window:
     rng = np.random.default_rng(seed)
     NP = n_free + n_fixed
     k = np.arange(NP, dtype=np.float64)
@@ -151,6 +153,14 @@ def make_window(n_free: int, n_fixed: int, n_points: int, seed: int,
     ang = rng.uniform(0.0, 2 * np.pi, size=E)
     obs[is_out] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)[is_out]
 
+    # stereo observations (Optimizer.cc:673-705): u_right = u - bf / z (+ noise) for a fraction of the edges
+    obs_right = None
+    if stereo_frac > 0.0:
+        Xc_all = np.einsum('eij,ej->ei', Rcw[edge_pose], truth_points[edge_point]) + tcw[edge_pose]
+        ur = obs[:, 0] - bf / Xc_all[:, 2] + rng.normal(0.0, pix_sigma, size=E)
+        st = (rng.random(E) < stereo_frac) & (ur >= 0.0)
+        obs_right = np.where(st, ur, -1.0)
+
     truth_poses = np.zeros((NP, 7))
     poses = np.zeros((NP, 7))
     fixed = np.zeros(NP, dtype=np.uint8)
@@ -170,7 +180,8 @@ def make_window(n_free: int, n_fixed: int, n_points: int, seed: int,
     return Window(poses=poses, pose_fixed=fixed, points=_f32(points), edge_pose=edge_pose,
                   edge_point=edge_point, obs=_f32(obs), inv_sigma2=np.ones(E),
                   truth_poses=truth_poses, truth_points=truth_points,
-                  meta=dict(seed=seed, K=n_free, F=n_fixed, P=n_points, E=E, outliers=int(is_out.sum())))
+                  meta=dict(seed=seed, K=n_free, F=n_fixed, P=n_points, E=E, outliers=int(is_out.sum())),
+                  obs_right=None if obs_right is None else np.where(obs_right >= 0, _f32(obs_right), -1.0), bf=bf if obs_right is not None else 0.0)
 
 
 def cfg(name: str, seed: int | None = None) -> Window:

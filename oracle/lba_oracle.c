@@ -179,6 +179,28 @@ void lba_oracle_edge(const double qt[7], const double X[3], const double obs[2],
     edge_jacobians(R, Xc, cam, Jp, Jc);
 }
 
+/* g2o EdgeStereoSE3ProjectXYZ (types_six_dof_expmap; instantiated at src/Optimizer.cc:680): third residual
+ * u_r - (fx x/z + cx - bf/z) and its Jacobian rows: row 2 of J_point = row 0 - bf R(2,:)/z^2, row 2 of
+ * J_pose = row 0 + [-bf y/z^2, +bf x/z^2, 0, 0, 0, -bf/z^2]. */
+static inline double stereo_error(const double Xc[3], double ur, const double cam[4], double bf)
+{
+    return ur - (cam[0] * Xc[0] / Xc[2] + cam[2] - bf / Xc[2]);
+}
+
+static inline void stereo_rows(const double R[9], const double Xc[3], double bf, const double Jp[6], const double Jc[12],
+                               double Jp2[3], double Jc2[6])
+{
+    const double x = Xc[0], y = Xc[1], z = Xc[2], z2 = z * z;
+    for (int j = 0; j < 3; ++j) Jp2[j] = Jp[j] - bf * R[6 + j] / z2;
+    for (int j = 0; j < 6; ++j) Jc2[j] = Jc[j];
+    Jc2[0] -= bf * y / z2; Jc2[1] += bf * x / z2; Jc2[5] -= bf / z2;
+}
+
+static inline int is_stereo(const lba_oracle_problem *pb, int e)
+{
+    return pb->obs_right && pb->obs_right[e] >= 0.0;
+}
+
 /* g2o RobustKernelHuber::robustify; delta = (double)sqrtf(5.0f) at src/Optimizer.cc:616, 660-662 */
 void lba_oracle_huber(double e, double delta, double rho[3])
 {
@@ -303,7 +325,7 @@ static void ws_init(ws_t *w, const lba_oracle_problem *pb)
     memcpy(w->points, pb->points, sizeof(double) * 3 * (size_t)P);
     /* g2o::SE3Quat(q, t) normalises on construction (src/Optimizer.cc:559) */
     for (int i = 0; i < NP; ++i) lba_oracle_se3_normalize(w->poses + 7 * i);
-    w->err = (double *)calloc(2 * (size_t)E + 2, sizeof(double));
+    w->err = (double *)calloc(3 * (size_t)E + 3, sizeof(double));
     w->Hpp = (double *)calloc(36 * (size_t)nf + 36, sizeof(double));
     w->bp = (double *)calloc(6 * (size_t)nf + 6, sizeof(double));
     w->Hll = (double *)calloc(9 * (size_t)P + 9, sizeof(double));
@@ -324,9 +346,10 @@ static double ws_errors(ws_t *w)
     for (int e = 0; e < pb->n_edges; ++e) {
         double Xc[3];
         lba_oracle_se3_map(w->poses + 7 * pb->edge_pose[e], w->points + 3 * pb->edge_point[e], Xc);
-        edge_error(Xc, pb->obs + 2 * e, w->cam, w->err + 2 * e);
-        const double *er = w->err + 2 * e;
-        const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1]);
+        edge_error(Xc, pb->obs + 2 * e, w->cam, w->err + 3 * e);
+        double *er = w->err + 3 * e;
+        er[2] = is_stereo(pb, e) ? stereo_error(Xc, pb->obs_right[e], w->cam, pb->bf) : 0.0;
+        const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
         if (pb->huber_delta > 0.0) {
             double rho[3];
             lba_oracle_huber(chi2, pb->huber_delta, rho);
@@ -355,29 +378,31 @@ static void ws_build(ws_t *w)
         lba_oracle_se3_map(qt, w->points + 3 * l, Xc);
         quat_to_R(qt, R);
         edge_jacobians(R, Xc, w->cam, A, B);
-        const double *er = w->err + 2 * e;
+        double A2[3] = { 0, 0, 0 }, B2[6] = { 0, 0, 0, 0, 0, 0 };      /* third row: stereo edges only */
+        if (is_stereo(pb, e)) stereo_rows(R, Xc, pb->bf, A, B, A2, B2);
+        const double *er = w->err + 3 * e;
         const double om = pb->inv_sigma2[e];
         double wgt = 1.0;
         if (pb->huber_delta > 0.0) {
             double rho[3];
-            lba_oracle_huber(om * (er[0] * er[0] + er[1] * er[1]), pb->huber_delta, rho);
+            lba_oracle_huber(om * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]), pb->huber_delta, rho);
             wgt = rho[1];
         }
         const double wo = wgt * om;                      /* robustInformation = rho1 * Omega */
-        const double r0 = -om * er[0] * wgt, r1 = -om * er[1] * wgt;   /* omega_r *= rho1 */
+        const double r0 = -om * er[0] * wgt, r1 = -om * er[1] * wgt, r2 = -om * er[2] * wgt;   /* omega_r *= rho1 */
         /* point vertex (never fixed) */
         double *Hl = w->Hll + 9 * l, *b_l = w->bl + 3 * l;
         for (int a = 0; a < 3; ++a) {
-            b_l[a] += A[a] * r0 + A[3 + a] * r1;
-            for (int c = 0; c < 3; ++c) Hl[a * 3 + c] += wo * (A[a] * A[c] + A[3 + a] * A[3 + c]);
+            b_l[a] += A[a] * r0 + A[3 + a] * r1 + A2[a] * r2;
+            for (int c = 0; c < 3; ++c) Hl[a * 3 + c] += wo * (A[a] * A[c] + A[3 + a] * A[3 + c] + A2[a] * A2[c]);
         }
         const int hi = w->hidx[ip];
         if (hi >= 0) {
             double *Hp = w->Hpp + 36 * hi, *b_p = w->bp + 6 * hi, *Hx = w->Hpl + 18 * e;
             for (int a = 0; a < 6; ++a) {
-                b_p[a] += B[a] * r0 + B[6 + a] * r1;
-                for (int c = 0; c < 6; ++c) Hp[a * 6 + c] += wo * (B[a] * B[c] + B[6 + a] * B[6 + c]);
-                for (int c = 0; c < 3; ++c) Hx[a * 3 + c] = wo * (B[a] * A[c] + B[6 + a] * A[3 + c]);
+                b_p[a] += B[a] * r0 + B[6 + a] * r1 + B2[a] * r2;
+                for (int c = 0; c < 6; ++c) Hp[a * 6 + c] += wo * (B[a] * B[c] + B[6 + a] * B[6 + c] + B2[a] * B2[c]);
+                for (int c = 0; c < 3; ++c) Hx[a * 3 + c] = wo * (B[a] * A[c] + B[6 + a] * A[3 + c] + B2[a] * A2[c]);
             }
         }
     }
@@ -604,8 +629,8 @@ int lba_oracle_solve(const lba_oracle_problem *pb, lba_oracle_result *res)
     memcpy(res->poses, w.poses, sizeof(double) * 7 * (size_t)NP);
     memcpy(res->points, w.points, sizeof(double) * 3 * (size_t)P);
     for (int e = 0; e < E; ++e) {
-        const double *er = w.err + 2 * e;
-        const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1]);
+        const double *er = w.err + 3 * e;
+        const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
         double Xc[3];
         lba_oracle_se3_map(w.poses + 7 * pb->edge_pose[e], w.points + 3 * pb->edge_point[e], Xc);
         const int out = (chi2 > pb->chi2_gate) || !(Xc[2] > 0.0);

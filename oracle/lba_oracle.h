@@ -47,6 +47,11 @@ typedef struct {
     int stale_error_quirk;       /* 1: chi2 from the edges' stored _error (g2o)    */
     int max_trials;              /* g2o maxTrialsAfterFailure property; 0 -> 10    */
     const volatile uint8_t *stop;/* forceStopFlag, may be NULL                     */
+    /* stereo observations: g2o::EdgeStereoSE3ProjectXYZ, built at src/Optimizer.cc:673-705 when
+     * mvuRight[idx] >= 0.  obs_right[e] >= 0: third measurement u_right, residual u_r - (u - bf/z);
+     * < 0 (or obs_right == NULL): monocular edge. */
+    const double *obs_right;     /* E or NULL                                      */
+    double bf;                   /* KeyFrame::mbf                                  */
 } lba_oracle_problem;
 
 #define LBA_ORACLE_MAX_TRACE 128

@@ -27,7 +27,8 @@ class _Problem(C.Structure):
                 ("edge_pose", _i), ("edge_point", _i), ("obs", _d), ("inv_sigma2", _d),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
-                ("max_iters", C.c_int), ("stale_error_quirk", C.c_int), ("max_trials", C.c_int), ("stop", _u)]
+                ("max_iters", C.c_int), ("stale_error_quirk", C.c_int), ("max_trials", C.c_int), ("stop", _u),
+                ("obs_right", _d), ("bf", C.c_double)]
 
 
 class _Result(C.Structure):
@@ -90,6 +91,10 @@ def _problem(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0)
     if stop is not None:
         keep["stop"] = stop
         pb.stop = _p(stop, _u)
+    if getattr(w, "obs_right", None) is not None:
+        keep["obs_right"] = np.ascontiguousarray(w.obs_right, np.float64)
+        pb.obs_right = _p(keep["obs_right"], _d)
+        pb.bf = float(w.bf)
     return pb, keep
 
 

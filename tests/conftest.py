@@ -26,6 +26,8 @@ def load_golden(name):
                      inv_sigma2=g["in_inv_sigma2"], cam=tuple(g["in_cam"]),
                      huber_delta=float(g["in_huber_delta"]), chi2_gate=float(g["in_chi2_gate"]),
                      max_iters=int(g["in_max_iters"]))
+    if "in_obs_right" in g.files and g["in_obs_right"].size:
+        w.obs_right, w.bf = g["in_obs_right"], float(g["in_bf"])
     out = {k[4:]: g[k] for k in g.files if k.startswith("out_")}
     return w, out
 

@@ -54,9 +54,16 @@ def huber(c, delta):
 
 
 def errors(Ts, X, w):
+    """(E,3) residuals; third component u_r - (u - bf/z) for stereo edges (g2o EdgeStereoSE3ProjectXYZ), else 0."""
     fx, fy, cx, cy = w.cam
     Xc = np.einsum("eij,ej->ei", Ts[w.edge_pose][:, :3, :3], X[w.edge_point]) + Ts[w.edge_pose][:, :3, 3]
-    e = w.obs - np.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy], 1)
+    u = fx * Xc[:, 0] / Xc[:, 2] + cx
+    e = np.zeros((w.n_edges, 3))
+    e[:, 0] = w.obs[:, 0] - u
+    e[:, 1] = w.obs[:, 1] - (fy * Xc[:, 1] / Xc[:, 2] + cy)
+    if w.obs_right is not None:
+        st = w.obs_right >= 0
+        e[st, 2] = w.obs_right[st] - (u[st] - w.bf / Xc[st, 2])
     return e, Xc
 
 
@@ -89,7 +96,9 @@ def lm_dense(w, max_iters=10):
         for k in range(E):
             ip, l = w.edge_pose[k], w.edge_point[k]
             x, y, z = Xc[k]
-            Jpi = np.array([[fx / z, 0, -fx * x / z ** 2], [0, fy / z, -fy * y / z ** 2]])
+            Jpi = np.array([[fx / z, 0, -fx * x / z ** 2], [0, fy / z, -fy * y / z ** 2], [0, 0, 0]])
+            if w.obs_right is not None and w.obs_right[k] >= 0:
+                Jpi[2] = [fx / z, 0, -fx * x / z ** 2 + w.bf / z ** 2]      # d(u - bf/z)/dXc
             A = -Jpi @ Ts[ip][:3, :3]
             skew = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
             B = -Jpi @ np.hstack([-skew, np.eye(3)])
@@ -144,6 +153,7 @@ def save(name, w, out):
         path, in_poses=w.poses, in_pose_fixed=w.pose_fixed, in_points=w.points, in_edge_pose=w.edge_pose,
         in_edge_point=w.edge_point, in_obs=w.obs, in_inv_sigma2=w.inv_sigma2, in_cam=np.array(w.cam),
         in_huber_delta=w.huber_delta, in_chi2_gate=w.chi2_gate, in_max_iters=w.max_iters,
+        in_obs_right=(w.obs_right if w.obs_right is not None else np.zeros(0)), in_bf=w.bf,
         **{"out_" + k: v for k, v in out.items()})
     print(name, w.meta, "iters", out["iters"], "trials", len(out["tr_lam"]),
           "accept", out["tr_accept"].tolist(), "outliers", int(out["outlier"].sum()))
@@ -161,6 +171,9 @@ def main():
     w = synth.make_window(3, 1, 40, seed=31, run_lo=2, run_hi=4)
     w.huber_delta = 0.0
     save("lba_norobust", w, lm_dense(w))
+    # stereo + monocular edges mixed (the reference's stereo branch, Optimizer.cc:673-705)
+    w = synth.make_window(5, 2, 80, seed=41, run_lo=2, run_hi=5, stereo_frac=0.6)
+    save("lba_stereo", w, lm_dense(w))
 
 
 if __name__ == "__main__":

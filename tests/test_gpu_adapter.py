@@ -43,6 +43,8 @@ def _write_window(path, w):
         f.write(np.ascontiguousarray(w.edge_pose, np.int32).tobytes())
         f.write(np.ascontiguousarray(w.edge_point, np.int32).tobytes())
         f.write(np.ascontiguousarray(w.obs, np.float64).tobytes())
+        if getattr(w, "obs_right", None) is not None:
+            f.write(struct.pack("d", w.bf)); f.write(np.ascontiguousarray(w.obs_right, np.float64).tobytes())
 
 
 def _read_out(path, w):
@@ -76,12 +78,15 @@ def _local_subwindow(w):
                        edge_pose=pmap[w.edge_pose[keep_e]].astype(np.int32), edge_point=lmap[w.edge_point[keep_e]].astype(np.int32),
                        obs=w.obs[keep_e], inv_sigma2=w.inv_sigma2[keep_e], cam=w.cam, huber_delta=w.huber_delta,
                        chi2_gate=w.chi2_gate, max_iters=w.max_iters)
+    if getattr(w, "obs_right", None) is not None:
+        sub.obs_right, sub.bf = w.obs_right[keep_e], w.bf
     return sub, used_pose, local_pt, keep_e
 
 
-@pytest.mark.parametrize("name", ["small", "cfg2"])
+@pytest.mark.parametrize("name", ["small", "cfg2", "stereo"])
 def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tmp_path, name):
-    w = synth.cfg(name)
+    # "stereo": a window whose keyframes hold stereo observations (mvuRight >= 0, Optimizer.cc:673-705)
+    w = synth.make_window(6, 2, 150, seed=43, run_lo=2, run_hi=5, stereo_frac=0.7) if name == "stereo" else synth.cfg(name)
     w.poses = _f32_pose(w.poses)                     # the doubles the adapter derives from the float map
     fin, fout = str(tmp_path / "w.bin"), str(tmp_path / "o.bin")
     _write_window(fin, w)

@@ -36,7 +36,7 @@ def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL):
     assert np.abs(r["poses"][fx] - o["poses"][fx]).max() < 1e-15
 
 
-@pytest.mark.parametrize("name", ["lba_tiny", "lba_small", "lba_hard", "lba_norobust"])
+@pytest.mark.parametrize("name", ["lba_tiny", "lba_small", "lba_hard", "lba_norobust", "lba_stereo"])
 def test_golden_fixtures(solver, oracle_mod, name):
     w, g = load_golden(name)
     r = solver.solve(w)
@@ -84,6 +84,18 @@ def test_large_window_takes_the_generic_pcg(solver, oracle_mod, built_lib):
     plan = built_lib.structure_probe(w)
     assert not plan["pcg_on_chip"]
     check_against(solver.solve(w), oracle_mod.solve(w), w)
+
+
+@pytest.mark.parametrize("frac", [1.0, 0.4])
+def test_stereo_edges(solver, oracle_mod, frac):
+    """g2o::EdgeStereoSE3ProjectXYZ (src/Optimizer.cc:673-705): 3-row edges, all-stereo and mixed with monocular ones."""
+    w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=frac)
+    assert (w.obs_right >= 0).mean() > 0.3
+    r, o = solver.solve(w), oracle_mod.solve(w)
+    check_against(r, o, w)
+    # the third residual matters: the monocular solution of the same window is a different one
+    wm = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=frac); wm.obs_right = None
+    assert np.abs(solver.solve(wm)["poses"] - r["poses"]).max() > 1e-6
 
 
 def test_runs_are_bitwise_reproducible(solver):

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import load_golden, quat_angle
 
-CASES = ["lba_tiny", "lba_small", "lba_hard", "lba_norobust"]
+CASES = ["lba_tiny", "lba_small", "lba_hard", "lba_norobust", "lba_stereo"]
 
 
 @pytest.mark.parametrize("name", CASES)
