@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X spec peak (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
-ROCPROF_NAME = {"k_schur": "movba::k_schur", "k_pcg": "movba::k_pcg_rows", "k_point<backsub>": "void movba::k_point<true>"}
+ROCPROF_NAME = {"k_schur": "movba::k_schur", "k_pcg": "movba::k_pcg_rows", "k_point<backsub>": "movba::k_point<true"}
 
 
 def measured_traffic(kernel_class):
@@ -40,7 +40,7 @@ def measured_traffic(kernel_class):
         return None, None
     d = json.load(open(files[-1]))
     for name, v in d["kernels"].items():
-        if name.startswith(ROCPROF_NAME.get(kernel_class, "?")):
+        if ROCPROF_NAME.get(kernel_class, "?") in name:
             return v["hbm_bytes_per_launch_raw"], os.path.basename(files[-1])
     return None, None
 
