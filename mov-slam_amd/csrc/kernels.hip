@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
     const Ctrl *c = w.ctrl;
     if (c->done) return;
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware block order: workgroups b, b+8, ... share an XCD (and its L2); give each XCD a contiguous run of
+    // work items, i.e. pose pairs of neighbouring keyframes, which gather the same map points
+    const int per_xcd = gridDim.x >> 3;
+    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int item = blk * 4 + (threadIdx.x >> 6);
     if (item >= w.nitems) return;
     const Item it = w.items[item];
     if (mode == 1 && !it.diag) return;
@@ -825,8 +829,9 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
-    if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode, trial);
-    else hipLaunchKernelGGL(k_schur<2>, dim3((w.nitems + 3) / 4), dim3(256), 0, s, w, mode, trial);
+    const int nblk = (((w.nitems + 3) / 4 + 7) / 8) * 8;             // multiple of 8: one contiguous run of items per XCD
+    if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3(nblk), dim3(256), 0, s, w, mode, trial);
+    else hipLaunchKernelGGL(k_schur<2>, dim3(nblk), dim3(256), 0, s, w, mode, trial);
     return hipGetLastError();
 }
 

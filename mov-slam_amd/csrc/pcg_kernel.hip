@@ -20,7 +20,8 @@
 //     rows of one wave form an aggregate with 6 coarse dofs; A_c^-1 (48 x 48) comes from k_coarse of the
 //     previous trial (built beside the LM chain on a side stream) and removes the low-frequency drift
 //     modes block-Jacobi cannot see: ~2.3x fewer CG iterations at cfg3;
-//   * per CG iteration: 3 workgroup barriers (+1 with the coarse level), 2 DPP wave reductions.
+//   * per CG iteration: 3 workgroup barriers, 2 DPP wave reductions (the coarse level rides on them: the
+//     restricted residual follows the recurrence r_c -= alpha P^T A p, whose P^T A p is published with p.Ap).
 // All reductions run in a fixed order: results are bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     double *Aci = red1 + kNW + 2;                         // kNC x kNC: inverse coarse matrix of the previous trial
     double *rcg = Aci + kNC * kNC;                        // kNC: restricted residual of every aggregate
     double *zstrip = rcg + kNC + 8 * wv;                  // 8 per wave: the wave's coarse correction
-    double *ypart = rcg + kNC + 8 * kNW;                  // 6 doubles per gather-list PAIR (+ one dummy strip)
+    double *rcw = rcg + kNC + 8 * kNW + kNC * wv;         // kNC per wave: the wave's copy of the restricted residual P^T r
+    double *ypart = rcg + kNC + 8 * kNW + kNC * kNW;      // 6 doubles per gather-list PAIR (+ one dummy strip)
     if (tid == 0) s_fail = 0;
     // coarse level: usable when k_coarse(trial - 1) left a valid inverse (never for the first trial)
     const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
@@ -265,6 +267,19 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    // coarse level state: every wave keeps its own LDS copy of the restricted residual P^T r (rcw)
+    const int ca = min(ln >> 3, 5), sub = ln & 7;
+    if (coarse) {
+        if (owner) r_lds[row] = r_r;
+        __syncthreads();
+        if (ln < kNC) {
+            const int g = ln / 6, a = ln - g * 6;
+            double t = 0.0;
+            for (int i = pp.wave_row0[g]; i < pp.wave_row0[g + 1]; ++i) t += r_lds[i * 6 + a];
+            rcw[ln] = t;
+        }
+        __syncthreads();
+    }
     auto precond = [&](double rv) {
         if (owner) r_lds[row] = rv;
         wave_lds_sync();
@@ -272,21 +287,10 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
         double s = m0.x * r0.x + m0.y * r0.y + m1.x * r1.x + m1.y * r1.y + m2.x * r2.x + m2.y * r2.y;
         if (coarse) {
-            // restriction inside the wave: lanes a < 6 add r over the wave's own block rows (<= 10), in row order
-            if (ln < 6) {
-                double v[10];
-#pragma unroll
-                for (int u = 0; u < 10; ++u) v[u] = r_lds[min(b0 + u, max(b1 - 1, b0)) * 6 + ln];
-                double t = 0.0;
-#pragma unroll
-                for (int u = 0; u < 10; ++u) t += (b0 + u < b1) ? v[u] : 0.0;
-                rcg[wv * 6 + ln] = t;
-            }
-            __syncthreads();                                  // every aggregate's restricted residual is in LDS
-            // z_c = A_c^-1 r_c for the wave's own 6 coarse rows: 8 lanes per row, 6 terms each, DPP sum
-            const int ca = min(ln >> 3, 5), sub = ln & 7;
+            // z_c = A_c^-1 r_c for the wave's own 6 coarse rows: 8 lanes per row; lane `sub` holds the restricted
+            // residual (rcw, kept current by the recurrence r_c -= alpha P^T A p) -> no workgroup barrier here
             const double2 *arow = reinterpret_cast<const double2 *>(Aci + (wv * 6 + ca) * kNC + sub * 6);
-            const double2 *rcv = reinterpret_cast<const double2 *>(rcg + sub * 6);
+            const double2 *rcv = reinterpret_cast<const double2 *>(rcw + sub * 6);
             const double2 a0 = arow[0], a1 = arow[1], a2 = arow[2], c0 = rcv[0], c1 = rcv[1], c2 = rcv[2];
             double t = a0.x * c0.x + a0.y * c0.y + a1.x * c1.x + a1.y * c1.y + a2.x * c2.x + a2.y * c2.y;
             t += dpp_mov0<0xb1>(t);
@@ -359,6 +363,21 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
                 for (int u = 0; u < kOwnBatch; ++u) Ap += (e + u < own_p1) ? v[u] : 0.0;
             }
             SEG_STAMP(1);
+            if (coarse) {
+                // P^T (A p) of this wave's aggregate, published with the p.Ap partial: the restricted residual then
+                // follows r_c -= alpha P^T A p in every wave without a barrier of its own
+                if (owner) r_lds[row] = Ap;
+                wave_lds_sync();
+                if (ln < 6) {
+                    double v[10];
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) v[u] = r_lds[min(b0 + u, max(b1 - 1, b0)) * 6 + ln];
+                    double t = 0.0;
+#pragma unroll
+                    for (int u = 0; u < 10; ++u) t += (b0 + u < b1) ? v[u] : 0.0;
+                    rcg[wv * 6 + ln] = t;
+                }
+            }
             {
                 const double ps = wave_sum_dpp(owner ? p_r * Ap : 0.0);
                 if (ln == 0) red0[wv] = ps;
@@ -371,6 +390,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             const double alpha = rz / pAp;
             x_r += alpha * p_r;
             r_r -= alpha * Ap;
+            if (coarse && ln < kNC) rcw[ln] -= alpha * rcg[ln];   // ordered before precond's reads by its wave-local sync
             z_r = precond(r_r);
             {
                 const double ps = wave_sum_dpp(owner ? r_r * z_r : 0.0);
@@ -443,7 +463,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + 6 * ((size_t)nrowent / 2 + 1)) * sizeof(double);
+    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + kNC * kNW + 6 * ((size_t)nrowent / 2 + 1)) * sizeof(double);
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list
