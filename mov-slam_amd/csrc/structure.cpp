@@ -1,18 +1,34 @@
 #include "structure.h"
 
+#ifdef MOVBA_STRUCT_TIMING
+#include <chrono>
+#include <cstdio>
+#define TPH(name) do { auto _n = std::chrono::steady_clock::now(); std::fprintf(stderr, "  %-18s %.3f ms\n", name, std::chrono::duration<double, std::milli>(_n - _t).count()); _t = _n; } while (0)
+#else
+#define TPH(name) do { } while (0)
+#endif
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
 namespace movba {
 
+
 int build_structure(const movba_lba_desc& d, Structure& s)
 {
+#ifdef MOVBA_STRUCT_TIMING
+    auto _t = std::chrono::steady_clock::now();
+#endif
     const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
     if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
     if ((NP && (!d.poses || !d.pose_fixed)) || (P && !d.points)) return MOVBA_ERR_ARG;
     if (E && (!d.edge_pose || !d.edge_point || !d.obs || !d.inv_sigma2)) return MOVBA_ERR_ARG;
-    s = Structure();
+    // keep the vectors' capacity across calls (a handle solves window after window: fresh 3 MB allocations
+    // would be paid in page faults every time)
+    s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0;
+    s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.row_ent.clear();
+    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear();
     s.NP = NP; s.P = P; s.E = E;
 
     // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization)
@@ -30,16 +46,23 @@ int build_structure(const movba_lba_desc& d, Structure& s)
 
     for (int l = 0; l < P; ++l) s.pt_start[l + 2] += s.pt_start[l + 1];
     s.perm.resize(E); s.g_pose.resize(E); s.g_point.resize(E);
-    for (int e = 0; e < E; ++e) {
-        const int pos = s.pt_start[d.edge_point[e] + 1]++;
-        s.perm[pos] = e;
+    if (s.already_grouped) {
+        // the reference's own edge order (map points in list order, Optimizer.cc:623-672): identity permutation
+        for (int e = 0; e < E; ++e) s.perm[e] = e;
+        if (E) { std::memcpy(s.g_pose.data(), d.edge_pose, sizeof(int32_t) * E); std::memcpy(s.g_point.data(), d.edge_point, sizeof(int32_t) * E); }
+        s.pt_start.erase(s.pt_start.begin());       // counts were accumulated one slot late for the counting sort
+    } else {
+        for (int e = 0; e < E; ++e) {
+            const int pos = s.pt_start[d.edge_point[e] + 1]++;
+            s.perm[pos] = e;
+        }
+        s.pt_start.pop_back();      // now pt_start[l]..pt_start[l+1], size P+1
+        for (int g = 0; g < E; ++g) {
+            s.g_pose[g] = d.edge_pose[s.perm[g]];
+            s.g_point[g] = d.edge_point[s.perm[g]];
+        }
     }
-    s.pt_start.pop_back();      // now pt_start[l]..pt_start[l+1], size P+1
-    for (int g = 0; g < E; ++g) {
-        s.g_pose[g] = d.edge_pose[s.perm[g]];
-        s.g_point[g] = d.edge_point[s.perm[g]];
-    }
-
+    TPH("group edges");
     s.hidx.assign(NP, -1);
     for (int i = 0; i < NP; ++i) {
         if (d.pose_fixed[i]) { s.n_fixed++; continue; }
@@ -71,12 +94,14 @@ int build_structure(const movba_lba_desc& d, Structure& s)
         }
         fe_start[l + 1] = (int32_t)fe_h.size();
     }
+    TPH("free lists");
     std::vector<int32_t> cnt((size_t)nf * (size_t)nf, 0);       // upper triangle used
     for (int l = 0; l < P; ++l)
         for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
             int32_t *row = &cnt[(size_t)fe_h[a] * nf];
             for (int b = a; b < fe_start[l + 1]; ++b) row[fe_h[b]]++;
         }
+    TPH("count pairs");
     // pair ids: the nf diagonal pairs first (pair k == (k,k)), then off-diagonal row-major
     std::vector<int32_t> pid((size_t)nf * (size_t)nf, -1);
     for (int i = 0; i < nf; ++i) { pid[(size_t)i * nf + i] = i; s.pair_i.push_back(i); s.pair_j.push_back(i); }
@@ -103,6 +128,7 @@ int build_structure(const movba_lba_desc& d, Structure& s)
                 for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int2{ ga, fe_g[b] };
             }
     }
+    TPH("fill entries");
     // ---- work items: chunks of a pair's entries ----
     int chunk = kSchurChunk;
     if (const char *ev = std::getenv("MOVBA_SCHUR_CHUNK")) { const int v = std::atoi(ev); if (v >= 64) chunk = v; }   // tuning knob
@@ -129,6 +155,7 @@ int build_structure(const movba_lba_desc& d, Structure& s)
         s.row_ptr[i + 1] = s.row_ptr[i] + (int32_t)rows[i].size();
         s.row_ent.insert(s.row_ent.end(), rows[i].begin(), rows[i].end());
     }
+    TPH("items+rows");
     return MOVBA_OK;
 }
 
