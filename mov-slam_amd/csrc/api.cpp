@@ -528,13 +528,15 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     if (res->poses) HIP_TRY(hipMemcpyAsync(sg + o_pose, w.st[cur].pose, nb_pose, hipMemcpyDeviceToHost, h->stream));
     if (res->points) HIP_TRY(hipMemcpyAsync(sg + o_pt, w.st[cur].point, nb_pt, hipMemcpyDeviceToHost, h->stream));
     if (res->chi2) HIP_TRY(hipMemcpyAsync(sg + o_chi, w.out_chi2, nb_chi, hipMemcpyDeviceToHost, h->stream));
-    if (res->outlier) HIP_TRY(hipMemcpyAsync(sg + o_out, w.out_outlier, (size_t)w.E, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(sg + o_out, w.out_outlier, (size_t)w.E, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (res->poses) std::memcpy(res->poses, sg + o_pose, nb_pose);
     if (res->points) std::memcpy(res->points, sg + o_pt, nb_pt);
     if (res->chi2) std::memcpy(res->chi2, sg + o_chi, nb_chi);
     if (res->outlier) std::memcpy(res->outlier, sg + o_out, (size_t)w.E);
-    res->iters_done = c.iters_done; res->n_solves = c.n_solves; res->n_outliers = c.n_outliers;
+    int n_out = 0;
+    for (int e = 0; e < w.E; ++e) n_out += sg[o_out + e] != 0;
+    res->iters_done = c.iters_done; res->n_solves = c.n_solves; res->n_outliers = n_out;
     res->pcg_iters = c.pcg_total_iters; res->last_rejected = c.last_rejected;
     res->lambda = c.lambda; res->cost0 = c.cost0; res->cost = c.F0;
     res->n_trace = c.n_trace;

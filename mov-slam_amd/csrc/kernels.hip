@@ -781,7 +781,7 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
 // --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
 {
-    Ctrl *c = w.ctrl;
+    const Ctrl *c = w.ctrl;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     int bad = 0;
     if (g < w.E) {
@@ -794,8 +794,8 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
         w.out_chi2[e] = chi2;
         w.out_outlier[e] = (uint8_t)bad;
     }
-    const unsigned long long m = __ballot(bad);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c->n_outliers, __popcll(m));
+    // (the outlier count is taken on the host from the downloaded flags: one contended atomic per wave
+    // made this kernel four times longer than its memory traffic)
 }
 
 // --------------------------------------------------------------------------------
