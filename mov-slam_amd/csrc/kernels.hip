@@ -80,29 +80,58 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     double *sR0 = sm + 12 * w.NP;                   // NP x 9 at cur   (BACKSUB)
     double *sxp = sR0 + (BACKSUB ? 9 * w.NP : 0);   // nfree x 6       (BACKSUB)
     double *red = sxp + (BACKSUB ? 6 * w.nfree : 0);// 4
-    for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
-    if (BACKSUB) {
-        for (int k = threadIdx.x; k < 9 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[(k / 9) * 12 + (k % 9)];
-        for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
-    }
-    __syncthreads();
+    int *shidx = reinterpret_cast<int *>(red + 4);  // NP              (BACKSUB)
 
+    // ---- everything this lane needs from HBM is requested before the LDS staging barrier, so that the
+    //      point / edge gathers and the pose staging overlap instead of queueing behind each other ----
     const int sub = threadIdx.x & (kPointGroup - 1);
     const int l = blockIdx.x * kPointsPerBlock + (threadIdx.x / kPointGroup);
     const bool valid = l < w.P;
     int begin = 0, end = 0;
     if (valid) { begin = w.pt_start[l]; end = w.pt_start[l + 1]; }
     double X[3] = { 0, 0, 0 };
-    if (valid) { X[0] = S0.point[3 * l]; X[1] = S0.point[3 * l + 1]; X[2] = S0.point[3 * l + 2]; }
-    double scale = 0.0;
+    double Hc[6] = { 1, 0, 0, 1, 0, 1 }, bc[3] = { 0, 0, 0 };
+    if (valid) {
+        X[0] = S0.point[3 * l]; X[1] = S0.point[3 * l + 1]; X[2] = S0.point[3 * l + 2];
+        if (BACKSUB) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Hc[k] = S0.Hll[6 * l + k];
+            bc[0] = S0.bl[3 * l]; bc[1] = S0.bl[3 * l + 1]; bc[2] = S0.bl[3 * l + 2];
+        }
+    }
+    // the lane's first two edges (a point with more than 16 observations takes the loop further down)
+    constexpr int kPre = 2;
+    int pg[kPre], pip[kPre];
+    double4 prc[kPre];
+    double2 pob[kPre];
+    double pom[kPre], pur[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; ++k) {
+        pg[k] = begin + sub + kPointGroup * k;
+        const int g = min(pg[k], max(end - 1, 0));
+        const bool in = pg[k] < end;
+        pip[k] = in ? w.g_pose[g] : 0;
+        prc[k] = (BACKSUB && in) ? *reinterpret_cast<const double4 *>(S0.rec + 4 * g) : make_double4(0, 0, 1, 0);
+        pob[k] = in ? *reinterpret_cast<const double2 *>(w.obs + 2 * g) : make_double2(0, 0);
+        pom[k] = in ? w.isig[g] : 0.0;
+        pur[k] = (STEREO && in) ? w.obs_r[g] : -1.0;
+    }
 
+    for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+    if (BACKSUB) {
+        for (int k = threadIdx.x; k < 9 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[(k / 9) * 12 + (k % 9)];
+        for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
+        for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
+    }
+    __syncthreads();
+
+    double scale = 0.0;
     if (BACKSUB) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int g = begin + sub; g < end; g += kPointGroup) {
-            const int ip = w.g_pose[g];
-            const int h = w.hidx[ip];
-            if (h < 0) continue;
-            const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
+        // x_l's right-hand side: sum over the free observers of B_il^T xp_i, rebuilt from the cached (Xc, w)
+        auto back_edge = [&](int g, int ip, const double4 &rc, double ur) {
+            const int h = shidx[ip];
+            if (h < 0) return;
             const double x = rc.x, y = rc.y, z = rc.z, wg = rc.w;
             const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
             const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
@@ -116,14 +145,20 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
             a0 += (a00 * R[0] + a02 * R[6]) * g0 + (a11 * R[3] + a12 * R[6]) * g1;
             a1 += (a00 * R[1] + a02 * R[7]) * g0 + (a11 * R[4] + a12 * R[7]) * g1;
             a2 += (a00 * R[2] + a02 * R[8]) * g0 + (a11 * R[5] + a12 * R[8]) * g1;
-            if (STEREO && w.obs_r[g] >= 0.0) {
+            if (STEREO && ur >= 0.0) {
                 // stereo row (g2o::EdgeStereoSE3ProjectXYZ): like row 0 with a02 -> a02 - bf/z^2
                 const double c02 = a02 - w.bf / (z * z);
                 const double t2 = (c02 * y) * xp[0] + (a00 * z - c02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + c02 * xp[5];
                 const double g2 = wg * t2;
                 a0 += (a00 * R[0] + c02 * R[6]) * g2; a1 += (a00 * R[1] + c02 * R[7]) * g2; a2 += (a00 * R[2] + c02 * R[8]) * g2;
             }
-        }
+            (void)g;
+        };
+#pragma unroll
+        for (int k = 0; k < kPre; ++k)
+            if (pg[k] < end) back_edge(pg[k], pip[k], prc[k], pur[k]);
+        for (int g = begin + sub + kPointGroup * kPre; g < end; g += kPointGroup)
+            back_edge(g, w.g_pose[g], *reinterpret_cast<const double4 *>(S0.rec + 4 * g), STEREO ? w.obs_r[g] : -1.0);
 #pragma unroll
         for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
             a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
@@ -131,10 +166,10 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         if (valid && end > begin) {
             double H[6], D[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) H[k] = S0.Hll[6 * l + k];
+            for (int k = 0; k < 6; ++k) H[k] = Hc[k];
             H[0] += lambda; H[3] += lambda; H[5] += lambda;
             inv3sym(H, D);
-            const double b0 = S0.bl[3 * l], b1 = S0.bl[3 * l + 1], b2 = S0.bl[3 * l + 2];
+            const double b0 = bc[0], b1 = bc[1], b2 = bc[2];
             const double c0 = b0 - a0, c1 = b1 - a1, c2 = b2 - a2;
             const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
             const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
@@ -147,21 +182,17 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     // ---- evaluate at the destination state ----
     double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, v0 = 0, v1 = 0, v2 = 0, F = 0.0;
     const double dsqr = w.huber_delta * w.huber_delta;
-    for (int g = begin + sub; g < end; g += kPointGroup) {
-        const int ip = w.g_pose[g];
+    auto eval_edge = [&](int g, int ip, const double2 &ob, double om, double ur) {
         const double *R = sRt + 12 * ip;
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
         const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
-        const double2 ob = *reinterpret_cast<const double2 *>(w.obs + 2 * g);
-        const double om = w.isig[g];
         const double e0 = ob.x - (w.fx * x / z + w.cx);
         const double e1 = ob.y - (w.fy * y / z + w.cy);
         double chi2 = e0 * (om * e0) + e1 * (om * e1);
         bool st = false;
         double e2 = 0.0;
         if (STEREO) {
-            const double ur = w.obs_r[g];
             st = ur >= 0.0;
             if (st) { e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
         }
@@ -195,7 +226,12 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
                 v0 += p20 * r2; v1 += p21 * r2; v2 += p22 * r2;
             }
         }
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < kPre; ++k)
+        if (pg[k] < end) eval_edge(pg[k], pip[k], pob[k], pom[k], pur[k]);
+    for (int g = begin + sub + kPointGroup * kPre; g < end; g += kPointGroup)
+        eval_edge(g, w.g_pose[g], *reinterpret_cast<const double2 *>(w.obs + 2 * g), w.isig[g], STEREO ? w.obs_r[g] : -1.0);
 #pragma unroll
     for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
         h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
@@ -804,7 +840,7 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
     size_t d = 12 * (size_t)w.NP + (backsub ? 9 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
-    return d * sizeof(double);
+    return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
 size_t pcg_lds_bytes(int nfree)

@@ -134,6 +134,28 @@ def test_stop_flag_set_before_the_call(solver, built_lib):
     assert r["status"] == 0 and r["n_solves"] >= 10
 
 
+def test_stop_flag_raised_while_solving(solver):
+    """Tracking raises mbAbortBA from another thread (LocalMapping.cc:162, 684); g2o polls it between LM trials.
+    The solve must end early (or normally, if it was faster than the flag) with a consistent, finite state."""
+    import threading
+    import time
+    w = synth.cfg("cfg3")
+    full = solver.solve(w)
+    stop = np.zeros(1, np.uint8)
+    out = {}
+    t = threading.Thread(target=lambda: out.update(r=solver.solve(w, stop=stop)))
+    t.start()
+    time.sleep(0.0006)
+    stop[0] = 1
+    t.join()
+    r = out["r"]
+    assert r["status"] == 0 and 1 <= r["n_solves"] <= full["n_solves"]
+    assert np.isfinite(r["poses"]).all() and np.isfinite(r["points"]).all()
+    assert r["cost"] <= r["cost0"]
+    k = r["n_solves"]
+    np.testing.assert_allclose(r["trace"]["f1"], full["trace"]["f1"][:k], rtol=1e-9)     # a prefix of the full run
+
+
 def test_no_fixed_keyframe_and_empty_window(solver, built_lib):
     w = synth.cfg("small"); w.pose_fixed = np.zeros_like(w.pose_fixed)
     assert solver.solve(w)["status"] == built_lib.NO_FIXED          # src/Optimizer.cc:525-529
