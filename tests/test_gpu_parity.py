@@ -141,19 +141,27 @@ def test_stop_flag_raised_while_solving(solver):
     import time
     w = synth.cfg("cfg3")
     full = solver.solve(w)
-    stop = np.zeros(1, np.uint8)
-    out = {}
-    t = threading.Thread(target=lambda: out.update(r=solver.solve(w, stop=stop)))
-    t.start()
-    time.sleep(0.0006)
-    stop[0] = 1
-    t.join()
-    r = out["r"]
-    assert r["status"] == 0 and 1 <= r["n_solves"] <= full["n_solves"]
-    assert np.isfinite(r["poses"]).all() and np.isfinite(r["points"]).all()
-    assert r["cost"] <= r["cost0"]
-    k = r["n_solves"]
-    np.testing.assert_allclose(r["trace"]["f1"], full["trace"]["f1"][:k], rtol=1e-9)     # a prefix of the full run
+    seen = set()
+    for delay in (0.0002, 0.002, 0.003, 0.004, 0.3):
+        stop = np.zeros(1, np.uint8)
+        out = {}
+        t = threading.Thread(target=lambda: out.update(r=solver.solve(w, stop=stop)))
+        t.start()
+        time.sleep(delay)
+        stop[0] = 1
+        t.join()
+        r = out["r"]
+        if r["status"] == 1:                       # raised before the solve started (Optimizer.cc:749-751): nothing written
+            np.testing.assert_array_equal(r["poses"], w.poses)
+            seen.add("before")
+            continue
+        assert r["status"] == 0 and 1 <= r["n_solves"] <= full["n_solves"]
+        assert np.isfinite(r["poses"]).all() and np.isfinite(r["points"]).all()
+        assert r["cost"] <= r["cost0"]
+        k = r["n_solves"]
+        np.testing.assert_allclose(r["trace"]["f1"], full["trace"]["f1"][:k], rtol=1e-9)     # a prefix of the full run
+        seen.add("during" if k < full["n_solves"] else "after")
+    assert "after" in seen                         # the 0.3 s delay always lets the solve finish
 
 
 def test_no_fixed_keyframe_and_empty_window(solver, built_lib):
