@@ -59,6 +59,8 @@ struct movba_handle {
     int early_status = MOVBA_OK;
     PcgParams pp{};
     bool rows_kernel = false;
+    char *scratch = nullptr;            // structure-pass temporaries (struct_kernels.hip)
+    size_t scratch_cap = 0;
     hipStream_t side = nullptr;         // k_coarse runs here, beside the LM chain
     std::vector<hipEvent_t> sync_ev;    // 2 per trial: schur done / coarse done
     // pose-only scratch
@@ -204,7 +206,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
-        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess) {
+        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess) {
         movba_destroy(h);
         return MOVBA_ERR_HIP;
     }
@@ -225,6 +227,7 @@ void movba_destroy(movba_handle *h)
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->arena) (void)hipFree(h->arena);
     if (h->pose_arena) (void)hipFree(h->pose_arena);
+    if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipHostFree(h->stage);
     if (h->hstat) (void)hipHostFree((void *)h->hstat);
     if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
@@ -260,9 +263,61 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     HIP_TRY(hipSetDevice(h->device));
     h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK;
     const double t0 = now_ms();
-    const int rc = build_structure(*d, h->st);
+    int rc = build_basic(*d, h->st);
     if (rc < 0) return rc;
     const Structure &s = h->st;
+    // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
+    // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
+    StructDev sd{};
+    const bool dev_structure = rc == MOVBA_OK && s.already_grouped && s.nfree > 0 && s.nfree <= 80 && s.n_fixed > 0 &&
+                               !std::getenv("MOVBA_HOST_STRUCTURE");
+    if (rc == MOVBA_OK && !dev_structure) {
+        rc = build_structure(*d, h->st);
+        if (rc < 0) return rc;
+    }
+    if (dev_structure) {
+        const int nf = s.nfree, nbins = nf * nf, nchunks = (s.P + 63) / 64;
+        Carver sc;
+        const size_t so_gpose = sc.take<int32_t>(s.E), so_pt = sc.take<int32_t>(s.P + 1), so_hidx = sc.take<int32_t>(s.NP);
+        const size_t s_h2d = sc.off;
+        const size_t so_cnt = sc.take<int32_t>(nbins), so_err = sc.take<int32_t>(4);
+        const size_t so_pid = sc.take<int32_t>(nbins), so_pptr = sc.take<int32_t>(nbins + 1);
+        const size_t so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
+        if (sc.off > h->scratch_cap) {
+            if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
+            const size_t cap = align_up(sc.off + sc.off / 4, 1 << 20);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch), cap));
+            h->scratch_cap = cap;
+        }
+        int rs = ensure_stage(h, std::max(s_h2d, (size_t)(nbins + 8) * sizeof(int32_t) * 2 + 4096)); if (rs) return rs;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        char *sg = h->stage, *sa = h->scratch;
+        std::memcpy(sg + so_gpose, s.g_pose.data(), sizeof(int32_t) * s.E);
+        std::memcpy(sg + so_pt, s.pt_start.data(), sizeof(int32_t) * (s.P + 1));
+        std::memcpy(sg + so_hidx, s.hidx.data(), sizeof(int32_t) * s.NP);
+        HIP_TRY(hipMemcpyAsync(sa, sg, s_h2d, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemsetAsync(sa + so_err, 0, 16, h->stream));
+        sd.P = s.P; sd.nfree = nf; sd.nchunks = nchunks;
+        sd.g_pose = reinterpret_cast<int32_t *>(sa + so_gpose); sd.pt_start = reinterpret_cast<int32_t *>(sa + so_pt);
+        sd.hidx = reinterpret_cast<int32_t *>(sa + so_hidx);
+        sd.cntw = reinterpret_cast<int32_t *>(sa + so_cntw); sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt);
+        sd.error = reinterpret_cast<int32_t *>(sa + so_err);
+        sd.pid = reinterpret_cast<int32_t *>(sa + so_pid); sd.pair_ptr = reinterpret_cast<int32_t *>(sa + so_pptr);
+        HIP_TRY(launch_struct_count(sd, h->stream));
+        // cnt and the error word are adjacent in the scratch carve: one D2H copy
+        HIP_TRY(hipMemcpyAsync(sg, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (*reinterpret_cast<const int32_t *>(sg + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
+        rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(sg));
+        if (rc < 0) return rc;
+        // pair ids / first entries for the fill kernel (launched once the arena is carved)
+        int32_t *pp32 = reinterpret_cast<int32_t *>(sg + nbins * sizeof(int32_t));
+        std::memcpy(sg, s.pid.data(), sizeof(int32_t) * nbins);
+        for (int p = 0; p <= s.npairs; ++p) pp32[p] = (int32_t)s.pair_ptr[p];
+        HIP_TRY(hipMemcpyAsync(sa + so_pid, sg, sizeof(int32_t) * nbins, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(sa + so_pptr, pp32, sizeof(int32_t) * (s.npairs + 1), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));       // the staging buffer is re-packed below
+    }
     h->stop = d->stop;
     if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
     else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
@@ -356,7 +411,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
             for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
         }
     }
-    std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int2) * (size_t)s.nentries);
+    if (!dev_structure) std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int2) * (size_t)s.nentries);
     std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
     std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
     std::memcpy(sg + o_pj, s.pair_j.data(), sizeof(int32_t) * s.npairs);
@@ -373,6 +428,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const double t2 = now_ms();
     h->prof.structure_ms += t2 - t1;
     HIP_TRY(hipMemcpyAsync(h->arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
+    if (dev_structure) {
+        sd.entries = reinterpret_cast<Int2 *>(h->arena + o_ent);
+        HIP_TRY(launch_struct_fill(sd, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->prof.upload_ms += now_ms() - t2;
     h->h2d_bytes = h2d;

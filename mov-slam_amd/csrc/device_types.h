@@ -97,6 +97,18 @@ struct DevWindow {
     uint8_t *out_outlier;
 };
 
+// Device view of the structure pass (struct_kernels.hip)
+struct StructDev {
+    int32_t P, nfree, nchunks, pad;
+    const int32_t *g_pose, *pt_start, *hidx;
+    int32_t *cntw;              // nfree^2 x nchunks: per-chunk counts, then their exclusive scan
+    int32_t *cnt;               // nfree^2: entries per pair bin
+    int32_t *error;             // set when a keyframe observes a point twice
+    const int32_t *pid;         // nfree^2 -> pair id        (fill)
+    const int32_t *pair_ptr;    // npairs+1                   (fill)
+    Int2 *entries;              //                            (fill)
+};
+
 struct PcgParams {
     double rel_tol;
     int32_t max_iters;

@@ -10,6 +10,9 @@ constexpr int kPcgRowsThreads = 512;    // 8 waves: 2 per SIMD, 256 VGPRs per la
 
 hipError_t configure_kernels(int unused);
 hipError_t configure_pcg_rows();
+hipError_t configure_struct_kernels();
+hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
+hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s);
 size_t pcg_lds_bytes(int nfree);

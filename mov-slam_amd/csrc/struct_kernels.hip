@@ -1,0 +1,114 @@
+// Device side of the structure pass: the per-pair entry lists of the schur kernel —
+// for every upper-triangle pose pair (i <= j), the (edge of i, edge of j) couples of the map points both
+// keyframes observe, in ascending point order — are counted and filled on the GPU instead of on the host.
+//
+// What it replaces in the reference is the part of g2o's BlockSolver::buildStructure that lays out the Hpl /
+// Hschur block pattern (called from optimizer.initializeOptimization(), /root/reference/src/Optimizer.cc:754);
+// on the host this pass cost as much as the whole GPU solve.
+//
+// One wave handles a chunk of 64 consecutive map points (one per lane).  For every pair bin (i * nf + j) the
+// wave builds, in LDS, the 64-bit mask of its points that contribute to the bin (atomic OR: the result does not
+// depend on the order of the atomics).  The rank of a point inside its chunk is the popcount of the lower lanes'
+// bits, the offset of the chunk inside the pair's list is an exclusive scan of the per-chunk counts, so the entry
+// order (pair, then point) is exactly the host builder's and does not depend on scheduling.
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+#include "kernels.h"
+
+namespace movba {
+
+// bins[b] |= bit of this lane, for every unordered couple of free observers (a <= b) of the lane's point
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long masks[];     // nf x nf
+    const int lane = threadIdx.x;
+    const int chunk = blockIdx.x;
+    const int nf = sd.nfree, nbins = nf * nf;
+    for (int b = lane; b < nbins; b += 64) masks[b] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int l = chunk * 64 + lane;
+    int begin = 0, end = 0;
+    if (l < sd.P) { begin = sd.pt_start[l]; end = sd.pt_start[l + 1]; }
+    const unsigned long long bit = 1ull << lane;
+    for (int a = begin; a < end; ++a) {
+        const int ha = sd.hidx[sd.g_pose[a]];
+        if (ha < 0) continue;
+        for (int b = a; b < end; ++b) {
+            const int hb = sd.hidx[sd.g_pose[b]];
+            if (hb < 0) continue;
+            if (b != a && hb == ha) { *sd.error = 1; continue; }          // same keyframe observing a point twice
+            const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
+            atomicOr(&masks[lo * nf + hi], bit);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!FILL) {
+        // per-chunk counts, bin-major so that one wave can scan a bin's chunks with coalesced loads
+        for (int b = lane; b < nbins; b += 64) sd.cntw[(size_t)b * sd.nchunks + chunk] = __popcll(masks[b]);
+    } else {
+        const unsigned long long lower = bit - 1ull;
+        for (int a = begin; a < end; ++a) {
+            const int ha = sd.hidx[sd.g_pose[a]];
+            if (ha < 0) continue;
+            for (int b = a; b < end; ++b) {
+                const int hb = sd.hidx[sd.g_pose[b]];
+                if (hb < 0 || (b != a && hb == ha)) continue;
+                const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
+                const int bin = lo * nf + hi;
+                const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)bin * sd.nchunks + chunk] + __popcll(masks[bin] & lower);
+                sd.entries[pos] = (ha <= hb) ? Int2{ a, b } : Int2{ b, a };      // edge of the lower hessian index first
+            }
+        }
+    }
+}
+
+// exclusive scan of every bin's per-chunk counts (in place) and the bin totals; one wave per bin
+__global__ __launch_bounds__(64) void k_struct_scan(StructDev sd)
+{
+    const int bin = blockIdx.x, lane = threadIdx.x;
+    int32_t *row = sd.cntw + (size_t)bin * sd.nchunks;
+    int carry = 0;
+    for (int c0 = 0; c0 < sd.nchunks; c0 += 64) {
+        const int c = c0 + lane;
+        const int v = c < sd.nchunks ? row[c] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (c < sd.nchunks) row[c] = carry + incl - v;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) sd.cnt[bin] = carry;
+}
+
+hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
+{
+    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree;
+    hipLaunchKernelGGL(k_struct_pairs<false>, dim3(sd.nchunks), dim3(64), lds, s, sd);
+    hipLaunchKernelGGL(k_struct_scan, dim3(sd.nfree * sd.nfree), dim3(64), 0, s, sd);
+    return hipGetLastError();
+}
+
+hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s)
+{
+    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree;
+    hipLaunchKernelGGL(k_struct_pairs<true>, dim3(sd.nchunks), dim3(64), lds, s, sd);
+    return hipGetLastError();
+}
+
+hipError_t configure_struct_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_struct_pairs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_struct_pairs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+}
+
+}  // namespace movba

@@ -1,34 +1,22 @@
 #include "structure.h"
 
-#ifdef MOVBA_STRUCT_TIMING
-#include <chrono>
-#include <cstdio>
-#define TPH(name) do { auto _n = std::chrono::steady_clock::now(); std::fprintf(stderr, "  %-18s %.3f ms\n", name, std::chrono::duration<double, std::milli>(_n - _t).count()); _t = _n; } while (0)
-#else
-#define TPH(name) do { } while (0)
-#endif
-
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
 namespace movba {
 
-
-int build_structure(const movba_lba_desc& d, Structure& s)
+int build_basic(const movba_lba_desc& d, Structure& s)
 {
-#ifdef MOVBA_STRUCT_TIMING
-    auto _t = std::chrono::steady_clock::now();
-#endif
     const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
     if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
     if ((NP && (!d.poses || !d.pose_fixed)) || (P && !d.points)) return MOVBA_ERR_ARG;
     if (E && (!d.edge_pose || !d.edge_point || !d.obs || !d.inv_sigma2)) return MOVBA_ERR_ARG;
-    // keep the vectors' capacity across calls (a handle solves window after window: fresh 3 MB allocations
+    // keep the vectors' capacity across calls (a handle solves window after window: fresh multi-MB allocations
     // would be paid in page faults every time)
     s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0;
     s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.row_ent.clear();
-    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear();
+    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.entries.clear();
     s.NP = NP; s.P = P; s.E = E;
 
     // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization)
@@ -62,20 +50,22 @@ int build_structure(const movba_lba_desc& d, Structure& s)
             s.g_point[g] = d.edge_point[s.perm[g]];
         }
     }
-    TPH("group edges");
     s.hidx.assign(NP, -1);
     for (int i = 0; i < NP; ++i) {
         if (d.pose_fixed[i]) { s.n_fixed++; continue; }
         if (pose_active[i]) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); }
     }
-    const int nf = s.nfree;
     for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
     if (E == 0) return MOVBA_EMPTY;
+    return MOVBA_OK;
+}
 
-    // ---- pose pairs sharing a point (block pattern of the reduced system) ----
-    // free observers of every point, flattened once: (hessian index, grouped edge), ascending hessian index
-    std::vector<int32_t> fe_start(P + 1, 0), fe_h, fe_g;
-    fe_h.reserve(E); fe_g.reserve(E);
+// free observers of every point, flattened: (hessian index, grouped edge), ascending hessian index
+static int free_lists(const Structure& s, std::vector<int32_t>& fe_start, std::vector<int32_t>& fe_h, std::vector<int32_t>& fe_g)
+{
+    const int P = s.P;
+    fe_start.assign(P + 1, 0); fe_h.clear(); fe_g.clear();
+    fe_h.reserve(s.E); fe_g.reserve(s.E);
     for (int l = 0; l < P; ++l) {
         const size_t base = fe_h.size();
         for (int g = s.pt_start[l]; g < s.pt_start[l + 1]; ++g) {
@@ -94,49 +84,37 @@ int build_structure(const movba_lba_desc& d, Structure& s)
         }
         fe_start[l + 1] = (int32_t)fe_h.size();
     }
-    TPH("free lists");
-    std::vector<int32_t> cnt((size_t)nf * (size_t)nf, 0);       // upper triangle used
-    for (int l = 0; l < P; ++l)
-        for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
-            int32_t *row = &cnt[(size_t)fe_h[a] * nf];
-            for (int b = a; b < fe_start[l + 1]; ++b) row[fe_h[b]]++;
-        }
-    TPH("count pairs");
+    return MOVBA_OK;
+}
+
+int finish_pairs(Structure& s, const int32_t* cnt)
+{
+    const int nf = s.nfree;
     // pair ids: the nf diagonal pairs first (pair k == (k,k)), then off-diagonal row-major
-    std::vector<int32_t> pid((size_t)nf * (size_t)nf, -1);
-    for (int i = 0; i < nf; ++i) { pid[(size_t)i * nf + i] = i; s.pair_i.push_back(i); s.pair_j.push_back(i); }
+    s.pid.assign((size_t)nf * (size_t)nf, -1);
+    s.pair_i.clear(); s.pair_j.clear();
+    for (int i = 0; i < nf; ++i) { s.pid[(size_t)i * nf + i] = i; s.pair_i.push_back(i); s.pair_j.push_back(i); }
     for (int i = 0; i < nf; ++i)
         for (int j = i + 1; j < nf; ++j)
             if (cnt[(size_t)i * nf + j] > 0) {
-                pid[(size_t)i * nf + j] = (int32_t)s.pair_i.size();
+                s.pid[(size_t)i * nf + j] = (int32_t)s.pair_i.size();
                 s.pair_i.push_back(i); s.pair_j.push_back(j);
             }
     s.npairs = (int)s.pair_i.size();
-    std::vector<int64_t> pair_ptr(s.npairs + 1, 0);
-    for (int p = 0; p < s.npairs; ++p) pair_ptr[p + 1] = pair_ptr[p] + cnt[(size_t)s.pair_i[p] * nf + s.pair_j[p]];
-    s.nentries = pair_ptr[s.npairs];
+    s.pair_ptr.assign(s.npairs + 1, 0);
+    for (int p = 0; p < s.npairs; ++p) s.pair_ptr[p + 1] = s.pair_ptr[p] + cnt[(size_t)s.pair_i[p] * nf + s.pair_j[p]];
+    s.nentries = s.pair_ptr[s.npairs];
     if (s.nentries > (int64_t)0x7fffffff) return MOVBA_ERR_ARG;
-    s.entries.resize((size_t)s.nentries);
-    {
-        std::vector<int32_t> cur(s.npairs);
-        for (int p = 0; p < s.npairs; ++p) cur[p] = (int32_t)pair_ptr[p];
-        Int2 *ent = s.entries.data();
-        for (int l = 0; l < P; ++l)
-            for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
-                const int32_t *prow = &pid[(size_t)fe_h[a] * nf];
-                const int32_t ga = fe_g[a];
-                for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int2{ ga, fe_g[b] };
-            }
-    }
-    TPH("fill entries");
+
     // ---- work items: chunks of a pair's entries ----
     int chunk = kSchurChunk;
     if (const char *ev = std::getenv("MOVBA_SCHUR_CHUNK")) { const int v = std::atoi(ev); if (v >= 64) chunk = v; }   // tuning knob
+    s.items.clear();
     s.pair_item_start.assign(s.npairs + 1, 0);
     for (int p = 0; p < s.npairs; ++p) {
         s.pair_item_start[p] = (int32_t)s.items.size();
-        for (int64_t b = pair_ptr[p]; b < pair_ptr[p + 1]; b += chunk)
-            s.items.push_back(Item{ p, (int32_t)b, (int32_t)std::min<int64_t>(b + chunk, pair_ptr[p + 1]), p < nf ? 1 : 0 });
+        for (int64_t b = s.pair_ptr[p]; b < s.pair_ptr[p + 1]; b += chunk)
+            s.items.push_back(Item{ p, (int32_t)b, (int32_t)std::min<int64_t>(b + chunk, s.pair_ptr[p + 1]), p < nf ? 1 : 0 });
     }
     s.pair_item_start[s.npairs] = (int32_t)s.items.size();
     s.nitems = (int)s.items.size();
@@ -149,13 +127,46 @@ int build_structure(const movba_lba_desc& d, Structure& s)
         if (i != j) rows[j].push_back(RowEnt{ p, i, 1, 0 });
     }
     s.row_ptr.assign(nf + 1, 0);
+    s.row_ent.clear();
     for (int i = 0; i < nf; ++i) {
         std::sort(rows[i].begin(), rows[i].end(), [](const RowEnt& a, const RowEnt& b) { return a.col < b.col; });
         if (rows[i].size() & 1) rows[i].push_back(RowEnt{ -1, 0, 0, 0 });      // lists are consumed in pairs; -1 = zero block
         s.row_ptr[i + 1] = s.row_ptr[i] + (int32_t)rows[i].size();
         s.row_ent.insert(s.row_ent.end(), rows[i].begin(), rows[i].end());
     }
-    TPH("items+rows");
+    return MOVBA_OK;
+}
+
+int build_structure(const movba_lba_desc& d, Structure& s)
+{
+    const int rc = build_basic(d, s);
+    if (rc != MOVBA_OK) return rc;
+    const int P = s.P, nf = s.nfree;
+
+    // ---- pose pairs sharing a point (block pattern of the reduced system), counted and filled on the host ----
+    std::vector<int32_t> fe_start, fe_h, fe_g;
+    const int rf = free_lists(s, fe_start, fe_h, fe_g);
+    if (rf != MOVBA_OK) return rf;
+    std::vector<int32_t> cnt((size_t)nf * (size_t)nf, 0);       // upper triangle used
+    for (int l = 0; l < P; ++l)
+        for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
+            int32_t *row = &cnt[(size_t)fe_h[a] * nf];
+            for (int b = a; b < fe_start[l + 1]; ++b) row[fe_h[b]]++;
+        }
+    const int rp = finish_pairs(s, cnt.data());
+    if (rp != MOVBA_OK) return rp;
+    s.entries.resize((size_t)s.nentries);
+    {
+        std::vector<int32_t> cur(s.npairs);
+        for (int p = 0; p < s.npairs; ++p) cur[p] = (int32_t)s.pair_ptr[p];
+        Int2 *ent = s.entries.data();
+        for (int l = 0; l < P; ++l)
+            for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
+                const int32_t *prow = &s.pid[(size_t)fe_h[a] * nf];
+                const int32_t ga = fe_g[a];
+                for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int2{ ga, fe_g[b] };
+            }
+    }
     return MOVBA_OK;
 }
 

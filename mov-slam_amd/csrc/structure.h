@@ -33,6 +33,8 @@ struct Structure {
     std::vector<int32_t> g_pose, g_point;   // E (grouped order)
     std::vector<int32_t> pair_i, pair_j;    // npairs (hessian indices, i <= j); pair k<nfree is (k,k)
     std::vector<int32_t> pair_item_start;   // npairs+1
+    std::vector<int64_t> pair_ptr;          // npairs+1: first entry of every pair
+    std::vector<int32_t> pid;               // nfree x nfree: pair id of (i <= j) or -1
     std::vector<Int2> entries;          // nentries: grouped edge indices (edge of i, edge of j)
     std::vector<Item> items;            // nitems
     std::vector<int32_t> row_ptr;       // nfree+1
@@ -49,7 +51,11 @@ void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg);
 
 constexpr int kSchurChunk = 512;        // entries per schur work item (one wave each)
 
-// Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.
+// Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.  build_structure = build_basic + pair counting + finish_pairs +
+// entry filling, all on the host; the upload path normally runs only build_basic and finish_pairs on the host and
+// leaves counting / filling to the device (struct_kernels.hip).
 int build_structure(const movba_lba_desc& d, Structure& s);
+int build_basic(const movba_lba_desc& d, Structure& s);        // validation, grouping by point, hessian indices
+int finish_pairs(Structure& s, const int32_t* cnt);           // cnt[i*nfree+j] (i <= j) -> pairs, items, gather lists
 
 }  // namespace movba

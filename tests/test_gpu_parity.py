@@ -98,6 +98,31 @@ def test_stereo_edges(solver, oracle_mod, frac):
     assert np.abs(solver.solve(wm)["poses"] - r["poses"]).max() > 1e-6
 
 
+@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged"])
+def test_device_structure_pass_equals_host_structure_pass(solver, name):
+    """The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip); MOVBA_HOST_STRUCTURE=1 forces the
+    host builder.  Same lists in the same order => bit-identical solves."""
+    import os
+    if name == "stereo":
+        w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5)
+    elif name == "ragged":
+        w = synth.make_window(5, 2, 150, seed=77, run_lo=1, run_hi=7, min_obs=1)
+        # observers of a point in descending keyframe order (the reference's std::map<KeyFrame*> order is arbitrary)
+        order = np.lexsort((-w.edge_pose, w.edge_point))
+        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[order], w.edge_point[order], w.obs[order], w.inv_sigma2[order]
+    else:
+        w = synth.cfg(name)
+    a = solver.solve(w)
+    os.environ["MOVBA_HOST_STRUCTURE"] = "1"
+    try:
+        b = solver.solve(w)
+    finally:
+        del os.environ["MOVBA_HOST_STRUCTURE"]
+    for k in ("poses", "points", "chi2", "outlier"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["trace"]["pcg"], b["trace"]["pcg"])
+
+
 def test_runs_are_bitwise_reproducible(solver):
     w = synth.cfg("cfg2")
     a = solver.solve(w); b = solver.solve(w)
