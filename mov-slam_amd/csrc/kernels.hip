@@ -264,10 +264,10 @@ __device__ __constant__ int8_t kDiagMirror[21] = {-1, 6, 12, 18, 24, 30, -1, 13,
 
 // Fixed-order reduction of NV per-lane values over the 64 lanes of a wave: two DPP steps sum each quad,
 // the 16 quad sums of every value go through a wave-private LDS strip ([NV][16] doubles) and lane k < NV
-// adds them up in order and stores the result to out[map(k)].  ~2k cycles for NV = 54, against ~30k
-// for NV butterfly reductions built on ds_bpermute shuffles.
+// adds them up in order (returned in lane k).  ~2k cycles for NV = 54, against ~30k for NV butterfly
+// reductions built on ds_bpermute shuffles.
 template <int NV>
-__device__ __forceinline__ void wave_reduce_store(double (&v)[NV], double *strip, int lane, double *out, const int8_t *omap)
+__device__ __forceinline__ double wave_reduce(double (&v)[NV], double *strip, int lane)
 {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -279,17 +279,17 @@ __device__ __forceinline__ void wave_reduce_store(double (&v)[NV], double *strip
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double s = 0.0;
     if (lane < NV) {
         const double2 *src = reinterpret_cast<const double2 *>(strip + lane * 16);
-        double s = 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { const double2 t = src[q]; s += t.x; s += t.y; }
-        out[omap ? omap[lane] : lane] = s;
     }
+    return s;                                   // lane k < NV holds the wave's sum of value k
 }
 
 // --------------------------------------------------------------------------------
-// k_schur: one wave per work item (a chunk of one pose pair's shared points).
+// k_schur: one workgroup (4 waves) per work item (a chunk of up to 2048 of one pose pair's shared points).
 // Per entry (edge of pose i, edge of pose j, both on point l) a lane rebuilds the
 // Jacobians from the cached camera-frame point and adds
 //     B_il Dinv_l B_jl^T = w_i w_j  Jc_i^T ( Jp_i Dinv_l Jp_j^T ) Jc_j          (6x6)
@@ -330,11 +330,13 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
     // XCD-aware block order: workgroups b, b+8, ... share an XCD (and its L2); give each XCD a contiguous run of
     // work items, i.e. pose pairs of neighbouring keyframes, which gather the same map points
     const int per_xcd = gridDim.x >> 3;
-    const int blk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int item = blk * 4 + (threadIdx.x >> 6);
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);     // one work item per workgroup
+    const int wv = threadIdx.x >> 6;
     if (item >= w.nitems) return;
     const Item it = w.items[item];
     if (mode == 1 && !it.diag) return;
+    // the four waves split the item's entries; their sums are combined in LDS in wave order
+    const int wbeg = it.begin + wv * (kSchurChunk / 4), wend = min(it.end, wbeg + kSchurChunk / 4);
     const int cur = c->cur;
     const double lambda = c->lambda;
     const DevState &S0 = w.st[cur];
@@ -346,7 +348,8 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
     double *out = w.part + (size_t)(trial & 1) * w.part_stride + (size_t)item * kPartStride;
     if (item == 0 && lane == 0) w.lam_snap[trial & 1] = lambda;      // for k_coarse(trial), which runs beside the LM chain
     __shared__ __attribute__((aligned(16))) double strips[4][54 * 16];
-    double *strip = strips[threadIdx.x >> 6];
+    __shared__ double wsum[4][64];
+    double *strip = strips[wv];
 
     if (it.diag) {
         double sa[21], ha[21], ca[6], ba[6];
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
 #pragma unroll
         for (int k = 0; k < 6; ++k) { ca[k] = 0.0; ba[k] = 0.0; }
 #pragma unroll 2
-        for (int k = it.begin + lane; k < it.end; k += 64) {
+        for (int k = wbeg + lane; k < wend; k += 64) {
             const int g = w.entries[k].x;
             const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
             const double2 rr = *reinterpret_cast<const double2 *>(S0.res + 2 * g);
@@ -423,18 +426,20 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
         for (int k = 0; k < 21; ++k) { all[k] = sa[k]; all[27 + k] = ha[k]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { all[21 + k] = ca[k]; all[48 + k] = ba[k]; }
-        // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
-        wave_reduce_store<54>(all, strip, lane, out, kDiagMap);
-        if (lane < 21) {
-            const int m = kDiagMirror[lane];
-            if (m >= 0) out[m] = out[kDiagMap[lane]];
+        wsum[wv][lane] = wave_reduce<54>(all, strip, lane);
+        __syncthreads();
+        if (wv == 0 && lane < 54) {
+            const double t = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
+            out[kDiagMap[lane]] = t;
+            // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
+            if (lane < 21 && kDiagMirror[lane] >= 0) out[kDiagMirror[lane]] = t;
         }
     } else {
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
 #pragma unroll 2
-        for (int k = it.begin + lane; k < it.end; k += 64) {
+        for (int k = wbeg + lane; k < wend; k += 64) {
             const Int2 en = w.entries[k];
             const double4 ri = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.x);
             const double4 rj = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.y);
@@ -475,7 +480,9 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
                 }
             }
         }
-        wave_reduce_store<36>(acc, strip, lane, out, nullptr);
+        wsum[wv][lane] = wave_reduce<36>(acc, strip, lane);
+        __syncthreads();
+        if (wv == 0 && lane < 36) out[lane] = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
     }
 }
 
@@ -865,7 +872,7 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
-    const int nblk = (((w.nitems + 3) / 4 + 7) / 8) * 8;             // multiple of 8: one contiguous run of items per XCD
+    const int nblk = ((w.nitems + 7) / 8) * 8;                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
     if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3(nblk), dim3(256), 0, s, w, mode, trial);
     else hipLaunchKernelGGL(k_schur<2>, dim3(nblk), dim3(256), 0, s, w, mode, trial);
     return hipGetLastError();

@@ -107,8 +107,7 @@ int finish_pairs(Structure& s, const int32_t* cnt)
     if (s.nentries > (int64_t)0x7fffffff) return MOVBA_ERR_ARG;
 
     // ---- work items: chunks of a pair's entries ----
-    int chunk = kSchurChunk;
-    if (const char *ev = std::getenv("MOVBA_SCHUR_CHUNK")) { const int v = std::atoi(ev); if (v >= 64) chunk = v; }   // tuning knob
+    const int chunk = kSchurChunk;
     s.items.clear();
     s.pair_item_start.assign(s.npairs + 1, 0);
     for (int p = 0; p < s.npairs; ++p) {

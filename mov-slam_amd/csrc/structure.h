@@ -49,7 +49,7 @@ struct Structure {
 // A_c = P^T S P (P = piecewise-constant prolongation over the aggregates).
 void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg);
 
-constexpr int kSchurChunk = 512;        // entries per schur work item (one wave each)
+constexpr int kSchurChunk = 2048;       // entries per schur work item (one workgroup of 4 waves each)
 
 // Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.  build_structure = build_basic + pair counting + finish_pairs +
 // entry filling, all on the host; the upload path normally runs only build_basic and finish_pairs on the host and
