@@ -61,8 +61,6 @@ struct movba_handle {
     bool rows_kernel = false;
     char *scratch = nullptr;            // structure-pass temporaries (struct_kernels.hip)
     size_t scratch_cap = 0;
-    hipStream_t side = nullptr;         // k_coarse runs here, beside the LM chain
-    std::vector<hipEvent_t> sync_ev;    // 2 per trial: schur done / coarse done
     // pose-only scratch
     char *pose_arena = nullptr;
     size_t pose_cap = 0;
@@ -202,8 +200,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
         h->own_stream = true;
     }
-    if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
         configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess) {
@@ -221,10 +218,7 @@ void movba_destroy(movba_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     harvest_events(h);
-    if (h->side) (void)hipStreamSynchronize(h->side);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : h->sync_ev) (void)hipEventDestroy(e);
-    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->arena) (void)hipFree(h->arena);
     if (h->pose_arena) (void)hipFree(h->pose_arena);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -346,7 +340,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     bool stereo = false;
     if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
     const size_t o_obsr = c.take<double>(stereo ? E : 0);
-    const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1);
+    const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<Item>(s.sched.size() + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
     std::vector<int32_t> lane_plan;
@@ -381,8 +375,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_st[b][9] = c.take<double>(stereo ? E : 0);
     }
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
-    const size_t o_part = c.take<double>(2 * part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
-    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(2 * 48 * 48), o_acitag = c.take<int32_t>(2), o_lamsnap = c.take<double>(2);
+    const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
+    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(2 * 48 * 48), o_acitag = c.take<int32_t>(2);
     const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
     const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
@@ -413,6 +407,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     }
     if (!dev_structure) std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int2) * (size_t)s.nentries);
     std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
+    std::memcpy(sg + o_sched, s.sched.data(), sizeof(Item) * s.sched.size());
     std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
     std::memcpy(sg + o_pj, s.pair_j.data(), sizeof(int32_t) * s.npairs);
     std::memcpy(sg + o_pis, s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
@@ -449,6 +444,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
     w.obs_r = reinterpret_cast<double *>(a + o_obsr); w.bf = d->bf; w.stereo = stereo ? 1 : 0;
     w.entries = reinterpret_cast<Int2 *>(a + o_ent); w.items = reinterpret_cast<Item *>(a + o_items);
+    w.sched = reinterpret_cast<Item *>(a + o_sched); w.sched_per_xcd = s.sched_per_xcd;
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
     w.row_ent = reinterpret_cast<RowEnt *>(a + o_rowent);
@@ -467,9 +463,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.res2 = reinterpret_cast<double *>(a + o_st[b][9]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
-    w.part_stride = part_stride; w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c);
+    w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c);
     w.aci = reinterpret_cast<double *>(a + o_aci); w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
-    w.lam_snap = reinterpret_cast<double *>(a + o_lamsnap);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev;
@@ -515,7 +510,6 @@ int movba_lba_run(movba_handle *h)
     pp.use_coarse = (h->opt.pcg_coarse && rows_kernel) ? 1 : 0;
 
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
-    int last_coarse = -1;
     const double t_start = now_ms();
     for (int t = 0; t < max_trials; ++t) {
         // stay at most run_ahead trial sets ahead of the device
@@ -532,25 +526,13 @@ int movba_lba_run(movba_handle *h)
         if (h->hstat->done) break;
         if (h->stop && *h->stop) h->hstat->stop = 1;
         if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
-        if (pp.use_coarse) {
-            // coarse level of trial t is built beside the chain and preconditions trial t+1
-            while ((int)h->sync_ev.size() < 2 * (t + 1)) {
-                hipEvent_t e = nullptr;
-                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                h->sync_ev.push_back(e);
-            }
-            HIP_TRY(hipEventRecord(h->sync_ev[2 * t], s));
-            HIP_TRY(hipStreamWaitEvent(h->side, h->sync_ev[2 * t], 0));
-            HIP_TRY(launch_coarse(w, pp, t, h->side));
-            HIP_TRY(hipEventRecord(h->sync_ev[2 * t + 1], h->side));
-            if (t > 0) HIP_TRY(hipStreamWaitEvent(s, h->sync_ev[2 * t - 1], 0));
-            last_coarse = t;
-        }
+#ifdef MOVBA_CLOCK_STAMP
+        if (std::getenv("MOVBA_MARK")) HIP_TRY(launch_mark(w, t, 2, s));
+#endif
         { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, t, s) : launch_pcg(w, pp, t, s)); }
         { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
     }
-    if (last_coarse >= 0) HIP_TRY(hipStreamWaitEvent(s, h->sync_ev[2 * last_coarse + 1], 0));   // side stream drained before the run ends
     { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }
     HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -561,8 +543,8 @@ int movba_lba_run(movba_handle *h)
     std::fprintf(stderr, "libmovba[stamp]: per-iteration segments (wave 0, cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_seg[k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
     std::fprintf(stderr, "\nlibmovba[stamp]: setup phases per launch (cycles):");
-    for (int k = 0; k < 6; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
-    std::fprintf(stderr, "\n");
+    for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
+    std::fprintf(stderr, "\nlibmovba[stamp]: decide(2) end %llu  mark %llu  pcg(3) start %llu (10 ns ticks)\n", h->ctrl_host->dbg_sch[0], h->ctrl_host->dbg_sch[2], h->ctrl_host->dbg_sch[1]);
 #endif
     h->ran = true;
     return MOVBA_OK;

@@ -1,59 +1,75 @@
-// k_coarse: coarse level of the two-level PCG preconditioner, built OFF the critical path.
+// Coarse level of the two-level PCG preconditioner, built OFF the critical path: the second workgroup of the
+// k_pcg_rows launch runs coarse_build() while the first one runs the conjugate gradients.
 //
 // For LM trial t it assembles the reduced matrix S from the schur work-item partials, forms
 // A_c = P^T S P over the keyframe aggregates (aggregate = the block rows one wave of k_pcg_rows
 // owns, 6 coarse dofs each, 48 x 48), inverts it by Gauss-Jordan in LDS and leaves A_c^-1 in HBM.
-// It runs on a side stream concurrently with k_pcg_rows(t); its result preconditions trial t+1
-// (a preconditioner need not be exact: a one-trial-old coarse inverse costs ~3 % more CG iterations
-// than a fresh one, and block-Jacobi alone ~2.3x more).  One workgroup; everything in fixed order,
-// so the lagged preconditioner is as reproducible as the rest of the solve.
+// Its result preconditions trial t+1 (a preconditioner need not be exact: a one-trial-old coarse
+// inverse costs ~3 % more CG iterations than a fresh one, and block-Jacobi alone ~2.3x more).
+// Everything in fixed order, so the lagged preconditioner is as reproducible as the rest of the solve.
+// (A separate kernel on a side stream did the same job at first: the two cross-stream event waits per
+// trial cost ~10 us of idle time on the LM chain, rocprofv3 kernel trace.)
+#pragma once
 #include <hip/hip_runtime.h>
 
 #include "device_math.h"
 #include "device_types.h"
-#include "kernels.h"
 
 namespace movba {
 
-namespace {
-constexpr int kT = 512;
-constexpr int kNW = kT / 64;
-constexpr int kNC = 6 * (kPcgRowsThreads / 64);
-}  // namespace
-
-__global__ __launch_bounds__(kT) void k_coarse(DevWindow w, PcgParams pp, int trial)
+// sm: >= kNC*kNC + 4*kNC + 2 doubles of LDS; 512 threads
+template <int kT, int kNC>
+__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm)
 {
-    __shared__ __attribute__((aligned(16))) double Ac[kNC * kNC];
-    __shared__ __attribute__((aligned(16))) double gj[4 * kNC];
-    __shared__ int s_bad;
-    const Ctrl *c = w.ctrl;
-    if (c->done) return;
+    constexpr int kNW = kT / 64;
+    double *Ac = sm;
+    double *gj = Ac + kNC * kNC;
+    int &s_bad = *reinterpret_cast<int *>(gj + 4 * kNC);
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     const int nf = w.nfree;
-    const double lambda = w.lam_snap[trial & 1];
-    const double *part = w.part + (size_t)(trial & 1) * w.part_stride;
+    const double *part = w.part;
     double *blocks = w.blocks_c;
     if (tid == 0) s_bad = 0;
     for (int idx = tid; idx < kNC * kNC; idx += kT) Ac[idx] = 0.0;
 
-    // ---- S blocks (upper triangle) from the partials, item order ----
-    for (int idx = tid; idx < w.npairs * 36; idx += kT) {
-        const int pr = idx / 36, k = idx - pr * 36;
-        const int i0 = w.pair_item_start[pr], i1 = w.pair_item_start[pr + 1];
-        double s = 0.0;
-        for (int itx = i0; itx < i1; ++itx) s += part[(size_t)itx * kPartStride + k];
-        double v = -s;
-        if (pr < nf) {
-            const int a = k / 6, b = k - a * 6;
-            const int u = a <= b ? ut6(a, b) : ut6(b, a);
-            double hpp = 0.0;
-            for (int itx = i0; itx < i1; ++itx) hpp += part[(size_t)itx * kPartStride + 42 + u];
-            v += hpp + (a == b ? lambda : 0.0);
+    // ---- S blocks (upper triangle) from the partials, item order; 4 elements per thread in flight ----
+    const int total = w.npairs * 36;
+    for (int base = tid; base < total; base += 4 * kT) {
+        int k[4], i0[4], i1[4], pr[4];
+        double s[4], hp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = min(base + u * kT, total - 1);
+            pr[u] = idx / 36; k[u] = idx - pr[u] * 36;
+            i0[u] = w.pair_item_start[pr[u]]; i1[u] = w.pair_item_start[pr[u] + 1];
         }
-        blocks[idx] = v;
+        int hu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int a = k[u] / 6, b = k[u] - a * 6;
+            hu[u] = 42 + (a <= b ? ut6(a, b) : ut6(b, a));
+            const bool any = i1[u] > i0[u];
+            const double *src = part + (size_t)(any ? i0[u] : 0) * kPartStride;
+            const double v0 = src[k[u]], v1 = src[hu[u]];
+            s[u] = any ? v0 : 0.0; hp[u] = (any && pr[u] < nf) ? v1 : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            for (int itx = i0[u] + 1; itx < i1[u]; ++itx) {
+                const double *src = part + (size_t)itx * kPartStride;
+                s[u] += src[k[u]];
+                if (pr[u] < nf) hp[u] += src[hu[u]];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * kT;
+            if (idx < total) {
+                const int a = k[u] / 6, b = k[u] - a * 6;
+                blocks[idx] = (pr[u] < nf) ? (hp[u] + (a == b ? lambda : 0.0)) - s[u] : -s[u];
+            }
+        }
     }
     __syncthreads();
-
     // ---- A_c = P^T S P: every coarse element is the fixed-order sum of its fine-block terms ----
     for (int idx = tid; idx < w.n_cblk * 36; idx += kT) {
         const int cb = idx / 36, k = idx - cb * 36, a = k / 6, b = k - a * 6;
@@ -113,10 +129,5 @@ __global__ __launch_bounds__(kT) void k_coarse(DevWindow w, PcgParams pp, int tr
     if (tid == 0) w.aci_tag[trial & 1] = s_bad ? -1 : trial;
 }
 
-hipError_t launch_coarse(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_coarse, dim3(1), dim3(kT), 0, s, w, pp, trial);
-    return hipGetLastError();
-}
 
 }  // namespace movba

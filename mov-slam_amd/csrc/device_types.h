@@ -10,7 +10,10 @@
 
 namespace movba {
 
-constexpr int kPartStride = 72;     // doubles per schur work-item partial
+#ifndef MOVBA_PART_STRIDE
+#define MOVBA_PART_STRIDE 72
+#endif
+constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-item partial
 // partial layout: [0,36) sum of B_i Dinv B_j^T (6x6 row-major)
 //                 [36,42) sum of B_i Dinv b_l           (diagonal pairs only)
 //                 [42,63) upper triangle of Hpp_ii      (diagonal pairs only)
@@ -42,7 +45,7 @@ struct Ctrl {
     int32_t n_solves, last_rejected, iters_done, n_trace;
     int32_t pcg_fail, pcg_last_iters, pcg_total_iters, n_outliers;
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
-    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8];
+    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8], dbg_sch[4];
 };
 
 // Written by k_decide into pinned host memory so the host can keep the queue fed
@@ -68,6 +71,8 @@ struct DevWindow {
     int32_t stereo, pad2;   // window has >= 1 stereo edge: 3-row kernels
     const Int2 *entries;
     const Item *items;
+    const Item *sched;      // k_schur launch schedule: 8 x sched_per_xcd slots (structure.h)
+    int32_t sched_per_xcd, pad3;
     const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;
     const RowEnt *row_ent;
     // k_pcg_rows: per (wave, lane, slot) plan {pair id or -1, transposed, col*6, first item, end item} (host-built)
@@ -80,11 +85,9 @@ struct DevWindow {
     const double *pose0, *point0;   // uploaded initial state (for reset)
     // reduced system
     double *part;       // 2 x nitems x kPartStride (double-buffered by trial parity)
-    size_t part_stride; // doubles between the two buffers
     double *blocks_c;   // npairs x 36: k_coarse's own copy of S
     double *aci;        // 2 x 48 x 48: inverse coarse matrices (by trial parity)
     int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable
-    double *lam_snap;   // 2: lambda of the trial (by parity), written by k_schur
     double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first
     double *bp;         // 6 nfree
     double *xp;         // 6 nfree

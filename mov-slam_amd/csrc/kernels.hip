@@ -42,6 +42,7 @@ __global__ void k_init_pose(DevWindow w)
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
         for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; }
+        c->dbg_sch[0] = ~0ull; c->dbg_sch[1] = 0; c->dbg_sch[2] = 0; c->dbg_sch[3] = 0;
     }
     if (i >= w.NP) return;
     double q[7];
@@ -289,7 +290,7 @@ __device__ __forceinline__ double wave_reduce(double (&v)[NV], double *strip, in
 }
 
 // --------------------------------------------------------------------------------
-// k_schur: one workgroup (4 waves) per work item (a chunk of up to 2048 of one pose pair's shared points).
+// k_schur: one workgroup (kSchurWaves waves) per work item (a chunk of up to 2048 of one pose pair's shared points).
 // Per entry (edge of pose i, edge of pose j, both on point l) a lane rebuilds the
 // Jacobians from the cached camera-frame point and adds
 //     B_il Dinv_l B_jl^T = w_i w_j  Jc_i^T ( Jp_i Dinv_l Jp_j^T ) Jc_j          (6x6)
@@ -321,22 +322,39 @@ __device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y
     }
 }
 
+#ifdef MOVBA_CLOCK_STAMP_SCHUR
+#define SCHUR_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        if (stamp_me) const_cast<Ctrl *>(c)->dbg_seg2[k] += _t - stamp_last; stamp_last = _t; } while (0)
+#else
+#define SCHUR_STAMP(k) do { } while (0)
+#endif
+
 template <int NR>
-__global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int mode, int trial)
 {
     const Ctrl *c = w.ctrl;
     if (c->done) return;
+#ifdef MOVBA_CLOCK_STAMP
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    const bool stamp_me = mode == 0 && blockIdx.x == 0 && threadIdx.x == 0;
+    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63;
-    // XCD-aware block order: workgroups b, b+8, ... share an XCD (and its L2); give each XCD a contiguous run of
-    // work items, i.e. pose pairs of neighbouring keyframes, which gather the same map points
-    const int per_xcd = gridDim.x >> 3;
-    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);     // one work item per workgroup
     const int wv = threadIdx.x >> 6;
-    if (item >= w.nitems) return;
-    const Item it = w.items[item];
-    if (mode == 1 && !it.diag) return;
-    // the four waves split the item's entries; their sums are combined in LDS in wave order
-    const int wbeg = it.begin + wv * (kSchurChunk / 4), wend = min(it.end, wbeg + kSchurChunk / 4);
+    // XCD-aware launch schedule (structure.cpp): workgroups b, b+8, ... share an XCD (and its L2) and take the slots of
+    // that XCD's segment in order
+    const int ipw = kSchurWaves / kSchurWPI;                // kSchurWPI waves share one work item
+    const int wg = (blockIdx.x & 7) * (w.sched_per_xcd / ipw) + (blockIdx.x >> 3);
+    const int sub = wv % kSchurWPI;
+    __shared__ __attribute__((aligned(16))) double strips[kSchurWaves][54 * 16];
+    __shared__ double wsum[kSchurWaves][64];
+    double *strip = strips[wv];
+    Item it = w.sched[wg * ipw + wv / kSchurWPI];
+    bool active = it.diag >= 0;
+    const int item = active ? (it.diag >> 1) : 0;
+    it.diag = active ? (it.diag & 1) : 0;
+    if (mode == 1 && !it.diag) active = false;
+    const int wbeg = it.begin + sub * (kSchurChunk / kSchurWPI), wend = active ? min(it.end, wbeg + kSchurChunk / kSchurWPI) : wbeg;
     const int cur = c->cur;
     const double lambda = c->lambda;
     const DevState &S0 = w.st[cur];
@@ -345,11 +363,9 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
     double Ri[9], Rj[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { Ri[k] = S0.Rt[12 * ip + k]; Rj[k] = S0.Rt[12 * jp + k]; }
-    double *out = w.part + (size_t)(trial & 1) * w.part_stride + (size_t)item * kPartStride;
-    if (item == 0 && lane == 0) w.lam_snap[trial & 1] = lambda;      // for k_coarse(trial), which runs beside the LM chain
-    __shared__ __attribute__((aligned(16))) double strips[4][54 * 16];
-    __shared__ double wsum[4][64];
-    double *strip = strips[wv];
+    double *out = w.part + (size_t)item * kPartStride;
+    (void)trial;
+    SCHUR_STAMP(2);
 
     if (it.diag) {
         double sa[21], ha[21], ca[6], ba[6];
@@ -384,9 +400,11 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
             if (mode == 1) continue;
             const int l = w.g_point[g];
             double H[6], D[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) H[q] = S0.Hll[6 * l + q];
-            H[0] += lambda; H[3] += lambda; H[5] += lambda;
+            {
+                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
+                const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+                H[0] = h0.x + lambda; H[1] = h0.y; H[2] = h1.x; H[3] = h1.y + lambda; H[4] = h2.x; H[5] = h2.y + lambda;
+            }
             inv3sym(H, D);
             const double bl0 = S0.bl[3 * l], bl1 = S0.bl[3 * l + 1], bl2 = S0.bl[3 * l + 2];
             double T[NR][3], M[NR][NR], pv[NR];
@@ -426,14 +444,9 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
         for (int k = 0; k < 21; ++k) { all[k] = sa[k]; all[27 + k] = ha[k]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { all[21 + k] = ca[k]; all[48 + k] = ba[k]; }
+        SCHUR_STAMP(3);
         wsum[wv][lane] = wave_reduce<54>(all, strip, lane);
-        __syncthreads();
-        if (wv == 0 && lane < 54) {
-            const double t = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
-            out[kDiagMap[lane]] = t;
-            // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
-            if (lane < 21 && kDiagMirror[lane] >= 0) out[kDiagMirror[lane]] = t;
-        }
+        SCHUR_STAMP(4);
     } else {
         double acc[36];
 #pragma unroll
@@ -445,9 +458,11 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
             const double4 rj = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.y);
             const int l = w.g_point[en.x];
             double H[6], D[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) H[q] = S0.Hll[6 * l + q];
-            H[0] += lambda; H[3] += lambda; H[5] += lambda;
+            {
+                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
+                const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2];
+                H[0] = h0.x + lambda; H[1] = h0.y; H[2] = h1.x; H[3] = h1.y + lambda; H[4] = h2.x; H[5] = h2.y + lambda;
+            }
             inv3sym(H, D);
             bool sti = false, stj = false;
             if (NR == 3) { sti = w.obs_r[en.x] >= 0.0; stj = w.obs_r[en.y] >= 0.0; }
@@ -481,9 +496,41 @@ __global__ __launch_bounds__(256) void k_schur(DevWindow w, int mode, int trial)
             }
         }
         wsum[wv][lane] = wave_reduce<36>(acc, strip, lane);
-        __syncthreads();
-        if (wv == 0 && lane < 36) out[lane] = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
     }
+#if defined(MOVBA_EXP_BARRIER) && MOVBA_EXP_BARRIER == 1
+    __syncthreads();
+#elif defined(MOVBA_EXP_BARRIER) && MOVBA_EXP_BARRIER == 2
+#else
+    if (kSchurWPI > 1) __syncthreads();
+#endif
+    SCHUR_STAMP(5);
+    if (active && sub == 0) {
+        double t = wsum[wv][lane];
+#pragma unroll
+        for (int q = 1; q < kSchurWPI; ++q) t += wsum[wv + q][lane];
+#ifdef MOVBA_SC1_STORE
+#define PART_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define PART_STORE(p, v) (*(p) = (v))
+#endif
+        if (it.diag) {
+            if (lane < 54) {
+                PART_STORE(&out[kDiagMap[lane]], t);
+                // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
+                if (lane < 21 && kDiagMirror[lane] >= 0) PART_STORE(&out[kDiagMirror[lane]], t);
+            }
+        } else if (lane < 36) PART_STORE(&out[lane], t);
+    }
+    SCHUR_STAMP(6);
+#ifdef MOVBA_CLOCK_STAMP
+    if (mode == 0 && trial == 3) {       // one launch: per-wave start/end (100 MHz ticks), read back through out_chi2
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long wave_t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2);
+        const int slot = blockIdx.x * kSchurWaves + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0) { dbg[2 * slot] = wave_t0; dbg[2 * slot + 1] = wave_t1; }
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------
@@ -547,7 +594,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp, 
     const int nf = w.nfree, n = 6 * nf;
     const int cur = c->cur;
     const double lambda = c->lambda;
-    const double *partials = w.part + (size_t)(trial & 1) * w.part_stride;
+    const double *partials = w.part;
     double *x = sm, *r = x + n, *z = r + n, *p = z + n, *Ap = p + n;
     double *minv = Ap + n;                  // nf x 36
     double *red0 = minv + 36 * nf;          // kPcgWaves
@@ -813,6 +860,9 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
         }
     }
     c->done = done;
+#ifdef MOVBA_CLOCK_STAMP
+    if (c->n_solves == 3) c->dbg_sch[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     __hip_atomic_store(&w.hstat->trials_done, c->n_solves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&w.hstat->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -834,6 +884,9 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
         const double zc = w.st[cur].rec[4 * g + 2];
         bad = (chi2 > w.chi2_gate) || !(zc > 0.0);
         const int e = w.perm[g];
+#ifdef MOVBA_CLOCK_STAMP
+        if (e >= 8192)
+#endif
         w.out_chi2[e] = chi2;
         w.out_outlier[e] = (uint8_t)bad;
     }
@@ -872,11 +925,16 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
-    const int nblk = ((w.nitems + 7) / 8) * 8;                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
-    if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3(nblk), dim3(256), 0, s, w, mode, trial);
-    else hipLaunchKernelGGL(k_schur<2>, dim3(nblk), dim3(256), 0, s, w, mode, trial);
+    const int nblk = 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI));                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
+    if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, mode, trial);
+    else hipLaunchKernelGGL(k_schur<2>, dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, mode, trial);
     return hipGetLastError();
 }
+
+#ifdef MOVBA_CLOCK_STAMP
+__global__ void k_mark(DevWindow w, int trial, int slot) { if (trial == 3 && threadIdx.x == 0) w.ctrl->dbg_sch[slot] = __builtin_amdgcn_s_memrealtime(); }
+hipError_t launch_mark(const DevWindow &w, int trial, int slot, hipStream_t s) { hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, s, w, trial, slot); return hipGetLastError(); }
+#endif
 
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
 {

@@ -17,14 +17,15 @@
 //   * the 6 rows of a block live in one wave, so the block-Jacobi preconditioner needs only a
 //     wave-local LDS exchange;
 //   * preconditioner = block-Jacobi + an aggregate coarse level (two-level additive Schwarz): the block
-//     rows of one wave form an aggregate with 6 coarse dofs; A_c^-1 (48 x 48) comes from k_coarse of the
-//     previous trial (built beside the LM chain on a side stream) and removes the low-frequency drift
+//     rows of one wave form an aggregate with 6 coarse dofs; A_c^-1 (48 x 48) comes from the previous trial
+//     (built by the SECOND workgroup of that launch, coarse_level.h, beside the CG) and removes the low-frequency drift
 //     modes block-Jacobi cannot see: ~2.3x fewer CG iterations at cfg3;
 //   * per CG iteration: 3 workgroup barriers, 2 DPP wave reductions (the coarse level rides on them: the
 //     restricted residual follows the recurrence r_c -= alpha P^T A p, whose P^T A p is published with p.Ap).
 // All reductions run in a fixed order: results are bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
+#include "coarse_level.h"
 #include "device_math.h"
 #include "device_types.h"
 #include "kernels.h"
@@ -85,10 +86,15 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int cur = c->cur;
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
+    if (trial == 3 && tid == 0 && blockIdx.x == 0) c->dbg_sch[1] = stamp_t0;
     unsigned long long setup_last = stamp_c0;
 #endif
     const double lambda = c->lambda;
-    const double *part = w.part + (size_t)(trial & 1) * w.part_stride;
+    if (blockIdx.x == 1) {          // second workgroup: coarse level of THIS trial's matrix, for the next trial
+        coarse_build<kT, kNC>(w, pp, trial, lambda, sm);
+        return;
+    }
+    const double *part = w.part;
     const int npad = (n + 1) & ~1;
 
     // LDS carve (16-byte aligned pieces, no static LDS in front of it)
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     double *rcw = rcg + kNC + 8 * kNW + kNC * wv;         // kNC per wave: the wave's copy of the restricted residual P^T r
     double *ypart = rcg + kNC + 8 * kNW + kNC * kNW;      // 6 doubles per gather-list PAIR (+ one dummy strip)
     if (tid == 0) s_fail = 0;
-    // coarse level: usable when k_coarse(trial - 1) left a valid inverse (never for the first trial)
+    // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial)
     const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
     if (coarse) {
         const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)((trial - 1) & 1) * kNC * kNC);
@@ -501,7 +507,7 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
 
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_rows, dim3(1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
+    hipLaunchKernelGGL(k_pcg_rows, dim3(pp.use_coarse ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ int build_basic(const movba_lba_desc& d, Structure& s)
     // keep the vectors' capacity across calls (a handle solves window after window: fresh multi-MB allocations
     // would be paid in page faults every time)
     s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0;
-    s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.row_ent.clear();
+    s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.sched.clear(); s.sched_per_xcd = 0; s.row_ent.clear();
     s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.entries.clear();
     s.NP = NP; s.P = P; s.E = E;
 
@@ -117,6 +117,41 @@ int finish_pairs(Structure& s, const int32_t* cnt)
     }
     s.pair_item_start[s.npairs] = (int32_t)s.items.size();
     s.nitems = (int)s.items.size();
+
+    // ---- launch schedule of k_schur: the MI355X dispatcher deals consecutive workgroups round-robin to the 8 XCDs,
+    // each with its own L2.  Items are ordered by block row (the pairs (i, *) gather the points keyframe i sees, so
+    // a contiguous run of rows shares its map points in one L2) and cut into 8 runs of equal estimated work, heavy
+    // items first inside a run; the diagonal items (Hpp, b and the Schur diagonal: ~1.5x the work per entry) are
+    // thereby spread over all XCDs instead of filling the first two. ----
+    {
+        const int ipw = kSchurWaves / kSchurWPI;
+        std::vector<int32_t> order(s.nitems);
+        for (int k = 0; k < s.nitems; ++k) order[k] = k;
+        auto weight = [&](int k) { const Item& it = s.items[k]; return (int64_t)(it.end - it.begin) * (it.diag ? 3 : 2) + 128; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return s.pair_i[s.items[a].pair] < s.pair_i[s.items[b].pair]; });
+        int64_t total = 0;
+        for (int k = 0; k < s.nitems; ++k) total += weight(k);
+        std::vector<std::vector<int32_t>> seg(8);
+        int64_t acc = 0; int x = 0;
+        for (int k : order) {
+            while (x < 7 && acc >= (total * (x + 1)) / 8) ++x;
+            seg[x].push_back(k);
+            acc += weight(k);
+        }
+        size_t longest = 1;
+        for (auto& v : seg) {
+            std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return weight(a) > weight(b); });
+            longest = std::max(longest, v.size());
+        }
+        s.sched_per_xcd = (int)((longest + ipw - 1) / ipw) * ipw;
+        s.sched.assign((size_t)8 * s.sched_per_xcd, Item{ 0, 0, 0, -1 });
+        for (int g = 0; g < 8; ++g)
+            for (size_t k = 0; k < seg[g].size(); ++k) {
+                Item it = s.items[seg[g][k]];
+                it.diag = (seg[g][k] << 1) | (it.diag ? 1 : 0);
+                s.sched[(size_t)g * s.sched_per_xcd + k] = it;
+            }
+    }
 
     // ---- block-row gather lists for y = S x with S given by its upper blocks ----
     std::vector<std::vector<RowEnt>> rows(nf);

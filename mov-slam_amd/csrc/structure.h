@@ -37,6 +37,10 @@ struct Structure {
     std::vector<int32_t> pid;               // nfree x nfree: pair id of (i <= j) or -1
     std::vector<Int2> entries;          // nentries: grouped edge indices (edge of i, edge of j)
     std::vector<Item> items;            // nitems
+    // k_schur launch schedule: 8 segments (one per XCD) of sched_per_xcd slots; a slot holds an item with its
+    // index in bits 1.. of `diag` (bit 0 = diagonal pair), or begin == end and diag < 0 for padding
+    std::vector<Item> sched;
+    int sched_per_xcd = 0;
     std::vector<int32_t> row_ptr;       // nfree+1
     std::vector<RowEnt> row_ent;        // mat-vec gather list per block row
     // coarse level of the two-level PCG preconditioner (build_coarse): keyframe aggregates, 6 dofs each
@@ -49,7 +53,14 @@ struct Structure {
 // A_c = P^T S P (P = piecewise-constant prolongation over the aggregates).
 void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg);
 
-constexpr int kSchurChunk = 2048;       // entries per schur work item (one workgroup of 4 waves each)
+#ifndef MOVBA_SCHUR_WAVES
+#define MOVBA_SCHUR_WAVES 4
+#define MOVBA_SCHUR_WPI 4
+#define MOVBA_SCHUR_EPW 512
+#endif
+constexpr int kSchurWaves = MOVBA_SCHUR_WAVES;      // waves per k_schur workgroup
+constexpr int kSchurWPI = MOVBA_SCHUR_WPI;          // waves that share one work item
+constexpr int kSchurChunk = MOVBA_SCHUR_EPW * kSchurWPI;       // entries per schur work item (one workgroup of 4 waves each)
 
 // Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.  build_structure = build_basic + pair counting + finish_pairs +
 // entry filling, all on the host; the upload path normally runs only build_basic and finish_pairs on the host and

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmovba.so")
+# MOVBA_LIB selects another build of the same library (diagnostic builds, e.g. -DMOVBA_CLOCK_STAMP)
+LIB_PATH = os.environ.get("MOVBA_LIB") or os.path.join(os.path.dirname(_HERE), "libmovba.so")
 
 MAX_TRACE = 128
 NKERNELS = 6
