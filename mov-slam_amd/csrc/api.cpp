@@ -526,9 +526,6 @@ int movba_lba_run(movba_handle *h)
         if (h->hstat->done) break;
         if (h->stop && *h->stop) h->hstat->stop = 1;
         if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
-#ifdef MOVBA_CLOCK_STAMP
-        if (std::getenv("MOVBA_MARK")) HIP_TRY(launch_mark(w, t, 2, s));
-#endif
         { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, t, s) : launch_pcg(w, pp, t, s)); }
         { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
@@ -544,7 +541,7 @@ int movba_lba_run(movba_handle *h)
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_seg[k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
     std::fprintf(stderr, "\nlibmovba[stamp]: setup phases per launch (cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
-    std::fprintf(stderr, "\nlibmovba[stamp]: decide(2) end %llu  mark %llu  pcg(3) start %llu (10 ns ticks)\n", h->ctrl_host->dbg_sch[0], h->ctrl_host->dbg_sch[2], h->ctrl_host->dbg_sch[1]);
+    std::fprintf(stderr, "\n");
 #endif
     h->ran = true;
     return MOVBA_OK;

@@ -20,9 +20,6 @@ size_t pcg_lds_bytes(int nfree);
 hipError_t launch_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s);
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s);
-#ifdef MOVBA_CLOCK_STAMP
-hipError_t launch_mark(const DevWindow &w, int trial, int slot, hipStream_t s);
-#endif
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s);
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s);

@@ -42,7 +42,6 @@ __global__ void k_init_pose(DevWindow w)
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
         for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; }
-        c->dbg_sch[0] = ~0ull; c->dbg_sch[1] = 0; c->dbg_sch[2] = 0; c->dbg_sch[3] = 0;
     }
     if (i >= w.NP) return;
     double q[7];
@@ -322,28 +321,119 @@ __device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y
     }
 }
 
-#ifdef MOVBA_CLOCK_STAMP_SCHUR
-#define SCHUR_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-        if (stamp_me) const_cast<Ctrl *>(c)->dbg_seg2[k] += _t - stamp_last; stamp_last = _t; } while (0)
-#else
-#define SCHUR_STAMP(k) do { } while (0)
-#endif
+// accumulates one diagonal-pair entry: ha += w C^T C (Hpp), ba += C^T (-w e) (b_p) and, unless HPP_ONLY, the Schur
+// terms sa += B Dinv B^T, ca += B Dinv b_l.  `wg` = 0 masks the entry out (all its contributions are exact zeros).
+template <int NR, bool HPP_ONLY>
+__device__ __forceinline__ void schur_diag_entry(const DevWindow &w, const double4 &rc, double wg, const double (&rv)[NR], bool st,
+                                                 const double (&Ri)[9], const double2 (&h)[3], const double (&bl)[3], double lambda,
+                                                 double (&sa)[21], double (&ha)[21], double (&ca)[6], double (&ba)[6])
+{
+    double P[NR][3], C[NR][6];
+    edge_rows<NR>(w, rc.x, rc.y, rc.z, Ri, st, P, C);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int m = 0; m < NR; ++m) ba[a] += C[m][a] * rv[m];
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            double t = 0.0;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) t += C[m][a] * C[m][b];
+            ha[ut6(a, b)] += wg * t;
+        }
+    }
+    if (HPP_ONLY) return;
+    double H[6], D[6];
+    H[0] = h[0].x + lambda; H[1] = h[0].y; H[2] = h[1].x; H[3] = h[1].y + lambda; H[4] = h[2].x; H[5] = h[2].y + lambda;
+    inv3sym(H, D);
+    double T[NR][3], M[NR][NR], pv[NR];
+    const double w2 = wg * wg;
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+        T[m][0] = P[m][0] * D[0] + P[m][1] * D[1] + P[m][2] * D[2];
+        T[m][1] = P[m][0] * D[1] + P[m][1] * D[3] + P[m][2] * D[4];
+        T[m][2] = P[m][0] * D[2] + P[m][1] * D[4] + P[m][2] * D[5];
+        pv[m] = wg * (T[m][0] * bl[0] + T[m][1] * bl[1] + T[m][2] * bl[2]);
+    }
+#pragma unroll
+    for (int m = 0; m < NR; ++m)
+#pragma unroll
+        for (int q = 0; q < NR; ++q) M[m][q] = w2 * (T[m][0] * P[q][0] + T[m][1] * P[q][1] + T[m][2] * P[q][2]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double u[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            u[q] = 0.0;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) u[q] += C[m][a] * M[m][q];
+        }
+#pragma unroll
+        for (int m = 0; m < NR; ++m) ca[a] += C[m][a] * pv[m];
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) sa[ut6(a, b)] += u[q] * C[q][b];
+        }
+    }
+}
 
+// accumulates one off-diagonal entry: acc += w_i w_j Jc_i^T (Jp_i Dinv Jp_j^T) Jc_j; `ww` = 0 masks the entry out
 template <int NR>
-__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int mode, int trial)
+__device__ __forceinline__ void schur_offdiag_entry(const DevWindow &w, const double4 &ri, const double4 &rj, double ww, bool sti, bool stj,
+                                                    const double (&Ri)[9], const double (&Rj)[9], const double2 (&h)[3], double lambda,
+                                                    double (&acc)[36])
+{
+    double H[6], D[6];
+    H[0] = h[0].x + lambda; H[1] = h[0].y; H[2] = h[1].x; H[3] = h[1].y + lambda; H[4] = h[2].x; H[5] = h[2].y + lambda;
+    inv3sym(H, D);
+    double P[NR][3], C[NR][6], Q[NR][3], Ec[NR][6];
+    edge_rows<NR>(w, ri.x, ri.y, ri.z, Ri, sti, P, C);
+    edge_rows<NR>(w, rj.x, rj.y, rj.z, Rj, stj, Q, Ec);
+    double M[NR][NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+        const double t0 = P[m][0] * D[0] + P[m][1] * D[1] + P[m][2] * D[2];
+        const double t1 = P[m][0] * D[1] + P[m][1] * D[3] + P[m][2] * D[4];
+        const double t2 = P[m][0] * D[2] + P[m][1] * D[4] + P[m][2] * D[5];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) M[m][q] = ww * (t0 * Q[q][0] + t1 * Q[q][1] + t2 * Q[q][2]);
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double u[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            u[q] = 0.0;
+#pragma unroll
+            for (int m = 0; m < NR; ++m) u[q] += C[m][a] * M[m][q];
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[a * 6 + b] += u[q] * Ec[q][b];
+        }
+    }
+}
+
+#ifndef MOVBA_SCHUR_BD
+#define MOVBA_SCHUR_BD 2
+#define MOVBA_SCHUR_BO 2
+#endif
+constexpr int kSchurBatchDiag = MOVBA_SCHUR_BD;     // entries per lane whose gathers are in flight together (diagonal items)
+constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
+
+// HPP_ONLY: diagonal pairs only, Hpp and b_p only (one launch per solve, seeds lambda)
+template <int NR, bool HPP_ONLY>
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
 {
     const Ctrl *c = w.ctrl;
     if (c->done) return;
-#ifdef MOVBA_CLOCK_STAMP
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-    const bool stamp_me = mode == 0 && blockIdx.x == 0 && threadIdx.x == 0;
-    const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: item, poses and rotations live in SGPRs
     // XCD-aware launch schedule (structure.cpp): workgroups b, b+8, ... share an XCD (and its L2) and take the slots of
     // that XCD's segment in order
-    const int ipw = kSchurWaves / kSchurWPI;                // kSchurWPI waves share one work item
+    constexpr int ipw = kSchurWaves / kSchurWPI;            // kSchurWPI waves share one work item
     const int wg = (blockIdx.x & 7) * (w.sched_per_xcd / ipw) + (blockIdx.x >> 3);
     const int sub = wv % kSchurWPI;
     __shared__ __attribute__((aligned(16))) double strips[kSchurWaves][54 * 16];
@@ -353,7 +443,7 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int mod
     bool active = it.diag >= 0;
     const int item = active ? (it.diag >> 1) : 0;
     it.diag = active ? (it.diag & 1) : 0;
-    if (mode == 1 && !it.diag) active = false;
+    if (HPP_ONLY && !it.diag) active = false;
     const int wbeg = it.begin + sub * (kSchurChunk / kSchurWPI), wend = active ? min(it.end, wbeg + kSchurChunk / kSchurWPI) : wbeg;
     const int cur = c->cur;
     const double lambda = c->lambda;
@@ -364,78 +454,44 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int mod
 #pragma unroll
     for (int k = 0; k < 9; ++k) { Ri[k] = S0.Rt[12 * ip + k]; Rj[k] = S0.Rt[12 * jp + k]; }
     double *out = w.part + (size_t)item * kPartStride;
-    (void)trial;
-    SCHUR_STAMP(2);
 
+    // Every batch issues the gathers of B entries per lane level by level (entry -> edge records -> point block) before
+    // any arithmetic: the loop is a chain of dependent L2 / fabric round trips, not bandwidth.
     if (it.diag) {
+        constexpr int B = kSchurBatchDiag;
         double sa[21], ha[21], ca[6], ba[6];
 #pragma unroll
         for (int k = 0; k < 21; ++k) { sa[k] = 0.0; ha[k] = 0.0; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { ca[k] = 0.0; ba[k] = 0.0; }
-#pragma unroll 2
-        for (int k = wbeg + lane; k < wend; k += 64) {
-            const int g = w.entries[k].x;
-            const double4 rc = *reinterpret_cast<const double4 *>(S0.rec + 4 * g);
-            const double2 rr = *reinterpret_cast<const double2 *>(S0.res + 2 * g);
-            const double wg = rc.w;
-            double rv[NR];
-            rv[0] = rr.x; rv[1] = rr.y;
-            bool st = false;
-            if (NR == 3) { st = w.obs_r[g] >= 0.0; rv[NR - 1] = st ? S0.res2[g] : 0.0; }
-            double P[NR][3], C[NR][6];
-            edge_rows<NR>(w, rc.x, rc.y, rc.z, Ri, st, P, C);
+        for (int base = wbeg; base < wend; base += 64 * B) {
+            int g[B]; bool ok[B];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
+            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; g[u] = w.entries[min(kk, wend - 1)].x; }
+            double4 rc[B]; double2 rr[B]; int l[B]; double r2[B]; bool st[B];
 #pragma unroll
-                for (int m = 0; m < NR; ++m) ba[a] += C[m][a] * rv[m];
-#pragma unroll
-                for (int b = a; b < 6; ++b) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NR; ++m) t += C[m][a] * C[m][b];
-                    ha[ut6(a, b)] += wg * t;
-                }
+            for (int u = 0; u < B; ++u) {
+                rc[u] = *reinterpret_cast<const double4 *>(S0.rec + 4 * g[u]);
+                rr[u] = *reinterpret_cast<const double2 *>(S0.res + 2 * g[u]);
+                l[u] = w.g_point[g[u]];
+                st[u] = false; r2[u] = 0.0;
+                if (NR == 3) { st[u] = w.obs_r[g[u]] >= 0.0; r2[u] = S0.res2[g[u]]; }
             }
-            if (mode == 1) continue;
-            const int l = w.g_point[g];
-            double H[6], D[6];
-            {
-                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
-                const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2];
-                H[0] = h0.x + lambda; H[1] = h0.y; H[2] = h1.x; H[3] = h1.y + lambda; H[4] = h2.x; H[5] = h2.y + lambda;
-            }
-            inv3sym(H, D);
-            const double bl0 = S0.bl[3 * l], bl1 = S0.bl[3 * l + 1], bl2 = S0.bl[3 * l + 2];
-            double T[NR][3], M[NR][NR], pv[NR];
-            const double w2 = wg * wg;
+            double2 h[B][3]; double bl[B][3];
 #pragma unroll
-            for (int m = 0; m < NR; ++m) {
-                T[m][0] = P[m][0] * D[0] + P[m][1] * D[1] + P[m][2] * D[2];
-                T[m][1] = P[m][0] * D[1] + P[m][1] * D[3] + P[m][2] * D[4];
-                T[m][2] = P[m][0] * D[2] + P[m][1] * D[4] + P[m][2] * D[5];
-                pv[m] = wg * (T[m][0] * bl0 + T[m][1] * bl1 + T[m][2] * bl2);
+            for (int u = 0; u < B; ++u) {
+                if (HPP_ONLY) { h[u][0] = h[u][1] = h[u][2] = make_double2(0.0, 0.0); bl[u][0] = bl[u][1] = bl[u][2] = 0.0; continue; }
+                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l[u]);      // 48-byte records: 16-byte aligned
+                h[u][0] = hp[0]; h[u][1] = hp[1]; h[u][2] = hp[2];
+                bl[u][0] = S0.bl[3 * l[u]]; bl[u][1] = S0.bl[3 * l[u] + 1]; bl[u][2] = S0.bl[3 * l[u] + 2];
             }
 #pragma unroll
-            for (int m = 0; m < NR; ++m)
-#pragma unroll
-                for (int q = 0; q < NR; ++q) M[m][q] = w2 * (T[m][0] * P[q][0] + T[m][1] * P[q][1] + T[m][2] * P[q][2]);
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double u[NR];
-#pragma unroll
-                for (int q = 0; q < NR; ++q) {
-                    u[q] = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NR; ++m) u[q] += C[m][a] * M[m][q];
-                }
-#pragma unroll
-                for (int m = 0; m < NR; ++m) ca[a] += C[m][a] * pv[m];
-#pragma unroll
-                for (int b = a; b < 6; ++b) {
-#pragma unroll
-                    for (int q = 0; q < NR; ++q) sa[ut6(a, b)] += u[q] * C[q][b];
-                }
+            for (int u = 0; u < B; ++u) {
+                const double m = ok[u] ? 1.0 : 0.0;
+                double rv[NR];
+                rv[0] = m * rr[u].x; rv[1] = m * rr[u].y;
+                if (NR == 3) rv[NR - 1] = (ok[u] && st[u]) ? r2[u] : 0.0;
+                schur_diag_entry<NR, HPP_ONLY>(w, rc[u], m * rc[u].w, rv, st[u], Ri, h[u], bl[u], lambda, sa, ha, ca, ba);
             }
         }
         // 54 sums: [0,21) upper triangle of sum B Dinv B^T, [21,27) B Dinv b_l, [27,48) upper Hpp, [48,54) b_p
@@ -444,93 +500,50 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int mod
         for (int k = 0; k < 21; ++k) { all[k] = sa[k]; all[27 + k] = ha[k]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { all[21 + k] = ca[k]; all[48 + k] = ba[k]; }
-        SCHUR_STAMP(3);
         wsum[wv][lane] = wave_reduce<54>(all, strip, lane);
-        SCHUR_STAMP(4);
     } else {
+        constexpr int B = kSchurBatchOff;
         double acc[36];
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
-#pragma unroll 2
-        for (int k = wbeg + lane; k < wend; k += 64) {
-            const Int2 en = w.entries[k];
-            const double4 ri = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.x);
-            const double4 rj = *reinterpret_cast<const double4 *>(S0.rec + 4 * en.y);
-            const int l = w.g_point[en.x];
-            double H[6], D[6];
-            {
-                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
-                const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2];
-                H[0] = h0.x + lambda; H[1] = h0.y; H[2] = h1.x; H[3] = h1.y + lambda; H[4] = h2.x; H[5] = h2.y + lambda;
+        for (int base = wbeg; base < wend; base += 64 * B) {
+            Int2 en[B]; bool ok[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; en[u] = w.entries[min(kk, wend - 1)]; }
+            double4 ri[B], rj[B]; int l[B]; bool sti[B], stj[B];
+#pragma unroll
+            for (int u = 0; u < B; ++u) {
+                ri[u] = *reinterpret_cast<const double4 *>(S0.rec + 4 * en[u].x);
+                rj[u] = *reinterpret_cast<const double4 *>(S0.rec + 4 * en[u].y);
+                l[u] = w.g_point[en[u].x];
+                sti[u] = false; stj[u] = false;
+                if (NR == 3) { sti[u] = w.obs_r[en[u].x] >= 0.0; stj[u] = w.obs_r[en[u].y] >= 0.0; }
             }
-            inv3sym(H, D);
-            bool sti = false, stj = false;
-            if (NR == 3) { sti = w.obs_r[en.x] >= 0.0; stj = w.obs_r[en.y] >= 0.0; }
-            double P[NR][3], C[NR][6], Q[NR][3], Ec[NR][6];
-            edge_rows<NR>(w, ri.x, ri.y, ri.z, Ri, sti, P, C);
-            edge_rows<NR>(w, rj.x, rj.y, rj.z, Rj, stj, Q, Ec);
-            const double ww = ri.w * rj.w;
-            double M[NR][NR];
+            double2 h[B][3];
 #pragma unroll
-            for (int m = 0; m < NR; ++m) {
-                const double t0 = P[m][0] * D[0] + P[m][1] * D[1] + P[m][2] * D[2];
-                const double t1 = P[m][0] * D[1] + P[m][1] * D[3] + P[m][2] * D[4];
-                const double t2 = P[m][0] * D[2] + P[m][1] * D[4] + P[m][2] * D[5];
-#pragma unroll
-                for (int q = 0; q < NR; ++q) M[m][q] = ww * (t0 * Q[q][0] + t1 * Q[q][1] + t2 * Q[q][2]);
+            for (int u = 0; u < B; ++u) {
+                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l[u]);
+                h[u][0] = hp[0]; h[u][1] = hp[1]; h[u][2] = hp[2];
             }
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double u[NR];
-#pragma unroll
-                for (int q = 0; q < NR; ++q) {
-                    u[q] = 0.0;
-#pragma unroll
-                    for (int m = 0; m < NR; ++m) u[q] += C[m][a] * M[m][q];
-                }
-#pragma unroll
-                for (int b = 0; b < 6; ++b) {
-#pragma unroll
-                    for (int q = 0; q < NR; ++q) acc[a * 6 + b] += u[q] * Ec[q][b];
-                }
-            }
+            for (int u = 0; u < B; ++u)
+                schur_offdiag_entry<NR>(w, ri[u], rj[u], ok[u] ? ri[u].w * rj[u].w : 0.0, sti[u], stj[u], Ri, Rj, h[u], lambda, acc);
         }
         wsum[wv][lane] = wave_reduce<36>(acc, strip, lane);
     }
-#if defined(MOVBA_EXP_BARRIER) && MOVBA_EXP_BARRIER == 1
-    __syncthreads();
-#elif defined(MOVBA_EXP_BARRIER) && MOVBA_EXP_BARRIER == 2
-#else
     if (kSchurWPI > 1) __syncthreads();
-#endif
-    SCHUR_STAMP(5);
     if (active && sub == 0) {
         double t = wsum[wv][lane];
 #pragma unroll
         for (int q = 1; q < kSchurWPI; ++q) t += wsum[wv + q][lane];
-#ifdef MOVBA_SC1_STORE
-#define PART_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
-#define PART_STORE(p, v) (*(p) = (v))
-#endif
         if (it.diag) {
             if (lane < 54) {
-                PART_STORE(&out[kDiagMap[lane]], t);
+                out[kDiagMap[lane]] = t;
                 // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
-                if (lane < 21 && kDiagMirror[lane] >= 0) PART_STORE(&out[kDiagMirror[lane]], t);
+                if (lane < 21 && kDiagMirror[lane] >= 0) out[kDiagMirror[lane]] = t;
             }
-        } else if (lane < 36) PART_STORE(&out[lane], t);
+        } else if (lane < 36) out[lane] = t;
     }
-    SCHUR_STAMP(6);
-#ifdef MOVBA_CLOCK_STAMP
-    if (mode == 0 && trial == 3) {       // one launch: per-wave start/end (100 MHz ticks), read back through out_chi2
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long wave_t1 = __builtin_amdgcn_s_memrealtime();
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2);
-        const int slot = blockIdx.x * kSchurWaves + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63) == 0) { dbg[2 * slot] = wave_t0; dbg[2 * slot + 1] = wave_t1; }
-    }
-#endif
 }
 
 // --------------------------------------------------------------------------------
@@ -860,9 +873,6 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
         }
     }
     c->done = done;
-#ifdef MOVBA_CLOCK_STAMP
-    if (c->n_solves == 3) c->dbg_sch[0] = __builtin_amdgcn_s_memrealtime();
-#endif
     __hip_atomic_store(&w.hstat->trials_done, c->n_solves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&w.hstat->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -884,9 +894,6 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
         const double zc = w.st[cur].rec[4 * g + 2];
         bad = (chi2 > w.chi2_gate) || !(zc > 0.0);
         const int e = w.perm[g];
-#ifdef MOVBA_CLOCK_STAMP
-        if (e >= 8192)
-#endif
         w.out_chi2[e] = chi2;
         w.out_outlier[e] = (uint8_t)bad;
     }
@@ -926,15 +933,16 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
     const int nblk = 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI));                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
-    if (w.stereo) hipLaunchKernelGGL(k_schur<3>, dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, mode, trial);
-    else hipLaunchKernelGGL(k_schur<2>, dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, mode, trial);
+    (void)trial;
+    if (mode == 1) {
+        if (w.stereo) hipLaunchKernelGGL((k_schur<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        else hipLaunchKernelGGL((k_schur<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+    } else {
+        if (w.stereo) hipLaunchKernelGGL((k_schur<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        else hipLaunchKernelGGL((k_schur<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+    }
     return hipGetLastError();
 }
-
-#ifdef MOVBA_CLOCK_STAMP
-__global__ void k_mark(DevWindow w, int trial, int slot) { if (trial == 3 && threadIdx.x == 0) w.ctrl->dbg_sch[slot] = __builtin_amdgcn_s_memrealtime(); }
-hipError_t launch_mark(const DevWindow &w, int trial, int slot, hipStream_t s) { hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, s, w, trial, slot); return hipGetLastError(); }
-#endif
 
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
 {

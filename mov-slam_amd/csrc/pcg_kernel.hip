@@ -86,7 +86,6 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int cur = c->cur;
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
-    if (trial == 3 && tid == 0 && blockIdx.x == 0) c->dbg_sch[1] = stamp_t0;
     unsigned long long setup_last = stamp_c0;
 #endif
     const double lambda = c->lambda;
