@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -492,12 +493,11 @@ int movba_lba_run(movba_handle *h)
     if (h->stop && *h->stop) { h->early_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
     const DevWindow &w = h->win;
     hipStream_t s = h->stream;
-    h->hstat->trials_done = 0; h->hstat->done = 0; h->hstat->stop = 0;
+    h->hstat->trials_done = 0; h->hstat->done = 0; h->hstat->stop = 0; h->hstat->it = 0;
 
     {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
         ScopedEvents ev(h, KC_SETUP);
         HIP_TRY(launch_init(w, s));
-        HIP_TRY(hipMemcpyAsync(w.st[0].point, w.point0, sizeof(double) * 3 * (size_t)w.P, hipMemcpyDeviceToDevice, s));
         HIP_TRY(launch_linearize(w, s));
         if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, 0, s));
         HIP_TRY(launch_lambda_init(w, s));
@@ -511,9 +511,29 @@ int movba_lba_run(movba_handle *h)
 
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
     const double t_start = now_ms();
-    for (int t = 0; t < max_trials; ++t) {
-        // stay at most run_ahead trial sets ahead of the device
-        while (!h->hstat->done && t - h->hstat->trials_done >= h->opt.run_ahead) {
+    // k_finalize + the Ctrl read-back are queued speculatively behind a trial that is likely the last one, so that the
+    // end of the solve does not wait for a host round trip; a later trial simply queues them again
+    int t = 0, final_after = -1;
+    auto queue_finalize = [&]() -> int {
+        { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }
+        HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+        final_after = t;
+        return MOVBA_OK;
+    };
+    for (; t < max_trials; ++t) {
+        // stay at most run_ahead trial sets ahead of the device, and never further than the outer iterations that are
+        // left: with R iterations to go at most R more trials run unless one is rejected, so the sets queued beyond that
+        // would almost always be no-op launches (~5 us each) at the end of the solve
+        // (trials_done is read before done and it: k_decide publishes them in the opposite order)
+        bool finished = false;
+        for (;;) {
+            const int td = h->hstat->trials_done;
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (h->hstat->done) { finished = true; break; }
+            const int left = w.max_iters - h->hstat->it;
+            const int limit = left < h->opt.run_ahead ? (left > 1 ? left : 1) : h->opt.run_ahead;
+            if (t - td < limit) break;
+            if (final_after != t && t - td < h->opt.run_ahead) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
             if (h->stop && *h->stop) h->hstat->stop = 1;
             if (now_ms() - t_start > 60000.0) {
                 std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
@@ -523,15 +543,14 @@ int movba_lba_run(movba_handle *h)
             __builtin_ia32_pause();
 #endif
         }
-        if (h->hstat->done) break;
+        if (finished) break;
         if (h->stop && *h->stop) h->hstat->stop = 1;
         if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
         { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, t, s) : launch_pcg(w, pp, t, s)); }
         { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
     }
-    { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }
-    HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+    if (final_after != t) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
     HIP_TRY(hipStreamSynchronize(s));
     harvest_events(h);
 #ifdef MOVBA_CLOCK_STAMP
@@ -539,6 +558,10 @@ int movba_lba_run(movba_handle *h)
                  h->ctrl_host->dbg_ticks, h->ctrl_host->dbg_ticks ? 0.1 * (double)h->ctrl_host->dbg_cycles / (double)h->ctrl_host->dbg_ticks : 0.0);
     std::fprintf(stderr, "libmovba[stamp]: per-iteration segments (wave 0, cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_seg[k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
+    for (int wv = 0; wv < 8; ++wv) {
+        std::fprintf(stderr, "\nlibmovba[stamp]:   wave %d:", wv);
+        for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_wseg[wv][k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
+    }
     std::fprintf(stderr, "\nlibmovba[stamp]: setup phases per launch (cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
     std::fprintf(stderr, "\n");

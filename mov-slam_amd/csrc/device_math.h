@@ -133,6 +133,12 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
 
+// a wave-uniform double moved to SGPRs (frees two VGPRs per value; VALU ops take it as a scalar operand)
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // Fixed-tree sum over the 64 lanes, result broadcast to every lane (wave-uniform).
 __device__ __forceinline__ double wave_sum_dpp(double v)
 {
@@ -143,6 +149,18 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
     v += dpp_mov0<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
     v += dpp_mov0<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3
     return readlane_f64(v, 63);
+}
+
+// Two independent sums at once (their DPP steps interleave, hiding each other's latency); results in (a, b).
+__device__ __forceinline__ void wave_sum_dpp2(double &a, double &b)
+{
+    a += dpp_mov0<0xb1>(a);             b += dpp_mov0<0xb1>(b);
+    a += dpp_mov0<0x4e>(a);             b += dpp_mov0<0x4e>(b);
+    a += dpp_mov0<0x141>(a);            b += dpp_mov0<0x141>(b);
+    a += dpp_mov0<0x140>(a);            b += dpp_mov0<0x140>(b);
+    a += dpp_mov0<0x142, 0xa>(a);       b += dpp_mov0<0x142, 0xa>(b);
+    a += dpp_mov0<0x143, 0xc>(a);       b += dpp_mov0<0x143, 0xc>(b);
+    a = readlane_f64(a, 63);            b = readlane_f64(b, 63);
 }
 
 // Sum over aligned groups of G adjacent lanes (G = 1, 2, 4 or 8), valid in every lane of the group.

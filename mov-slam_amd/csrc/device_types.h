@@ -45,7 +45,7 @@ struct Ctrl {
     int32_t n_solves, last_rejected, iters_done, n_trace;
     int32_t pcg_fail, pcg_last_iters, pcg_total_iters, n_outliers;
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
-    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8];
+    unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8], dbg_wseg[8][8];
 };
 
 // Written by k_decide into pinned host memory so the host can keep the queue fed
@@ -54,7 +54,7 @@ struct HostStatus {
     volatile int32_t trials_done;
     volatile int32_t done;
     volatile int32_t stop;      // host -> device: forceStopFlag seen by the host poll
-    int32_t pad;
+    volatile int32_t it;        // completed outer LM iterations (the host does not queue trials past the last possible one)
 };
 
 struct DevWindow {

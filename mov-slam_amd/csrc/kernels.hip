@@ -28,11 +28,19 @@
 namespace movba {
 
 // --------------------------------------------------------------------------------
-// k_init_pose: uploaded poses -> state 0 (normalised like SE3Quat's constructor), Rt cache
+// k_init_pose: uploaded poses -> state 0 (normalised like SE3Quat's constructor), Rt cache; uploaded points -> state 0
+// (in the same launch: a separate device-to-device copy costs a launch gap of its own at the start of every solve)
 // --------------------------------------------------------------------------------
 __global__ void k_init_pose(DevWindow w)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(w.point0);
+        double2 *dst = reinterpret_cast<double2 *>(w.st[0].point);
+        const int n2 = (3 * w.P) >> 1;
+        for (int k = i; k < n2; k += gridDim.x * blockDim.x) dst[k] = src[k];
+        if (i == 0 && ((3 * w.P) & 1)) w.st[0].point[3 * w.P - 1] = w.point0[3 * w.P - 1];
+    }
     if (i == 0) {
         Ctrl *c = w.ctrl;
         c->lambda = 0.0; c->nu = 2.0; c->F0 = 0.0; c->cost0 = 0.0;
@@ -41,7 +49,7 @@ __global__ void k_init_pose(DevWindow w)
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
-        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; }
+        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; for (int q = 0; q < 8; ++q) c->dbg_wseg[k][q] = 0; }
     }
     if (i >= w.NP) return;
     double q[7];
@@ -873,8 +881,10 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
         }
     }
     c->done = done;
-    __hip_atomic_store(&w.hstat->trials_done, c->n_solves, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&w.hstat->done, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // `done` and `it` first, the trial counter last (release): a host that sees trial n counted also sees whether it was the last
+    __hip_atomic_store(&w.hstat->it, c->it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w.hstat->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w.hstat->trials_done, c->n_solves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // --------------------------------------------------------------------------------
@@ -918,8 +928,10 @@ size_t pcg_lds_bytes(int nfree)
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s)
 {
-    const int nb = (w.NP > 0 ? (w.NP + 63) / 64 : 1);
-    hipLaunchKernelGGL(k_init_pose, dim3(nb), dim3(64), 0, s, w);
+    const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;
+    int nb = (work + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    hipLaunchKernelGGL(k_init_pose, dim3(nb), dim3(256), 0, s, w);
     return hipGetLastError();
 }
 

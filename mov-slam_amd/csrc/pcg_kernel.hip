@@ -50,12 +50,13 @@ constexpr int kNW = kT / 64;
 constexpr int kOwnBatch = 10;           // pair sums an owner lane loads per LDS round trip
 constexpr int kNC = 6 * kNW;            // coarse dofs: one aggregate (6 dofs) per wave
 
+// fixed-order sum of the kNW wave partials (a balanced tree: three dependent adds instead of seven)
 __device__ __forceinline__ double sum_fixed(const double *red)
 {
-    double s = red[0];
-#pragma unroll
-    for (int k = 1; k < kNW; ++k) s += red[k];
-    return s;
+    static_assert(kNW == 8, "tree written for 8 waves");
+    const double2 *r2 = reinterpret_cast<const double2 *>(red);
+    const double2 a = r2[0], b = r2[1], c = r2[2], d = r2[3];
+    return ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
 }
 
 // element (r,c) of the damped reduced-matrix block `pr` (upper-triangle pair id), summed from the
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
     if (c->done) return;
-    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int tid = threadIdx.x, ln = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: row ranges and their predicates live in SGPRs
     const int nf = w.nfree, n = 6 * nf;
     const int cur = c->cur;
 #ifdef MOVBA_CLOCK_STAMP
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     double *rcg = Aci + kNC * kNC;                        // kNC: restricted residual of every aggregate
     double *zstrip = rcg + kNC + 8 * wv;                  // 8 per wave: the wave's coarse correction
     double *rcw = rcg + kNC + 8 * kNW + kNC * wv;         // kNC per wave: the wave's copy of the restricted residual P^T r
-    double *ypart = rcg + kNC + 8 * kNW + kNC * kNW;      // 6 doubles per gather-list PAIR (+ one dummy strip)
+    double *ypart = rcg + kNC + 8 * kNW + 2 * kNC * kNW;  // 6 doubles per gather-list PAIR (+ one dummy strip); scw sits in front
     if (tid == 0) s_fail = 0;
     // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial)
     const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int nrowent = w.row_ptr[nf];
     const int P0 = w.row_ptr[b0] >> 1, P1 = w.row_ptr[b1] >> 1;      // the wave's entry pairs
     const int own_p0 = owner ? (w.row_ptr[bi] >> 1) : 0, own_p1 = owner ? (w.row_ptr[bi + 1] >> 1) : 0;
-    const int own_last = max(own_p1 - 1, 0);
+    const int own_cnt = own_p1 - own_p0;                  // pair sums of this lane's row (0 for non-owners)
+    const int nb = b1 - b0;                               // block rows of this wave (wave-uniform)
 
     // ---- overflow only: materialise S in L2 for the list tails that do not fit in VGPRs ----
     if (pp.overflow) {
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int my_pair = P0 + ln;
     const bool have_pair = my_pair < P1;
     const int yslot = (have_pair ? my_pair : (nrowent >> 1)) * 6;     // lanes without a pair write the dummy strip
+    const double *yown = ypart + own_p0 * 6 + ba;         // first pair sum of this lane's row
     const int4 *plan = reinterpret_cast<const int4 *>(w.lane_plan) + (size_t)tid * 2;
     const int4 pl0 = plan[0], pl1 = plan[1];
     // owner lanes: items of the diagonal pair (bi, bi) carry b_p and B Dinv b_l
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     }
     SETUP_STAMP(0);
     // right-hand side b_S = b_p - sum B Dinv b_l and b_p itself (owner lanes): loads 6 items deep
-    double r_r = 0.0, bp_r = 0.0;
+    double r_r = 0.0;
     if (owner) {
         double cc = 0.0, bb = 0.0;
         for (int i0 = oi0; i0 < oi1; i0 += 6) {
@@ -209,7 +213,6 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #pragma unroll
             for (int u = 0; u < 6; ++u) { const bool in = i0 + u < oi1; cc += in ? cv[u] : 0.0; bb += in ? bv[u] : 0.0; }
         }
-        bp_r = bb;
         r_r = bb - cc;
         w.bp[row] = bb;
     }
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     }
     __syncthreads();
 
-    double x_r = 0.0, z_r = 0.0, p_r = 0.0;
+    double x_r = 0.0, z_r = 0.0;
     // z = Minv r: a block's six rows sit in one wave, so its residuals are exchanged through LDS
     // without a workgroup barrier (LDS operations of one wave execute in order)
     const double2 *mrow = reinterpret_cast<const double2 *>(minv + (owner ? bi * 36 + ba * 6 : 0));
@@ -290,14 +293,14 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         wave_lds_sync();
         const double2 m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
         const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
-        double s = m0.x * r0.x + m0.y * r0.y + m1.x * r1.x + m1.y * r1.y + m2.x * r2.x + m2.y * r2.y;
+        double s = (m0.x * r0.x + m0.y * r0.y) + (m1.x * r1.x + m1.y * r1.y) + (m2.x * r2.x + m2.y * r2.y);
         if (coarse) {
             // z_c = A_c^-1 r_c for the wave's own 6 coarse rows: 8 lanes per row; lane `sub` holds the restricted
             // residual (rcw, kept current by the recurrence r_c -= alpha P^T A p) -> no workgroup barrier here
             const double2 *arow = reinterpret_cast<const double2 *>(Aci + (wv * 6 + ca) * kNC + sub * 6);
             const double2 *rcv = reinterpret_cast<const double2 *>(rcw + sub * 6);
             const double2 a0 = arow[0], a1 = arow[1], a2 = arow[2], c0 = rcv[0], c1 = rcv[1], c2 = rcv[2];
-            double t = a0.x * c0.x + a0.y * c0.y + a1.x * c1.x + a1.y * c1.y + a2.x * c2.x + a2.y * c2.y;
+            double t = (a0.x * c0.x + a0.y * c0.y) + (a1.x * c1.x + a1.y * c1.y) + (a2.x * c2.x + a2.y * c2.y);
             t += dpp_mov0<0xb1>(t);
             t += dpp_mov0<0x4e>(t);
             t += dpp_mov0<0x141>(t);
@@ -307,27 +310,35 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         }
         return owner ? s : 0.0;
     };
-    z_r = precond(r_r);
-    p_r = z_r;
-    {
-        const double ps = wave_sum_dpp(owner ? r_r * z_r : 0.0);
-        if (ln == 0) red1[wv] = ps;
-    }
-    if (owner) p_lds[row] = p_r;
-    __syncthreads();
-    double rz = sum_fixed(red1);
-    const double rz0 = rz;
-    const double thresh = pp.rel_tol * pp.rel_tol * rz0;
-    bool fail = s_fail != 0 || !(rz0 >= 0.0) || !isfinite(rz0);
+    // ---- conjugate gradients, single-reduction form (Chronopoulos & Gear): with z = Minv r and w = A z,
+    //   gamma' = r.z, delta = w.z  (ONE reduction) -> beta = gamma'/gamma, alpha = gamma' / (delta - beta gamma'/alpha),
+    //   p = z + beta p, s = w + beta s (= A p), x += alpha p, r -= alpha s.
+    // Same iterates as textbook CG in exact arithmetic; two workgroup barriers and one reduction per iteration instead
+    // of three and two.  The restricted residual P^T r follows r_c -= alpha P^T s with P^T s = P^T w + beta P^T s.
+    double p_r = 0.0, s_r = 0.0;
+    double *scw = rcw + kNC * kNW;                        // kNC per wave: P^T s of every aggregate (wave-private copy)
+    if (ln < kNC) scw[ln] = 0.0;
+    double inv_gamma = 1.0, inv_alpha = 0.0, alpha = 0.0, thresh = 0.0;
+    bool fail = s_fail != 0;
+    bool first = true;
     int iters = 0;
 
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, seg_last = __builtin_amdgcn_s_memtime();
 #endif
-    if (!fail && rz0 > 0.0) {
+    if (!fail) {
         for (iters = 1; iters <= pp.max_iters; ++iters) {
             SEG_STAMP(7);
-            // ---- y = B0 p_c0 + B1 p_c1 for this lane's pair, parked in the wave's strip of ypart ----
+            // ---- x += alpha p, r -= alpha s, z = Minv r (wave-local) ----
+            x_r += alpha * p_r;
+            r_r -= alpha * s_r;
+            if (coarse && ln < kNC) rcw[ln] -= alpha * scw[ln];   // ordered before precond's reads by its wave-local sync
+            z_r = precond(r_r);
+            if (owner) p_lds[row] = z_r;                      // the vector the mat-vec multiplies
+            SEG_STAMP(0);
+            __syncthreads();                                  // (A) z visible
+            SEG_STAMP(1);
+            // ---- y = B0 z_c0 + B1 z_c1 for this lane's pair, parked in the wave's strip of ypart ----
             // (branch-free: a lane without a pair multiplies zeros and writes the dummy strip)
             {
                 const double2 *pa = reinterpret_cast<const double2 *>(p_lds + colo[0]);
@@ -356,62 +367,67 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
                 }
                 for (int a = 0; a < 6; ++a) ypart[pq * 6 + a] = y[a];
             }
-            SEG_STAMP(0);
+            SEG_STAMP(2);
             wave_lds_sync();
             // owner: add up its row's pair sums in list order; loads issued together, adds in order
-            double Ap = 0.0;
-            for (int e = own_p0; e < own_p1; e += kOwnBatch) {
-                double v[kOwnBatch];
+            double w_r = 0.0;
+            {
+                // loads at fixed offsets from the row's first pair sum (no per-load address arithmetic); the slots past the
+                // row's end hold other rows' sums (or the padding behind ypart) and are masked out
+                const double *yb = yown;
+                for (int e = 0; e < own_cnt; e += kOwnBatch, yb += 6 * kOwnBatch) {
+                    double v[kOwnBatch];
 #pragma unroll
-                for (int u = 0; u < kOwnBatch; ++u) v[u] = ypart[min(e + u, own_last) * 6 + ba];   // unconditional, clamped
+                    for (int u = 0; u < kOwnBatch; ++u) v[u] = yb[6 * u];
 #pragma unroll
-                for (int u = 0; u < kOwnBatch; ++u) Ap += (e + u < own_p1) ? v[u] : 0.0;
+                    for (int u = 0; u < kOwnBatch; ++u) v[u] = (e + u < own_cnt) ? v[u] : 0.0;
+                    // fixed tree over the batch (depth 4 instead of a 10-long chain)
+                    static_assert(kOwnBatch == 10, "tree written for 10");
+                    w_r += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (v[8] + v[9]);
+                }
             }
-            SEG_STAMP(1);
+            SEG_STAMP(3);
             if (coarse) {
-                // P^T (A p) of this wave's aggregate, published with the p.Ap partial: the restricted residual then
-                // follows r_c -= alpha P^T A p in every wave without a barrier of its own
-                if (owner) r_lds[row] = Ap;
+                // P^T w of this wave's aggregate, published with the dot-product partials
+                if (owner) r_lds[row] = w_r;
                 wave_lds_sync();
                 if (ln < 6) {
+                    // rows b0 .. b0+9 at fixed offsets; the ones past the wave's last row are masked by a wave-uniform predicate
+                    const double *rb = r_lds + b0 * 6 + ln;
                     double v[10];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) v[u] = r_lds[min(b0 + u, max(b1 - 1, b0)) * 6 + ln];
-                    double t = 0.0;
+                    for (int u = 0; u < 10; ++u) v[u] = rb[6 * u];
 #pragma unroll
-                    for (int u = 0; u < 10; ++u) t += (b0 + u < b1) ? v[u] : 0.0;
-                    rcg[wv * 6 + ln] = t;
+                    for (int u = 0; u < 10; ++u) v[u] = (u < nb) ? v[u] : 0.0;
+                    rcg[wv * 6 + ln] = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (v[8] + v[9]);
                 }
             }
             {
-                const double ps = wave_sum_dpp(owner ? p_r * Ap : 0.0);
-                if (ln == 0) red0[wv] = ps;
-            }
-            SEG_STAMP(2);
-            __syncthreads();                                  // (1) p.Ap partials visible; all reads of p done
-            SEG_STAMP(3);
-            const double pAp = sum_fixed(red0);
-            if (!(pAp > 0.0) || !isfinite(pAp)) { fail = true; break; }
-            const double alpha = rz / pAp;
-            x_r += alpha * p_r;
-            r_r -= alpha * Ap;
-            if (coarse && ln < kNC) rcw[ln] -= alpha * rcg[ln];   // ordered before precond's reads by its wave-local sync
-            z_r = precond(r_r);
-            {
-                const double ps = wave_sum_dpp(owner ? r_r * z_r : 0.0);
-                if (ln == 0) red1[wv] = ps;
+                double g = owner ? r_r * z_r : 0.0, d = owner ? w_r * z_r : 0.0;
+                wave_sum_dpp2(g, d);
+                if (ln == 0) { red0[wv] = g; red1[wv] = d; }
             }
             SEG_STAMP(4);
-            __syncthreads();                                  // (2) r.z partials visible
+            __syncthreads();                                  // (B) r.z, w.z and P^T w visible; all reads of z done
             SEG_STAMP(5);
-            const double rzn = sum_fixed(red1);
-            if (!isfinite(rzn)) { fail = true; break; }
-            if (rzn <= thresh) break;
-            const double beta = rzn / rz;
-            rz = rzn;
+            const double g = uniform_f64(sum_fixed(red0)), delta = uniform_f64(sum_fixed(red1));
+            if (!isfinite(g) || !isfinite(delta)) { fail = true; break; }
+            if (first) {
+                thresh = uniform_f64(pp.rel_tol * pp.rel_tol * g);
+                if (!(g >= 0.0)) { fail = true; break; }
+                if (g == 0.0) { iters = 0; break; }
+            }
+            if (!first && g <= thresh) break;
+            const double beta = uniform_f64(first ? 0.0 : g * inv_gamma);
+            const double den = delta - beta * g * inv_alpha;          // = p.Ap of the new search direction
+            if (!(den > 0.0)) { fail = true; break; }
+            inv_gamma = uniform_f64(1.0 / g);                         // independent of the alpha chain: the two divisions overlap
+            alpha = uniform_f64(g / den);
+            inv_alpha = uniform_f64(den * inv_gamma);
+            first = false;
             p_r = z_r + beta * p_r;
-            if (owner) p_lds[row] = p_r;
-            __syncthreads();                                  // (3) new search direction visible
+            s_r = w_r + beta * s_r;
+            if (coarse && ln < kNC) scw[ln] = rcg[ln] + beta * scw[ln];
             SEG_STAMP(6);
         }
         if (iters > pp.max_iters) iters = pp.max_iters;
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const double xv = (fail || !owner) ? 0.0 : x_r;
     if (owner) { w.xp[row] = xv; p_lds[row] = xv; }
     {
-        const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + bp_r) : 0.0);
+        const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + w.bp[row]) : 0.0);
         if (ln == 0) red0[wv] = ps;
     }
     __syncthreads();
@@ -451,6 +467,9 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
         S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
     }
+#ifdef MOVBA_CLOCK_STAMP
+    if (ln == 0) for (int k = 0; k < 8; ++k) c->dbg_wseg[wv][k] += seg[k];
+#endif
     if (tid == 0) {
         w.scale_part[w.n_pt_blocks] = scs;
         c->pcg_fail = fail ? 1 : 0;
@@ -468,7 +487,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + kNC * kNW + 6 * ((size_t)nrowent / 2 + 1)) * sizeof(double);
+    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + 2 * kNC * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch)) * sizeof(double);
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list
