@@ -84,8 +84,8 @@ struct DevWindow {
     DevState st[2];
     const double *pose0, *point0;   // uploaded initial state (for reset)
     // reduced system
-    double *part;       // 2 x nitems x kPartStride (double-buffered by trial parity)
-    double *blocks_c;   // npairs x 36: k_coarse's own copy of S
+    double *part;       // nitems x kPartStride: k_schur work-item partials
+    double *blocks_c;   // npairs x 36: the coarse-level workgroup's own copy of S (coarse_level.h)
     double *aci;        // 2 x 48 x 48: inverse coarse matrices (by trial parity)
     int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable
     double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first
