@@ -341,7 +341,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     bool stereo = false;
     if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
     const size_t o_obsr = c.take<double>(stereo ? E : 0);
-    const size_t o_ent = c.take<Int2>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<Item>(s.sched.size() + 1);
+    const size_t o_slot = c.take<int32_t>(E);
+    const size_t o_ent = c.take<Int4>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<SchedItem>(s.sched.size() + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
     std::vector<int32_t> lane_plan;
@@ -366,7 +367,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
     const size_t h2d = c.off;
     // ---- device-only region ----
-    size_t o_st[2][10];
+    size_t o_st[2][11];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
         o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
@@ -374,6 +375,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_st[b][6] = c.take<double>(2 * (size_t)E);  o_st[b][7] = c.take<double>(E);
         o_st[b][8] = c.take<double>(nb);
         o_st[b][9] = c.take<double>(stereo ? E : 0);
+        o_st[b][10] = c.take<double>(8 * (size_t)E);
     }
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
     const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
@@ -393,6 +395,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_gpoint, s.g_point.data(), sizeof(int32_t) * E);
     std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
     std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
+    std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
     std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
     std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
     {
@@ -406,9 +409,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
             for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
         }
     }
-    if (!dev_structure) std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int2) * (size_t)s.nentries);
+    if (!dev_structure) std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int4) * (size_t)s.nentries);
     std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
-    std::memcpy(sg + o_sched, s.sched.data(), sizeof(Item) * s.sched.size());
+    std::memcpy(sg + o_sched, s.sched.data(), sizeof(SchedItem) * s.sched.size());
     std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
     std::memcpy(sg + o_pj, s.pair_j.data(), sizeof(int32_t) * s.npairs);
     std::memcpy(sg + o_pis, s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
@@ -425,7 +428,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     h->prof.structure_ms += t2 - t1;
     HIP_TRY(hipMemcpyAsync(h->arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
     if (dev_structure) {
-        sd.entries = reinterpret_cast<Int2 *>(h->arena + o_ent);
+        sd.entries = reinterpret_cast<Int4 *>(h->arena + o_ent);
+        sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
         HIP_TRY(launch_struct_fill(sd, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -444,8 +448,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
     w.obs_r = reinterpret_cast<double *>(a + o_obsr); w.bf = d->bf; w.stereo = stereo ? 1 : 0;
-    w.entries = reinterpret_cast<Int2 *>(a + o_ent); w.items = reinterpret_cast<Item *>(a + o_items);
-    w.sched = reinterpret_cast<Item *>(a + o_sched); w.sched_per_xcd = s.sched_per_xcd;
+    w.slot = reinterpret_cast<int32_t *>(a + o_slot);
+    w.entries = reinterpret_cast<Int4 *>(a + o_ent); w.items = reinterpret_cast<Item *>(a + o_items);
+    w.sched = reinterpret_cast<SchedItem *>(a + o_sched); w.sched_per_xcd = s.sched_per_xcd;
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
     w.row_ent = reinterpret_cast<RowEnt *>(a + o_rowent);
@@ -462,6 +467,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.res = reinterpret_cast<double *>(a + o_st[b][6]); S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
         S.res2 = reinterpret_cast<double *>(a + o_st[b][9]);
+        S.erec = reinterpret_cast<double *>(a + o_st[b][10]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c);

@@ -34,6 +34,7 @@ struct DevState {
     double *chi2;    // E
     double *res2;    // E: -w e2 of stereo edges (stereo windows only)
     double *Fpart;   // n_pt_blocks robust-cost partials of this state
+    double *erec;    // E_free x 8, POSE-major (DevWindow::slot): (Xc.x Xc.y Xc.z w | -w e0, -w e1, -w e2, stereo flag) for k_schur
 };
 
 // LM controller state, lives in HBM; every kernel reads it, k_decide/k_pcg/k_lambda_init write it.
@@ -69,9 +70,10 @@ struct DevWindow {
     const double *obs_r;    // E: right-image u of stereo observations, < 0 = monocular edge (stereo windows only)
     double bf;              // KeyFrame::mbf
     int32_t stereo, pad2;   // window has >= 1 stereo edge: 3-row kernels
-    const Int2 *entries;
+    const int32_t *slot;    // E: pose-major slot of a grouped edge (-1: edge of a fixed pose)
+    const Int4 *entries;    // (slot of the edge of pose i, slot of the edge of pose j, map point, 0)
     const Item *items;
-    const Item *sched;      // k_schur launch schedule: 8 x sched_per_xcd slots (structure.h)
+    const SchedItem *sched; // k_schur launch schedule: 8 x sched_per_xcd slots (structure.h)
     int32_t sched_per_xcd, pad3;
     const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;
     const RowEnt *row_ent;
@@ -109,7 +111,8 @@ struct StructDev {
     int32_t *error;             // set when a keyframe observes a point twice
     const int32_t *pid;         // nfree^2 -> pair id        (fill)
     const int32_t *pair_ptr;    // npairs+1                   (fill)
-    Int2 *entries;              //                            (fill)
+    const int32_t *slot;        // E: pose-major slot of a grouped edge (fill)
+    Int4 *entries;              //                            (fill)
 };
 
 struct PcgParams {

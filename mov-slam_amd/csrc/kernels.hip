@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     }
     // the lane's first two edges (a point with more than 16 observations takes the loop further down)
     constexpr int kPre = 2;
-    int pg[kPre], pip[kPre];
+    int pg[kPre], pip[kPre], psl[kPre];
     double4 prc[kPre];
     double2 pob[kPre];
     double pom[kPre], pur[kPre];
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         const int g = min(pg[k], max(end - 1, 0));
         const bool in = pg[k] < end;
         pip[k] = in ? w.g_pose[g] : 0;
+        psl[k] = in ? w.slot[g] : -1;
         prc[k] = (BACKSUB && in) ? *reinterpret_cast<const double4 *>(S0.rec + 4 * g) : make_double4(0, 0, 1, 0);
         pob[k] = in ? *reinterpret_cast<const double2 *>(w.obs + 2 * g) : make_double2(0, 0);
         pom[k] = in ? w.isig[g] : 0.0;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     // ---- evaluate at the destination state ----
     double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, v0 = 0, v1 = 0, v2 = 0, F = 0.0;
     const double dsqr = w.huber_delta * w.huber_delta;
-    auto eval_edge = [&](int g, int ip, const double2 &ob, double om, double ur) {
+    auto eval_edge = [&](int g, int ip, int sl, const double2 &ob, double om, double ur) {
         const double *R = sRt + 12 * ip;
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
@@ -215,6 +216,11 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         *reinterpret_cast<double4 *>(S1.rec + 4 * g) = make_double4(x, y, z, wg);
         *reinterpret_cast<double2 *>(S1.res + 2 * g) = make_double2(r0, r1);
         S1.chi2[g] = chi2;
+        if (sl >= 0) {      // pose-major copy for the schur pass (edges of free keyframes): one 64-byte record
+            double4 *er = reinterpret_cast<double4 *>(S1.erec + 8 * (size_t)sl);
+            er[0] = make_double4(x, y, z, wg);
+            er[1] = make_double4(r0, r1, STEREO ? -wg * e2 : 0.0, (STEREO && st) ? 1.0 : 0.0);
+        }
         F += rho0;
         const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
         const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
@@ -237,9 +243,9 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     };
 #pragma unroll
     for (int k = 0; k < kPre; ++k)
-        if (pg[k] < end) eval_edge(pg[k], pip[k], pob[k], pom[k], pur[k]);
+        if (pg[k] < end) eval_edge(pg[k], pip[k], psl[k], pob[k], pom[k], pur[k]);
     for (int g = begin + sub + kPointGroup * kPre; g < end; g += kPointGroup)
-        eval_edge(g, w.g_pose[g], *reinterpret_cast<const double2 *>(w.obs + 2 * g), w.isig[g], STEREO ? w.obs_r[g] : -1.0);
+        eval_edge(g, w.g_pose[g], w.slot[g], *reinterpret_cast<const double2 *>(w.obs + 2 * g), w.isig[g], STEREO ? w.obs_r[g] : -1.0);
 #pragma unroll
     for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
         h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
@@ -435,37 +441,45 @@ constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
 template <int NR, bool HPP_ONLY>
 __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
 {
-    const Ctrl *c = w.ctrl;
-    if (c->done) return;
+#ifdef MOVBA_CLOCK_STAMP
+    unsigned long long wst[5];
+    wst[0] = __builtin_amdgcn_s_memrealtime();
+#define WSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); wst[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WSTAMP(k) do { } while (0)
+#endif
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: item, poses and rotations live in SGPRs
     // XCD-aware launch schedule (structure.cpp): workgroups b, b+8, ... share an XCD (and its L2) and take the slots of
-    // that XCD's segment in order
+    // that XCD's segment in order.  The slot is fetched together with the LM state (one scalar round trip).
     constexpr int ipw = kSchurWaves / kSchurWPI;            // kSchurWPI waves share one work item
     const int wg = (blockIdx.x & 7) * (w.sched_per_xcd / ipw) + (blockIdx.x >> 3);
+    const SchedItem it = w.sched[wg * ipw + wv / kSchurWPI];
+    const Ctrl *c = w.ctrl;
+    if (c->done) return;
     const int sub = wv % kSchurWPI;
     __shared__ __attribute__((aligned(16))) double strips[kSchurWaves][54 * 16];
     __shared__ double wsum[kSchurWaves][64];
     double *strip = strips[wv];
-    Item it = w.sched[wg * ipw + wv / kSchurWPI];
-    bool active = it.diag >= 0;
-    const int item = active ? (it.diag >> 1) : 0;
-    it.diag = active ? (it.diag & 1) : 0;
-    if (HPP_ONLY && !it.diag) active = false;
-    const int wbeg = it.begin + sub * (kSchurChunk / kSchurWPI), wend = active ? min(it.end, wbeg + kSchurChunk / kSchurWPI) : wbeg;
+    bool active = it.tag >= 0;
+    const int item = active ? (it.tag >> 1) : 0;
+    const bool is_diag = active && (it.tag & 1);
+    if (HPP_ONLY && !is_diag) active = false;
+    const int epw = (it.end - it.begin + kSchurWPI - 1) / kSchurWPI;          // entries per wave: the item split evenly
+    const int wbeg = it.begin + sub * epw, wend = active ? min(it.end, wbeg + epw) : wbeg;
     const int cur = c->cur;
     const double lambda = c->lambda;
     const DevState &S0 = w.st[cur];
-    const int ip = w.free_pose[w.pair_i[it.pair]];
-    const int jp = w.free_pose[w.pair_j[it.pair]];
+    const int ip = it.pose_i, jp = it.pose_j;
     double Ri[9], Rj[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { Ri[k] = S0.Rt[12 * ip + k]; Rj[k] = S0.Rt[12 * jp + k]; }
     double *out = w.part + (size_t)item * kPartStride;
+    WSTAMP(1);
 
     // Every batch issues the gathers of B entries per lane level by level (entry -> edge records -> point block) before
     // any arithmetic: the loop is a chain of dependent L2 / fabric round trips, not bandwidth.
-    if (it.diag) {
+    if (is_diag) {
         constexpr int B = kSchurBatchDiag;
         double sa[21], ha[21], ca[6], ba[6];
 #pragma unroll
@@ -473,33 +487,30 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
 #pragma unroll
         for (int k = 0; k < 6; ++k) { ca[k] = 0.0; ba[k] = 0.0; }
         for (int base = wbeg; base < wend; base += 64 * B) {
-            int g[B]; bool ok[B];
+            Int4 en[B]; bool ok[B];
 #pragma unroll
-            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; g[u] = w.entries[min(kk, wend - 1)].x; }
-            double4 rc[B]; double2 rr[B]; int l[B]; double r2[B]; bool st[B];
-#pragma unroll
-            for (int u = 0; u < B; ++u) {
-                rc[u] = *reinterpret_cast<const double4 *>(S0.rec + 4 * g[u]);
-                rr[u] = *reinterpret_cast<const double2 *>(S0.res + 2 * g[u]);
-                l[u] = w.g_point[g[u]];
-                st[u] = false; r2[u] = 0.0;
-                if (NR == 3) { st[u] = w.obs_r[g[u]] >= 0.0; r2[u] = S0.res2[g[u]]; }
-            }
-            double2 h[B][3]; double bl[B][3];
+            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; en[u] = w.entries[min(kk, wend - 1)]; }
+            // the diagonal pair of keyframe i lists ALL its edges in map-point order = consecutive pose-major records:
+            // the record loads of a wave are contiguous 64-byte lines
+            double4 rc[B], rq[B]; double2 h[B][3]; double bl[B][3];
 #pragma unroll
             for (int u = 0; u < B; ++u) {
+                const double4 *er = reinterpret_cast<const double4 *>(S0.erec + 8 * (size_t)en[u].x);
+                rc[u] = er[0]; rq[u] = er[1];
                 if (HPP_ONLY) { h[u][0] = h[u][1] = h[u][2] = make_double2(0.0, 0.0); bl[u][0] = bl[u][1] = bl[u][2] = 0.0; continue; }
-                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l[u]);      // 48-byte records: 16-byte aligned
+                const int l = en[u].z;
+                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
                 h[u][0] = hp[0]; h[u][1] = hp[1]; h[u][2] = hp[2];
-                bl[u][0] = S0.bl[3 * l[u]]; bl[u][1] = S0.bl[3 * l[u] + 1]; bl[u][2] = S0.bl[3 * l[u] + 2];
+                bl[u][0] = S0.bl[3 * l]; bl[u][1] = S0.bl[3 * l + 1]; bl[u][2] = S0.bl[3 * l + 2];
             }
 #pragma unroll
             for (int u = 0; u < B; ++u) {
                 const double m = ok[u] ? 1.0 : 0.0;
+                const bool st = NR == 3 && rq[u].w != 0.0;
                 double rv[NR];
-                rv[0] = m * rr[u].x; rv[1] = m * rr[u].y;
-                if (NR == 3) rv[NR - 1] = (ok[u] && st[u]) ? r2[u] : 0.0;
-                schur_diag_entry<NR, HPP_ONLY>(w, rc[u], m * rc[u].w, rv, st[u], Ri, h[u], bl[u], lambda, sa, ha, ca, ba);
+                rv[0] = m * rq[u].x; rv[1] = m * rq[u].y;
+                if (NR == 3) rv[NR - 1] = (ok[u] && st) ? rq[u].z : 0.0;
+                schur_diag_entry<NR, HPP_ONLY>(w, rc[u], m * rc[u].w, rv, st, Ri, h[u], bl[u], lambda, sa, ha, ca, ba);
             }
         }
         // 54 sums: [0,21) upper triangle of sum B Dinv B^T, [21,27) B Dinv b_l, [27,48) upper Hpp, [48,54) b_p
@@ -508,6 +519,7 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
         for (int k = 0; k < 21; ++k) { all[k] = sa[k]; all[27 + k] = ha[k]; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { all[21 + k] = ca[k]; all[48 + k] = ba[k]; }
+        WSTAMP(2);
         wsum[wv][lane] = wave_reduce<54>(all, strip, lane);
     } else {
         constexpr int B = kSchurBatchOff;
@@ -515,36 +527,35 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
 #pragma unroll
         for (int k = 0; k < 36; ++k) acc[k] = 0.0;
         for (int base = wbeg; base < wend; base += 64 * B) {
-            Int2 en[B]; bool ok[B];
+            Int4 en[B]; bool ok[B];
 #pragma unroll
             for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; en[u] = w.entries[min(kk, wend - 1)]; }
-            double4 ri[B], rj[B]; int l[B]; bool sti[B], stj[B];
+            // edges of keyframe i (and of j) shared with the other one, in map-point order: ascending pose-major records
+            double4 ri[B], rj[B]; double2 h[B][3]; bool sti[B], stj[B];
 #pragma unroll
             for (int u = 0; u < B; ++u) {
-                ri[u] = *reinterpret_cast<const double4 *>(S0.rec + 4 * en[u].x);
-                rj[u] = *reinterpret_cast<const double4 *>(S0.rec + 4 * en[u].y);
-                l[u] = w.g_point[en[u].x];
+                const double4 *ei = reinterpret_cast<const double4 *>(S0.erec + 8 * (size_t)en[u].x);
+                const double4 *ej = reinterpret_cast<const double4 *>(S0.erec + 8 * (size_t)en[u].y);
+                ri[u] = ei[0]; rj[u] = ej[0];
                 sti[u] = false; stj[u] = false;
-                if (NR == 3) { sti[u] = w.obs_r[en[u].x] >= 0.0; stj[u] = w.obs_r[en[u].y] >= 0.0; }
-            }
-            double2 h[B][3];
-#pragma unroll
-            for (int u = 0; u < B; ++u) {
-                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l[u]);
+                if (NR == 3) { sti[u] = S0.erec[8 * (size_t)en[u].x + 7] != 0.0; stj[u] = S0.erec[8 * (size_t)en[u].y + 7] != 0.0; }
+                const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * en[u].z);
                 h[u][0] = hp[0]; h[u][1] = hp[1]; h[u][2] = hp[2];
             }
 #pragma unroll
             for (int u = 0; u < B; ++u)
                 schur_offdiag_entry<NR>(w, ri[u], rj[u], ok[u] ? ri[u].w * rj[u].w : 0.0, sti[u], stj[u], Ri, Rj, h[u], lambda, acc);
         }
+        WSTAMP(2);
         wsum[wv][lane] = wave_reduce<36>(acc, strip, lane);
     }
+    WSTAMP(3);
     if (kSchurWPI > 1) __syncthreads();
     if (active && sub == 0) {
         double t = wsum[wv][lane];
 #pragma unroll
         for (int q = 1; q < kSchurWPI; ++q) t += wsum[wv + q][lane];
-        if (it.diag) {
+        if (is_diag) {
             if (lane < 54) {
                 out[kDiagMap[lane]] = t;
                 // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
@@ -552,6 +563,16 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
             }
         } else if (lane < 36) out[lane] = t;
     }
+#ifdef MOVBA_CLOCK_STAMP
+    WSTAMP(4);
+    if (!HPP_ONLY && lane == 0 && c->n_solves == 3) {        // one launch: per-wave stamps (100 MHz ticks), read back through out_chi2
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 8 * (size_t)(blockIdx.x * kSchurWaves + wv);
+        for (int k = 0; k < 5; ++k) dbg[k] = wst[k];
+        dbg[5] = (unsigned long long)(wend - wbeg);
+        dbg[6] = (unsigned long long)is_diag | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 40);
+        dbg[7] = 1;
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------
@@ -904,6 +925,9 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
         const double zc = w.st[cur].rec[4 * g + 2];
         bad = (chi2 > w.chi2_gate) || !(zc > 0.0);
         const int e = w.perm[g];
+#ifdef MOVBA_CLOCK_STAMP
+        if (e >= 32768)
+#endif
         w.out_chi2[e] = chi2;
         w.out_outlier[e] = (uint8_t)bad;
     }

@@ -97,6 +97,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     }
     const double *part = w.part;
     const int npad = (n + 1) & ~1;
+    const int nrowent_all = w.row_ptr[nf];
 
     // LDS carve (16-byte aligned pieces, no static LDS in front of it)
     double *p_lds = sm;                                   // n
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     double *zstrip = rcg + kNC + 8 * wv;                  // 8 per wave: the wave's coarse correction
     double *rcw = rcg + kNC + 8 * kNW + kNC * wv;         // kNC per wave: the wave's copy of the restricted residual P^T r
     double *ypart = rcg + kNC + 8 * kNW + 2 * kNC * kNW;  // 6 doubles per gather-list PAIR (+ one dummy strip); scw sits in front
+    double *sdiag = ypart + 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);     // nf x 36: the damped diagonal blocks S_ii
     if (tid == 0) s_fail = 0;
     // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial)
     const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int row = b0 * 6 + ln;
     const bool owner = ln < 6 * (b1 - b0);
     const int bi = owner ? row / 6 : 0, ba = owner ? row - bi * 6 : 0;
-    const int nrowent = w.row_ptr[nf];
+    const int nrowent = nrowent_all;
     const int P0 = w.row_ptr[b0] >> 1, P1 = w.row_ptr[b1] >> 1;      // the wave's entry pairs
     const int own_p0 = owner ? (w.row_ptr[bi] >> 1) : 0, own_p1 = owner ? (w.row_ptr[bi + 1] >> 1) : 0;
     const int own_cnt = own_p1 - own_p0;                  // pair sums of this lane's row (0 for non-owners)
@@ -136,7 +138,6 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             const int pr = idx / 36, k = idx - pr * 36;
             const double v = s_block_elem(part, pr, w.pair_item_start[pr], w.pair_item_start[pr + 1], k / 6, k % 6, lambda, nf);
             w.blocks[idx] = v;
-            if (pr < nf) minv[idx] = v;                     // diagonal blocks: input of the preconditioner
         }
         __syncthreads();
     }
@@ -153,43 +154,64 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int4 pl0 = plan[0], pl1 = plan[1];
     // owner lanes: items of the diagonal pair (bi, bi) carry b_p and B Dinv b_l
     const int oi0 = owner ? w.pair_item_start[bi] : 0, oi1 = owner ? w.pair_item_start[bi + 1] : 0;
+    // ---- diagonal blocks and right-hand side, cooperatively: owner lane (bi, ba) sums ROW ba of S_ii = Hpp + lambda I -
+    // sum B Dinv B^T, b_p and B Dinv b_l over the work items of pair (bi, bi), four items in flight: the cost does not
+    // grow with the number of items a long diagonal pair is cut into ----
+    double r_r = 0.0;
+    if (owner) {
+        int hu[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) hu[q] = 42 + (ba <= q ? ut6(ba, q) : ut6(q, ba));
+        double s6[6] = { 0, 0, 0, 0, 0, 0 }, h6[6] = { 0, 0, 0, 0, 0, 0 }, cc = 0.0, bb = 0.0;
+        for (int i0 = oi0; i0 < oi1; i0 += 4) {
+            double sv[4][6], hv[4][6], cv[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double *src = part + (size_t)min(i0 + u, oi1 - 1) * kPartStride;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { sv[u][q] = src[ba * 6 + q]; hv[u][q] = src[hu[q]]; }
+                cv[u] = src[36 + ba]; bv[u] = src[63 + ba];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = i0 + u < oi1;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { s6[q] += in ? sv[u][q] : 0.0; h6[q] += in ? hv[u][q] : 0.0; }
+                cc += in ? cv[u] : 0.0; bb += in ? bv[u] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sdiag[bi * 36 + ba * 6 + q] = (h6[q] + (q == ba ? lambda : 0.0)) - s6[q];
+        r_r = bb - cc;
+        w.bp[row] = bb;
+    }
+    SETUP_STAMP(0);
+    __syncthreads();
+
+    // ---- this lane's pair of oriented blocks: off-diagonal ones straight from the partials, diagonal ones from LDS ----
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         colo[k] = 0;
-        // raw = sum over the pair's work items of the 6x6 partial (wide, independent loads), then
-        // S_block = [Hpp + lambda I] - raw, oriented for this entry
         double raw[36];
 #pragma unroll
         for (int q = 0; q < 36; ++q) raw[q] = 0.0;
-        bool valid = false, tr = false, diag = false;
+        bool valid = false, tr = false;
         {
             const int4 pl = k ? pl1 : pl0;
             if (pl.x >= 0) {
-                valid = true; tr = ((pl.y >> 30) & 1) != 0; diag = pl.x < nf;
+                valid = true; tr = ((pl.y >> 30) & 1) != 0;
                 colo[k] = pl.y & 0x3fffffff;
-                const int i0 = pl.z, i1 = pl.w;
-                for (int itx = i0; itx < i1; ++itx) {
-                    const double2 *src = reinterpret_cast<const double2 *>(part + (size_t)itx * kPartStride);
+                if (pl.x < nf) {
+                    const double2 *src = reinterpret_cast<const double2 *>(sdiag + pl.x * 36);
 #pragma unroll
-                    for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] += v.x; raw[2 * q + 1] += v.y; }
-                }
+                    for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] = v.x; raw[2 * q + 1] = v.y; }
+                } else {
+                    // S_block = - sum over the pair's work items of the 6x6 partial (wide, independent loads)
+                    for (int itx = pl.z; itx < pl.w; ++itx) {
+                        const double2 *src = reinterpret_cast<const double2 *>(part + (size_t)itx * kPartStride);
 #pragma unroll
-                for (int q = 0; q < 36; ++q) raw[q] = -raw[q];
-                if (diag) {
-                    double hpp[21];
-#pragma unroll
-                    for (int q = 0; q < 21; ++q) hpp[q] = 0.0;
-                    for (int itx = i0; itx < i1; ++itx) {
-                        const double *src = part + (size_t)itx * kPartStride + 42;
-#pragma unroll
-                        for (int q = 0; q < 21; ++q) hpp[q] += src[q];
+                        for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] -= v.x; raw[2 * q + 1] -= v.y; }
                     }
-#pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) raw[a * 6 + q] += hpp[a <= q ? ut6(a, q) : ut6(q, a)] + (a == q ? lambda : 0.0);
-#pragma unroll
-                    for (int q = 0; q < 36; ++q) minv[pl.x * 36 + q] = raw[q];       // S_ii: input of the preconditioner
                 }
             }
         }
@@ -198,32 +220,13 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #pragma unroll
             for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = valid ? (tr ? raw[q * 6 + a] : raw[a * 6 + q]) : 0.0;
     }
-    SETUP_STAMP(0);
-    // right-hand side b_S = b_p - sum B Dinv b_l and b_p itself (owner lanes): loads 6 items deep
-    double r_r = 0.0;
-    if (owner) {
-        double cc = 0.0, bb = 0.0;
-        for (int i0 = oi0; i0 < oi1; i0 += 6) {
-            double cv[6], bv[6];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const double *src = part + (size_t)min(i0 + u, oi1 - 1) * kPartStride;
-                cv[u] = src[36 + ba]; bv[u] = src[63 + ba];
-            }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) { const bool in = i0 + u < oi1; cc += in ? cv[u] : 0.0; bb += in ? bv[u] : 0.0; }
-        }
-        r_r = bb - cc;
-        w.bp[row] = bb;
-    }
     SETUP_STAMP(1);
-    __syncthreads();
 
     // ---- block-Jacobi preconditioner: invert each 6x6 diagonal block in place (Cholesky) ----
     for (int i = tid; i < nf; i += kT) {
         double L[36], Li[36];
 #pragma unroll
-        for (int k = 0; k < 36; ++k) L[k] = minv[i * 36 + k];
+        for (int k = 0; k < 36; ++k) L[k] = sdiag[i * 36 + k];
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + 2 * kNC * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch)) * sizeof(double);
+    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + 2 * kNC * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list

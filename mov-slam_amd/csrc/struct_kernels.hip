@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
                 const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
                 const int bin = lo * nf + hi;
                 const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)bin * sd.nchunks + chunk] + __popcll(masks[bin] & lower);
-                sd.entries[pos] = (ha <= hb) ? Int2{ a, b } : Int2{ b, a };      // edge of the lower hessian index first
+                // pose-major slots of the two edges, the one of the lower hessian index first
+                sd.entries[pos] = (ha <= hb) ? Int4{ sd.slot[a], sd.slot[b], l, 0 } : Int4{ sd.slot[b], sd.slot[a], l, 0 };
             }
         }
     }

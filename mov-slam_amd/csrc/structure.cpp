@@ -56,6 +56,15 @@ int build_basic(const movba_lba_desc& d, Structure& s)
         if (pose_active[i]) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); }
     }
     for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
+    // pose-major slots: the edges of free pose h occupy [pstart[h], pstart[h+1]) in ascending map-point order, so the
+    // schur pass reads the per-edge records of one keyframe as (nearly) contiguous memory
+    {
+        std::vector<int32_t> pstart(s.nfree + 1, 0);
+        for (int g = 0; g < E; ++g) { const int h = s.hidx[s.g_pose[g]]; if (h >= 0) pstart[h + 1]++; }
+        for (int h = 0; h < s.nfree; ++h) pstart[h + 1] += pstart[h];
+        s.slot.resize(E);
+        for (int g = 0; g < E; ++g) { const int h = s.hidx[s.g_pose[g]]; s.slot[g] = h >= 0 ? pstart[h]++ : -1; }
+    }
     if (E == 0) return MOVBA_EMPTY;
     return MOVBA_OK;
 }
@@ -107,10 +116,13 @@ int finish_pairs(Structure& s, const int32_t* cnt)
     if (s.nentries > (int64_t)0x7fffffff) return MOVBA_ERR_ARG;
 
     // ---- work items: chunks of a pair's entries ----
-    const int chunk = kSchurChunk;
     s.items.clear();
     s.pair_item_start.assign(s.npairs + 1, 0);
     for (int p = 0; p < s.npairs; ++p) {
+        // a pair that does not fit one work item is cut into equal parts (not full chunks plus a small remainder)
+        const int64_t cap = p < nf ? kSchurChunkDiag : kSchurChunk, len = s.pair_ptr[p + 1] - s.pair_ptr[p];
+        const int64_t parts = (len + cap - 1) / cap;
+        const int64_t chunk = parts > 0 ? ((len + parts - 1) / parts + 3) / 4 * 4 : cap;      // multiple of 4: whole entries per wave
         s.pair_item_start[p] = (int32_t)s.items.size();
         for (int64_t b = s.pair_ptr[p]; b < s.pair_ptr[p + 1]; b += chunk)
             s.items.push_back(Item{ p, (int32_t)b, (int32_t)std::min<int64_t>(b + chunk, s.pair_ptr[p + 1]), p < nf ? 1 : 0 });
@@ -144,12 +156,12 @@ int finish_pairs(Structure& s, const int32_t* cnt)
             longest = std::max(longest, v.size());
         }
         s.sched_per_xcd = (int)((longest + ipw - 1) / ipw) * ipw;
-        s.sched.assign((size_t)8 * s.sched_per_xcd, Item{ 0, 0, 0, -1 });
+        s.sched.assign((size_t)8 * s.sched_per_xcd, SchedItem{ 0, 0, -1, 0, 0, { 0, 0, 0 } });
         for (int g = 0; g < 8; ++g)
             for (size_t k = 0; k < seg[g].size(); ++k) {
-                Item it = s.items[seg[g][k]];
-                it.diag = (seg[g][k] << 1) | (it.diag ? 1 : 0);
-                s.sched[(size_t)g * s.sched_per_xcd + k] = it;
+                const Item& it = s.items[seg[g][k]];
+                s.sched[(size_t)g * s.sched_per_xcd + k] = SchedItem{ it.begin, it.end, (seg[g][k] << 1) | (it.diag ? 1 : 0),
+                                                                     s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], { 0, 0, 0 } };
             }
     }
 
@@ -193,12 +205,12 @@ int build_structure(const movba_lba_desc& d, Structure& s)
     {
         std::vector<int32_t> cur(s.npairs);
         for (int p = 0; p < s.npairs; ++p) cur[p] = (int32_t)s.pair_ptr[p];
-        Int2 *ent = s.entries.data();
+        Int4 *ent = s.entries.data();
         for (int l = 0; l < P; ++l)
             for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
                 const int32_t *prow = &s.pid[(size_t)fe_h[a] * nf];
                 const int32_t ga = fe_g[a];
-                for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int2{ ga, fe_g[b] };
+                for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int4{ s.slot[ga], s.slot[fe_g[b]], l, 0 };
             }
     }
     return MOVBA_OK;

@@ -17,7 +17,10 @@
 namespace movba {
 
 struct Int2 { int32_t x, y; };
+struct Int4 { int32_t x, y, z, w; };
 struct Item { int32_t pair, begin, end, diag; };   // entries [begin,end) of one pair
+// one slot of the k_schur launch schedule: everything a workgroup needs to start, in one 32-byte scalar load
+struct SchedItem { int32_t begin, end, tag /* (item << 1) | diagonal, -1 = padding */, pose_i, pose_j /* pose indices of the pair */, pad[3]; };
 struct RowEnt { int32_t block, col, transposed, pad; };
 
 struct Structure {
@@ -35,11 +38,11 @@ struct Structure {
     std::vector<int32_t> pair_item_start;   // npairs+1
     std::vector<int64_t> pair_ptr;          // npairs+1: first entry of every pair
     std::vector<int32_t> pid;               // nfree x nfree: pair id of (i <= j) or -1
-    std::vector<Int2> entries;          // nentries: grouped edge indices (edge of i, edge of j)
+    std::vector<int32_t> slot;          // E: pose-major position of a grouped edge among the edges of FREE poses (-1: fixed pose)
+    std::vector<Int4> entries;          // nentries: (pose-major slot of the edge of i, of the edge of j, map point, 0)
     std::vector<Item> items;            // nitems
-    // k_schur launch schedule: 8 segments (one per XCD) of sched_per_xcd slots; a slot holds an item with its
-    // index in bits 1.. of `diag` (bit 0 = diagonal pair), or begin == end and diag < 0 for padding
-    std::vector<Item> sched;
+    // k_schur launch schedule: 8 segments (one per XCD) of sched_per_xcd slots
+    std::vector<SchedItem> sched;
     int sched_per_xcd = 0;
     std::vector<int32_t> row_ptr;       // nfree+1
     std::vector<RowEnt> row_ent;        // mat-vec gather list per block row
@@ -58,8 +61,12 @@ void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg);
 #define MOVBA_SCHUR_WPI 4
 #define MOVBA_SCHUR_EPW 512
 #endif
+#ifndef MOVBA_SCHUR_EPW_DIAG
+#define MOVBA_SCHUR_EPW_DIAG 128
+#endif
 constexpr int kSchurWaves = MOVBA_SCHUR_WAVES;      // waves per k_schur workgroup
 constexpr int kSchurWPI = MOVBA_SCHUR_WPI;          // waves that share one work item
+constexpr int kSchurChunkDiag = MOVBA_SCHUR_EPW_DIAG * kSchurWPI;   // diagonal pairs (all edges of a keyframe, ~1.5x the work per entry) are cut finer
 constexpr int kSchurChunk = MOVBA_SCHUR_EPW * kSchurWPI;       // entries per schur work item (one workgroup of 4 waves each)
 
 // Returns MOVBA_OK / MOVBA_ERR_ARG / MOVBA_EMPTY.  build_structure = build_basic + pair counting + finish_pairs +
