@@ -363,7 +363,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     }
     const size_t ncb = s.cblk_g.size();
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
-    const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1);
+    const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1);
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
     const size_t h2d = c.off;
     // ---- device-only region ----
@@ -379,7 +379,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     }
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
     const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
-    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(2 * 48 * 48), o_acitag = c.take<int32_t>(2);
+    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(2 * kCoarseDim * kCoarseDim), o_acitag = c.take<int32_t>(2);
     const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
     const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
@@ -422,6 +422,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_ch, s.cblk_h.data(), sizeof(int32_t) * ncb);
     std::memcpy(sg + o_cp, s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
     std::memcpy(sg + o_ce, s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
+    std::memcpy(sg + o_cij, s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
     std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
     std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
     const double t2 = now_ms();
@@ -458,6 +459,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.n_agg = s.n_agg; w.n_cblk = (int32_t)ncb;
     w.cblk_g = reinterpret_cast<int32_t *>(a + o_cg); w.cblk_h = reinterpret_cast<int32_t *>(a + o_ch);
     w.cblk_ptr = reinterpret_cast<int32_t *>(a + o_cp); w.cblk_ent = reinterpret_cast<int32_t *>(a + o_ce);
+    w.cblk_ij = reinterpret_cast<int32_t *>(a + o_cij);
     w.pose0 = reinterpret_cast<double *>(a + o_pose0); w.point0 = reinterpret_cast<double *>(a + o_point0);
     for (int b = 0; b < 2; ++b) {
         DevState &S = w.st[b];

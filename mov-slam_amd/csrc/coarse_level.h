@@ -3,7 +3,11 @@
 //
 // For LM trial t it assembles the reduced matrix S from the schur work-item partials, forms
 // A_c = P^T S P over the keyframe aggregates (aggregate = the block rows one wave of k_pcg_rows
-// owns, 6 coarse dofs each, 48 x 48), inverts it by Gauss-Jordan in LDS and leaves A_c^-1 in HBM.
+// owns; 12 coarse dofs each: the 6 pose components constant over the aggregate and the same 6 varying
+// linearly with the keyframe index; 96 x 96), inverts it by Gauss-Jordan in LDS and leaves A_c^-1 in HBM.
+// The linear modes matter: late LM iterations (small lambda) are dominated by smooth bending of the
+// trajectory between the fixed keyframes, which piecewise-constant modes resolve poorly: cfg3 needs
+// 397 CG iterations per window solve with the 6 constant modes alone and ~235 with the 12.
 // Its result preconditions trial t+1 (a preconditioner need not be exact: a one-trial-old coarse
 // inverse costs ~3 % more CG iterations than a fresh one, and block-Jacobi alone ~2.3x more).
 // Everything in fixed order, so the lagged preconditioner is as reproducible as the rest of the solve.
@@ -17,117 +21,239 @@
 
 namespace movba {
 
-// sm: >= kNC*kNC + 4*kNC + 2 doubles of LDS; 512 threads
-template <int kT, int kNC>
+// sm: >= kNC*kNC + 5*kNC + 4 doubles of LDS; 512 threads
+template <int kT, int kNC, int kPA>
 __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm)
 {
-    constexpr int kNW = kT / 64;
     double *Ac = sm;
     double *gj = Ac + kNC * kNC;
-    int &s_bad = *reinterpret_cast<int *>(gj + 4 * kNC);
-    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    int &s_bad = *reinterpret_cast<int *>(gj + 5 * kNC + 2);     // gj: 4 kNC snapshot + 2 pivots + kNC scaling, then the flag
+    const int tid = threadIdx.x;
     const int nf = w.nfree;
+#ifdef MOVBA_CLOCK_STAMP
+    unsigned long long cst_last = __builtin_amdgcn_s_memtime();
+#define COARSE_STAMP(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (tid == 0) w.ctrl->dbg_seg2[k] += _t - cst_last; cst_last = _t; } while (0)
+#else
+#define COARSE_STAMP(k) do { } while (0)
+#endif
     const double *part = w.part;
     double *blocks = w.blocks_c;
     if (tid == 0) s_bad = 0;
     for (int idx = tid; idx < kNC * kNC; idx += kT) Ac[idx] = 0.0;
 
-    // ---- S blocks (upper triangle) from the partials, item order; 4 elements per thread in flight ----
-    const int total = w.npairs * 36;
-    for (int base = tid; base < total; base += 4 * kT) {
-        int k[4], i0[4], i1[4], pr[4];
-        double s[4], hp[4];
+    // ---- S blocks (upper triangle) from the partials, item order.  Off-diagonal pairs (one work item almost always):
+    // 8 elements per thread in flight; diagonal pairs (cut into several finer items): 8 items of one element in flight ----
+    const int total = w.npairs * 36, ndiag = nf * 36;
+    for (int base = ndiag + tid; base < total; base += 8 * kT) {
+        int k[8], i0[8], i1[8];
+        double s[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int idx = min(base + u * kT, total - 1);
-            pr[u] = idx / 36; k[u] = idx - pr[u] * 36;
-            i0[u] = w.pair_item_start[pr[u]]; i1[u] = w.pair_item_start[pr[u] + 1];
-        }
-        int hu[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int a = k[u] / 6, b = k[u] - a * 6;
-            hu[u] = 42 + (a <= b ? ut6(a, b) : ut6(b, a));
-            const bool any = i1[u] > i0[u];
-            const double *src = part + (size_t)(any ? i0[u] : 0) * kPartStride;
-            const double v0 = src[k[u]], v1 = src[hu[u]];
-            s[u] = any ? v0 : 0.0; hp[u] = (any && pr[u] < nf) ? v1 : 0.0;
+            const int pr = idx / 36;
+            k[u] = idx - pr * 36;
+            i0[u] = w.pair_item_start[pr]; i1[u] = w.pair_item_start[pr + 1];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            for (int itx = i0[u] + 1; itx < i1[u]; ++itx) {
-                const double *src = part + (size_t)itx * kPartStride;
-                s[u] += src[k[u]];
-                if (pr[u] < nf) hp[u] += src[hu[u]];
-            }
+        for (int u = 0; u < 8; ++u) s[u] = part[(size_t)i0[u] * kPartStride + k[u]];         // every pair has >= 1 item
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u)
+            for (int itx = i0[u] + 1; itx < i1[u]; ++itx) s[u] += part[(size_t)itx * kPartStride + k[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
             const int idx = base + u * kT;
-            if (idx < total) {
-                const int a = k[u] / 6, b = k[u] - a * 6;
-                blocks[idx] = (pr[u] < nf) ? (hp[u] + (a == b ? lambda : 0.0)) - s[u] : -s[u];
-            }
+            if (idx < total) blocks[idx] = -s[u];
+        }
+    }
+    for (int base = tid; base < ndiag; base += 4 * kT) {
+        // four diagonal elements per thread at a time, up to 6 work items of each in flight
+        int k[4], hu[4], i0[4], i1[4];
+        double s[4] = { 0, 0, 0, 0 }, hp[4] = { 0, 0, 0, 0 };
+        int nmax = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int idx = min(base + m * kT, ndiag - 1);
+            const int pr = idx / 36;
+            k[m] = idx - pr * 36;
+            const int a = k[m] / 6, b = k[m] - a * 6;
+            hu[m] = 42 + (a <= b ? ut6(a, b) : ut6(b, a));
+            i0[m] = w.pair_item_start[pr]; i1[m] = w.pair_item_start[pr + 1];
+            nmax = max(nmax, i1[m] - i0[m]);
+        }
+        for (int o = 0; o < nmax; o += 6) {
+            double sv[4][6], hv[4][6];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    const double *src = part + (size_t)min(i0[m] + o + u, i1[m] - 1) * kPartStride;
+                    sv[m][u] = src[k[m]]; hv[m][u] = src[hu[m]];
+                }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int u = 0; u < 6; ++u) { const bool in = i0[m] + o + u < i1[m]; s[m] += in ? sv[m][u] : 0.0; hp[m] += in ? hv[m][u] : 0.0; }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int idx = base + m * kT;
+            if (idx < ndiag) blocks[idx] = (hp[m] + ((k[m] % 7 == 0) ? lambda : 0.0)) - s[m];     // k = 7 a: diagonal element
         }
     }
     __syncthreads();
-    // ---- A_c = P^T S P: every coarse element is the fixed-order sum of its fine-block terms ----
-    for (int idx = tid; idx < w.n_cblk * 36; idx += kT) {
-        const int cb = idx / 36, k = idx - cb * 36, a = k / 6, b = k - a * 6;
-        const int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
-        double sum = 0.0;
-        for (int t = t0; t < t1; t += 8) {
-            double v[8];
+    COARSE_STAMP(2);
+    // ---- A_c = P^T S P.  Coarse dof (g, d, a): aggregate g, mode d (0: constant, 1: linear in the keyframe index,
+    // phi_1(i) = (i - c_g) / h_g), pose component a.  One thread per (coarse block, a, b): it walks the block's fine terms
+    // once, in list order, and accumulates the four mode combinations phi_d(i) phi_e(j) together. ----
+    constexpr int kU = 3;                                   // work items per thread in flight (cfg3: 4.5 per thread in all)
+    for (int idx0 = tid; idx0 < w.n_cblk * 36; idx0 += kU * kT) {
+        int t0[kU], t1[kU], ab[kU], tab[kU], gh[kU];
+        double cg[kU], ch[kU], ig[kU], ih[kU], s00[kU], s01[kU], s10[kU], s11[kU];
+        int nt = 0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int pk = w.cblk_ent[min(t + u, t1 - 1)];
-                v[u] = blocks[(size_t)(pk >> 1) * 36 + ((pk & 1) ? b * 6 + a : a * 6 + b)];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sum += (t + u < t1) ? v[u] : 0.0;
+        for (int m = 0; m < kU; ++m) {
+            const int idx = idx0 + m * kT;
+            const bool on = idx < w.n_cblk * 36;
+            const int cb = on ? idx / 36 : 0;
+            ab[m] = on ? idx - cb * 36 : 0;
+            const int a = ab[m] / 6, b = ab[m] - a * 6;
+            tab[m] = b * 6 + a;
+            const int g = w.cblk_g[cb], h = w.cblk_h[cb];
+            gh[m] = on ? (g << 8) | h : -1;
+            const int g0 = pp.wave_row0[g], g1 = pp.wave_row0[g + 1], h0 = pp.wave_row0[h], h1 = pp.wave_row0[h + 1];
+            cg[m] = g0 + 0.5 * (g1 - g0 - 1); ch[m] = h0 + 0.5 * (h1 - h0 - 1);
+            ig[m] = 1.0 / fmax(1.0, 0.5 * (g1 - g0)); ih[m] = 1.0 / fmax(1.0, 0.5 * (h1 - h0));
+            t0[m] = w.cblk_ptr[cb]; t1[m] = on ? w.cblk_ptr[cb + 1] : t0[m];
+            nt = max(nt, t1[m] - t0[m]);
+            s00[m] = s01[m] = s10[m] = s11[m] = 0.0;
         }
-        Ac[(w.cblk_g[cb] * 6 + a) * kNC + w.cblk_h[cb] * 6 + b] = sum;
+        for (int t = 0; t < nt; t += 8) {
+            int pk[kU][8], ij[kU][8];
+            double v[kU][8];
+#pragma unroll
+            for (int m = 0; m < kU; ++m)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int tt = min(t0[m] + t + u, max(t1[m] - 1, t0[m]));
+                    pk[m][u] = w.cblk_ent[tt]; ij[m][u] = w.cblk_ij[tt];
+                }
+#pragma unroll
+            for (int m = 0; m < kU; ++m)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[m][u] = blocks[(size_t)(pk[m][u] >> 1) * 36 + ((pk[m][u] & 1) ? tab[m] : ab[m])];
+#pragma unroll
+            for (int m = 0; m < kU; ++m)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double x = (t0[m] + t + u < t1[m]) ? v[m][u] : 0.0;
+                    const double pi = ((ij[m][u] >> 16) - cg[m]) * ig[m], pj = ((ij[m][u] & 0xffff) - ch[m]) * ih[m];
+                    s00[m] += x; s01[m] += pj * x; s10[m] += pi * x; s11[m] += pi * pj * x;
+                }
+        }
+#pragma unroll
+        for (int m = 0; m < kU; ++m)
+            if (gh[m] >= 0) {
+                double *dst = Ac + ((gh[m] >> 8) * kPA + ab[m] / 6) * kNC + (gh[m] & 0xff) * kPA + ab[m] % 6;
+                dst[0] = s00[m]; dst[6] = s01[m]; dst[6 * kNC] = s10[m]; dst[6 * kNC + 6] = s11[m];
+            }
     }
-    // aggregates without rows (fewer block rows than waves): identity rows keep A_c invertible
-    if (tid < kNC && pp.wave_row0[tid / 6 + 1] == pp.wave_row0[tid / 6]) Ac[tid * kNC + tid] = 1.0;
+    __syncthreads();
+    // dofs without support (an aggregate with no rows; the linear modes of an aggregate with a single row): identity
+    // rows keep A_c invertible, their restricted residual is always zero
+    if (tid < kNC) {
+        const int g = tid / kPA, d = (tid - g * kPA) / 6, nrows = pp.wave_row0[g + 1] - pp.wave_row0[g];
+        if (nrows == 0 || (d == 1 && nrows < 2)) {
+            for (int j = 0; j < kNC; ++j) { Ac[tid * kNC + j] = 0.0; Ac[j * kNC + tid] = 0.0; }
+        }
+    }
+    __syncthreads();
+    if (tid < kNC) {
+        const int g = tid / kPA, d = (tid - g * kPA) / 6, nrows = pp.wave_row0[g + 1] - pp.wave_row0[g];
+        if (nrows == 0 || (d == 1 && nrows < 2)) Ac[tid * kNC + tid] = 1.0;
+    }
     __syncthreads();
 
-    // ---- in-place Gauss-Jordan inverse (SPD, no pivoting), one barrier per pivot ----
-    for (int j = tid; j < kNC; j += kT) { gj[j] = Ac[j]; gj[kNC + j] = Ac[j * kNC]; }
+    COARSE_STAMP(3);
+    // ---- Gauss-Jordan inverse of the symmetrically scaled matrix D A_c D (unit diagonal), the matrix held in REGISTERS:
+    // thread (rg, cg) owns rows 3 rg .. 3 rg + 2 x columns 6 cg .. 6 cg + 5 (32 x 16 threads x 18 elements = 96 x 96).
+    // Per pivot k every thread reads the snapshot of row k and column k (double-buffered in LDS) and updates its tile with
+    // ONE formula, a_ij -= c_i r_j / p: the snapshot is published with r_k = p + 1 and c_k = p - 1, which turns the pivot
+    // row into r_j / p, the pivot column into -c_i / p and the pivot into 1 / p (accurate because the scaled pivots are
+    // <= 1).  The pivot loop is unrolled by 6 so that the tile row / column holding pivot k + 1 are compile-time indices.
+    static_assert(kNC == 96 && kT == 512, "tile layout written for 96 x 96 on 512 threads");
+    double *dsc = gj + 4 * kNC + 2;                         // kNC: 1 / sqrt(diagonal)
+    if (tid < kNC) { const double d = Ac[tid * kNC + tid]; dsc[tid] = (d > 0.0 && isfinite(d)) ? 1.0 / sqrt(d) : 0.0; if (!(d > 0.0) || !isfinite(d)) s_bad = 1; }
     __syncthreads();
-    bool bad = false;
-    for (int k = 0; k < kNC; ++k) {
-        const double *rk = gj + (k & 1) * 2 * kNC, *ck = rk + kNC;
-        double *rn = gj + ((k + 1) & 1) * 2 * kNC, *cn = rn + kNC;
-        const double piv = rk[k];
-        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }
-        const double pinv = 1.0 / piv;
-        if (ln < kNC) {
-            const int j = ln;
-            const double rj = rk[j];
-            double av[kNC / kNW], cv[kNC / kNW];
+    const int rg = tid >> 4, cg = tid & 15;
+    double t[3][6];
 #pragma unroll
-            for (int m = 0; m < kNC / kNW; ++m) { av[m] = Ac[(wv + kNW * m) * kNC + j]; cv[m] = ck[wv + kNW * m]; }
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int m = 0; m < kNC / kNW; ++m) {
-                const int i = wv + kNW * m;
-                double v = av[m] - cv[m] * rj * pinv;
-                v = (j == k) ? -cv[m] * pinv : v;
-                v = (i == k) ? ((j == k) ? pinv : rj * pinv) : v;
-                Ac[i * kNC + j] = v;
-                if (i == k + 1) rn[j] = v;
-                if (j == k + 1) cn[i] = v;
+        for (int q = 0; q < 6; ++q) t[r][q] = Ac[(3 * rg + r) * kNC + 6 * cg + q] * dsc[3 * rg + r] * dsc[6 * cg + q];
+    // snapshot of pivot 0
+    if (rg == 0) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) gj[6 * cg + q] = t[0][q] + ((cg == 0 && q == 0) ? 1.0 : 0.0);
+    }
+    if (cg == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) gj[kNC + 3 * rg + r] = t[r][0] - ((rg == 0 && r == 0) ? 1.0 : 0.0);
+    }
+    if (tid == 0) gj[4 * kNC] = t[0][0];
+    __syncthreads();
+    bool bad = s_bad != 0;
+    for (int kk = 0; kk < kNC / 6 && !bad; ++kk) {
+#pragma unroll
+        for (int c6 = 0; c6 < 6; ++c6) {
+            const int k = 6 * kk + c6;
+            const double *rk = gj + (k & 1) * 2 * kNC, *ck = rk + kNC;
+            double *rn = gj + ((k + 1) & 1) * 2 * kNC, *cn = rn + kNC;
+            const double piv = gj[4 * kNC + (k & 1)];
+            if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }
+            // reciprocal by v_rcp_f64 and two Newton steps (the scaled pivots are in (0, 1]; this is a preconditioner)
+            double pinv = __builtin_amdgcn_rcp(piv);
+            pinv = pinv * (2.0 - piv * pinv);
+            pinv = pinv * (2.0 - piv * pinv);
+            double rj[6], ci[3];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) rj[q] = rk[6 * cg + q] * pinv;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ci[r] = ck[3 * rg + r];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) t[r][q] -= ci[r] * rj[q];
+            // publish row / column / pivot k + 1 (static tile indices)
+            constexpr int kDummy = 0; (void)kDummy;
+            const int k1 = k + 1;
+            if (k1 < kNC) {
+                const int rn_r = (c6 + 1) % 3, cn_c = (c6 + 1) % 6;
+                const int rgn = k1 / 3, cgn = k1 / 6;
+                if (rg == rgn) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) rn[6 * cg + q] = t[rn_r][q] + ((cg == cgn && q == cn_c) ? 1.0 : 0.0);
+                }
+                if (cg == cgn) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) cn[3 * rg + r] = t[r][cn_c] - ((rg == rgn && r == rn_r) ? 1.0 : 0.0);
+                }
+                if (rg == rgn && cg == cgn) gj[4 * kNC + (k1 & 1)] = t[rn_r][cn_c];
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (bad && tid == 0) s_bad = 1;
     __syncthreads();
-    // ---- publish: A_c^-1 for trial+1 and its validity tag ----
+    COARSE_STAMP(4);
+    // ---- publish: A_c^-1 = D (D A_c D)^-1 D for trial+1 and its validity tag ----
     double *dst = w.aci + (size_t)(trial & 1) * kNC * kNC;
-    for (int idx = tid; idx < kNC * kNC; idx += kT) dst[idx] = Ac[idx];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dst[(3 * rg + r) * kNC + 6 * cg + q] = t[r][q] * dsc[3 * rg + r] * dsc[6 * cg + q];
     __syncthreads();
     if (tid == 0) w.aci_tag[trial & 1] = s_bad ? -1 : trial;
+    COARSE_STAMP(5);
 }
-
 
 }  // namespace movba

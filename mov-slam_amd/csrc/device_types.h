@@ -13,6 +13,9 @@ namespace movba {
 #ifndef MOVBA_PART_STRIDE
 #define MOVBA_PART_STRIDE 72
 #endif
+// coarse level of the k_pcg_rows preconditioner: one aggregate per wave, 12 dofs each (6 constant + 6 linear-in-keyframe-index modes)
+constexpr int kCoarsePerAgg = 12;
+constexpr int kCoarseDim = kCoarsePerAgg * (512 / 64);
 constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-item partial
 // partial layout: [0,36) sum of B_i Dinv B_j^T (6x6 row-major)
 //                 [36,42) sum of B_i Dinv b_l           (diagonal pairs only)
@@ -81,14 +84,14 @@ struct DevWindow {
     const int32_t *lane_plan;   // kPcgRowsThreads x 2 x 4 int32
     // coarse level of the PCG preconditioner
     int32_t n_agg, n_cblk;
-    const int32_t *cblk_g, *cblk_h, *cblk_ptr, *cblk_ent;
+    const int32_t *cblk_g, *cblk_h, *cblk_ptr, *cblk_ent, *cblk_ij;
     // state
     DevState st[2];
     const double *pose0, *point0;   // uploaded initial state (for reset)
     // reduced system
     double *part;       // nitems x kPartStride: k_schur work-item partials
     double *blocks_c;   // npairs x 36: the coarse-level workgroup's own copy of S (coarse_level.h)
-    double *aci;        // 2 x 48 x 48: inverse coarse matrices (by trial parity)
+    double *aci;        // 2 x kCoarseDim x kCoarseDim: inverse coarse matrices (by trial parity)
     int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable
     double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first
     double *bp;         // 6 nfree

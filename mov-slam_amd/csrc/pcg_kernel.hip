@@ -48,7 +48,9 @@ namespace {
 constexpr int kT = kPcgRowsThreads;     // 512 = 8 waves, 2 per SIMD -> 256 VGPRs per lane
 constexpr int kNW = kT / 64;
 constexpr int kOwnBatch = 10;           // pair sums an owner lane loads per LDS round trip
-constexpr int kNC = 6 * kNW;            // coarse dofs: one aggregate (6 dofs) per wave
+constexpr int kPA = kCoarsePerAgg;       // coarse dofs per aggregate: 6 constant + 6 linear-in-keyframe-index modes
+constexpr int kNC = kPA * kNW;          // coarse dofs: one aggregate per wave
+static_assert(kNC == kCoarseDim, "coarse dimension");
 
 // fixed-order sum of the kNW wave partials (a balanced tree: three dependent adds instead of seven)
 __device__ __forceinline__ double sum_fixed(const double *red)
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #endif
     const double lambda = c->lambda;
     if (blockIdx.x == 1) {          // second workgroup: coarse level of THIS trial's matrix, for the next trial
-        coarse_build<kT, kNC>(w, pp, trial, lambda, sm);
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm);
         return;
     }
     const double *part = w.part;
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     int &s_fail = *reinterpret_cast<int *>(red1 + kNW);
     double *Aci = red1 + kNW + 2;                         // kNC x kNC: inverse coarse matrix of the previous trial
     double *rcg = Aci + kNC * kNC;                        // kNC: restricted residual of every aggregate
-    double *zstrip = rcg + kNC + 8 * wv;                  // 8 per wave: the wave's coarse correction
-    double *rcw = rcg + kNC + 8 * kNW + kNC * wv;         // kNC per wave: the wave's copy of the restricted residual P^T r
-    double *ypart = rcg + kNC + 8 * kNW + 2 * kNC * kNW;  // 6 doubles per gather-list PAIR (+ one dummy strip); scw sits in front
+    double *zstrip = rcg + kNC + 32 * wv;                 // 16 per wave: the wave's coarse correction z_c = A_c^-1 P^T r (kPA used)
+    double *ustrip = zstrip + 16;                         // 16 per wave: A_c^-1 P^T s of the wave's aggregate
+    double *ypart = rcg + kNC + 32 * kNW;                 // 6 doubles per gather-list PAIR (+ one dummy strip)
     double *sdiag = ypart + 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);     // nf x 36: the damped diagonal blocks S_ii
     if (tid == 0) s_fail = 0;
     // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial)
@@ -278,18 +280,61 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // coarse level state: every wave keeps its own LDS copy of the restricted residual P^T r (rcw)
-    const int ca = min(ln >> 3, 5), sub = ln & 7;
-    if (coarse) {
-        if (owner) r_lds[row] = r_r;
-        __syncthreads();
-        if (ln < kNC) {
-            const int g = ln / 6, a = ln - g * 6;
-            double t = 0.0;
-            for (int i = pp.wave_row0[g]; i < pp.wave_row0[g + 1]; ++i) t += r_lds[i * 6 + a];
-            rcw[ln] = t;
+    // Coarse level.  Coarse dof (g, d, a): aggregate g = the block rows of wave g, mode d (0 constant, 1 linear:
+    // phi(i) = (i - c_g) / h_g), pose component a (same c_g, h_g as coarse_level.h).  Each wave keeps the coarse correction
+    // of ITS aggregate, z_c = (A_c^-1 P^T r)[own 12 rows], in a 16-double LDS strip.  z_c is not recomputed from the
+    // residual every iteration: r -= alpha s gives z_c -= alpha u_c with u_c = A_c^-1 P^T s, and s = w + beta s gives
+    // u_c = A_c^-1 (P^T w) + beta u_c.  P^T w of every aggregate is published with the dot products, so the one dense
+    // product per iteration, A_c^-1[own rows, :] (P^T w), runs right after the reduction barrier, beside the scalar
+    // recurrences, and the preconditioner itself only reads two values of the strip.
+    const double agg_c = uniform_f64(b0 + 0.5 * (nb - 1)), agg_ih = uniform_f64(1.0 / fmax(1.0, 0.5 * nb));
+    const double agg_cc = uniform_f64(0.5 * (nb - 1));                  // the aggregate's centre, counted from its first row
+    const double phi = owner ? (bi - agg_c) * agg_ih : 0.0;            // this lane's row in its aggregate's linear mode
+    const int crow = min(ln >> 2, kPA - 1), cq = ln & 3;                // coarse product: 4 lanes per coarse row, 24 columns each
+    // restriction of a vector held one value per owner lane: P^T v of this wave's aggregate -> rcg[wv * kPA ..]
+    auto restrict_own = [&](double v_r) {
+        if (owner) r_lds[row] = v_r;
+        wave_lds_sync();
+        if (ln < kPA) {
+            // rows b0 .. b0+9 at fixed offsets; the ones past the wave's last row are masked by a wave-uniform
+            // predicate; lanes 0-5 sum them (constant modes), lanes 6-11 weight them by the linear mode
+            const int a = ln < 6 ? ln : ln - 6;
+            const double *rb = r_lds + b0 * 6 + a;
+            double v[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = rb[6 * u];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) v[u] = (u < nb) ? v[u] : 0.0;
+            const double tc = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (v[8] + v[9]);
+            // sum_u (u - cc) v_u / h = (sum_u u v_u - cc sum_u v_u) / h, with the row offsets u as constants
+            const double ti = (((v[1] + 2.0 * v[2]) + (3.0 * v[3] + 4.0 * v[4])) + ((5.0 * v[5] + 6.0 * v[6]) + (7.0 * v[7] + 8.0 * v[8]))) + 9.0 * v[9];
+            rcg[wv * kPA + ln] = ln < 6 ? tc : (ti - agg_cc * tc) * agg_ih;
         }
+    };
+    // (A_c^-1 v_c)[own row crow], v_c = rcg (all aggregates, visible after a workgroup barrier): valid in lanes with cq == 0
+    auto coarse_rows = [&]() {
+        const double2 *arow = reinterpret_cast<const double2 *>(Aci + (wv * kPA + crow) * kNC + cq * 24);
+        const double2 *rcv = reinterpret_cast<const double2 *>(rcg + cq * 24);
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma nounroll
+        for (int q = 0; q < 12; q += 4) {          // three rounds of 8 loads: the registers are full of S
+            const double2 a0 = arow[q], a1 = arow[q + 1], a2 = arow[q + 2], a3 = arow[q + 3];
+            const double2 c0 = rcv[q], c1 = rcv[q + 1], c2 = rcv[q + 2], c3 = rcv[q + 3];
+            t0 += a0.x * c0.x + a0.y * c0.y; t1 += a1.x * c1.x + a1.y * c1.y;
+            t2 += a2.x * c2.x + a2.y * c2.y; t3 += a3.x * c3.x + a3.y * c3.y;
+        }
+        double t = (t0 + t1) + (t2 + t3);
+        t += dpp_mov0<0xb1>(t);
+        t += dpp_mov0<0x4e>(t);
+        return t;
+    };
+    if (coarse) {
+        restrict_own(r_r);
+        if (ln < 16) ustrip[ln] = 0.0;
         __syncthreads();
+        const double t = coarse_rows();
+        if (cq == 0 && ln < 4 * kPA) zstrip[ln >> 2] = t;
+        __syncthreads();                                      // rcg is rewritten inside the loop
     }
     auto precond = [&](double rv) {
         if (owner) r_lds[row] = rv;
@@ -297,20 +342,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         const double2 m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
         const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
         double s = (m0.x * r0.x + m0.y * r0.y) + (m1.x * r1.x + m1.y * r1.y) + (m2.x * r2.x + m2.y * r2.y);
-        if (coarse) {
-            // z_c = A_c^-1 r_c for the wave's own 6 coarse rows: 8 lanes per row; lane `sub` holds the restricted
-            // residual (rcw, kept current by the recurrence r_c -= alpha P^T A p) -> no workgroup barrier here
-            const double2 *arow = reinterpret_cast<const double2 *>(Aci + (wv * 6 + ca) * kNC + sub * 6);
-            const double2 *rcv = reinterpret_cast<const double2 *>(rcw + sub * 6);
-            const double2 a0 = arow[0], a1 = arow[1], a2 = arow[2], c0 = rcv[0], c1 = rcv[1], c2 = rcv[2];
-            double t = (a0.x * c0.x + a0.y * c0.y) + (a1.x * c1.x + a1.y * c1.y) + (a2.x * c2.x + a2.y * c2.y);
-            t += dpp_mov0<0xb1>(t);
-            t += dpp_mov0<0x4e>(t);
-            t += dpp_mov0<0x141>(t);
-            if (sub == 0 && ln < 48) zstrip[ln >> 3] = t;
-            wave_lds_sync();
-            if (owner) s += zstrip[ba];
-        }
+        if (coarse && owner) s += zstrip[ba] + phi * zstrip[6 + ba];
         return owner ? s : 0.0;
     };
     // ---- conjugate gradients, single-reduction form (Chronopoulos & Gear): with z = Minv r and w = A z,
@@ -319,8 +351,6 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     // Same iterates as textbook CG in exact arithmetic; two workgroup barriers and one reduction per iteration instead
     // of three and two.  The restricted residual P^T r follows r_c -= alpha P^T s with P^T s = P^T w + beta P^T s.
     double p_r = 0.0, s_r = 0.0;
-    double *scw = rcw + kNC * kNW;                        // kNC per wave: P^T s of every aggregate (wave-private copy)
-    if (ln < kNC) scw[ln] = 0.0;
     double inv_gamma = 1.0, inv_alpha = 0.0, alpha = 0.0, thresh = 0.0;
     bool fail = s_fail != 0;
     bool first = true;
@@ -335,7 +365,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             // ---- x += alpha p, r -= alpha s, z = Minv r (wave-local) ----
             x_r += alpha * p_r;
             r_r -= alpha * s_r;
-            if (coarse && ln < kNC) rcw[ln] -= alpha * scw[ln];   // ordered before precond's reads by its wave-local sync
+            if (coarse && ln < kPA) zstrip[ln] -= alpha * ustrip[ln];     // z_c -= alpha u_c; ordered before precond's reads by its wave-local sync
             z_r = precond(r_r);
             if (owner) p_lds[row] = z_r;                      // the vector the mat-vec multiplies
             SEG_STAMP(0);
@@ -390,21 +420,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
                 }
             }
             SEG_STAMP(3);
-            if (coarse) {
-                // P^T w of this wave's aggregate, published with the dot-product partials
-                if (owner) r_lds[row] = w_r;
-                wave_lds_sync();
-                if (ln < 6) {
-                    // rows b0 .. b0+9 at fixed offsets; the ones past the wave's last row are masked by a wave-uniform predicate
-                    const double *rb = r_lds + b0 * 6 + ln;
-                    double v[10];
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) v[u] = rb[6 * u];
-#pragma unroll
-                    for (int u = 0; u < 10; ++u) v[u] = (u < nb) ? v[u] : 0.0;
-                    rcg[wv * 6 + ln] = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (v[8] + v[9]);
-                }
-            }
+            if (coarse) restrict_own(w_r);                    // P^T w of this wave's aggregate, published with the dot-product partials
             {
                 double g = owner ? r_r * z_r : 0.0, d = owner ? w_r * z_r : 0.0;
                 wave_sum_dpp2(g, d);
@@ -413,6 +429,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             SEG_STAMP(4);
             __syncthreads();                                  // (B) r.z, w.z and P^T w visible; all reads of z done
             SEG_STAMP(5);
+            // the dense coarse product of this iteration, issued before the scalar recurrences (independent of them)
+            const double yc = coarse ? coarse_rows() : 0.0;
             const double g = uniform_f64(sum_fixed(red0)), delta = uniform_f64(sum_fixed(red1));
             if (!isfinite(g) || !isfinite(delta)) { fail = true; break; }
             if (first) {
@@ -430,7 +448,10 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             first = false;
             p_r = z_r + beta * p_r;
             s_r = w_r + beta * s_r;
-            if (coarse && ln < kNC) scw[ln] = rcg[ln] + beta * scw[ln];
+            if (coarse) {
+                if (cq == 0 && ln < 4 * kPA) ustrip[ln >> 2] = yc + beta * ustrip[ln >> 2];
+                wave_lds_sync();                              // u_c is read by lanes 0-11 at the top of the next iteration
+            }
             SEG_STAMP(6);
         }
         if (iters > pp.max_iters) iters = pp.max_iters;
@@ -490,7 +511,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 8 * kNW + 2 * kNC * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
+    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 32 * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list

@@ -220,21 +220,25 @@ void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg)
 {
     const int nf = s.nfree, G = n_agg;
     s.n_agg = G;
-    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ent.clear(); s.cblk_ptr.assign(1, 0);
+    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ent.clear(); s.cblk_ij.clear(); s.cblk_ptr.assign(1, 0);
     std::vector<int32_t> agg_of(nf, 0);
     for (int g = 0; g < G; ++g)
         for (int i = agg_row0[g]; i < agg_row0[g + 1]; ++i) agg_of[i] = g;
-    std::vector<std::vector<int32_t>> lists((size_t)G * G);
+    std::vector<std::vector<int32_t>> lists((size_t)G * G), ijs((size_t)G * G);
     for (int i = 0; i < nf; ++i)
         for (int e = s.row_ptr[i]; e < s.row_ptr[i + 1]; ++e)
-            if (s.row_ent[e].block >= 0)
-                lists[(size_t)agg_of[i] * G + agg_of[s.row_ent[e].col]].push_back((s.row_ent[e].block << 1) | (s.row_ent[e].transposed ? 1 : 0));
+            if (s.row_ent[e].block >= 0) {
+                const size_t b = (size_t)agg_of[i] * G + agg_of[s.row_ent[e].col];
+                lists[b].push_back((s.row_ent[e].block << 1) | (s.row_ent[e].transposed ? 1 : 0));
+                ijs[b].push_back((i << 16) | s.row_ent[e].col);
+            }
     for (int g = 0; g < G; ++g)
         for (int h = 0; h < G; ++h) {
             const std::vector<int32_t>& l = lists[(size_t)g * G + h];
             if (l.empty()) continue;
             s.cblk_g.push_back(g); s.cblk_h.push_back(h);
             s.cblk_ent.insert(s.cblk_ent.end(), l.begin(), l.end());
+            s.cblk_ij.insert(s.cblk_ij.end(), ijs[(size_t)g * G + h].begin(), ijs[(size_t)g * G + h].end());
             s.cblk_ptr.push_back((int32_t)s.cblk_ent.size());
         }
 }

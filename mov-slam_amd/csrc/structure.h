@@ -50,6 +50,7 @@ struct Structure {
     int n_agg = 0;
     std::vector<int32_t> cblk_g, cblk_h, cblk_ptr;   // non-empty coarse blocks (g,h) and their term lists
     std::vector<int32_t> cblk_ent;      // (pair id << 1 | transposed): fine blocks summed into the coarse block
+    std::vector<int32_t> cblk_ij;       // (block row << 16 | block column) of the same term: weights of the linear coarse modes
 };
 
 // Aggregate g = block rows [agg_row0[g], agg_row0[g+1]): fills the coarse block term lists of
