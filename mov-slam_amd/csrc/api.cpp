@@ -363,7 +363,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     }
     const size_t ncb = s.cblk_g.size();
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
-    const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1);
+    const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
     const size_t h2d = c.off;
     // ---- device-only region ----
@@ -423,6 +423,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_cp, s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
     std::memcpy(sg + o_ce, s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
     std::memcpy(sg + o_cij, s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
+    std::memcpy(sg + o_multi, s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
     std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
     std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
     const double t2 = now_ms();
@@ -460,6 +461,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.cblk_g = reinterpret_cast<int32_t *>(a + o_cg); w.cblk_h = reinterpret_cast<int32_t *>(a + o_ch);
     w.cblk_ptr = reinterpret_cast<int32_t *>(a + o_cp); w.cblk_ent = reinterpret_cast<int32_t *>(a + o_ce);
     w.cblk_ij = reinterpret_cast<int32_t *>(a + o_cij);
+    w.multi_pairs = reinterpret_cast<int32_t *>(a + o_multi); w.n_multi = (int32_t)s.multi_pairs.size();
     w.pose0 = reinterpret_cast<double *>(a + o_pose0); w.point0 = reinterpret_cast<double *>(a + o_point0);
     for (int b = 0; b < 2; ++b) {
         DevState &S = w.st[b];

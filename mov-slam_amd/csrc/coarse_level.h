@@ -43,27 +43,14 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
 
     // ---- S blocks (upper triangle) from the partials, item order.  Off-diagonal pairs (one work item almost always):
     // 8 elements per thread in flight; diagonal pairs (cut into several finer items): 8 items of one element in flight ----
-    const int total = w.npairs * 36, ndiag = nf * 36;
-    for (int base = ndiag + tid; base < total; base += 8 * kT) {
-        int k[8], i0[8], i1[8];
-        double s[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = min(base + u * kT, total - 1);
-            const int pr = idx / 36;
-            k[u] = idx - pr * 36;
-            i0[u] = w.pair_item_start[pr]; i1[u] = w.pair_item_start[pr + 1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] = part[(size_t)i0[u] * kPartStride + k[u]];         // every pair has >= 1 item
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            for (int itx = i0[u] + 1; itx < i1[u]; ++itx) s[u] += part[(size_t)itx * kPartStride + k[u]];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * kT;
-            if (idx < total) blocks[idx] = -s[u];
-        }
+    const int ndiag = nf * 36;
+    // off-diagonal pairs cut into several work items (more than kSchurChunk shared points: rare) are materialised too;
+    // single-item pairs are read straight from their partial by the A_c pass
+    for (int idx = tid; idx < w.n_multi * 36; idx += kT) {
+        const int m = idx / 36, k = idx - m * 36, pr = w.multi_pairs[m];
+        double sacc = 0.0;
+        for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx) sacc += part[(size_t)itx * kPartStride + k];
+        blocks[pr * 36 + k] = -sacc;
     }
     for (int base = tid; base < ndiag; base += 4 * kT) {
         // four diagonal elements per thread at a time, up to 6 work items of each in flight
@@ -140,12 +127,16 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
 #pragma unroll
             for (int m = 0; m < kU; ++m)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[m][u] = blocks[(size_t)(pk[m][u] >> 1) * 36 + ((pk[m][u] & 1) ? tab[m] : ab[m])];
+                for (int u = 0; u < 8; ++u) {
+                    const int e = pk[m][u], off = (e & 2) ? tab[m] : ab[m];
+                    const double *src = (e & 1) ? part + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
+                    v[m][u] = src[off];
+                }
 #pragma unroll
             for (int m = 0; m < kU; ++m)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const double x = (t0[m] + t + u < t1[m]) ? v[m][u] : 0.0;
+                    const double x = (t0[m] + t + u < t1[m]) ? ((pk[m][u] & 1) ? -v[m][u] : v[m][u]) : 0.0;
                     const double pi = ((ij[m][u] >> 16) - cg[m]) * ig[m], pj = ((ij[m][u] & 0xffff) - ch[m]) * ih[m];
                     s00[m] += x; s01[m] += pj * x; s10[m] += pi * x; s11[m] += pi * pj * x;
                 }

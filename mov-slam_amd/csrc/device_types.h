@@ -85,6 +85,8 @@ struct DevWindow {
     // coarse level of the PCG preconditioner
     int32_t n_agg, n_cblk;
     const int32_t *cblk_g, *cblk_h, *cblk_ptr, *cblk_ent, *cblk_ij;
+    const int32_t *multi_pairs; // off-diagonal pairs cut into several work items
+    int32_t n_multi, pad4;
     // state
     DevState st[2];
     const double *pose0, *point0;   // uploaded initial state (for reset)

@@ -221,6 +221,9 @@ void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg)
     const int nf = s.nfree, G = n_agg;
     s.n_agg = G;
     s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ent.clear(); s.cblk_ij.clear(); s.cblk_ptr.assign(1, 0);
+    s.multi_pairs.clear();
+    for (int p = nf; p < s.npairs; ++p)
+        if (s.pair_item_start[p + 1] - s.pair_item_start[p] > 1) s.multi_pairs.push_back(p);
     std::vector<int32_t> agg_of(nf, 0);
     for (int g = 0; g < G; ++g)
         for (int i = agg_row0[g]; i < agg_row0[g + 1]; ++i) agg_of[i] = g;
@@ -229,7 +232,12 @@ void build_coarse(Structure& s, const int32_t* agg_row0, int n_agg)
         for (int e = s.row_ptr[i]; e < s.row_ptr[i + 1]; ++e)
             if (s.row_ent[e].block >= 0) {
                 const size_t b = (size_t)agg_of[i] * G + agg_of[s.row_ent[e].col];
-                lists[b].push_back((s.row_ent[e].block << 1) | (s.row_ent[e].transposed ? 1 : 0));
+                // term source: a pair held in ONE work item is read straight from that item's partial (value = -partial);
+                // diagonal pairs and pairs cut into several items come from the materialised block (coarse_level.h)
+                const int pr = s.row_ent[e].block;
+                const bool single = pr >= nf && s.pair_item_start[pr + 1] - s.pair_item_start[pr] == 1;
+                const int src_idx = single ? s.pair_item_start[pr] : pr;
+                lists[b].push_back((src_idx << 2) | (s.row_ent[e].transposed ? 2 : 0) | (single ? 1 : 0));
                 ijs[b].push_back((i << 16) | s.row_ent[e].col);
             }
     for (int g = 0; g < G; ++g)

@@ -49,7 +49,9 @@ struct Structure {
     // coarse level of the two-level PCG preconditioner (build_coarse): keyframe aggregates, 6 dofs each
     int n_agg = 0;
     std::vector<int32_t> cblk_g, cblk_h, cblk_ptr;   // non-empty coarse blocks (g,h) and their term lists
-    std::vector<int32_t> cblk_ent;      // (pair id << 1 | transposed): fine blocks summed into the coarse block
+    std::vector<int32_t> cblk_ent;      // fine blocks summed into the coarse block: (index << 2 | transposed << 1 | source); source 1:
+                                        // index = work item whose partial is the block (negated), source 0: index = pair id (materialised block)
+    std::vector<int32_t> multi_pairs;   // off-diagonal pairs cut into several work items (materialised by the coarse workgroup)
     std::vector<int32_t> cblk_ij;       // (block row << 16 | block column) of the same term: weights of the linear coarse modes
 };
 

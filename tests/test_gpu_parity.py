@@ -78,6 +78,15 @@ def test_dense_covisibility_window_spills_list_tails_to_l2(solver, oracle_mod, b
     check_against(solver.solve(w), oracle_mod.solve(w), w)
 
 
+def test_pairs_sharing_thousands_of_points_are_cut_into_several_work_items(solver, oracle_mod, built_lib):
+    """Few keyframes all seeing every point: off-diagonal pairs exceed one schur work item (2048 entries), so their
+    partials are summed over several items in the PCG setup and materialised by the coarse-level workgroup."""
+    w = synth.make_window(6, 2, 6000, seed=17, run_lo=8, run_hi=8)
+    plan = built_lib.structure_probe(w)
+    assert plan["n_items"] >= plan["n_pairs"] + 2 * (plan["n_pairs"] - plan["n_free"]) and plan["pcg_on_chip"]
+    check_against(solver.solve(w), oracle_mod.solve(w), w)
+
+
 def test_large_window_takes_the_generic_pcg(solver, oracle_mod, built_lib):
     """More free keyframes than the on-chip PCG's 8 waves x 10 block rows: generic kernel, S in L2."""
     w = synth.make_window(90, 6, 4000, seed=9, run_lo=2, run_hi=8)
