@@ -181,24 +181,37 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int q = 0; q < 6; ++q) t[r][q] = Ac[(3 * rg + r) * kNC + 6 * cg + q] * dsc[3 * rg + r] * dsc[6 * cg + q];
-    // snapshot of pivot 0
-    if (rg == 0) {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) gj[6 * cg + q] = t[0][q] + ((cg == 0 && q == 0) ? 1.0 : 0.0);
+    // Groups of 6 pivots (aggregate g, mode d) without support are identity rows and columns: eliminating them changes
+    // nothing, so they are skipped (small windows: fewer keyframes than 2 per wave have no linear modes at all).
+    unsigned live = 0;
+    for (int q = 0; q < kNC / 6; ++q) {
+        const int nrows = pp.wave_row0[(q >> 1) + 1] - pp.wave_row0[q >> 1];
+        if (!(nrows == 0 || ((q & 1) && nrows < 2))) live |= 1u << q;
     }
-    if (cg == 0) {
+    int kk = live ? __builtin_ctz(live) : kNC / 6;
+    // snapshot of the first live pivot
+    if (kk < kNC / 6) {
+        if (rg == 2 * kk) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) gj[kNC + 3 * rg + r] = t[r][0] - ((rg == 0 && r == 0) ? 1.0 : 0.0);
+            for (int q = 0; q < 6; ++q) gj[6 * cg + q] = t[0][q] + ((cg == kk && q == 0) ? 1.0 : 0.0);
+        }
+        if (cg == kk) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) gj[kNC + 3 * rg + r] = t[r][0] - ((rg == 2 * kk && r == 0) ? 1.0 : 0.0);
+        }
+        if (rg == 2 * kk && cg == kk) gj[4 * kNC] = t[0][0];
     }
-    if (tid == 0) gj[4 * kNC] = t[0][0];
     __syncthreads();
     bool bad = s_bad != 0;
-    for (int kk = 0; kk < kNC / 6 && !bad; ++kk) {
+    while (kk < kNC / 6 && !bad) {
+        const unsigned later = kk < 31 ? (live & ~((2u << kk) - 1u)) : 0u;
+        const int next = later ? __builtin_ctz(later) : kNC / 6;
 #pragma unroll
         for (int c6 = 0; c6 < 6; ++c6) {
             const int k = 6 * kk + c6;
+            const int k1 = c6 < 5 ? k + 1 : 6 * next;                             // the next live pivot (k is odd when it jumps, 6 next even)
             const double *rk = gj + (k & 1) * 2 * kNC, *ck = rk + kNC;
-            double *rn = gj + ((k + 1) & 1) * 2 * kNC, *cn = rn + kNC;
+            double *rn = gj + (k1 & 1) * 2 * kNC, *cn = rn + kNC;
             const double piv = gj[4 * kNC + (k & 1)];
             if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }
             // reciprocal by v_rcp_f64 and two Newton steps (the scaled pivots are in (0, 1]; this is a preconditioner)
@@ -214,9 +227,7 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) t[r][q] -= ci[r] * rj[q];
-            // publish row / column / pivot k + 1 (static tile indices)
-            constexpr int kDummy = 0; (void)kDummy;
-            const int k1 = k + 1;
+            // publish row / column / pivot k1 (static tile indices: k1 = k + 1 inside a group, the first of a group after it)
             if (k1 < kNC) {
                 const int rn_r = (c6 + 1) % 3, cn_c = (c6 + 1) % 6;
                 const int rgn = k1 / 3, cgn = k1 / 6;
@@ -232,6 +243,7 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
             }
             __syncthreads();
         }
+        kk = next;
     }
     if (bad && tid == 0) s_bad = 1;
     __syncthreads();

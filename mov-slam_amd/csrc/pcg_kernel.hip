@@ -108,8 +108,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     double *red0 = minv + 36 * nf;                        // kNW
     double *red1 = red0 + kNW;                            // kNW
     int &s_fail = *reinterpret_cast<int *>(red1 + kNW);
-    double *Aci = red1 + kNW + 2;                         // kNC x kNC: inverse coarse matrix of the previous trial
-    double *rcg = Aci + kNC * kNC;                        // kNC: restricted residual of every aggregate
+    float *Acf = reinterpret_cast<float *>(red1 + kNW + 2); // kNC x kNC floats: inverse coarse matrix of the previous trial
+    double *rcg = red1 + kNW + 2 + kNC * kNC / 2;         // kNC: restricted vector of every aggregate
     double *zstrip = rcg + kNC + 32 * wv;                 // 16 per wave: the wave's coarse correction z_c = A_c^-1 P^T r (kPA used)
     double *ustrip = zstrip + 16;                         // 16 per wave: A_c^-1 P^T s of the wave's aggregate
     double *ypart = rcg + kNC + 32 * kNW;                 // 6 doubles per gather-list PAIR (+ one dummy strip)
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
     if (coarse) {
         const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)((trial - 1) & 1) * kNC * kNC);
-        double2 *dst = reinterpret_cast<double2 *>(Aci);
-        for (int idx = tid; idx < kNC * kNC / 2; idx += kT) dst[idx] = src[idx];
+        float2 *dst = reinterpret_cast<float2 *>(Acf);
+        for (int idx = tid; idx < kNC * kNC / 2; idx += kT) { const double2 v = src[idx]; dst[idx] = make_float2((float)v.x, (float)v.y); }
     }
 
     // ---- ownership: wave wv owns block rows [b0, b1); lane ln < 6*(b1-b0) owns scalar row b0*6 + ln ----
@@ -311,19 +311,22 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             rcg[wv * kPA + ln] = ln < 6 ? tc : (ti - agg_cc * tc) * agg_ih;
         }
     };
-    // (A_c^-1 v_c)[own row crow], v_c = rcg (all aggregates, visible after a workgroup barrier): valid in lanes with cq == 0
+    // (A_c^-1 v_c)[own row crow], v_c = rcg (all aggregates, visible after a workgroup barrier): valid in lanes with cq == 0.
+    // A_c^-1 sits in LDS rounded to fp32: as a preconditioner the inverse needs no more (same CG iteration counts), and
+    // this product reads all 96 x 96 entries every iteration: in fp64 that was more LDS traffic than the rest of the
+    // iteration together.
     auto coarse_rows = [&]() {
-        const double2 *arow = reinterpret_cast<const double2 *>(Aci + (wv * kPA + crow) * kNC + cq * 24);
+        const float4 *arow = reinterpret_cast<const float4 *>(Acf + (wv * kPA + crow) * kNC + cq * 24);
         const double2 *rcv = reinterpret_cast<const double2 *>(rcg + cq * 24);
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-#pragma nounroll
-        for (int q = 0; q < 12; q += 4) {          // three rounds of 8 loads: the registers are full of S
-            const double2 a0 = arow[q], a1 = arow[q + 1], a2 = arow[q + 2], a3 = arow[q + 3];
-            const double2 c0 = rcv[q], c1 = rcv[q + 1], c2 = rcv[q + 2], c3 = rcv[q + 3];
-            t0 += a0.x * c0.x + a0.y * c0.y; t1 += a1.x * c1.x + a1.y * c1.y;
-            t2 += a2.x * c2.x + a2.y * c2.y; t3 += a3.x * c3.x + a3.y * c3.y;
+        double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q += 2) {
+            const float4 a0 = arow[q], a1 = arow[q + 1];
+            const double2 c0 = rcv[2 * q], c1 = rcv[2 * q + 1], c2 = rcv[2 * q + 2], c3 = rcv[2 * q + 3];
+            t0 += ((double)a0.x * c0.x + (double)a0.y * c0.y) + ((double)a0.z * c1.x + (double)a0.w * c1.y);
+            t1 += ((double)a1.x * c2.x + (double)a1.y * c2.y) + ((double)a1.z * c3.x + (double)a1.w * c3.y);
         }
-        double t = (t0 + t1) + (t2 + t3);
+        double t = t0 + t1;
         t += dpp_mov0<0xb1>(t);
         t += dpp_mov0<0x4e>(t);
         return t;
@@ -511,7 +514,9 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    return (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC + kNC + 32 * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
+    const size_t solve = (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC / 2 + kNC + 32 * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
+    const size_t coarse = ((size_t)kNC * kNC + 5 * kNC + 8) * sizeof(double);      // the second workgroup (coarse_level.h)
+    return solve > coarse ? solve : coarse;
 }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list
