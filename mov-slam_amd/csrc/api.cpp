@@ -372,9 +372,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
         o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
         o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);
-        o_st[b][6] = c.take<double>(2 * (size_t)E);  o_st[b][7] = c.take<double>(E);
+        o_st[b][6] = 0;  o_st[b][7] = c.take<double>(E);
         o_st[b][8] = c.take<double>(nb);
-        o_st[b][9] = c.take<double>(stereo ? E : 0);
+        o_st[b][9] = 0;
         o_st[b][10] = c.take<double>(8 * (size_t)E);
     }
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
@@ -468,9 +468,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.pose = reinterpret_cast<double *>(a + o_st[b][0]); S.Rt = reinterpret_cast<double *>(a + o_st[b][1]);
         S.point = reinterpret_cast<double *>(a + o_st[b][2]); S.Hll = reinterpret_cast<double *>(a + o_st[b][3]);
         S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.rec = reinterpret_cast<double *>(a + o_st[b][5]);
-        S.res = reinterpret_cast<double *>(a + o_st[b][6]); S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
+        S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
-        S.res2 = reinterpret_cast<double *>(a + o_st[b][9]);
         S.erec = reinterpret_cast<double *>(a + o_st[b][10]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);

@@ -32,10 +32,8 @@ struct DevState {
     double *point;   // P x 3
     double *Hll;     // P x 6   (xx xy xz yy yz zz), undamped
     double *bl;      // P x 3
-    double *rec;     // E x 4   (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2)
-    double *res;     // E x 2   (-w e0, -w e1)
+    double *rec;     // E x 4   (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2), point-major: back-substitution and the depth test
     double *chi2;    // E
-    double *res2;    // E: -w e2 of stereo edges (stereo windows only)
     double *Fpart;   // n_pt_blocks robust-cost partials of this state
     double *erec;    // E_free x 8, POSE-major (DevWindow::slot): (Xc.x Xc.y Xc.z w | -w e0, -w e1, -w e2, stereo flag) for k_schur
 };

@@ -214,7 +214,6 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         const double wg = rho1 * om;
         const double r0 = -wg * e0, r1 = -wg * e1;
         *reinterpret_cast<double4 *>(S1.rec + 4 * g) = make_double4(x, y, z, wg);
-        *reinterpret_cast<double2 *>(S1.res + 2 * g) = make_double2(r0, r1);
         S1.chi2[g] = chi2;
         if (sl >= 0) {      // pose-major copy for the schur pass (edges of free keyframes): one 64-byte record
             double4 *er = reinterpret_cast<double4 *>(S1.erec + 8 * (size_t)sl);
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         v0 += p00 * r0 + p10 * r1; v1 += p01 * r0 + p11 * r1; v2 += p02 * r0 + p12 * r1;
         if (STEREO) {
             const double r2 = -wg * e2;
-            S1.res2[g] = r2;
             if (st) {
                 const double c02 = a02 - w.bf / (z * z);
                 const double p20 = a00 * R[0] + c02 * R[6], p21 = a00 * R[1] + c02 * R[7], p22 = a00 * R[2] + c02 * R[8];
