@@ -21,7 +21,7 @@
 
 namespace movba {
 
-// sm: >= kNC*kNC + 5*kNC + 4 doubles of LDS; 512 threads
+// sm: >= kNC*kNC + 5*kNC + 8 doubles + 2 ints per coarse term (= gather-list entry) of LDS; 512 threads
 template <int kT, int kNC, int kPA>
 __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm)
 {
@@ -92,61 +92,56 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     // ---- A_c = P^T S P.  Coarse dof (g, d, a): aggregate g, mode d (0: constant, 1: linear in the keyframe index,
     // phi_1(i) = (i - c_g) / h_g), pose component a.  One thread per (coarse block, a, b): it walks the block's fine terms
     // once, in list order, and accumulates the four mode combinations phi_d(i) phi_e(j) together. ----
-    constexpr int kU = 3;                                   // work items per thread in flight (cfg3: 4.5 per thread in all)
-    for (int idx0 = tid; idx0 < w.n_cblk * 36; idx0 += kU * kT) {
-        int t0[kU], t1[kU], ab[kU], tab[kU], gh[kU];
-        double cg[kU], ch[kU], ig[kU], ih[kU], s00[kU], s01[kU], s10[kU], s11[kU];
-        int nt = 0;
+    // centre and inverse half-width of every aggregate (the linear mode's phi), once, in LDS
+    double *aggc = gj;                                      // 2 x (kNC / kPA) doubles; gj is not in use yet
+    if (tid < kNC / kPA) {
+        const int g0 = pp.wave_row0[tid], g1 = pp.wave_row0[tid + 1];
+        aggc[tid] = g0 + 0.5 * (g1 - g0 - 1); aggc[kNC / kPA + tid] = 1.0 / fmax(1.0, 0.5 * (g1 - g0));
+    }
+    // the term lists themselves go to LDS first (one coalesced pass): the gathers below then depend on ONE global
+    // round trip per batch instead of two
+    int *tent = reinterpret_cast<int *>(gj + 5 * kNC + 8), *tij = tent + w.cblk_ptr[w.n_cblk];
+    for (int q = tid; q < w.cblk_ptr[w.n_cblk]; q += kT) { tent[q] = w.cblk_ent[q]; tij[q] = w.cblk_ij[q]; }
+    __syncthreads();
+    // Thread (cb, a) owns row a of coarse block cb = (g, h) in all four mode combinations: it walks the block's term
+    // list once (8 terms = 48 gathers in flight), so no thread pads its list to a longer neighbour's.
+    for (int wi = tid; wi < w.n_cblk * 6; wi += kT) {
+        const int cb = wi / 6, a = wi - cb * 6;
+        const int g = w.cblk_g[cb], h = w.cblk_h[cb];
+        const double cg = aggc[g], ch = aggc[h], ig = aggc[kNC / kPA + g], ih = aggc[kNC / kPA + h];
+        const int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
+        double s00[6], s01[6], s10[6], s11[6];
 #pragma unroll
-        for (int m = 0; m < kU; ++m) {
-            const int idx = idx0 + m * kT;
-            const bool on = idx < w.n_cblk * 36;
-            const int cb = on ? idx / 36 : 0;
-            ab[m] = on ? idx - cb * 36 : 0;
-            const int a = ab[m] / 6, b = ab[m] - a * 6;
-            tab[m] = b * 6 + a;
-            const int g = w.cblk_g[cb], h = w.cblk_h[cb];
-            gh[m] = on ? (g << 8) | h : -1;
-            const int g0 = pp.wave_row0[g], g1 = pp.wave_row0[g + 1], h0 = pp.wave_row0[h], h1 = pp.wave_row0[h + 1];
-            cg[m] = g0 + 0.5 * (g1 - g0 - 1); ch[m] = h0 + 0.5 * (h1 - h0 - 1);
-            ig[m] = 1.0 / fmax(1.0, 0.5 * (g1 - g0)); ih[m] = 1.0 / fmax(1.0, 0.5 * (h1 - h0));
-            t0[m] = w.cblk_ptr[cb]; t1[m] = on ? w.cblk_ptr[cb + 1] : t0[m];
-            nt = max(nt, t1[m] - t0[m]);
-            s00[m] = s01[m] = s10[m] = s11[m] = 0.0;
-        }
-        for (int t = 0; t < nt; t += 8) {
-            int pk[kU][8], ij[kU][8];
-            double v[kU][8];
+        for (int m = 0; m < 6; ++m) s00[m] = s01[m] = s10[m] = s11[m] = 0.0;
+        for (int t = t0; t < t1; t += 8) {
+            int pk[8], ij[8];
+            double v[8][6];
 #pragma unroll
-            for (int m = 0; m < kU; ++m)
+            for (int u = 0; u < 8; ++u) { const int tt = min(t + u, t1 - 1); pk[u] = tent[tt]; ij[u] = tij[tt]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int tt = min(t0[m] + t + u, max(t1[m] - 1, t0[m]));
-                    pk[m][u] = w.cblk_ent[tt]; ij[m][u] = w.cblk_ij[tt];
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int e = pk[u];
+                const double *src = (e & 1) ? part + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
+                // row a of the (possibly transposed) fine block
+                const int o0 = (e & 2) ? a : a * 6, st = (e & 2) ? 6 : 1;
 #pragma unroll
-            for (int m = 0; m < kU; ++m)
+                for (int m = 0; m < 6; ++m) v[u][m] = src[o0 + st * m];
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int e = pk[m][u], off = (e & 2) ? tab[m] : ab[m];
-                    const double *src = (e & 1) ? part + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
-                    v[m][u] = src[off];
-                }
+            for (int u = 0; u < 8; ++u) {
+                const bool in = t + u < t1;
+                const double sgn = in ? ((pk[u] & 1) ? -1.0 : 1.0) : 0.0;
+                const double pi = ((ij[u] >> 16) - cg) * ig, pj = ((ij[u] & 0xffff) - ch) * ih;
 #pragma unroll
-            for (int m = 0; m < kU; ++m)
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const double x = (t0[m] + t + u < t1[m]) ? ((pk[m][u] & 1) ? -v[m][u] : v[m][u]) : 0.0;
-                    const double pi = ((ij[m][u] >> 16) - cg[m]) * ig[m], pj = ((ij[m][u] & 0xffff) - ch[m]) * ih[m];
+                for (int m = 0; m < 6; ++m) {
+                    const double x = sgn * v[u][m];
                     s00[m] += x; s01[m] += pj * x; s10[m] += pi * x; s11[m] += pi * pj * x;
                 }
-        }
-#pragma unroll
-        for (int m = 0; m < kU; ++m)
-            if (gh[m] >= 0) {
-                double *dst = Ac + ((gh[m] >> 8) * kPA + ab[m] / 6) * kNC + (gh[m] & 0xff) * kPA + ab[m] % 6;
-                dst[0] = s00[m]; dst[6] = s01[m]; dst[6 * kNC] = s10[m]; dst[6 * kNC + 6] = s11[m];
             }
+        }
+        double *dst = Ac + (g * kPA + a) * kNC + h * kPA;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
     }
     __syncthreads();
     // dofs without support (an aggregate with no rows; the linear modes of an aggregate with a single row): identity
