@@ -247,7 +247,10 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
                 info->pcg_max_wave_entries = std::max(info->pcg_max_wave_entries, s.row_ptr[pp.wave_row0[wv + 1]] - s.row_ptr[pp.wave_row0[wv]]);
         }
     }
-    if (edge_perm) std::memcpy(edge_perm, s.perm.data(), sizeof(int32_t) * s.perm.size());
+    if (edge_perm) {
+        if (s.perm.empty()) for (int e = 0; e < s.E; ++e) edge_perm[e] = e;       // already grouped: identity
+        else std::memcpy(edge_perm, s.perm.data(), sizeof(int32_t) * s.perm.size());
+    }
     if (free_index) std::memcpy(free_index, s.hidx.data(), sizeof(int32_t) * s.hidx.size());
     return rc;
 }
@@ -258,91 +261,143 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     HIP_TRY(hipSetDevice(h->device));
     h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK;
     const double t0 = now_ms();
+    static const bool lap_on = std::getenv("MOVBA_TIME_UPLOAD") != nullptr;
+    double lap_t = t0;
+    auto lap = [&](const char *what) { if (lap_on) { const double t = now_ms(); std::fprintf(stderr, "libmovba[upload]: %-28s %.3f ms\n", what, t - lap_t); lap_t = t; } };
     int rc = build_basic(*d, h->st);
+    lap("build_basic");
     if (rc < 0) return rc;
     const Structure &s = h->st;
+    h->stop = d->stop;
+    if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
+    else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
+    if (h->early_status != MOVBA_OK) { h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK; }
+    if ((size_t)(21 * s.NP + 6 * s.nfree + 4) * sizeof(double) > 150 * 1024) {
+        std::fprintf(stderr, "libmovba: %d keyframes exceed the point kernels' LDS staging budget\n", s.NP);
+        return MOVBA_ERR_ARG;
+    }
+    const int NP = s.NP, P = s.P, E = s.E, nf = s.nfree;
+    const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
+
+    // ---- edge region of the arena: everything known after the O(E) grouping pass.  It is packed and its H2D copy queued
+    // NOW, so that the transfer runs while the pair structure is still being worked out ----
+    Carver c;
+    // (what the device structure pass reads comes first: it is copied ahead of the rest)
+    const size_t o_gpose = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1), o_hidx = c.take<int32_t>(NP);
+    const size_t edge_a_bytes = c.off;
+    const size_t o_gpoint = c.take<int32_t>(E);
+    const size_t o_perm = c.take<int32_t>(s.already_grouped ? 0 : E), o_free = c.take<int32_t>(nf + 1);
+    const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
+    bool stereo = false;
+    if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
+    const size_t o_obsr = c.take<double>(stereo ? E : 0);
+    const size_t o_slot = c.take<int32_t>(E);
+    const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
+    const size_t edge_bytes = c.off;
+    const int nbins = nf * nf;
+    const size_t misc_bytes = (size_t)(nbins + 8) * sizeof(int32_t) * 2 + 4096;         // counts back / pair ids out (device structure pass)
+    int rc2 = ensure_stage(h, edge_bytes + misc_bytes); if (rc2) return rc2;
+    // first sizing of the arena: room for the states and pair lists too, so that it is not reallocated a moment later
+    if (edge_bytes > h->arena_cap) { rc2 = ensure_arena(h, 10 * edge_bytes); if (rc2) return rc2; }
+    HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
+    char *sg = h->stage;
+    auto pack_edges = [&]() {
+        std::memcpy(sg + o_gpose, s.g_pose.data(), sizeof(int32_t) * E);
+        std::memcpy(sg + o_gpoint, s.g_point.data(), sizeof(int32_t) * E);
+        std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
+        if (!s.already_grouped) std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
+        std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
+        std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
+        std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
+        double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
+        double *obr = reinterpret_cast<double *>(sg + o_obsr);
+        if (s.already_grouped) {        // the reference's own edge order: straight copies
+            std::memcpy(obs, d->obs, sizeof(double) * 2 * (size_t)E);
+            std::memcpy(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
+            if (stereo) std::memcpy(obr, d->obs_right, sizeof(double) * (size_t)E);
+        } else {
+            for (int g = 0; g < E; ++g) {
+                const int e = s.perm[g];
+                obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
+            }
+            if (stereo) for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
+        }
+        std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
+        std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+    };
+    pack_edges();
+    lap("pack edge region");
+    const double t_up0 = now_ms();
+    HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_a_bytes, hipMemcpyHostToDevice, h->stream));
+    char *arena_at_edge_copy = h->arena;
+    double upload_host_ms = now_ms() - t_up0;
+    bool edge_b_queued = false;
+    auto queue_edge_b = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, edge_bytes - edge_a_bytes, hipMemcpyHostToDevice, h->stream));
+        edge_b_queued = true;
+        return MOVBA_OK;
+    };
+
     // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
     // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
     StructDev sd{};
-    const bool dev_structure = rc == MOVBA_OK && s.already_grouped && s.nfree > 0 && s.nfree <= 80 && s.n_fixed > 0 &&
-                               !std::getenv("MOVBA_HOST_STRUCTURE");
-    if (rc == MOVBA_OK && !dev_structure) {
+    const bool dev_structure = s.already_grouped && s.nfree > 0 && s.nfree <= 80 && !std::getenv("MOVBA_HOST_STRUCTURE");
+    size_t so_pid = 0, so_pptr = 0, so_cntw = 0, so_cnt = 0, so_err = 0;
+    if (!dev_structure) {
         rc = build_structure(*d, h->st);
         if (rc < 0) return rc;
-    }
-    if (dev_structure) {
-        const int nf = s.nfree, nbins = nf * nf, nchunks = (s.P + 63) / 64;
+    } else {
+        const int nchunks = (s.P + 63) / 64;
         Carver sc;
-        const size_t so_gpose = sc.take<int32_t>(s.E), so_pt = sc.take<int32_t>(s.P + 1), so_hidx = sc.take<int32_t>(s.NP);
-        const size_t s_h2d = sc.off;
-        const size_t so_cnt = sc.take<int32_t>(nbins), so_err = sc.take<int32_t>(4);
-        const size_t so_pid = sc.take<int32_t>(nbins), so_pptr = sc.take<int32_t>(nbins + 1);
-        const size_t so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
+        so_cnt = sc.take<int32_t>(nbins); so_err = sc.take<int32_t>(4);
+        so_pid = sc.take<int32_t>(nbins); so_pptr = sc.take<int32_t>(nbins + 1);
+        so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
         if (sc.off > h->scratch_cap) {
             if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
             const size_t cap = align_up(sc.off + sc.off / 4, 1 << 20);
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch), cap));
             h->scratch_cap = cap;
         }
-        int rs = ensure_stage(h, std::max(s_h2d, (size_t)(nbins + 8) * sizeof(int32_t) * 2 + 4096)); if (rs) return rs;
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        char *sg = h->stage, *sa = h->scratch;
-        std::memcpy(sg + so_gpose, s.g_pose.data(), sizeof(int32_t) * s.E);
-        std::memcpy(sg + so_pt, s.pt_start.data(), sizeof(int32_t) * (s.P + 1));
-        std::memcpy(sg + so_hidx, s.hidx.data(), sizeof(int32_t) * s.NP);
-        HIP_TRY(hipMemcpyAsync(sa, sg, s_h2d, hipMemcpyHostToDevice, h->stream));
+        char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;    // tail of the staging buffer: the pair region is packed in front of it
         HIP_TRY(hipMemsetAsync(sa + so_err, 0, 16, h->stream));
         sd.P = s.P; sd.nfree = nf; sd.nchunks = nchunks;
-        sd.g_pose = reinterpret_cast<int32_t *>(sa + so_gpose); sd.pt_start = reinterpret_cast<int32_t *>(sa + so_pt);
-        sd.hidx = reinterpret_cast<int32_t *>(sa + so_hidx);
+        // grouped edges, point ranges and hessian indices are read where the edge copy just put them
+        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
+        sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
         sd.cntw = reinterpret_cast<int32_t *>(sa + so_cntw); sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt);
         sd.error = reinterpret_cast<int32_t *>(sa + so_err);
         sd.pid = reinterpret_cast<int32_t *>(sa + so_pid); sd.pair_ptr = reinterpret_cast<int32_t *>(sa + so_pptr);
         HIP_TRY(launch_struct_count(sd, h->stream));
         // cnt and the error word are adjacent in the scratch carve: one D2H copy
-        HIP_TRY(hipMemcpyAsync(sg, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(misc, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (*reinterpret_cast<const int32_t *>(sg + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
-        rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(sg));
+        if (*reinterpret_cast<const int32_t *>(misc + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
+        lap("edge H2D + count kernel + D2H");
+        // observations, point ids, slots and initial estimates cross the bus while the host lays out the pairs
+        { const int rq = queue_edge_b(); if (rq) return rq; }
+        rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
+        lap("finish_pairs");
         if (rc < 0) return rc;
         // pair ids / first entries for the fill kernel (launched once the arena is carved)
-        int32_t *pp32 = reinterpret_cast<int32_t *>(sg + nbins * sizeof(int32_t));
-        std::memcpy(sg, s.pid.data(), sizeof(int32_t) * nbins);
+        int32_t *pp32 = reinterpret_cast<int32_t *>(misc + nbins * sizeof(int32_t));
+        std::memcpy(misc, s.pid.data(), sizeof(int32_t) * nbins);
         for (int p = 0; p <= s.npairs; ++p) pp32[p] = (int32_t)s.pair_ptr[p];
-        HIP_TRY(hipMemcpyAsync(sa + so_pid, sg, sizeof(int32_t) * nbins, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(sa + so_pid, misc, sizeof(int32_t) * nbins, hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(sa + so_pptr, pp32, sizeof(int32_t) * (s.npairs + 1), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));       // the staging buffer is re-packed below
+        lap("pid/pair_ptr H2D enqueue");
     }
-    h->stop = d->stop;
-    if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
-    else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
-    const double t1 = now_ms();
-    h->prof.structure_ms += t1 - t0;
-    if (h->early_status != MOVBA_OK) { h->uploaded = true; return MOVBA_OK; }
+    if (!edge_b_queued) { const int rq = queue_edge_b(); if (rq) return rq; }
     if (pcg_lds_bytes(s.nfree) > 150 * 1024) {
         std::fprintf(stderr, "libmovba: %d free keyframes exceed the single-workgroup PCG's LDS budget\n", s.nfree);
         return MOVBA_ERR_ARG;
     }
-    if ((size_t)(21 * s.NP + 6 * s.nfree + 4) * sizeof(double) > 150 * 1024) {
-        std::fprintf(stderr, "libmovba: %d keyframes exceed the point kernels' LDS staging budget\n", s.NP);
-        return MOVBA_ERR_ARG;
-    }
-
     h->pp = PcgParams{};
     h->rows_kernel = pcg_rows_supported(s.nfree, s.row_ptr.data(), &h->pp);
     if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
-    const int NP = s.NP, P = s.P, E = s.E, nf = s.nfree;
-    const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
-    // ---- carve the H2D region ----
-    Carver c;
-    const size_t o_gpose = c.take<int32_t>(E), o_gpoint = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1);
-    const size_t o_perm = c.take<int32_t>(E), o_hidx = c.take<int32_t>(NP), o_free = c.take<int32_t>(nf + 1);
-    const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
-    bool stereo = false;
-    if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
-    const size_t o_obsr = c.take<double>(stereo ? E : 0);
-    const size_t o_slot = c.take<int32_t>(E);
-    const size_t o_ent = c.take<Int4>((size_t)s.nentries + 1), o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<SchedItem>(s.sched.size() + 1);
+    lap("pcg plan + coarse lists");
+
+    // ---- pair region (second H2D copy) ----
+    const size_t o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<SchedItem>(s.sched.size() + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
     std::vector<int32_t> lane_plan;
@@ -364,9 +419,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t ncb = s.cblk_g.size();
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
-    const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
+    const size_t o_ent_h2d = dev_structure ? 0 : c.take<Int4>((size_t)s.nentries + 1);       // host-built entry lists travel with the pair region
     const size_t h2d = c.off;
     // ---- device-only region ----
+    const size_t o_ent = dev_structure ? c.take<Int4>((size_t)s.nentries + 1) : o_ent_h2d;
     size_t o_st[2][11];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
@@ -385,31 +441,23 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
     const size_t total = c.off;
 
-    int rc2 = ensure_arena(h, total); if (rc2) return rc2;
-    rc2 = ensure_stage(h, std::max(h2d, (size_t)(7 * NP + 3 * P + E) * sizeof(double) + E + 4096)); if (rc2) return rc2;
-    HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
-
-    // ---- pack ----
-    char *sg = h->stage;
-    std::memcpy(sg + o_gpose, s.g_pose.data(), sizeof(int32_t) * E);
-    std::memcpy(sg + o_gpoint, s.g_point.data(), sizeof(int32_t) * E);
-    std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
-    std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
-    std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
-    std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
-    std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
-    {
-        double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
-        for (int g = 0; g < E; ++g) {
-            const int e = s.perm[g];
-            obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
-        }
-        if (stereo) {
-            double *obr = reinterpret_cast<double *>(sg + o_obsr);
-            for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
-        }
+    rc2 = ensure_arena(h, total); if (rc2) return rc2;
+    if (h->arena != arena_at_edge_copy) {
+        // the arena grew: queue the edge region again (the staging copy is intact) and re-point the structure pass
+        HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_bytes, hipMemcpyHostToDevice, h->stream));
+        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
+        sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
     }
-    if (!dev_structure) std::memcpy(sg + o_ent, s.entries.data(), sizeof(Int4) * (size_t)s.nentries);
+    if (h2d + misc_bytes > h->stage_cap) {
+        // (rare: huge host-built entry lists) a bigger staging buffer: ensure_stage drains the stream first, so the edge copy
+        // has landed; the edge region is packed again only to keep the buffer self-consistent
+        rc2 = ensure_stage(h, h2d + misc_bytes); if (rc2) return rc2;
+        sg = h->stage;
+        pack_edges();
+    }
+
+    // ---- pack the pair region ----
+    if (!dev_structure) std::memcpy(sg + o_ent_h2d, s.entries.data(), sizeof(Int4) * (size_t)s.nentries);
     std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
     std::memcpy(sg + o_sched, s.sched.data(), sizeof(SchedItem) * s.sched.size());
     std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
@@ -424,18 +472,18 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_ce, s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
     std::memcpy(sg + o_cij, s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
     std::memcpy(sg + o_multi, s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
-    std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
-    std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+    lap("carve + pack pair region");
     const double t2 = now_ms();
-    h->prof.structure_ms += t2 - t1;
-    HIP_TRY(hipMemcpyAsync(h->arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
+    h->prof.structure_ms += (t2 - t0) - upload_host_ms;
+    HIP_TRY(hipMemcpyAsync(h->arena + edge_bytes, sg + edge_bytes, h2d - edge_bytes, hipMemcpyHostToDevice, h->stream));
     if (dev_structure) {
         sd.entries = reinterpret_cast<Int4 *>(h->arena + o_ent);
         sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
         HIP_TRY(launch_struct_fill(sd, h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->prof.upload_ms += now_ms() - t2;
+    lap("pair H2D + fill kernel + sync");
+    h->prof.upload_ms += now_ms() - t2 + upload_host_ms;
     h->h2d_bytes = h2d;
 
     // ---- device view ----
@@ -446,7 +494,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.max_iters = d->max_iters; w.flags = d->flags; w.max_trials = d->max_trials > 0 ? d->max_trials : 10;
     w.fx = d->fx; w.fy = d->fy; w.cx = d->cx; w.cy = d->cy; w.huber_delta = d->huber_delta; w.chi2_gate = d->chi2_gate;
     w.g_pose = reinterpret_cast<int32_t *>(a + o_gpose); w.g_point = reinterpret_cast<int32_t *>(a + o_gpoint);
-    w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = reinterpret_cast<int32_t *>(a + o_perm);
+    w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = s.already_grouped ? nullptr : reinterpret_cast<int32_t *>(a + o_perm);
     w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
     w.obs_r = reinterpret_cast<double *>(a + o_obsr); w.bf = d->bf; w.stereo = stereo ? 1 : 0;

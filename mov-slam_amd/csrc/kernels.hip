@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
         const double chi2 = w.st[sel].chi2[g];
         const double zc = w.st[cur].rec[4 * g + 2];
         bad = (chi2 > w.chi2_gate) || !(zc > 0.0);
-        const int e = w.perm[g];
+        const int e = w.perm ? w.perm[g] : g;          // null: the caller's edges were already grouped by map point
 #ifdef MOVBA_CLOCK_STAMP
         if (e >= 32768)
 #endif

@@ -19,27 +19,33 @@ int build_basic(const movba_lba_desc& d, Structure& s)
     s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.entries.clear();
     s.NP = NP; s.P = P; s.E = E;
 
-    // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization)
-    std::vector<uint8_t> pose_active(NP, 0);
+    // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization).  ONE pass over the caller's
+    // edges: validation, edges per pose, edges per point, and whether the edges already come grouped by map point.
+    s.pose_edges.assign(NP + 1, 0);
     s.pt_start.assign(P + 2, 0);
-    for (int e = 0; e < E; ++e) {
-        const int ip = d.edge_pose[e], l = d.edge_point[e];
-        if (ip < 0 || ip >= NP || l < 0 || l >= P) return MOVBA_ERR_ARG;
-        pose_active[ip] = 1;
-        s.pt_start[l + 2]++;
+    {
+        int prev_l = -1;
+        bool grouped = true;
+        for (int e = 0; e < E; ++e) {
+            const int ip = d.edge_pose[e], l = d.edge_point[e];
+            if (ip < 0 || ip >= NP || l < 0 || l >= P) return MOVBA_ERR_ARG;
+            s.pose_edges[ip]++;
+            s.pt_start[l + 2]++;
+            grouped &= l >= prev_l;
+            prev_l = l;
+        }
+        s.already_grouped = grouped;      // identity permutation iff the caller's edges are in ascending point order
     }
-    // identity permutation iff the caller's edges are already in ascending point order
-    for (int e = 1; e < E && s.already_grouped; ++e)
-        if (d.edge_point[e] < d.edge_point[e - 1]) s.already_grouped = false;
-
     for (int l = 0; l < P; ++l) s.pt_start[l + 2] += s.pt_start[l + 1];
-    s.perm.resize(E); s.g_pose.resize(E); s.g_point.resize(E);
+    s.g_pose.resize(E); s.g_point.resize(E);
     if (s.already_grouped) {
         // the reference's own edge order (map points in list order, Optimizer.cc:623-672): identity permutation
-        for (int e = 0; e < E; ++e) s.perm[e] = e;
+        // (perm stays empty: the upload path copies the per-edge arrays as they are)
+        s.perm.clear();
         if (E) { std::memcpy(s.g_pose.data(), d.edge_pose, sizeof(int32_t) * E); std::memcpy(s.g_point.data(), d.edge_point, sizeof(int32_t) * E); }
         s.pt_start.erase(s.pt_start.begin());       // counts were accumulated one slot late for the counting sort
     } else {
+        s.perm.resize(E);
         for (int e = 0; e < E; ++e) {
             const int pos = s.pt_start[d.edge_point[e] + 1]++;
             s.perm[pos] = e;
@@ -51,19 +57,21 @@ int build_basic(const movba_lba_desc& d, Structure& s)
         }
     }
     s.hidx.assign(NP, -1);
-    for (int i = 0; i < NP; ++i) {
-        if (d.pose_fixed[i]) { s.n_fixed++; continue; }
-        if (pose_active[i]) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); }
-    }
-    for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
     // pose-major slots: the edges of free pose h occupy [pstart[h], pstart[h+1]) in ascending map-point order, so the
     // schur pass reads the per-edge records of one keyframe as (nearly) contiguous memory
+    std::vector<int32_t>& pstart = s.pose_slot0;
+    pstart.assign(NP + 1, -1);
+    int run = 0;
+    for (int i = 0; i < NP; ++i) {
+        if (d.pose_fixed[i]) { s.n_fixed++; continue; }
+        if (s.pose_edges[i] > 0) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); pstart[i] = run; run += s.pose_edges[i]; }
+    }
+    for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
+    s.slot.resize(E);
     {
-        std::vector<int32_t> pstart(s.nfree + 1, 0);
-        for (int g = 0; g < E; ++g) { const int h = s.hidx[s.g_pose[g]]; if (h >= 0) pstart[h + 1]++; }
-        for (int h = 0; h < s.nfree; ++h) pstart[h + 1] += pstart[h];
-        s.slot.resize(E);
-        for (int g = 0; g < E; ++g) { const int h = s.hidx[s.g_pose[g]]; s.slot[g] = h >= 0 ? pstart[h]++ : -1; }
+        const int32_t *gp = s.g_pose.data();
+        int32_t *sl = s.slot.data(), *ps = pstart.data();
+        for (int g = 0; g < E; ++g) { const int i = gp[g]; const int v = ps[i]; sl[g] = v; ps[i] = v + (v >= 0); }
     }
     if (E == 0) return MOVBA_EMPTY;
     return MOVBA_OK;

@@ -31,7 +31,8 @@ struct Structure {
     int n_fixed = 0;
     std::vector<int32_t> hidx;          // NP: hessian index or -1
     std::vector<int32_t> free_pose;     // nfree: pose index
-    std::vector<int32_t> perm;          // E: grouped position -> caller edge
+    std::vector<int32_t> perm;          // E: grouped position -> caller edge; EMPTY when the caller's order is already grouped (identity)
+    std::vector<int32_t> pose_edges, pose_slot0;   // scratch of build_basic: edges per pose, first pose-major slot of a free pose
     std::vector<int32_t> pt_start;      // P+1
     std::vector<int32_t> g_pose, g_point;   // E (grouped order)
     std::vector<int32_t> pair_i, pair_j;    // npairs (hessian indices, i <= j); pair k<nfree is (k,k)
