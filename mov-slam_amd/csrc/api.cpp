@@ -564,7 +564,10 @@ int movba_lba_run(movba_handle *h)
     pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 4 * 6 * (w.nfree > 0 ? w.nfree : 1);
     const int nrowent = (int)h->st.row_ent.size();
     const bool rows_kernel = h->rows_kernel;
-    pp.use_coarse = (h->opt.pcg_coarse && rows_kernel) ? 1 : 0;
+    // 1: coarse level built beside the solve, one trial old; 2: small window (<= one keyframe per wave), built first and fresh
+    bool one_row_per_wave = true;
+    for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) one_row_per_wave &= pp.wave_row0[wv + 1] - pp.wave_row0[wv] <= 1;
+    pp.use_coarse = (h->opt.pcg_coarse && rows_kernel) ? (one_row_per_wave ? 2 : 1) : 0;
 
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
     const double t_start = now_ms();

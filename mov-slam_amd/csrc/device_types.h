@@ -123,7 +123,7 @@ struct PcgParams {
     int32_t max_iters;
     int32_t wave_row0[17];      // k_pcg_rows: wave wv owns block rows [wave_row0[wv], wave_row0[wv+1])
     int32_t overflow;           // k_pcg_rows: some wave has more gather entries than fit in VGPRs
-    int32_t use_coarse;         // k_pcg_rows: add the aggregate coarse-level correction to block-Jacobi
+    int32_t use_coarse;         // k_pcg_rows: add the aggregate coarse-level correction to block-Jacobi (1: lagged, 2: fresh)
 };
 
 }  // namespace movba

@@ -93,7 +93,13 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     unsigned long long setup_last = stamp_c0;
 #endif
     const double lambda = c->lambda;
-    if (blockIdx.x == 1) {          // second workgroup: coarse level of THIS trial's matrix, for the next trial
+    // use_coarse == 2 (windows with at most one keyframe per wave: the coarse space is the whole space): the coarse level
+    // is built FIRST, by this workgroup, from THIS trial's matrix, and the solve below converges in a couple of iterations
+    const bool fresh = pp.use_coarse == 2;
+    if (fresh) {
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm);
+        __syncthreads();
+    } else if (blockIdx.x == 1) {   // second workgroup: coarse level of THIS trial's matrix, for the next trial
         coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm);
         return;
     }
@@ -116,9 +122,10 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     double *sdiag = ypart + 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);     // nf x 36: the damped diagonal blocks S_ii
     if (tid == 0) s_fail = 0;
     // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial)
-    const bool coarse = pp.use_coarse && trial > 0 && w.aci_tag[(trial - 1) & 1] == trial - 1;
+    const int ctrial = fresh ? trial : trial - 1;         // the trial whose coarse matrix preconditions this solve
+    const bool coarse = pp.use_coarse && ctrial >= 0 && w.aci_tag[ctrial & 1] == ctrial;
     if (coarse) {
-        const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)((trial - 1) & 1) * kNC * kNC);
+        const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)(ctrial & 1) * kNC * kNC);
         float2 *dst = reinterpret_cast<float2 *>(Acf);
         for (int idx = tid; idx < kNC * kNC / 2; idx += kT) { const double2 v = src[idx]; dst[idx] = make_float2((float)v.x, (float)v.y); }
     }
@@ -345,6 +352,8 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
         const double2 m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
         const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
         double s = (m0.x * r0.x + m0.y * r0.y) + (m1.x * r1.x + m1.y * r1.y) + (m2.x * r2.x + m2.y * r2.y);
+        // fresh mode: every aggregate is one keyframe, the coarse space is the whole space and A_c^-1 is S^-1 itself
+        if (fresh && coarse) s = 0.0;
         if (coarse && owner) s += zstrip[ba] + phi * zstrip[6 + ba];
         return owner ? s : 0.0;
     };
@@ -539,6 +548,12 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
         if (out) for (; wv < kNW; ++wv) out[wv + 1] = nfree;
         return b == nfree;
     };
+    if (nfree <= kNW) {
+        // one keyframe per wave: the aggregates are single keyframes and the coarse level is the exact inverse (fresh mode)
+        for (int wv = 0; wv <= kNW; ++wv) pp->wave_row0[wv] = wv < nfree ? wv : nfree;
+        pp->overflow = 0;
+        return true;
+    }
     int lo = 1, hi = nrowent > 1 ? nrowent : 1;
     while (lo < hi) {
         const int mid = (lo + hi) / 2;
@@ -554,7 +569,7 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
 
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_rows, dim3(pp.use_coarse ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
+    hipLaunchKernelGGL(k_pcg_rows, dim3(pp.use_coarse == 1 ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
     return hipGetLastError();
 }
 
