@@ -1,0 +1,44 @@
+"""Randomised GPU-vs-oracle parity sweep over window shapes (run on a GPU box): free/fixed keyframe counts around every
+code-path boundary (one keyframe per wave, two rows per aggregate, VGPR overflow, generic PCG), track lengths, stereo."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+from movba import synth, capi
+from oracle import oracle
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+s = capi.Solver()
+worst = dict(dq=0.0, dt=0.0, pt=0.0, outl=0)
+bad = 0
+for it in range(n):
+    K = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 12, 15, 16, 17, 20, 24, 31, 40, 50, 64, 79, 81, 95]))
+    F = int(rng.integers(1, 6))
+    P = int(rng.choice([200, 600, 1500, 5000]))
+    lo = int(rng.integers(2, 5)); hi = int(min(K + F, lo + rng.integers(0, 12)))
+    stereo = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
+    seed = int(rng.integers(1, 10 ** 6))
+    try:
+        w = synth.make_window(K, F, P, seed=seed, run_lo=lo, run_hi=max(lo, hi), stereo_frac=stereo)
+    except Exception as e:          # degenerate generator input
+        continue
+    ro = oracle.solve(w)
+    try:
+        rg = s.solve(w)
+    except capi.MovbaError as e:
+        print(f"[{it}] K={K} F={F} P={P} run {lo}-{hi} stereo {stereo}: GPU refused: {e}")
+        continue
+    fr = w.pose_fixed == 0
+    dq = np.abs(ro['poses'][:, :4] - rg['poses'][:, :4]).max(); dt = np.abs(ro['poses'][:, 4:] - rg['poses'][:, 4:]).max()
+    pt = np.abs(ro['points'] - rg['points']).max() if w.n_points else 0.0
+    guard = np.abs(ro['chi2'] - w.chi2_gate) <= 1e-6
+    outl = int(((ro['outlier'] != rg['outlier']) & ~guard).sum())
+    same = np.array_equal(ro['trace']['accept'], rg['trace']['accept'])
+    ok = dq < 1e-8 and dt < 1e-8 and pt < 1e-6 and outl == 0 and same and ro['n_solves'] == rg['n_solves']
+    worst['dq'] = max(worst['dq'], dq); worst['dt'] = max(worst['dt'], dt); worst['pt'] = max(worst['pt'], pt); worst['outl'] += outl
+    if not ok:
+        bad += 1
+        print(f"[{it}] MISMATCH K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} outl {outl} accept_same {same} solves {ro['n_solves']}/{rg['n_solves']} pcg {rg['pcg_iters']}", flush=True)
+print(f"{n} windows, {bad} mismatches; worst dq {worst['dq']:.2e} dt {worst['dt']:.2e} pt {worst['pt']:.2e}")
+sys.exit(1 if bad else 0)

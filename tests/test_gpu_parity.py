@@ -87,6 +87,20 @@ def test_pairs_sharing_thousands_of_points_are_cut_into_several_work_items(solve
     check_against(solver.solve(w), oracle_mod.solve(w), w)
 
 
+def test_random_window_shapes_around_every_code_path_boundary(solver, oracle_mod):
+    """Seeded sweep over keyframe counts at the boundaries of the solver's code paths (one keyframe per wave / fresh coarse
+    level, two rows per aggregate, 80 keyframes = last on-chip size, generic PCG beyond), track lengths and stereo mixes."""
+    rng = np.random.default_rng(7)
+    for _ in range(24):
+        K = int(rng.choice([1, 2, 5, 8, 9, 12, 16, 17, 24, 40, 64, 80, 81]))
+        F = int(rng.integers(1, 5))
+        P = int(rng.choice([200, 600, 1500]))
+        lo = int(rng.integers(2, 5)); hi = int(min(K + F, lo + rng.integers(0, 10)))
+        w = synth.make_window(K, F, P, seed=int(rng.integers(1, 10 ** 6)), run_lo=lo, run_hi=max(lo, hi),
+                              stereo_frac=float(rng.choice([0.0, 0.0, 0.6])))
+        check_against(solver.solve(w), oracle_mod.solve(w), w)
+
+
 def test_large_window_takes_the_generic_pcg(solver, oracle_mod, built_lib):
     """More free keyframes than the on-chip PCG's 8 waves x 10 block rows: generic kernel, S in L2."""
     w = synth.make_window(90, 6, 4000, seed=9, run_lo=2, run_hi=8)
