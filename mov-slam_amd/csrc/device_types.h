@@ -22,7 +22,10 @@ constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-ite
 //                 [42,63) upper triangle of Hpp_ii      (diagonal pairs only)
 //                 [63,69) b_p,i                          (diagonal pairs only)
 constexpr int kPointGroup = 8;      // lanes cooperating on one map point
-constexpr int kPointBlock = 256;    // threads per block of the point kernels
+#ifndef MOVBA_POINT_BLOCK
+#define MOVBA_POINT_BLOCK 256
+#endif
+constexpr int kPointBlock = MOVBA_POINT_BLOCK;    // threads per block of the point kernels
 constexpr int kPointsPerBlock = kPointBlock / kPointGroup;
 constexpr int kMaxTrace = MOVBA_MAX_TRACE;
 

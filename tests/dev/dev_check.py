@@ -1,6 +1,6 @@
 """Developer check: GPU path vs oracle on the synthetic configs (run on a GPU box)."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 from movba import synth, capi

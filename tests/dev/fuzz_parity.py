@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity sweep over window shapes (run on a GPU box): free/fixed keyframe counts around every
 code-path boundary (one keyframe per wave, two rows per aggregate, VGPR overflow, generic PCG), track lengths, stereo."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 from movba import synth, capi

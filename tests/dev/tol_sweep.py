@@ -1,6 +1,6 @@
 """PCG stopping tolerance vs parity and CG iteration count (run on a GPU box)."""
 import sys, time, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 from movba import synth, capi
