@@ -377,7 +377,18 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             // ---- x += alpha p, r -= alpha s, z = Minv r (wave-local) ----
             x_r += alpha * p_r;
             r_r -= alpha * s_r;
-            if (coarse && ln < kPA) zstrip[ln] -= alpha * ustrip[ln];     // z_c -= alpha u_c; ordered before precond's reads by its wave-local sync
+            if (coarse) {
+                if ((iters & 63) == 0) {
+                    // every 64 iterations z_c is recomputed from the residual itself, so that rounding drift of the
+                    // recurrence cannot build up in long solves (ill-conditioned windows)
+                    __syncthreads();                          // all reads of rcg from the previous iteration are done
+                    restrict_own(r_r);
+                    __syncthreads();
+                    const double zc = coarse_rows();
+                    if (cq == 0 && ln < 4 * kPA) zstrip[ln >> 2] = zc;
+                    __syncthreads();                          // rcg is rewritten before the next reduction barrier
+                } else if (ln < kPA) zstrip[ln] -= alpha * ustrip[ln];  // z_c -= alpha u_c; ordered before precond's reads by its wave-local sync
+            }
             z_r = precond(r_r);
             if (owner) p_lds[row] = z_r;                      // the vector the mat-vec multiplies
             SEG_STAMP(0);
