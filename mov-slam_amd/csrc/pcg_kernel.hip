@@ -17,11 +17,14 @@
 //   * the 6 rows of a block live in one wave, so the block-Jacobi preconditioner needs only a
 //     wave-local LDS exchange;
 //   * preconditioner = block-Jacobi + an aggregate coarse level (two-level additive Schwarz): the block
-//     rows of one wave form an aggregate with 6 coarse dofs; A_c^-1 (48 x 48) comes from the previous trial
-//     (built by the SECOND workgroup of that launch, coarse_level.h, beside the CG) and removes the low-frequency drift
-//     modes block-Jacobi cannot see: ~2.3x fewer CG iterations at cfg3;
-//   * per CG iteration: 3 workgroup barriers, 2 DPP wave reductions (the coarse level rides on them: the
-//     restricted residual follows the recurrence r_c -= alpha P^T A p, whose P^T A p is published with p.Ap).
+//     rows of one wave form an aggregate with 12 coarse dofs (the 6 pose components constant over the aggregate
+//     and varying linearly with the keyframe index); A_c^-1 (96 x 96, kept in LDS as fp32) comes from the
+//     previous trial (built by the SECOND workgroup of that launch, coarse_level.h, beside the CG) and removes
+//     the smooth drift / bending modes block-Jacobi cannot see: 869 -> 247 CG iterations per cfg3 window solve.
+//     A window with at most one keyframe per wave builds the (then exact) inverse first and solves in ~3 iterations;
+//   * single-reduction conjugate gradients (Chronopoulos & Gear): per iteration 2 workgroup barriers and ONE pair of
+//     DPP wave reductions; each wave's coarse correction follows a recurrence, its dense product runs behind the
+//     reduction barrier on the restricted mat-vec result that is published with the dot products.
 // All reductions run in a fixed order: results are bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 

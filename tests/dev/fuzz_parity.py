@@ -37,6 +37,8 @@ for it in range(n):
     same = np.array_equal(ro['trace']['accept'], rg['trace']['accept'])
     ok = dq < 1e-8 and dt < 1e-8 and pt < 1e-6 and outl == 0 and same and ro['n_solves'] == rg['n_solves']
     worst['dq'] = max(worst['dq'], dq); worst['dt'] = max(worst['dt'], dt); worst['pt'] = max(worst['pt'], pt); worst['outl'] += outl
+    if ok and (dt > 1e-9 or dq > 1e-10):
+        print(f"[{it}] close to tolerance: K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} pcg {rg['pcg_iters']} per trial {rg['trace']['pcg'].tolist()}", flush=True)
     if not ok:
         bad += 1
         print(f"[{it}] MISMATCH K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} outl {outl} accept_same {same} solves {ro['n_solves']}/{rg['n_solves']} pcg {rg['pcg_iters']}", flush=True)
