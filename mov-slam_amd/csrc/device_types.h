@@ -93,6 +93,7 @@ struct DevWindow {
     const double *pose0, *point0;   // uploaded initial state (for reset)
     // reduced system
     double *part;       // nitems x kPartStride: k_schur work-item partials
+    double *blocks_ov;  // overflow windows only: oriented copies of the blocks of the gather-list tails (entry e at 36 e)
     double *blocks_c;   // npairs x 36: the coarse-level workgroup's own copy of S (coarse_level.h)
     double *aci;        // 2 x kCoarseDim x kCoarseDim: inverse coarse matrices (by trial parity)
     int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable

@@ -82,6 +82,9 @@ __device__ __forceinline__ double s_block_elem(const double *part, int pr, int i
 
 }  // namespace
 
+// OVERFLOW: some wave's gather list does not fit its 64 VGPR-resident pairs; the tail is multiplied from an L2 copy of S
+// (a separate instantiation: its extra live values must not cost the common case registers)
+template <bool OVERFLOW>
 __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -145,11 +148,22 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     const int nb = b1 - b0;                               // block rows of this wave (wave-uniform)
 
     // ---- overflow only: materialise S in L2 for the list tails that do not fit in VGPRs ----
-    if (pp.overflow) {
+    if (OVERFLOW) {
         for (int idx = tid; idx < w.npairs * 36; idx += kT) {
             const int pr = idx / 36, k = idx - pr * 36;
             const double v = s_block_elem(part, pr, w.pair_item_start[pr], w.pair_item_start[pr + 1], k / 6, k % 6, lambda, nf);
             w.blocks[idx] = v;
+        }
+        __syncthreads();
+        // oriented copies of the tail entries (those beyond the wave's 64 VGPR-resident pairs), so that the mat-vec reads
+        // them with wide row-major loads and no per-element orientation test
+        for (int e = 2 * (P0 + 64) + ln; e < 2 * P1; e += 64) {
+            const RowEnt re = w.row_ent[e];
+            double *dst = w.blocks_ov + (size_t)e * 36;
+            for (int q = 0; q < 36; ++q) {
+                const int a = q / 6, b = q - a * 6;
+                dst[q] = re.block < 0 ? 0.0 : w.blocks[(size_t)re.block * 36 + (re.transposed ? b * 6 + a : q)];
+            }
         }
         __syncthreads();
     }
@@ -413,18 +427,22 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
                 double2 *yo = reinterpret_cast<double2 *>(ypart + yslot);
                 yo[0] = make_double2(y[0], y[1]); yo[1] = make_double2(y[2], y[3]); yo[2] = make_double2(y[4], y[5]);
             }
-            for (int pq = P0 + ln + 64; pq < P1; pq += 64) {          // overflow pairs: blocks from the L2 copy
-                double y[6] = { 0, 0, 0, 0, 0, 0 };
-                for (int k = 0; k < 2; ++k) {
-                    const RowEnt re = w.row_ent[2 * pq + k];
-                    if (re.block < 0) continue;
-                    const double *B = w.blocks + (size_t)re.block * 36;
-                    const double *pv = p_lds + re.col * 6;
-                    for (int a = 0; a < 6; ++a)
+            if (OVERFLOW) for (int pq = P0 + ln + 64; pq < P1; pq += 64) {          // overflow pairs: oriented blocks from the L2 copy
+                const int c0 = w.row_ent[2 * pq].col * 6, c1 = w.row_ent[2 * pq + 1].col * 6;
+                const double2 *B = reinterpret_cast<const double2 *>(w.blocks_ov + (size_t)(2 * pq) * 36);
+                const double2 *pa = reinterpret_cast<const double2 *>(p_lds + c0);
+                const double2 *pb = reinterpret_cast<const double2 *>(p_lds + c1);
+                const double2 a0 = pa[0], a1 = pa[1], a2 = pa[2], c0v = pb[0], c1v = pb[1], c2v = pb[2];
+                double y[6];
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) y[a] += (re.transposed ? B[q * 6 + a] : B[a * 6 + q]) * pv[q];
+                for (int a = 0; a < 6; ++a) {
+                    const double2 u0 = B[3 * a], u1 = B[3 * a + 1], u2 = B[3 * a + 2];
+                    const double2 v0 = B[18 + 3 * a], v1 = B[18 + 3 * a + 1], v2 = B[18 + 3 * a + 2];
+                    y[a] = (u0.x * a0.x + u0.y * a0.y + u1.x * a1.x + u1.y * a1.y + u2.x * a2.x + u2.y * a2.y) +
+                           (v0.x * c0v.x + v0.y * c0v.y + v1.x * c1v.x + v1.y * c1v.y + v2.x * c2v.x + v2.y * c2v.y);
                 }
-                for (int a = 0; a < 6; ++a) ypart[pq * 6 + a] = y[a];
+                double2 *yo = reinterpret_cast<double2 *>(ypart + pq * 6);
+                yo[0] = make_double2(y[0], y[1]); yo[1] = make_double2(y[2], y[3]); yo[2] = make_double2(y[4], y[5]);
             }
             SEG_STAMP(2);
             wave_lds_sync();
@@ -583,13 +601,16 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
 
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_pcg_rows, dim3(pp.use_coarse == 1 ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
+    if (pp.overflow) hipLaunchKernelGGL(k_pcg_rows<true>, dim3(pp.use_coarse == 1 ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
+    else hipLaunchKernelGGL(k_pcg_rows<false>, dim3(pp.use_coarse == 1 ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
     return hipGetLastError();
 }
 
 hipError_t configure_pcg_rows()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_rows), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 }
 
 }  // namespace movba
