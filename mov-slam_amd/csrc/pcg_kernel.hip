@@ -149,20 +149,45 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 
     // ---- overflow only: materialise S in L2 for the list tails that do not fit in VGPRs ----
     if (OVERFLOW) {
-        for (int idx = tid; idx < w.npairs * 36; idx += kT) {
-            const int pr = idx / 36, k = idx - pr * 36;
-            const double v = s_block_elem(part, pr, w.pair_item_start[pr], w.pair_item_start[pr + 1], k / 6, k % 6, lambda, nf);
-            w.blocks[idx] = v;
-        }
-        __syncthreads();
-        // oriented copies of the tail entries (those beyond the wave's 64 VGPR-resident pairs), so that the mat-vec reads
-        // them with wide row-major loads and no per-element orientation test
-        for (int e = 2 * (P0 + 64) + ln; e < 2 * P1; e += 64) {
-            const RowEnt re = w.row_ent[e];
-            double *dst = w.blocks_ov + (size_t)e * 36;
-            for (int q = 0; q < 36; ++q) {
-                const int a = q / 6, b = q - a * 6;
-                dst[q] = re.block < 0 ? 0.0 : w.blocks[(size_t)re.block * 36 + (re.transposed ? b * 6 + a : q)];
+        // oriented copies of the wave's tail entries (those beyond its 64 VGPR-resident pairs), summed straight from the
+        // work-item partials, 8 elements per lane in flight: the mat-vec reads them with wide row-major loads
+        const int e0 = 2 * (P0 + 64), ntail = max(2 * P1 - e0, 0) * 36;
+        for (int base = ln; base < ntail; base += 8 * 64) {
+            int q[8], src[8], hu[8], i0[8], i1[8], pr[8];
+            double sv[8], hv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = min(base + 64 * u, ntail - 1);
+                const int e = e0 + idx / 36;
+                q[u] = idx - (idx / 36) * 36;
+                const RowEnt re = w.row_ent[e];
+                const int a = q[u] / 6, b = q[u] - a * 6;
+                pr[u] = re.block;
+                src[u] = re.transposed ? b * 6 + a : q[u];
+                hu[u] = 42 + (a <= b ? ut6(a, b) : ut6(b, a));
+                i0[u] = re.block >= 0 ? w.pair_item_start[re.block] : 0;
+                i1[u] = re.block >= 0 ? w.pair_item_start[re.block + 1] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double *rec = part + (size_t)i0[u] * kPartStride;
+                sv[u] = i1[u] > i0[u] ? rec[src[u]] : 0.0;
+                hv[u] = (i1[u] > i0[u] && pr[u] < nf) ? rec[hu[u]] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                for (int itx = i0[u] + 1; itx < i1[u]; ++itx) {
+                    const double *rec = part + (size_t)itx * kPartStride;
+                    sv[u] += rec[src[u]];
+                    if (pr[u] < nf) hv[u] += rec[hu[u]];
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + 64 * u;
+                if (idx < ntail) {
+                    const bool dg = pr[u] >= 0 && pr[u] < nf;
+                    w.blocks_ov[(size_t)e0 * 36 + idx] = dg ? (hv[u] + (q[u] % 7 == 0 ? lambda : 0.0)) - sv[u] : -sv[u];
+                }
             }
         }
         __syncthreads();
