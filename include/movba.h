@@ -155,6 +155,10 @@ typedef struct {
     int32_t pcg_overflow;       /* 1: some gather-list tails are read from an L2 copy          */
     int32_t pcg_max_wave_entries; /* largest number of gather entries dealt to one wave       */
     int32_t n_row_entries;      /* gather-list entries incl. padding                          */
+    int32_t n_sched_slots;      /* slots of the schur launch schedule (8 XCD segments)        */
+    int32_t sched_items;        /* work items found in the schedule (must equal n_items)      */
+    int32_t sched_max_permille; /* heaviest XCD segment / mean segment weight, x1000          */
+    int32_t slots_ok;           /* pose-major edge slots are a bijection onto 0..E_free-1     */
 } movba_structure_info;
 int  movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info,
                            int32_t *edge_perm /* E or NULL */, int32_t *free_index /* n_poses or NULL */);

@@ -247,6 +247,26 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
                 info->pcg_max_wave_entries = std::max(info->pcg_max_wave_entries, s.row_ptr[pp.wave_row0[wv + 1]] - s.row_ptr[pp.wave_row0[wv]]);
         }
     }
+    {   // launch schedule and pose-major slots: self-checks reported to the caller (CPU tests)
+        info->n_sched_slots = (int32_t)s.sched.size(); info->sched_items = 0; info->sched_max_permille = 0; info->slots_ok = 1;
+        std::vector<uint8_t> seen(s.nitems > 0 ? s.nitems : 1, 0);
+        int64_t segw[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tot = 0;
+        for (size_t k = 0; k < s.sched.size(); ++k) {
+            const SchedItem &it = s.sched[k];
+            if (it.tag < 0) continue;
+            const int item = it.tag >> 1;
+            if (item >= s.nitems || seen[item] || s.items[item].begin != it.begin || s.items[item].end != it.end) { info->sched_items = -1; break; }
+            seen[item] = 1; info->sched_items++;
+            const int64_t wgt = (int64_t)(it.end - it.begin) * ((it.tag & 1) ? 3 : 2) + 128;
+            if (s.sched_per_xcd > 0) segw[k / s.sched_per_xcd] += wgt;
+            tot += wgt;
+        }
+        if (tot > 0) { int64_t mx = 0; for (int64_t v : segw) mx = std::max(mx, v); info->sched_max_permille = (int32_t)(mx * 8000 / tot); }
+        int64_t nfree_edges = 0;
+        for (int32_t v : s.slot) nfree_edges += v >= 0;
+        std::vector<uint8_t> hit((size_t)nfree_edges + 1, 0);
+        for (int32_t v : s.slot) if (v >= 0) { if (v >= nfree_edges || hit[v]) { info->slots_ok = 0; break; } hit[v] = 1; }
+    }
     if (edge_perm) {
         if (s.perm.empty()) for (int e = 0; e < s.E; ++e) edge_perm[e] = e;       // already grouped: identity
         else std::memcpy(edge_perm, s.perm.data(), sizeof(int32_t) * s.perm.size());

@@ -63,7 +63,8 @@ class Profile(C.Structure):
 class StructureInfo(C.Structure):
     _fields_ = [("n_free", C.c_int32), ("n_pairs", C.c_int32), ("n_entries", C.c_int64), ("n_items", C.c_int32),
                 ("max_degree", C.c_int32), ("already_grouped", C.c_int32), ("pcg_on_chip", C.c_int32),
-                ("pcg_overflow", C.c_int32), ("pcg_max_wave_entries", C.c_int32), ("n_row_entries", C.c_int32)]
+                ("pcg_overflow", C.c_int32), ("pcg_max_wave_entries", C.c_int32), ("n_row_entries", C.c_int32),
+                ("n_sched_slots", C.c_int32), ("sched_items", C.c_int32), ("sched_max_permille", C.c_int32), ("slots_ok", C.c_int32)]
 
 
 class PoseDesc(C.Structure):
@@ -158,7 +159,8 @@ def structure_probe(w):
     return dict(status=rc, n_free=info.n_free, n_pairs=info.n_pairs, n_entries=info.n_entries, n_items=info.n_items,
                 max_degree=info.max_degree, already_grouped=bool(info.already_grouped), pcg_on_chip=bool(info.pcg_on_chip),
                 pcg_overflow=bool(info.pcg_overflow), pcg_max_wave_entries=info.pcg_max_wave_entries,
-                n_row_entries=info.n_row_entries, perm=perm, free_index=fidx)
+                n_row_entries=info.n_row_entries, n_sched_slots=info.n_sched_slots, sched_items=info.sched_items,
+                sched_max_permille=info.sched_max_permille, slots_ok=bool(info.slots_ok), perm=perm, free_index=fidx)
 
 
 class Solver:

@@ -26,7 +26,7 @@ def test_ctypes_struct_sizes_match_header_layout(built_lib):
     # int32 x3 (+pad) | 7 pointers | 6 doubles | 2 int32 + u32 (+pad) | pointer
     assert ctypes.sizeof(built_lib.LbaDesc) == 16 + 7 * 8 + 6 * 8 + 16 + 8 + 16
     assert ctypes.sizeof(built_lib.Options) == 24
-    assert ctypes.sizeof(built_lib.StructureInfo) == 48
+    assert ctypes.sizeof(built_lib.StructureInfo) == 64
 
 
 def _np_structure(w):
@@ -56,6 +56,21 @@ def test_structure_probe_matches_numpy(built_lib, name):
     assert s["n_free"] == (hidx >= 0).sum() and s["n_entries"] == n_entries and s["n_pairs"] == n_pairs
     assert np.array_equal(s["perm"], np.arange(w.n_edges))
     assert s["max_degree"] == np.bincount(w.edge_point).max()
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 20, 2, 3), (10, 2, 2000, 2, 6), (50, 10, 20000, 2, 10), (6, 2, 6000, 8, 8), (40, 4, 3000, 10, 30)])
+def test_schur_launch_schedule_and_pose_major_slots(built_lib, shape):
+    """Host plan of the schur pass: every work item sits in exactly one slot of the 8 XCD segments, the segments carry
+    about the same estimated work, and the pose-major edge slots are a bijection onto the free keyframes' edges."""
+    K, F, P, lo, hi = shape
+    w = synth.make_window(K, F, P, seed=5, run_lo=lo, run_hi=hi)
+    s = built_lib.structure_probe(w)
+    assert s["status"] == 0 and s["slots_ok"]
+    assert s["sched_items"] == s["n_items"] and s["n_sched_slots"] % 8 == 0 and s["n_sched_slots"] >= s["n_items"]
+    if s["n_items"] >= 64:          # enough items to balance: the heaviest XCD segment is within 25 % of the mean
+        assert s["sched_max_permille"] <= 1250, s["sched_max_permille"]
+    # diagonal pairs are cut finer than off-diagonal ones, never below one item per pair
+    assert s["n_items"] >= s["n_pairs"]
 
 
 def test_structure_probe_groups_shuffled_edges_stably(built_lib):
