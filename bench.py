@@ -166,6 +166,14 @@ def main():
                                    "note": "whole LM iteration (all kernels + launch gaps); latency-bound, not bandwidth-bound"},
                          "kernel_ms_per_step_all_classes": {k: v["ms"] for k, v in prof_all.items()}},
         }
+        if world == 1:
+            # for information only (never `value`): the whole movba_lba_solve call with host buffers in and out
+            # (host structure pass + H2D + solve + D2H), median of 10
+            ts = []
+            for _ in range(10):
+                t1 = time.perf_counter(); solver.solve(w); ts.append(time.perf_counter() - t1)
+            ts.sort()
+            out["config"]["pcie_and_structure_inclusive_ms_per_window_solve"] = 1e3 * ts[len(ts) // 2]
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle                       # CPU baseline leg: the oracle as the timed "port"
             oracle.build()
