@@ -188,6 +188,24 @@ def main():
                                    "sample": f"{n} full solves of the same window ({solves} LM iterations, {el:.1f} s), "
                                              "single-threaded restated-g2o oracle (oracle/lba_oracle.c, -O3 -march=native)",
                                    "host_cpus": os.cpu_count(), "ms_per_window_solve": 1e3 * el / n}
+            # context: the same restatement with its edge loops spread over the host cores of this box's share
+            # (OpenMP build; the dense Cholesky stays serial).  g2o as the reference builds it is single-threaded, so the
+            # figure above stays THE baseline.
+            try:
+                ncore = oracle.set_omp_threads(min(16, oracle.host_core_share()))      # (torch's OpenMP runtime is already up: the environment variable would be ignored)
+                oracle.solve(w, omp=True)                   # thread pool start-up
+                n2, solves2, t2 = 0, 0, time.perf_counter()
+                while True:
+                    o2 = oracle.solve(w, omp=True)
+                    n2 += 1; solves2 += o2["n_solves"]
+                    el2 = time.perf_counter() - t2
+                    if el2 >= min(args.cpu_seconds, 5.0) or n2 >= 200:
+                        break
+                out["cpu_baseline_all_cores"] = {"value": solves2 / el2, "unit": "LM iterations/s", "cores": ncore,
+                                                 "kind": "port-openmp", "ms_per_window_solve": 1e3 * el2 / n2,
+                                                 "sample": f"{n2} full solves ({el2:.1f} s), OpenMP build of the same oracle source"}
+            except Exception as exc:                        # context only: never fail the bench for it
+                out["cpu_baseline_all_cores"] = {"error": str(exc)}
             # parity spot-check of what was timed
             out["config"]["parity_vs_oracle"] = {
                 "pose_max_abs": float(np.abs(res["poses"] - o["poses"]).max()),

@@ -14,6 +14,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ------------------------------------------------------------------------- */
 /* SE3Quat (g2o types/slam3d/se3quat.h): unit quaternion (x,y,z,w) + t       */
@@ -343,6 +346,9 @@ static double ws_errors(ws_t *w)
 {
     const lba_oracle_problem *pb = w->pb;
     double F = 0.0;
+#ifdef _OPENMP          /* all-cores variant (liblba_oracle_omp.so, timing context only): the sum order differs */
+#pragma omp parallel for reduction(+ : F) schedule(static)
+#endif
     for (int e = 0; e < pb->n_edges; ++e) {
         double Xc[3];
         lba_oracle_se3_map(w->poses + 7 * pb->edge_pose[e], w->points + 3 * pb->edge_point[e], Xc);
@@ -363,15 +369,12 @@ static double ws_errors(ws_t *w)
 
 /* BlockSolver<6,3>::buildSystem: per edge linearizeOplus + constructQuadraticForm
  * (g2o BaseBinaryEdge), sequential in edge order. */
-static void ws_build(ws_t *w)
+/* one edge of buildSystem; Hpp / bp are where the pose blocks accumulate (the workspace's, or a thread's own copy in the
+ * OpenMP variant) */
+static inline void ws_build_edge(ws_t *w, int e, double *Hpp, double *bp)
 {
     const lba_oracle_problem *pb = w->pb;
-    const int nf = w->nfree, P = pb->n_points;
-    memset(w->Hpp, 0, sizeof(double) * 36 * (size_t)nf);
-    memset(w->bp, 0, sizeof(double) * 6 * (size_t)nf);
-    memset(w->Hll, 0, sizeof(double) * 9 * (size_t)P);
-    memset(w->bl, 0, sizeof(double) * 3 * (size_t)P);
-    for (int e = 0; e < pb->n_edges; ++e) {
+    {
         const int ip = pb->edge_pose[e], l = pb->edge_point[e];
         const double *qt = w->poses + 7 * ip;
         double Xc[3], R[9], A[6], B[12];
@@ -398,7 +401,7 @@ static void ws_build(ws_t *w)
         }
         const int hi = w->hidx[ip];
         if (hi >= 0) {
-            double *Hp = w->Hpp + 36 * hi, *b_p = w->bp + 6 * hi, *Hx = w->Hpl + 18 * e;
+            double *Hp = Hpp + 36 * hi, *b_p = bp + 6 * hi, *Hx = w->Hpl + 18 * e;
             for (int a = 0; a < 6; ++a) {
                 b_p[a] += B[a] * r0 + B[6 + a] * r1 + B2[a] * r2;
                 for (int c = 0; c < 6; ++c) Hp[a * 6 + c] += wo * (B[a] * B[c] + B[6 + a] * B[6 + c] + B2[a] * B2[c]);
@@ -407,6 +410,37 @@ static void ws_build(ws_t *w)
         }
     }
 }
+
+static void ws_build(ws_t *w)
+{
+    const lba_oracle_problem *pb = w->pb;
+    const int nf = w->nfree, P = pb->n_points;
+    memset(w->Hpp, 0, sizeof(double) * 36 * (size_t)nf);
+    memset(w->bp, 0, sizeof(double) * 6 * (size_t)nf);
+    memset(w->Hll, 0, sizeof(double) * 9 * (size_t)P);
+    memset(w->bl, 0, sizeof(double) * 3 * (size_t)P);
+#ifdef _OPENMP
+    /* edge-parallel by map point (a point's block is touched by its own edges only); pose blocks go to per-thread copies */
+#pragma omp parallel
+    {
+        double *tH = (double *)calloc(36 * (size_t)nf + 36, sizeof(double)), *tb = (double *)calloc(6 * (size_t)nf + 6, sizeof(double));
+#pragma omp for schedule(static)
+        for (int l = 0; l < P; ++l)
+            for (int sidx = w->pt_start[l]; sidx < w->pt_start[l + 1]; ++sidx) ws_build_edge(w, w->pt_edges[sidx], tH, tb);
+#pragma omp critical
+        {
+            for (int k = 0; k < 36 * nf; ++k) w->Hpp[k] += tH[k];
+            for (int k = 0; k < 6 * nf; ++k) w->bp[k] += tb[k];
+        }
+        free(tH); free(tb);
+    }
+#else
+    for (int e = 0; e < pb->n_edges; ++e) ws_build_edge(w, e, w->Hpp, w->bp);
+#endif
+}
+
+static void ws_schur_point(ws_t *w, int l, double lambda, double *S, double *coef);
+static int ws_solve_tail(ws_t *w, int keep_S);
 
 /* BlockSolver::solve with Schur complement + exact reduced solve + back-substitution
  * (SURVEY A.7). lambda is added to every diagonal scalar of Hpp and Hll (setLambda). */
@@ -421,8 +455,35 @@ static int ws_solve(ws_t *w, double lambda, int keep_S)
             for (int c = 0; c < 6; ++c)
                 S[(6 * i + a) * n + 6 * i + c] = w->Hpp[36 * i + a * 6 + c] + (a == c ? lambda : 0.0);
     double *coef = (double *)calloc((size_t)n + 1, sizeof(double));
-    for (int l = 0; l < P; ++l) {
-        if (!w->pt_active[l]) continue;
+#ifdef _OPENMP
+#pragma omp parallel
+    {
+        /* per-thread copies of the reduced matrix and of B Dinv b_l, summed afterwards */
+        double *tS = (double *)calloc((size_t)n * (size_t)n + 1, sizeof(double)), *tc = (double *)calloc((size_t)n + 1, sizeof(double));
+#pragma omp for schedule(static)
+        for (int l = 0; l < P; ++l) ws_schur_point(w, l, lambda, tS, tc);
+#pragma omp critical
+        {
+            for (size_t k = 0; k < (size_t)n * (size_t)n; ++k) S[k] += tS[k];
+            for (int k = 0; k < n; ++k) coef[k] += tc[k];
+        }
+        free(tS); free(tc);
+    }
+#else
+    for (int l = 0; l < P; ++l) ws_schur_point(w, l, lambda, S, coef);
+#endif
+    for (int i = 0; i < n; ++i) w->bS[i] = w->bp[i] - coef[i];
+    free(coef);
+    return ws_solve_tail(w, keep_S);
+}
+
+/* Schur-complement contribution of map point l (and Dinv_l, kept for the back-substitution) */
+static void ws_schur_point(ws_t *w, int l, double lambda, double *S, double *coef)
+{
+    const lba_oracle_problem *pb = w->pb;
+    const int n = 6 * w->nfree;
+    {
+        if (!w->pt_active[l]) return;
         double D[9];
         memcpy(D, w->Hll + 9 * l, sizeof D);
         D[0] += lambda; D[4] += lambda; D[8] += lambda;
@@ -455,8 +516,14 @@ static int ws_solve(ws_t *w, double lambda, int keep_S)
             }
         }
     }
-    for (int i = 0; i < n; ++i) w->bS[i] = w->bp[i] - coef[i];
-    free(coef);
+}
+
+/* exact reduced solve + back-substitution */
+static int ws_solve_tail(ws_t *w, int keep_S)
+{
+    const lba_oracle_problem *pb = w->pb;
+    const int nf = w->nfree, n = 6 * nf, P = pb->n_points;
+    double *S = w->S;
     int ok = 1;
     if (n > 0) {
         double *Sw = S;
@@ -468,6 +535,9 @@ static int ws_solve(ws_t *w, double lambda, int keep_S)
         if (keep_S) free(Sw);
     }
     if (!ok) return 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int l = 0; l < P; ++l) {
         double *x = w->xl + 3 * l;
         x[0] = x[1] = x[2] = 0.0;
@@ -773,4 +843,17 @@ int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
     memcpy(pose_out, pose, sizeof pose);
     free(err); free(level1);
     return n - n_bad;
+}
+
+/* OpenMP build only (liblba_oracle_omp.so): number of threads of the all-cores timing variant; returns what is in force
+ * (1 in the serial library). */
+int lba_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }

@@ -123,6 +123,9 @@ typedef struct {
 int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
                         uint8_t *outlier, double *chi2);
 
+/* threads of the OpenMP timing variant (liblba_oracle_omp.so); the serial library always answers 1 */
+int lba_oracle_set_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif

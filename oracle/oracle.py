@@ -50,12 +50,15 @@ class _PoseProblem(C.Structure):
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "lba_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    omp = os.path.join(_HERE, "liblba_oracle_omp.so")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src) or not os.path.exists(omp) \
+            or os.path.getmtime(omp) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB
 
 
 _lib = None
+_lib_omp = None
 
 
 def lib():
@@ -66,6 +69,32 @@ def lib():
         _lib.lba_oracle_linearize.restype = C.c_int
         _lib.lba_oracle_pose_opt.restype = C.c_int
     return _lib
+
+
+def lib_omp():
+    """The OpenMP build of the same source (all host cores): timing context only, never the parity reference."""
+    global _lib_omp
+    if _lib_omp is None:
+        build()
+        _lib_omp = C.CDLL(os.path.join(_HERE, "liblba_oracle_omp.so"))
+        _lib_omp.lba_oracle_solve.restype = C.c_int
+        _lib_omp.lba_oracle_set_threads.restype = C.c_int
+    return _lib_omp
+
+
+def host_core_share() -> int:
+    """CPUs this process may really use: the cgroup quota when there is one, else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(float(quota) / float(period)))
+    except (OSError, ValueError):
+        pass
+    return len(os.sched_getaffinity(0))
+
+
+def set_omp_threads(n: int) -> int:
+    return lib_omp().lba_oracle_set_threads(int(n))
 
 
 def _p(a, t):
@@ -98,14 +127,15 @@ def _problem(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0)
     return pb, keep
 
 
-def solve(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0) -> dict:
-    """Optimizer::LocalBundleAdjustment's solve + outlier gate on a flattened window."""
+def solve(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0, omp=False) -> dict:
+    """Optimizer::LocalBundleAdjustment's solve + outlier gate on a flattened window.
+    omp=True runs the OpenMP build (all host cores, OMP_NUM_THREADS): timing context only."""
     pb, keep = _problem(w, stale_error_quirk, stop, max_iters, max_trials)
     poses = np.zeros((w.n_poses, 7)); points = np.zeros((w.n_points, 3))
     chi2 = np.zeros(w.n_edges); outlier = np.zeros(w.n_edges, np.uint8)
     res = _Result()
     res.poses = _p(poses, _d); res.points = _p(points, _d); res.chi2 = _p(chi2, _d); res.outlier = _p(outlier, _u)
-    status = lib().lba_oracle_solve(C.byref(pb), C.byref(res))
+    status = (lib_omp() if omp else lib()).lba_oracle_solve(C.byref(pb), C.byref(res))
     n = res.n_trace
     return dict(status=status, poses=poses, points=points, chi2=chi2, outlier=outlier,
                 iters_done=res.iters_done, n_solves=res.n_solves, n_outliers=res.n_outliers,

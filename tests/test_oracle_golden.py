@@ -30,3 +30,14 @@ def test_oracle_matches_golden(oracle_mod, name):
 def test_hard_case_has_rejected_trials():
     _, g = load_golden("lba_hard")
     assert (g["tr_accept"] == 0).sum() >= 3      # the fixture must exercise pop() / lambda growth
+
+
+@pytest.mark.parametrize("name", ["lba_small", "lba_hard", "lba_stereo"])
+def test_openmp_build_of_the_oracle_agrees_with_the_serial_one(oracle_mod, name):
+    """bench.py times the OpenMP build for context only; its sums run in a different order, nothing else differs."""
+    w, _ = load_golden(name)
+    a, b = oracle_mod.solve(w), oracle_mod.solve(w, omp=True)
+    assert np.array_equal(a["trace"]["accept"], b["trace"]["accept"]) and a["n_solves"] == b["n_solves"]
+    np.testing.assert_allclose(b["poses"], a["poses"], atol=1e-10)
+    np.testing.assert_allclose(b["points"], a["points"], atol=1e-9)
+    assert np.array_equal(a["outlier"], b["outlier"])
