@@ -456,7 +456,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
     const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
     const size_t o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s.row_ent.size() * 36 + 2 : 2);
-    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(2 * kCoarseDim * kCoarseDim), o_acitag = c.take<int32_t>(2);
+    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2), o_acitag = c.take<int32_t>(2);
     const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
     const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
@@ -543,7 +543,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c); w.blocks_ov = reinterpret_cast<double *>(a + o_blocks_ov);
-    w.aci = reinterpret_cast<double *>(a + o_aci); w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
+    w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev;

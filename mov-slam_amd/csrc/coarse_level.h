@@ -21,9 +21,13 @@
 
 namespace movba {
 
+#ifndef MOVBA_COARSE_EXTRAPOLATE
+#define MOVBA_COARSE_EXTRAPOLATE 1
+#endif
+
 // sm: >= kNC*kNC + 5*kNC + 8 doubles + 2 ints per coarse term (= gather-list entry) of LDS; 512 threads
 template <int kT, int kNC, int kPA>
-__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm)
+__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm, bool extrapolate)
 {
     double *Ac = sm;
     double *gj = Ac + kNC * kNC;
@@ -158,6 +162,36 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
         if (nrows == 0 || (d == 1 && nrows < 2)) Ac[tid * kNC + tid] = 1.0;
     }
     __syncthreads();
+    // ---- the inverse is for the NEXT trial, whose matrix is not this one: lambda will most likely be a third of today's
+    // (OptimizationAlgorithmLevenberg's factor after a good step), and the weakly constrained modes of S scale with
+    // lambda.  Model A_c(lambda) as affine through this build and the previous one and invert the prediction
+    // A + gamma (A - A_prev), gamma = (lambda/3 - lambda) / (lambda - lambda_prev) clamped to [-1, 1/3]  (gamma < 0: a convex
+    // combination; gamma = 1/3 stays positive definite while A > A_prev / 4, and a lost pivot only costs the coarse level
+    // for one trial).  cfg3: 247 -> ~215 CG iterations per window solve.  Not in fresh mode (the matrix is this trial's). ----
+    if (extrapolate) {
+        double *prev = w.ac_prev;
+        const double lam_prev = prev[kNC * kNC], trial_prev = prev[kNC * kNC + 1];
+        double gamma = 0.0;
+        if (trial >= 1 && trial_prev == (double)(trial - 1) && lambda != lam_prev && MOVBA_COARSE_EXTRAPOLATE) {
+            gamma = (lambda * (1.0 / 3.0) - lambda) / (lambda - lam_prev);
+            gamma = fmin(fmax(gamma, -1.0), 1.0 / 3.0);
+            if (!isfinite(gamma)) gamma = 0.0;
+        }
+        constexpr int kPer = kNC * kNC / kT;
+        static_assert(kPer * kT == kNC * kNC, "one pass");
+        double pv[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) pv[u] = prev[tid + u * kT];
+        __syncthreads();        // lambda / trial of the previous build have been read by everyone
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+            const double a = Ac[tid + u * kT];
+            prev[tid + u * kT] = a;
+            if (gamma != 0.0) Ac[tid + u * kT] = a + gamma * (a - pv[u]);    // (the first build of a solve finds stale memory in prev)
+        }
+        if (tid == 0) { prev[kNC * kNC] = lambda; prev[kNC * kNC + 1] = (double)trial; }
+        __syncthreads();
+    }
 
     COARSE_STAMP(3);
     // ---- Gauss-Jordan inverse of the symmetrically scaled matrix D A_c D (unit diagonal), the matrix held in REGISTERS:

@@ -97,6 +97,7 @@ struct DevWindow {
     double *blocks_c;   // npairs x 36: the coarse-level workgroup's own copy of S (coarse_level.h)
     double *aci;        // 2 x kCoarseDim x kCoarseDim: inverse coarse matrices (by trial parity)
     int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable
+    double *ac_prev;    // kCoarseDim^2 + 2: coarse matrix of the previous build, then its lambda and its trial (coarse_level.h)
     double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first
     double *bp;         // 6 nfree
     double *xp;         // 6 nfree

@@ -48,6 +48,7 @@ __global__ void k_init_pose(DevWindow w)
         c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
+        w.ac_prev[kCoarseDim * kCoarseDim + 1] = -1.0;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
         for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; for (int q = 0; q < 8; ++q) c->dbg_wseg[k][q] = 0; }
     }

@@ -103,10 +103,10 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     // is built FIRST, by this workgroup, from THIS trial's matrix, and the solve below converges in a couple of iterations
     const bool fresh = pp.use_coarse == 2;
     if (fresh) {
-        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm);
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false);
         __syncthreads();
     } else if (blockIdx.x == 1) {   // second workgroup: coarse level of THIS trial's matrix, for the next trial
-        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm);
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true);
         return;
     }
     const double *part = w.part;
