@@ -40,7 +40,7 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
 #else
 #define COARSE_STAMP(k) do { } while (0)
 #endif
-    const double *part = w.part;
+    const double *part = w.part, *part_ = part;
     double *blocks = w.blocks_c;
     if (tid == 0) s_bad = 0;
     for (int idx = tid; idx < kNC * kNC; idx += kT) Ac[idx] = 0.0;
@@ -108,13 +108,19 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     for (int q = tid; q < w.cblk_ptr[w.n_cblk]; q += kT) { tent[q] = w.cblk_ent[q]; tij[q] = w.cblk_ij[q]; }
     __syncthreads();
     // Thread (cb, a) owns row a of coarse block cb = (g, h) in all four mode combinations: it walks the block's term
-    // list once (8 terms = 48 gathers in flight), so no thread pads its list to a longer neighbour's.
-    for (int wi = tid; wi < w.n_cblk * 6; wi += kT) {
-        const int cb = wi / 6, a = wi - cb * 6;
+    // list once (8 terms = 48 gathers in flight), so no thread pads its list to a longer neighbour's.  When there are
+    // threads to spare (n_cblk * 12 <= 512: always with 8 aggregates) two threads share a row: the first takes the front
+    // of the list (whole batches of 8), the second the rest, and the second's sums are added after the first's are stored.
+    const int nw = w.n_cblk * 6;
+    const bool split = 2 * nw <= kT;
+    auto walk = [&](int cb, int a, int part, double (&s00)[6], double (&s01)[6], double (&s10)[6], double (&s11)[6]) {
         const int g = w.cblk_g[cb], h = w.cblk_h[cb];
         const double cg = aggc[g], ch = aggc[h], ig = aggc[kNC / kPA + g], ih = aggc[kNC / kPA + h];
-        const int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
-        double s00[6], s01[6], s10[6], s11[6];
+        int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
+        if (split) {
+            const int n = t1 - t0, front = min(n, (((n + 1) >> 1) + 7) & ~7);
+            if (part == 0) t1 = t0 + front; else t0 += front;
+        }
 #pragma unroll
         for (int m = 0; m < 6; ++m) s00[m] = s01[m] = s10[m] = s11[m] = 0.0;
         for (int t = t0; t < t1; t += 8) {
@@ -125,7 +131,7 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int e = pk[u];
-                const double *src = (e & 1) ? part + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
+                const double *src = (e & 1) ? part_ + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
                 // row a of the (possibly transposed) fine block
                 const int o0 = (e & 2) ? a : a * 6, st = (e & 2) ? 6 : 1;
 #pragma unroll
@@ -143,9 +149,30 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
                 }
             }
         }
-        double *dst = Ac + (g * kPA + a) * kNC + h * kPA;
+        return Ac + (g * kPA + a) * kNC + h * kPA;
+    };
+    if (split) {
+        const bool active = tid < 2 * nw;
+        const int half = tid >= nw, wi = tid - half * nw;
+        double s00[6], s01[6], s10[6], s11[6];
+        double *dst = nullptr;
+        if (active) dst = walk(wi / 6, wi - (wi / 6) * 6, half, s00, s01, s10, s11);
+        if (active && !half) {
 #pragma unroll
-        for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
+            for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
+        }
+        __syncthreads();
+        if (active && half) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { dst[m] += s00[m]; dst[6 + m] += s01[m]; dst[6 * kNC + m] += s10[m]; dst[6 * kNC + 6 + m] += s11[m]; }
+        }
+    } else {
+        for (int wi = tid; wi < nw; wi += kT) {
+            double s00[6], s01[6], s10[6], s11[6];
+            double *dst = walk(wi / 6, wi - (wi / 6) * 6, 0, s00, s01, s10, s11);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
+        }
     }
     __syncthreads();
     // dofs without support (an aggregate with no rows; the linear modes of an aggregate with a single row): identity
