@@ -7,9 +7,11 @@
 // linearly with the keyframe index; 96 x 96), inverts it by Gauss-Jordan in LDS and leaves A_c^-1 in HBM.
 // The linear modes matter: late LM iterations (small lambda) are dominated by smooth bending of the
 // trajectory between the fixed keyframes, which piecewise-constant modes resolve poorly: cfg3 needs
-// 397 CG iterations per window solve with the 6 constant modes alone and ~235 with the 12.
-// Its result preconditions trial t+1 (a preconditioner need not be exact: a one-trial-old coarse
-// inverse costs ~3 % more CG iterations than a fresh one, and block-Jacobi alone ~2.3x more).
+// 397 CG iterations per window solve with the 6 constant modes alone and 247 with the 12.
+// Its result preconditions trial t+1.  A preconditioner need not be exact, but a one-trial-old coarse matrix
+// costs ~30 % more CG iterations than a fresh one (lambda drops to a third per good step and the weakly
+// constrained modes follow it), so what is inverted is a PREDICTION of trial t+1's matrix from this build and
+// the previous one (below): 215 iterations, against ~185 with fresh matrices and ~870 with block-Jacobi alone.
 // Everything in fixed order, so the lagged preconditioner is as reproducible as the rest of the solve.
 // (A separate kernel on a side stream did the same job at first: the two cross-stream event waits per
 // trial cost ~10 us of idle time on the LM chain, rocprofv3 kernel trace.)

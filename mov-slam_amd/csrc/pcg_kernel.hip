@@ -20,7 +20,7 @@
 //     rows of one wave form an aggregate with 12 coarse dofs (the 6 pose components constant over the aggregate
 //     and varying linearly with the keyframe index); A_c^-1 (96 x 96, kept in LDS as fp32) comes from the
 //     previous trial (built by the SECOND workgroup of that launch, coarse_level.h, beside the CG) and removes
-//     the smooth drift / bending modes block-Jacobi cannot see: 869 -> 247 CG iterations per cfg3 window solve.
+//     the smooth drift / bending modes block-Jacobi cannot see: 869 -> 215 CG iterations per cfg3 window solve.
 //     A window with at most one keyframe per wave builds the (then exact) inverse first and solves in ~3 iterations;
 //   * single-reduction conjugate gradients (Chronopoulos & Gear): per iteration 2 workgroup barriers and ONE pair of
 //     DPP wave reductions; each wave's coarse correction follows a recurrence, its dense product runs behind the
