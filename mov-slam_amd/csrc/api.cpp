@@ -571,7 +571,7 @@ int movba_lba_run(movba_handle *h)
     if (h->stop && *h->stop) { h->early_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
     const DevWindow &w = h->win;
     hipStream_t s = h->stream;
-    h->hstat->trials_done = 0; h->hstat->done = 0; h->hstat->stop = 0; h->hstat->it = 0;
+    h->hstat->progress = 0; h->hstat->stop = 0;
 
     {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
         ScopedEvents ev(h, KC_SETUP);
@@ -605,13 +605,13 @@ int movba_lba_run(movba_handle *h)
         // stay at most run_ahead trial sets ahead of the device, and never further than the outer iterations that are
         // left: with R iterations to go at most R more trials run unless one is rejected, so the sets queued beyond that
         // would almost always be no-op launches (~5 us each) at the end of the solve
-        // (trials_done is read before done and it: k_decide publishes them in the opposite order)
+        // (k_decide publishes trials_done, it and done as one word)
         bool finished = false;
         for (;;) {
-            const int td = h->hstat->trials_done;
-            std::atomic_thread_fence(std::memory_order_acquire);
-            if (h->hstat->done) { finished = true; break; }
-            const int left = w.max_iters - h->hstat->it;
+            const uint64_t pg = h->hstat->progress;
+            const int td = (int)(pg & 0xffffff), it_done = (int)((pg >> 24) & 0xffffff);
+            if ((pg >> 48) & 1) { finished = true; break; }
+            const int left = w.max_iters - it_done;
             const int limit = left < h->opt.run_ahead ? (left > 1 ? left : 1) : h->opt.run_ahead;
             if (t - td < limit) break;
             if (final_after != t && t - td < h->opt.run_ahead) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }

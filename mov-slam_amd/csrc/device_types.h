@@ -56,10 +56,16 @@ struct Ctrl {
 // Written by k_decide into pinned host memory so the host can keep the queue fed
 // without a stream synchronise per trial.
 struct HostStatus {
-    volatile int32_t trials_done;
-    volatile int32_t done;
+    // device -> host, ONE word so that one store (one PCIe write acknowledgement) publishes a consistent triple:
+    // bits 0-23 trials_done, 24-47 completed outer LM iterations (the host does not queue trials past the last possible
+    // one), bit 48 done
+    volatile uint64_t progress;
     volatile int32_t stop;      // host -> device: forceStopFlag seen by the host poll
-    volatile int32_t it;        // completed outer LM iterations (the host does not queue trials past the last possible one)
+    int32_t pad;
+    static constexpr uint64_t pack(int trials_done, int it, int done)
+    {
+        return (uint64_t)(uint32_t)trials_done | ((uint64_t)(uint32_t)it << 24) | ((uint64_t)(done ? 1 : 0) << 48);
+    }
 };
 
 struct DevWindow {

@@ -837,22 +837,30 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp, 
 __global__ __launch_bounds__(64) void k_decide(DevWindow w)
 {
     Ctrl *c = w.ctrl;
-    if (c->done) return;
     const int lane = threadIdx.x;
+    // Lane-strided partial sums, loads issued 10 deep (a plain loop would pay one round trip per term; 10 x 64 covers
+    // cfg3's 625 blocks in one round).  The kernel is a chain of memory round trips (the launch boundary has just
+    // invalidated the L2), so the first round is requested before anything of Ctrl is known: the cost partials of BOTH
+    // states, and before the `done` test.
+    constexpr int kDeep = 10;
+    double f0[kDeep], f1[kDeep], sv[kDeep];
+    auto request = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
+            f0[u] = w.st[0].Fpart[k]; f1[u] = w.st[1].Fpart[k]; sv[u] = w.scale_part[k];
+        }
+    };
+    request(lane);
+    if (c->done) return;
     const int cur = c->cur;
     double F1 = 0.0, scale = 0.0;
-    // lane-strided partial sums, loads issued 8 deep (a plain loop would pay one L2 round trip per term)
-    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * 8) {
-        double fv[8], sv[8];
+    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * kDeep) {
+        if (k0 != lane) request(k0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
-            fv[u] = w.st[cur ^ 1].Fpart[k]; sv[u] = w.scale_part[k];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kDeep; ++u) {
             const bool in = k0 + 64 * u < w.n_pt_blocks;
-            F1 += in ? fv[u] : 0.0; scale += in ? sv[u] : 0.0;
+            F1 += in ? (cur ? f0[u] : f1[u]) : 0.0; scale += in ? sv[u] : 0.0;
         }
     }
     F1 = wave_sum(F1);
@@ -901,10 +909,9 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
         }
     }
     c->done = done;
-    // `done` and `it` first, the trial counter last (release): a host that sees trial n counted also sees whether it was the last
-    __hip_atomic_store(&w.hstat->it, c->it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&w.hstat->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&w.hstat->trials_done, c->n_solves, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // one word, one store: the host sees a consistent (trials_done, it, done), and the launch ends behind ONE write
+    // acknowledgement from host memory instead of a chain of them
+    __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // --------------------------------------------------------------------------------
