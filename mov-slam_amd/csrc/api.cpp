@@ -51,6 +51,8 @@ struct movba_handle {
     HostStatus *hstat = nullptr;        // pinned, mapped
     HostStatus *hstat_dev = nullptr;
     Ctrl *ctrl_host = nullptr;          // pinned copy of the device Ctrl
+    Ctrl *ctrl_host_dev = nullptr;      // its device view (written by k_finalize)
+    char *stage_dev = nullptr;          // device view of the pinned staging buffer (written by k_export)
     // current window
     bool uploaded = false, ran = false;
     Structure st;
@@ -148,7 +150,8 @@ int ensure_stage(movba_handle *h, size_t bytes)
     if (bytes <= h->stage_cap) return MOVBA_OK;
     if (h->stage) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipHostFree(h->stage)); h->stage = nullptr; h->stage_cap = 0; }
     const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->stage), cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->stage), cap, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->stage_dev), h->stage, 0));
     h->stage_cap = cap;
     return MOVBA_OK;
 }
@@ -203,7 +206,8 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     }
     if (hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&h->ctrl_host_dev), h->ctrl_host, 0) != hipSuccess ||
         configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess) {
         movba_destroy(h);
         return MOVBA_ERR_HIP;
@@ -502,8 +506,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
         HIP_TRY(launch_struct_fill(sd, h->stream));
     }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    lap("pair H2D + fill kernel + sync");
+    // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were
+    // copied to the staging buffer already (the next upload synchronises before it refills it)
+    lap("pair H2D + fill kernel (queued)");
     h->prof.upload_ms += now_ms() - t2 + upload_host_ms;
     h->h2d_bytes = h2d;
 
@@ -546,7 +551,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
-    w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev;
+    w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev; w.ctrl_out = h->ctrl_host_dev;
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     h->uploaded = true;
     return MOVBA_OK;
@@ -596,8 +601,7 @@ int movba_lba_run(movba_handle *h)
     // end of the solve does not wait for a host round trip; a later trial simply queues them again
     int t = 0, final_after = -1;
     auto queue_finalize = [&]() -> int {
-        { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }
-        HIP_TRY(hipMemcpyAsync(h->ctrl_host, w.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+        { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }        // (also writes Ctrl to h->ctrl_host)
         final_after = t;
         return MOVBA_OK;
     };
@@ -663,14 +667,20 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     const double t0 = now_ms();
     const DevWindow &w = h->win;
     const Ctrl &c = *h->ctrl_host;
-    const int cur = c.cur;
     const size_t nb_pose = sizeof(double) * 7 * (size_t)w.NP, nb_pt = sizeof(double) * 3 * (size_t)w.P, nb_chi = sizeof(double) * (size_t)w.E;
     char *sg = h->stage;
     const size_t o_pose = 0, o_pt = align_up(nb_pose, 256), o_chi = o_pt + align_up(nb_pt, 256), o_out = o_chi + align_up(nb_chi, 256);
-    if (res->poses) HIP_TRY(hipMemcpyAsync(sg + o_pose, w.st[cur].pose, nb_pose, hipMemcpyDeviceToHost, h->stream));
-    if (res->points) HIP_TRY(hipMemcpyAsync(sg + o_pt, w.st[cur].point, nb_pt, hipMemcpyDeviceToHost, h->stream));
-    if (res->chi2) HIP_TRY(hipMemcpyAsync(sg + o_chi, w.out_chi2, nb_chi, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(sg + o_out, w.out_outlier, (size_t)w.E, hipMemcpyDeviceToHost, h->stream));
+    {
+        int rs = ensure_stage(h, o_out + align_up((size_t)w.E + 8, 256)); if (rs) return rs;
+        sg = h->stage;
+        char *sd = h->stage_dev;
+        ExportDst dst;
+        dst.poses = res->poses ? reinterpret_cast<unsigned long long *>(sd + o_pose) : nullptr;
+        dst.points = res->points ? reinterpret_cast<unsigned long long *>(sd + o_pt) : nullptr;
+        dst.chi2 = res->chi2 ? reinterpret_cast<unsigned long long *>(sd + o_chi) : nullptr;
+        dst.outlier = reinterpret_cast<unsigned long long *>(sd + o_out);
+        HIP_TRY(launch_export(w, dst, h->stream));
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (res->poses) std::memcpy(res->poses, sg + o_pose, nb_pose);
     if (res->points) std::memcpy(res->points, sg + o_pt, nb_pt);

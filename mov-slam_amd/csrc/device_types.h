@@ -111,6 +111,7 @@ struct DevWindow {
     double *hmax_part;  // n_pt_blocks
     Ctrl *ctrl;
     HostStatus *hstat;  // device view of the pinned status block
+    Ctrl *ctrl_out;     // device view of the host's pinned copy of Ctrl: written by k_finalize (no copy engine at the end of a solve)
     // outputs (caller edge order)
     double *out_chi2;
     uint8_t *out_outlier;

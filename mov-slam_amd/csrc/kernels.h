@@ -25,5 +25,8 @@ hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStr
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s);
 hipError_t launch_decide(const DevWindow &w, hipStream_t s);
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s);
+// destinations of k_export in the host's pinned staging buffer (device view; null = not wanted), as 64-bit words
+struct ExportDst { unsigned long long *poses, *points, *chi2, *outlier; };
+hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s);
 
 }  // namespace movba

@@ -939,6 +939,35 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
     }
     // (the outlier count is taken on the host from the downloaded flags: one contended atomic per wave
     // made this kernel four times longer than its memory traffic)
+    // the controller state goes to the host's pinned copy from here: a separate small device-to-host copy behind the last
+    // kernel costs more than these few hundred stores across the bus
+    if (blockIdx.x == 0) {
+        static_assert(sizeof(Ctrl) % 8 == 0, "copied as 64-bit words");
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(w.ctrl_out);
+        for (int k = threadIdx.x; k < (int)(sizeof(Ctrl) / 8); k += blockDim.x) dst[k] = src[k];
+    }
+}
+
+// --------------------------------------------------------------------------------
+// k_export: results -> the host's pinned staging buffer, written across the bus by the kernel itself.  Four separate
+// device-to-host copies cost ~0.1 ms EACH when they are small (cfg2: 0.45 ms per download), one launch costs ~10 us.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
+{
+    const Ctrl *c = w.ctrl;
+    const int cur = c->cur;
+    const unsigned long long *pose = reinterpret_cast<const unsigned long long *>(w.st[cur].pose);
+    const unsigned long long *point = reinterpret_cast<const unsigned long long *>(w.st[cur].point);
+    const unsigned long long *chi2 = reinterpret_cast<const unsigned long long *>(w.out_chi2);
+    const unsigned long long *outl = reinterpret_cast<const unsigned long long *>(w.out_outlier);     // (allocations are padded to 256 bytes)
+    const long n0 = d.poses ? 7L * w.NP : 0, n1 = n0 + (d.points ? 3L * w.P : 0), n2 = n1 + (d.chi2 ? (long)w.E : 0), n3 = n2 + ((long)w.E + 7) / 8;
+    for (long k = blockIdx.x * (long)blockDim.x + threadIdx.x; k < n3; k += (long)gridDim.x * blockDim.x) {
+        if (k < n0) d.poses[k] = pose[k];
+        else if (k < n1) d.points[k - n0] = point[k - n0];
+        else if (k < n2) d.chi2[k - n1] = chi2[k - n1];
+        else d.outlier[k - n2] = outl[k - n2];
+    }
 }
 
 // --------------------------------------------------------------------------------
@@ -1014,6 +1043,15 @@ hipError_t launch_decide(const DevWindow &w, hipStream_t s)
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s)
 {
     hipLaunchKernelGGL(k_finalize, dim3((w.E + 255) / 256), dim3(256), 0, s, w);
+    return hipGetLastError();
+}
+
+hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
+{
+    const long words = 7L * w.NP + 3L * w.P + w.E + (w.E + 7) / 8;
+    long nb = (words + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    hipLaunchKernelGGL(k_export, dim3((unsigned)nb), dim3(256), 0, s, w, d);
     return hipGetLastError();
 }
 
