@@ -18,6 +18,7 @@
 
 #include "device_types.h"
 #include "kernels.h"
+#include "pose_kernels.h"
 #include "movba.h"
 #include "structure.h"
 
@@ -208,7 +209,8 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->ctrl_host_dev), h->ctrl_host, 0) != hipSuccess ||
-        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess) {
+        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess ||
+        configure_pose_kernels() != hipSuccess) {
         movba_destroy(h);
         return MOVBA_ERR_HIP;
     }
@@ -752,8 +754,6 @@ int movba_reset_profile(movba_handle *h)
 // ---------------------------------------------------------------------------------------
 // Optimizer::PoseOptimization (/root/reference/src/Optimizer.cc:397-459)
 // ---------------------------------------------------------------------------------------
-#include "pose_kernels.h"
-
 extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_pose_result *res)
 {
     if (!h || !d || !res) return MOVBA_ERR_ARG;
@@ -769,7 +769,8 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     const size_t h2d = c.off;
     const size_t o_chi = c.take<double>(n), o_pose = c.take<double>(8), o_lvl = c.take<uint8_t>(n);
     const size_t total = c.off;
-    if (total > h->pose_cap) {
+    const bool staged = pose_opt_staged_lds_bytes(n) <= 150 * 1024;
+    if (!staged && total > h->pose_cap) {
         if (h->pose_arena) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->pose_arena)); h->pose_arena = nullptr; h->pose_cap = 0; }
         const size_t cap = align_up(2 * total, 1 << 16);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->pose_arena), cap));
@@ -782,16 +783,17 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)n);
     double *isg = reinterpret_cast<double *>(sg + o_is);
     for (int i = 0; i < n; ++i) isg[i] = d->inv_sigma2 ? d->inv_sigma2[i] : 1.0;
-    HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
+    // staged (up to ~3 000 matches): the kernel reads the pinned buffer itself and writes its results back into it
+    if (!staged) HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
     PoseDev p{};
     p.n = n; p.rounds = d->rounds; p.its = d->its_per_round;
     p.fx = d->fx; p.fy = d->fy; p.cx = d->cx; p.cy = d->cy; p.huber_delta = d->huber_delta; p.chi2_gate = d->chi2_gate;
     for (int k = 0; k < 7; ++k) p.pose0[k] = d->pose0[k];
-    char *a = h->pose_arena;
+    char *a = staged ? h->stage_dev : h->pose_arena;
     p.Xw = reinterpret_cast<double *>(a + o_X); p.obs = reinterpret_cast<double *>(a + o_obs); p.isig = reinterpret_cast<double *>(a + o_is);
     p.chi2 = reinterpret_cast<double *>(a + o_chi); p.pose_out = reinterpret_cast<double *>(a + o_pose); p.level1 = reinterpret_cast<uint8_t *>(a + o_lvl);
-    HIP_TRY(launch_pose_opt(p, h->stream));
-    HIP_TRY(hipMemcpyAsync(sg + o_chi, a + o_chi, total - o_chi, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(launch_pose_opt(p, staged, h->stream));
+    if (!staged) HIP_TRY(hipMemcpyAsync(sg + o_chi, a + o_chi, total - o_chi, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double *po = reinterpret_cast<const double *>(sg + o_pose);
     for (int k = 0; k < 7; ++k) res->pose[k] = po[k];

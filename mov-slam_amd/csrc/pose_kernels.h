@@ -18,6 +18,10 @@ struct PoseDev {
     double *pose_out;       // 8: pose (7) + inlier count
 };
 
-hipError_t launch_pose_opt(const PoseDev &p, hipStream_t s);
+// staged: inputs and outputs are device views of pinned host memory, the kernel keeps the matches in LDS
+// (pose_opt_staged_lds_bytes(n) must fit the 150 KB granted by configure_pose_kernels())
+size_t pose_opt_staged_lds_bytes(int n);
+hipError_t configure_pose_kernels();
+hipError_t launch_pose_opt(const PoseDev &p, bool staged, hipStream_t s);
 
 }  // namespace movba

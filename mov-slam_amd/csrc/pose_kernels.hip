@@ -166,10 +166,25 @@ __device__ bool solve6(const double Hu[21], double lambda, const double b[6], do
 
 }  // namespace
 
+// STAGED: the matches are read ONCE from where the host left them (its pinned staging buffer, across the bus) into LDS,
+// every pass of the 4 x 10 iterations then reads LDS, and the results are written straight back to the pinned buffer: no
+// copy engine on either side of the launch (small copies cost ~0.1 ms each, as much as the kernel itself).
+template <bool STAGED>
 __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 {
     __shared__ double lds[kW * 28];
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int tid = threadIdx.x;
+    const double *Xw = p.Xw, *obs = p.obs, *isig = p.isig;
+    uint8_t *level1 = p.level1;
+    if (STAGED) {
+        double *sX = dyn, *so = sX + 3 * p.n, *si = so + 2 * p.n;
+        for (int i = tid; i < 3 * p.n; i += kT) sX[i] = p.Xw[i];
+        for (int i = tid; i < 2 * p.n; i += kT) so[i] = p.obs[i];
+        for (int i = tid; i < p.n; i += kT) si[i] = p.isig[i];
+        Xw = sX; obs = so; isig = si;
+        level1 = reinterpret_cast<uint8_t *>(si + p.n);
+    }
     const double dsqr = p.huber_delta * p.huber_delta;
     double pose0[7];
 #pragma unroll
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     double pose[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) pose[k] = pose0[k];
-    for (int i = tid; i < p.n; i += kT) p.level1[i] = 0;
+    for (int i = tid; i < p.n; i += kT) level1[i] = 0;
     __syncthreads();
 
     // robust cost of the active matches at a pose
@@ -187,13 +202,13 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         q2R(T, R);
         double F[1] = { 0.0 };
         for (int i = tid; i < p.n; i += kT) {
-            if (p.level1[i]) continue;
-            const double X0 = p.Xw[3 * i], X1 = p.Xw[3 * i + 1], X2 = p.Xw[3 * i + 2];
+            if (level1[i]) continue;
+            const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
             const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
             const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
             const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-            const double om = p.isig[i];
-            const double e0 = p.obs[2 * i] - (p.fx * x / z + p.cx), e1 = p.obs[2 * i + 1] - (p.fy * y / z + p.cy);
+            const double om = isig[i];
+            const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
             const double chi2 = e0 * (om * e0) + e1 * (om * e1);
             F[0] += (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) ? 2.0 * sqrt(chi2) * p.huber_delta - dsqr : chi2;
         }
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 #pragma unroll
         for (int k = 0; k < 7; ++k) pose[k] = pose0[k];
         double cnt[1] = { 0.0 };
-        for (int i = tid; i < p.n; i += kT) cnt[0] += p.level1[i] ? 0.0 : 1.0;
+        for (int i = tid; i < p.n; i += kT) cnt[0] += level1[i] ? 0.0 : 1.0;
         reduce_all<1>(cnt, lds);
         bool ok = cnt[0] > 0.0;
         double lambda = 0.0, ni = 2.0;
@@ -219,13 +234,13 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 #pragma unroll
             for (int k = 0; k < 28; ++k) acc[k] = 0.0;
             for (int i = tid; i < p.n; i += kT) {
-                if (p.level1[i]) continue;
-                const double X0 = p.Xw[3 * i], X1 = p.Xw[3 * i + 1], X2 = p.Xw[3 * i + 2];
+                if (level1[i]) continue;
+                const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
                 const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
                 const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
                 const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-                const double om = p.isig[i];
-                const double e0 = p.obs[2 * i] - (p.fx * x / z + p.cx), e1 = p.obs[2 * i + 1] - (p.fy * y / z + p.cy);
+                const double om = isig[i];
+                const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
                 const double chi2 = e0 * (om * e0) + e1 * (om * e1);
                 double rho0 = chi2, rho1 = 1.0;
                 if (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) {
@@ -291,21 +306,25 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         double nb[1] = { 0.0 };
         __syncthreads();
         for (int i = tid; i < p.n; i += kT) {
-            const double X0 = p.Xw[3 * i], X1 = p.Xw[3 * i + 1], X2 = p.Xw[3 * i + 2];
+            const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
             const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
             const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
             const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-            const double om = p.isig[i];
-            const double e0 = p.obs[2 * i] - (p.fx * x / z + p.cx), e1 = p.obs[2 * i + 1] - (p.fy * y / z + p.cy);
+            const double om = isig[i];
+            const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
             const double chi2 = e0 * (om * e0) + e1 * (om * e1);
             const int bad = (chi2 > p.chi2_gate) || !(z > 0.0);
             p.chi2[i] = chi2;
-            p.level1[i] = (uint8_t)bad;
+            level1[i] = (uint8_t)bad;
             nb[0] += bad;
         }
         reduce_all<1>(nb, lds);
         n_bad = (int)nb[0];
         if (p.n - n_bad < 10) break;
+    }
+    if (STAGED) {
+        __syncthreads();
+        for (int i = tid; i < p.n; i += kT) p.level1[i] = level1[i];
     }
     if (tid == 0) {
 #pragma unroll
@@ -314,9 +333,17 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     }
 }
 
-hipError_t launch_pose_opt(const PoseDev &p, hipStream_t s)
+size_t pose_opt_staged_lds_bytes(int n) { return (size_t)n * 6 * sizeof(double) + (((size_t)n + 15) & ~(size_t)15); }
+
+hipError_t configure_pose_kernels()
 {
-    hipLaunchKernelGGL(k_pose_opt, dim3(1), dim3(kT), 0, s, p);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+}
+
+hipError_t launch_pose_opt(const PoseDev &p, bool staged, hipStream_t s)
+{
+    if (staged) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kT), pose_opt_staged_lds_bytes(p.n), s, p);
+    else hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(kT), 0, s, p);
     return hipGetLastError();
 }
 

@@ -282,3 +282,14 @@ def test_pose_optimization_matches_oracle(solver, oracle_mod):
     assert np.abs(r["pose"][4:] - f["truth"][4:]).max() < 0.02
     few = solver.pose_opt(f["Xw"][:3], f["obs"][:3], f["pose0"], f["cam"], 5.0, 25.0)
     assert few["status"] == 3 and few["n_inliers"] == 0      # < 4 matches: Optimizer.cc:415-418
+
+
+def test_pose_optimization_beyond_the_lds_staging_limit(solver, oracle_mod):
+    """More matches than the kernel can keep in LDS (~3 000): the device-memory path of the same kernel."""
+    f = synth.make_frame(n=4000, seed=77)
+    r = solver.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0)
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0)
+    assert r["status"] == 0 and r["n_inliers"] == o["n_inliers"]
+    assert np.abs(r["pose"] - o["pose"]).max() < 1e-9
+    mism = r["outlier"] != o["outlier"]
+    assert (np.abs(o["chi2"][mism] - 25.0) <= GUARD).all()
