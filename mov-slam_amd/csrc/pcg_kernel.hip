@@ -275,7 +275,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 
     // ---- block-Jacobi preconditioner: invert each 6x6 diagonal block in place (Cholesky) ----
     for (int i = tid; i < nf; i += kT) {
-        double L[36], Li[36];
+        double L[36], Li[36], rinv[6];
 #pragma unroll
         for (int k = 0; k < 36; ++k) L[k] = sdiag[i * 36 + k];
         bool ok = true;
@@ -285,14 +285,19 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #pragma unroll
             for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
             if (!(d > 0.0)) ok = false;
-            d = sqrt(d);
-            L[j * 6 + j] = d;
+            // 1 / sqrt(d) by v_rsq_f64 and two Newton steps, the only "division" of the column (this is a preconditioner:
+            // the chain of 6 square roots and 36 divisions was ~2 us in front of every solve with one wave at work)
+            double ri = __builtin_amdgcn_rsq(d);
+            ri = ri * (1.5 - 0.5 * d * ri * ri);
+            ri = ri * (1.5 - 0.5 * d * ri * ri);
+            rinv[j] = ri;
+            L[j * 6 + j] = d * ri;
 #pragma unroll
             for (int q = j + 1; q < 6; ++q) {
                 double s = L[q * 6 + j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) s -= L[q * 6 + k] * L[j * 6 + k];
-                L[q * 6 + j] = s / d;
+                L[q * 6 + j] = s * ri;
             }
         }
 #pragma unroll
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
                 double s = (rw == col) ? 1.0 : 0.0;
 #pragma unroll
                 for (int k = col; k < rw; ++k) s -= L[rw * 6 + k] * Li[k * 6 + col];
-                Li[rw * 6 + col] = s / L[rw * 6 + rw];
+                Li[rw * 6 + col] = s * rinv[rw];
             }
         }
 #pragma unroll
