@@ -100,9 +100,10 @@ def main():
     solver.upload(w)                                     # window resident in HBM from here on
     pose_buf = torch.empty((1, w.n_poses, 7), dtype=torch.float64, device=dev)
 
+    solver.set_pose_export(pose_buf.data_ptr(), pose_buf.numel() * 8)     # the solve's last kernel leaves the poses here
+
     def step():
         solver.run()                                     # whole LM loop on the device, returns after the stream drained
-        solver.export_poses_device(pose_buf.data_ptr(), pose_buf.numel() * 8)
         return shard.gather_poses(pose_buf) if world > 1 else pose_buf
 
     def barrier():

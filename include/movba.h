@@ -137,6 +137,10 @@ int  movba_lba_download(movba_handle *h, movba_lba_result *res);      /* D2H + c
 /* Copy the optimised poses (n_poses x 7 f64) into a caller-owned DEVICE buffer on the
  * handle's stream — what the RCCL all-gather of independent windows sends. */
 int  movba_lba_export_poses_device(movba_handle *h, void *dst_device, int64_t capacity_bytes);
+/* The same without a copy of its own: register a DEVICE buffer once and every later movba_lba_run leaves
+ * the optimised poses in it (written by the solve's last kernel; valid when movba_lba_run returns).
+ * NULL unregisters.  The buffer must stay allocated while it is registered. */
+int  movba_lba_set_pose_export(movba_handle *h, void *dst_device, int64_t capacity_bytes);
 
 int  movba_get_profile(movba_handle *h, movba_profile *out);
 int  movba_reset_profile(movba_handle *h);

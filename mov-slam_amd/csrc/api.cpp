@@ -53,6 +53,8 @@ struct movba_handle {
     HostStatus *hstat_dev = nullptr;
     Ctrl *ctrl_host = nullptr;          // pinned copy of the device Ctrl
     Ctrl *ctrl_host_dev = nullptr;      // its device view (written by k_finalize)
+    double *pose_export = nullptr;      // registered device buffer for the final poses
+    int64_t pose_export_cap = 0;
     char *stage_dev = nullptr;          // device view of the pinned staging buffer (written by k_export)
     // current window
     bool uploaded = false, ran = false;
@@ -576,6 +578,8 @@ int movba_lba_run(movba_handle *h)
     if (h->early_status != MOVBA_OK) { h->ran = true; return h->early_status; }
     // early return before the solve (src/Optimizer.cc:749-751)
     if (h->stop && *h->stop) { h->early_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
+    // (a registered export buffer too small for this window is ignored rather than overrun)
+    h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
     const DevWindow &w = h->win;
     hipStream_t s = h->stream;
     h->hstat->progress = 0; h->hstat->stop = 0;
@@ -724,6 +728,14 @@ int movba_lba_export_poses_device(movba_handle *h, void *dst, int64_t cap)
     const size_t nb = sizeof(double) * 7 * (size_t)w.NP;
     if (cap < (int64_t)nb) return MOVBA_ERR_ARG;
     HIP_TRY(hipMemcpyAsync(dst, w.st[h->ctrl_host->cur].pose, nb, hipMemcpyDeviceToDevice, h->stream));
+    return MOVBA_OK;
+}
+
+int movba_lba_set_pose_export(movba_handle *h, void *dst, int64_t cap)
+{
+    if (!h || (dst && cap <= 0)) return MOVBA_ERR_ARG;
+    h->pose_export = static_cast<double *>(dst);
+    h->pose_export_cap = dst ? cap : 0;
     return MOVBA_OK;
 }
 

@@ -111,6 +111,7 @@ struct DevWindow {
     double *hmax_part;  // n_pt_blocks
     Ctrl *ctrl;
     HostStatus *hstat;  // device view of the pinned status block
+    double *pose_export; // caller's registered device buffer for the final poses (NP x 7), or null; written by k_finalize
     Ctrl *ctrl_out;     // device view of the host's pinned copy of Ctrl: written by k_finalize (no copy engine at the end of a solve)
     // outputs (caller edge order)
     double *out_chi2;

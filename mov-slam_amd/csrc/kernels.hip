@@ -947,6 +947,11 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(w.ctrl_out);
         for (int k = threadIdx.x; k < (int)(sizeof(Ctrl) / 8); k += blockDim.x) dst[k] = src[k];
     }
+    // final poses into the caller's registered device buffer (movba_lba_set_pose_export: what the all-gather sends)
+    if (w.pose_export && blockIdx.x == gridDim.x - 1) {
+        const double *src = w.st[c->cur].pose;
+        for (int k = threadIdx.x; k < 7 * w.NP; k += blockDim.x) w.pose_export[k] = src[k];
+    }
 }
 
 // --------------------------------------------------------------------------------

@@ -80,7 +80,7 @@ class PoseResult(C.Structure):
 
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
            "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
-           "movba_lba_export_poses_device", "movba_get_profile", "movba_reset_profile",
+           "movba_lba_export_poses_device", "movba_lba_set_pose_export", "movba_get_profile", "movba_reset_profile",
            "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask"]
 
 _lib = None
@@ -105,6 +105,7 @@ def lib():
         L.movba_lba_reset.argtypes = [C.c_void_p]
         L.movba_lba_download.argtypes = [C.c_void_p, C.POINTER(LbaResult)]
         L.movba_lba_export_poses_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.movba_lba_set_pose_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.movba_get_profile.argtypes = [C.c_void_p, C.POINTER(Profile)]
         L.movba_reset_profile.argtypes = [C.c_void_p]
         L.movba_set_profile_mask.argtypes = [C.c_void_p, C.c_int32]
@@ -244,6 +245,12 @@ class Solver:
         rc = lib().movba_lba_export_poses_device(self._h, C.c_void_p(dst_ptr), nbytes)
         if rc != OK:
             raise MovbaError(f"movba_lba_export_poses_device: {status_string(rc)}")
+
+    def set_pose_export(self, dst_ptr: int, nbytes: int):
+        """Register a device buffer that every later run() leaves the optimised poses in (0 unregisters)."""
+        rc = lib().movba_lba_set_pose_export(self._h, C.c_void_p(dst_ptr) if dst_ptr else None, nbytes)
+        if rc != OK:
+            raise MovbaError(f"movba_lba_set_pose_export: {status_string(rc)}")
 
     def profile(self) -> dict:
         p = Profile()

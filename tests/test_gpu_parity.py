@@ -293,3 +293,27 @@ def test_pose_optimization_beyond_the_lds_staging_limit(solver, oracle_mod):
     assert np.abs(r["pose"] - o["pose"]).max() < 1e-9
     mism = r["outlier"] != o["outlier"]
     assert (np.abs(o["chi2"][mism] - 25.0) <= GUARD).all()
+
+
+def test_registered_pose_export_buffer_receives_the_final_poses(solver):
+    """movba_lba_set_pose_export: the solve's last kernel leaves the poses in the caller's device buffer (what the
+    all-gather of independent windows sends); movba_lba_export_poses_device copies the same values."""
+    import torch
+    w = synth.cfg("small")
+    dev = torch.device("cuda:0")
+    buf = torch.full((w.n_poses, 7), -1.0, dtype=torch.float64, device=dev)
+    buf2 = torch.empty_like(buf)
+    solver.set_pose_export(buf.data_ptr(), buf.numel() * 8)
+    try:
+        solver.upload(w); solver.run()
+        solver.export_poses_device(buf2.data_ptr(), buf2.numel() * 8)
+        r = solver.download()
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(buf.cpu().numpy(), r["poses"]) and np.array_equal(buf2.cpu().numpy(), r["poses"])
+        # a registered buffer that is too small for the window is left alone
+        tiny = torch.full((7,), -1.0, dtype=torch.float64, device=dev)
+        solver.set_pose_export(tiny.data_ptr(), 56)
+        solver.run(); torch.cuda.synchronize(dev)
+        assert (tiny.cpu().numpy() == -1.0).all()
+    finally:
+        solver.set_pose_export(0, 0)
