@@ -3,10 +3,13 @@
 
 A "step" is one complete local-BA solve (what Optimizer::LocalBundleAdjustment runs at
 /root/reference/src/Optimizer.cc:754-755 plus the gate at :757-775) of one synthetic
-covisibility window per rank, with the flattened window already resident in HBM
-(movba_lba_upload done before the timed region); the metric counts the linear solves
-(accepted + rejected LM trials) those steps performed.  With N > 1 every rank owns an
-independent window (BASELINE cfg5: weak scaling, no data-path collective) and the
+covisibility window per rank through movba_lba_solve: SURVEY.md 8(d)'s timed region, from
+"flattened host arrays ready" to "poses, points, chi2 and outlier flags back in host
+memory" (structure pass, H2D, every launch, D2H) — the same region the CPU baseline is
+timed on.  The metric counts the linear solves (accepted + rejected LM trials) those steps
+performed.  The rate with the window already resident in HBM (movba_lba_run alone) is
+reported beside it as config.resident_window, never as `value`.  With N > 1 every rank owns
+an independent window (BASELINE cfg5: weak scaling, no data-path collective) and the
 optimised keyframe poses are all-gathered over RCCL inside the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -97,13 +100,14 @@ def main():
 
     stream = torch.cuda.current_stream(dev)
     solver = capi.Solver(device=local_rank, stream=stream.cuda_stream)
-    solver.upload(w)                                     # window resident in HBM from here on
     pose_buf = torch.empty((1, w.n_poses, 7), dtype=torch.float64, device=dev)
 
     solver.set_pose_export(pose_buf.data_ptr(), pose_buf.numel() * 8)     # the solve's last kernel leaves the poses here
+    last = {}
 
     def step():
-        solver.run()                                     # whole LM loop on the device, returns after the stream drained
+        # host arrays in -> structure pass + H2D + whole LM loop on the device + D2H -> host arrays out
+        last["res"] = solver.solve(w)
         return shard.gather_poses(pose_buf) if world > 1 else pose_buf
 
     def barrier():
@@ -127,9 +131,9 @@ def main():
         gathered = step()
     barrier()
     dt = time.perf_counter() - t0
-    res = solver.download()
+    res = last["res"]
     prof = solver.profile()
-    solves_local = res["n_solves"] * args.steps
+    solves_local = res["n_solves"] * args.steps         # the same window every step: bit-identical solves
 
     tt = torch.tensor([dt], dtype=torch.float64, device=dev)
     ss = torch.tensor([float(solves_local)], dtype=torch.float64, device=dev)
@@ -145,6 +149,14 @@ def main():
         achieved = ab[dominant] / avg_s / 1e9 if avg_s > 0 else 0.0
         chain_gbs = ab["B_iter"] * res["n_solves"] * args.steps / dt / 1e9
         traffic, traffic_src = measured_traffic(dominant)
+        per_kernel = {}
+        for kc in KERNEL_CLASSES[:3]:
+            v = prof_all[kc]
+            a_s = v["ms"] / max(v["launches"], 1) * 1e-3
+            gbs = ab[kc] / a_s / 1e9 if a_s > 0 else 0.0
+            tr, _ = measured_traffic(kc)
+            per_kernel[kc] = {"avg_launch_us": a_s * 1e6, "algorithmic_bytes_per_launch": ab[kc], "achieved": gbs,
+                              "frac": gbs / HBM_PEAK_GBS, "traffic": tr}
         out = {
             "metric": "local-BA iterations/sec (50 KF x 20k MapPoint window)" if args.config == "cfg3"
                       else "local-BA iterations/sec (10 KF x 2k MapPoint window)",
@@ -165,19 +177,36 @@ def main():
                          "launches_timed": dk["launches"],
                          "chain": {"B_iter_bytes": ab["B_iter"], "achieved": chain_gbs, "frac": chain_gbs / HBM_PEAK_GBS,
                                    "note": "whole LM iteration (all kernels + launch gaps); latency-bound, not bandwidth-bound"},
+                         "per_kernel": per_kernel, "per_kernel_note": "HIP events around every launch of one untimed solve",
                          "kernel_ms_per_step_all_classes": {k: v["ms"] for k, v in prof_all.items()}},
         }
+        out["config"]["timed_region"] = ("movba_lba_solve: host arrays in -> structure pass, H2D, all launches, D2H -> results in "
+                                         "host memory (SURVEY 8d); identical region for cpu_baseline")
+        out["config"]["host_phase_ms_per_step"] = {k: prof[k] / args.steps for k in ("structure_ms", "upload_ms", "download_ms")}
         if world == 1:
-            # for information only (never `value`): the whole movba_lba_solve call with host buffers in and out
-            # (host structure pass + H2D + solve + D2H), median of 10
-            ts = []
-            for _ in range(10):
-                t1 = time.perf_counter(); solver.solve(w); ts.append(time.perf_counter() - t1)
-            ts.sort()
-            out["config"]["pcie_and_structure_inclusive_ms_per_window_solve"] = 1e3 * ts[len(ts) // 2]
+            # for information only (never `value`): the LM loop alone with the window already resident in HBM
+            # (movba_lba_upload once, then movba_lba_run per step)
+            solver.set_profile_mask(0)
+            solver.upload(w)
+            solver.run(); torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                solver.run()
+            torch.cuda.synchronize(dev)
+            tr_ = time.perf_counter() - t1
+            out["config"]["resident_window"] = {"lm_iterations_per_s": res["n_solves"] * args.steps / tr_,
+                                                "ms_per_window_solve": 1e3 * tr_ / args.steps,
+                                                "note": "movba_lba_run only; no structure pass, H2D or D2H in the region"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle                       # CPU baseline leg: the oracle as the timed "port"
-            oracle.build()
+            oracle.build(force=True)                        # -march=native of THIS box's host cores
+            cpu_model = "unknown"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip(); break
+            except OSError:
+                pass
             n, solves, t_cpu0 = 0, 0, time.perf_counter()
             while True:
                 o = oracle.solve(w)
@@ -188,7 +217,8 @@ def main():
             out["cpu_baseline"] = {"value": solves / el, "unit": "LM iterations/s", "cores": 1, "kind": "port",
                                    "sample": f"{n} full solves of the same window ({solves} LM iterations, {el:.1f} s), "
                                              "single-threaded restated-g2o oracle (oracle/lba_oracle.c, -O3 -march=native)",
-                                   "host_cpus": os.cpu_count(), "ms_per_window_solve": 1e3 * el / n}
+                                   "host_cpus": os.cpu_count(), "cpu_model": cpu_model, "ms_per_window_solve": 1e3 * el / n,
+                                   "region": "host arrays in -> host arrays out (lba_oracle_solve), as the GPU value"}
             # context: the same restatement with its edge loops spread over the host cores of this box's share
             # (OpenMP build; the dense Cholesky stays serial).  g2o as the reference builds it is single-threaded, so the
             # figure above stays THE baseline.

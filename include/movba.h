@@ -128,7 +128,10 @@ void movba_destroy(movba_handle *h);
 int  movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_result *res);
 
 /* The same in three phases, for callers that keep the window resident in HBM
- * (bench.py times movba_lba_run alone; the window can be re-run after movba_lba_reset). */
+ * (the window can be re-run after movba_lba_reset).  desc->stop is the one caller pointer the
+ * phased API keeps: from movba_lba_upload until the next upload / solve on the handle, read by
+ * every movba_lba_run in between; it must stay valid that long (or be NULL).  A raised flag
+ * makes that run return MOVBA_STOPPED; the next run looks at the flag again. */
 int  movba_lba_upload(movba_handle *h, const movba_lba_desc *desc);   /* host structure + H2D */
 int  movba_lba_reset(movba_handle *h);                                /* restore uploaded state on device */
 int  movba_lba_run(movba_handle *h);                                  /* LM loop on device; returns after stream sync */

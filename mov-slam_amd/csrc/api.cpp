@@ -46,6 +46,7 @@ struct movba_handle {
     // device arena
     char *arena = nullptr;
     size_t arena_cap = 0;
+    uint64_t arena_gen = 0;             // bumped by every (re)allocation: hipFree + hipMalloc may return the same address
     // pinned staging
     char *stage = nullptr;
     size_t stage_cap = 0;
@@ -62,7 +63,8 @@ struct movba_handle {
     DevWindow win{};
     size_t h2d_bytes = 0;
     const volatile uint8_t *stop = nullptr;
-    int early_status = MOVBA_OK;
+    int early_status = MOVBA_OK;        // decided at upload (MOVBA_EMPTY / MOVBA_NO_FIXED): holds for every run of the window
+    int run_status = MOVBA_OK;          // decided per run (MOVBA_STOPPED when the flag was up before the solve)
     PcgParams pp{};
     bool rows_kernel = false;
     char *scratch = nullptr;            // structure-pass temporaries (struct_kernels.hip)
@@ -145,6 +147,7 @@ int ensure_arena(movba_handle *h, size_t bytes)
     const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->arena), cap));
     h->arena_cap = cap;
+    h->arena_gen += 1;
     return MOVBA_OK;
 }
 
@@ -357,7 +360,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     lap("pack edge region");
     const double t_up0 = now_ms();
     HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_a_bytes, hipMemcpyHostToDevice, h->stream));
-    char *arena_at_edge_copy = h->arena;
+    const uint64_t arena_gen_at_edge_copy = h->arena_gen;
     double upload_host_ms = now_ms() - t_up0;
     bool edge_b_queued = false;
     auto queue_edge_b = [&]() -> int {
@@ -471,8 +474,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t total = c.off;
 
     rc2 = ensure_arena(h, total); if (rc2) return rc2;
-    if (h->arena != arena_at_edge_copy) {
-        // the arena grew: queue the edge region again (the staging copy is intact) and re-point the structure pass
+    if (h->arena_gen != arena_gen_at_edge_copy) {
+        // the arena was reallocated (told by its generation: the new allocation may sit at the old address): queue the
+        // edge region again (the staging copy is intact) and re-point the structure pass
         HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_bytes, hipMemcpyHostToDevice, h->stream));
         sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
         sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
@@ -574,10 +578,10 @@ int movba_lba_run(movba_handle *h)
     if (!h) return MOVBA_ERR_ARG;
     if (!h->uploaded) return MOVBA_ERR_STATE;
     HIP_TRY(hipSetDevice(h->device));
-    h->ran = false;
+    h->ran = false; h->run_status = MOVBA_OK;
     if (h->early_status != MOVBA_OK) { h->ran = true; return h->early_status; }
-    // early return before the solve (src/Optimizer.cc:749-751)
-    if (h->stop && *h->stop) { h->early_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
+    // early return before the solve (src/Optimizer.cc:749-751); not sticky: the next run looks at the flag again
+    if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
     // (a registered export buffer too small for this window is ignored rather than overrun)
     h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
     const DevWindow &w = h->win;
@@ -666,10 +670,11 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     if (!h || !res) return MOVBA_ERR_ARG;
     if (!h->uploaded || !h->ran) return MOVBA_ERR_STATE;
     HIP_TRY(hipSetDevice(h->device));
-    res->status = h->early_status;
+    const int pre = h->early_status != MOVBA_OK ? h->early_status : h->run_status;
+    res->status = pre;
     res->iters_done = 0; res->n_solves = 0; res->n_outliers = 0; res->pcg_iters = 0; res->last_rejected = 0;
     res->lambda = 0; res->cost0 = 0; res->cost = 0; res->n_trace = 0;
-    if (h->early_status != MOVBA_OK) return h->early_status;
+    if (pre != MOVBA_OK) return pre;
     const double t0 = now_ms();
     const DevWindow &w = h->win;
     const Ctrl &c = *h->ctrl_host;
@@ -723,7 +728,7 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
 int movba_lba_export_poses_device(movba_handle *h, void *dst, int64_t cap)
 {
     if (!h || !dst) return MOVBA_ERR_ARG;
-    if (!h->uploaded || !h->ran || h->early_status != MOVBA_OK) return MOVBA_ERR_STATE;
+    if (!h->uploaded || !h->ran || h->early_status != MOVBA_OK || h->run_status != MOVBA_OK) return MOVBA_ERR_STATE;
     const DevWindow &w = h->win;
     const size_t nb = sizeof(double) * 7 * (size_t)w.NP;
     if (cap < (int64_t)nb) return MOVBA_ERR_ARG;

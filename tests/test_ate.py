@@ -11,11 +11,12 @@ from movba import ate, capture, synth
 def test_ate_reproduces_the_reference_evaluators_number_on_its_committed_sample():
     """evaluation/tartanair_eval/evaluation/{pose_est,pose_gt}.txt through the reference's own
     tartanair_evaluator.py give ate_score 6.7469, ATE scale 9.5516 over 591 keyframes."""
-    d = np.load(os.path.join(GOLDEN, "tartanair_sample_trajectories.npz"))
+    d = np.load(os.path.join(GOLDEN, "tartanair_sample_trajectories.npz"))      # tests/golden/make_tartanair_fixture.py
     r = ate.ate_tartanair(d["pose_gt"], d["pose_est"], scale=True)
-    assert r["n"] == 591
-    assert abs(r["ate"] - 6.7469) < 5e-5
-    assert abs(r["scale"] - 9.5516) < 5e-5
+    # expected_* are what the reference's own evaluator returned on the pair when the fixture was generated
+    assert r["n"] == int(d["expected_n"]) == 591
+    assert abs(r["ate"] - float(d["expected_ate"])) < 1e-9 and abs(float(d["expected_ate"]) - 6.7469) < 5e-5
+    assert abs(r["scale"] - float(d["expected_scale"])) < 1e-9 and abs(float(d["expected_scale"]) - 9.5516) < 5e-5
 
 
 def test_ate_is_zero_for_a_scaled_rotated_copy_and_positive_with_noise():

@@ -317,3 +317,63 @@ def test_registered_pose_export_buffer_receives_the_final_poses(solver):
         assert (tiny.cpu().numpy() == -1.0).all()
     finally:
         solver.set_pose_export(0, 0)
+
+
+def test_cfg5_windows_on_the_hip_path(solver, oracle_mod):
+    """BASELINE.json configs[4]: the eight cfg3-shaped windows (seeds 2000-2007) that the 8-GPU run shards one per rank,
+    solved here one after the other on one GPU against the oracle.  Four of them reject a trial late in the solve, so
+    g2o's pop() / lambda *= nu branch is exercised at full size."""
+    from movba import shard
+    rejected = 0
+    for wid in range(8):
+        w = synth.make_window(50, 10, 20000, shard.window_seed(wid), run_lo=2, run_hi=10)
+        r, o = solver.solve(w), oracle_mod.solve(w)
+        check_against(r, o, w)
+        rejected += int((r["trace"]["accept"] == 0).sum())
+    assert rejected >= 1
+
+
+def test_cfg3_size_window_far_from_the_optimum_rejects_trials(solver, oracle_mod):
+    """cfg3 shape with 3 degree / 0.2 m / 0.5 m start errors and 10 % gross outliers: consecutive accept / reject / accept
+    decisions (12 linear solves in 10 outer iterations)."""
+    w = synth.make_window(50, 10, 20000, 3003, run_lo=2, run_hi=10, rot_sigma_deg=3.0, trans_sigma=0.2, point_sigma=0.5,
+                          outlier_frac=0.1)
+    r, o = solver.solve(w), oracle_mod.solve(w)
+    assert (o["trace"]["accept"] == 0).sum() >= 2 and o["n_solves"] > o["iters_done"]
+    check_against(r, o, w)
+
+
+def test_arena_regrowth_on_one_handle(built_lib, oracle_mod):
+    """a handle whose arena is reallocated in the middle of an upload (small window first, then one whose total
+    exceeds the capacity although its edge region fits) must queue the edge region again even when the new allocation
+    lands on the old address.  Permuted edges force the host structure path, where nothing else sits above the arena."""
+    s = built_lib.Solver()
+    try:
+        small = synth.make_window(3, 1, 60, seed=3, run_lo=2, run_hi=3)
+        check_against(s.solve(small), oracle_mod.solve(small), small)
+        rng = np.random.default_rng(8)
+        for K, P, lo, hi in ((6, 400, 2, 4), (16, 3000, 4, 12), (30, 9000, 6, 20)):
+            w = synth.make_window(K, 2, P, seed=100 + K, run_lo=lo, run_hi=hi)
+            p = rng.permutation(w.n_edges)
+            w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[p], w.edge_point[p], w.obs[p], w.inv_sigma2[p]
+            check_against(s.solve(w), oracle_mod.solve(w), w)
+            w2 = synth.make_window(K, 2, P, seed=200 + K, run_lo=lo, run_hi=hi)       # grouped order: device structure path
+            check_against(s.solve(w2), oracle_mod.solve(w2), w2)
+    finally:
+        s.close()
+
+
+def test_raised_stop_flag_is_not_sticky_in_the_phased_api(solver, built_lib):
+    """a flag that was up at one movba_lba_run must not stop the later runs of the resident window."""
+    w = synth.cfg("small")
+    stop = np.ones(1, np.uint8)
+    solver.upload(w, stop=stop)
+    assert solver.run() == built_lib.STOPPED
+    r = solver.download()
+    assert r["status"] == built_lib.STOPPED and r["n_solves"] == 0
+    np.testing.assert_array_equal(r["poses"], w.poses)
+    stop[0] = 0
+    assert solver.run() == 0
+    r = solver.download()
+    assert r["status"] == 0 and r["n_solves"] >= 10
+    assert np.array_equal(r["poses"], solver.solve(w)["poses"])
