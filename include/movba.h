@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MOVBA_VERSION 1
+#define MOVBA_VERSION 2
 
 /* status codes */
 #define MOVBA_OK              0
@@ -92,13 +92,19 @@ typedef struct {
     double  tr_f1[MOVBA_MAX_TRACE];
     double  tr_rho[MOVBA_MAX_TRACE];
     int32_t tr_accept[MOVBA_MAX_TRACE];
-    int32_t tr_pcg_iters[MOVBA_MAX_TRACE];
+    int32_t tr_pcg_iters[MOVBA_MAX_TRACE];   /* PCG iterations of the trial; -1: solved by the direct solver */
+    /* Reduced solve (LinearSolverCSparse in the reference, Optimizer.cc:535): on-chip PCG for windows of up to 80 free
+     * keyframes, dense Cholesky otherwise and from the first trial whose PCG gave up (breakdown or iteration cap). */
+    int32_t n_direct;           /* trials solved by the direct solver                                          */
+    int32_t direct_from;        /* n_solves at the switch to the direct solver (0: whole solve), -1: never     */
+    int32_t n_chol_fail;        /* trials whose factorisation met a non-positive pivot: rejected, as g2o does  */
+    int32_t n_pcg_giveups;      /* 0 or 1: the PCG gave up once, the solve went on with the direct solver      */
 } movba_lba_result;
 
 /* Solver options (all have defaults; pass NULL to movba_create for defaults). */
 typedef struct {
     double pcg_rel_tol;         /* stop when sqrt(r.z / r0.z0) <= tol       (default 1e-10)   */
-    int32_t pcg_max_iters;      /* per solve                                 (default 4*6K)    */
+    int32_t pcg_max_iters;      /* per solve; reaching it hands the trial to the direct solver (default 200) */
     int32_t run_ahead;          /* trial sets the host keeps queued ahead    (default 2)       */
     int32_t profile;            /* bit k set: bracket launches of kernel class k (see movba_profile)
                                  * with HIP events on the handle's stream; 0x3f = all          */

@@ -215,6 +215,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->ctrl_host_dev), h->ctrl_host, 0) != hipSuccess ||
         configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess ||
+        configure_dense_kernels() != hipSuccess ||
         configure_pose_kernels() != hipSuccess) {
         movba_destroy(h);
         return MOVBA_ERR_HIP;
@@ -303,10 +304,6 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
     else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
     if (h->early_status != MOVBA_OK) { h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK; }
-    if ((size_t)(21 * s.NP + 6 * s.nfree + 4) * sizeof(double) > 150 * 1024) {
-        std::fprintf(stderr, "libmovba: %d keyframes exceed the point kernels' LDS staging budget\n", s.NP);
-        return MOVBA_ERR_ARG;
-    }
     const int NP = s.NP, P = s.P, E = s.E, nf = s.nfree;
     const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
 
@@ -418,10 +415,6 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         lap("pid/pair_ptr H2D enqueue");
     }
     if (!edge_b_queued) { const int rq = queue_edge_b(); if (rq) return rq; }
-    if (pcg_lds_bytes(s.nfree) > 150 * 1024) {
-        std::fprintf(stderr, "libmovba: %d free keyframes exceed the single-workgroup PCG's LDS budget\n", s.nfree);
-        return MOVBA_ERR_ARG;
-    }
     h->pp = PcgParams{};
     h->rows_kernel = pcg_rows_supported(s.nfree, s.row_ptr.data(), &h->pp);
     if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
@@ -450,6 +443,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t ncb = s.cblk_g.size();
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
+    const size_t o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
     const size_t o_ent_h2d = dev_structure ? 0 : c.take<Int4>((size_t)s.nentries + 1);       // host-built entry lists travel with the pair region
     const size_t h2d = c.off;
     // ---- device-only region ----
@@ -471,6 +465,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
     const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
+    // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
+    const int ntile = dense_ntile(nf);
+    const size_t o_dtiles = c.take<double>(dense_tiles_doubles(nf)), o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1), o_dfail = c.take<int32_t>(4);
     const size_t total = c.off;
 
     rc2 = ensure_arena(h, total); if (rc2) return rc2;
@@ -505,6 +502,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sg + o_ce, s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
     std::memcpy(sg + o_cij, s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
     std::memcpy(sg + o_multi, s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
+    std::memcpy(sg + o_pid, s.pid.data(), sizeof(int32_t) * (size_t)nf * nf);
     lap("carve + pack pair region");
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
@@ -561,6 +559,11 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev; w.ctrl_out = h->ctrl_host_dev;
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
+    w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
+    w.dense.pid = reinterpret_cast<const int32_t *>(a + o_pid); w.dense.fail = reinterpret_cast<int32_t *>(a + o_dfail);
+    w.dense.ntile = ntile; w.dense.n = 6 * nf;
+    w.direct_only = h->rows_kernel ? 0 : 1;
+    w.lds_poses = point_lds_need(NP, nf) <= kPointLdsLimit ? 1 : 0;
     h->uploaded = true;
     return MOVBA_OK;
 }
@@ -597,13 +600,18 @@ int movba_lba_run(movba_handle *h)
     }
     PcgParams pp = h->pp;
     pp.rel_tol = h->opt.pcg_rel_tol;
-    pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 4 * 6 * (w.nfree > 0 ? w.nfree : 1);
+    // PCG cap: past ~200 iterations the direct solver is cheaper than carrying on, and a system that slow to converge is
+    // one whose iterative answer would depart from the exact step anyway (see the park in k_pcg_rows)
+    pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 200;
     const int nrowent = (int)h->st.row_ent.size();
-    const bool rows_kernel = h->rows_kernel;
     // 1: coarse level built beside the solve, one trial old; 2: small window (<= one keyframe per wave), built first and fresh
     bool one_row_per_wave = true;
     for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) one_row_per_wave &= pp.wave_row0[wv + 1] - pp.wave_row0[wv] <= 1;
-    pp.use_coarse = (h->opt.pcg_coarse && rows_kernel) ? (one_row_per_wave ? 2 : 1) : 0;
+    pp.use_coarse = (h->opt.pcg_coarse && h->rows_kernel) ? (one_row_per_wave ? 2 : 1) : 0;
+    // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
+    bool direct = !h->rows_kernel;
+    int pauses_seen = 0;
+    h->hstat->pause_seq = 0;
 
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
     const double t_start = now_ms();
@@ -615,38 +623,67 @@ int movba_lba_run(movba_handle *h)
         final_after = t;
         return MOVBA_OK;
     };
-    for (; t < max_trials; ++t) {
-        // stay at most run_ahead trial sets ahead of the device, and never further than the outer iterations that are
-        // left: with R iterations to go at most R more trials run unless one is rejected, so the sets queued beyond that
-        // would almost always be no-op launches (~5 us each) at the end of the solve
-        // (k_decide publishes trials_done, it and done as one word)
-        bool finished = false;
-        for (;;) {
-            const uint64_t pg = h->hstat->progress;
-            const int td = (int)(pg & 0xffffff), it_done = (int)((pg >> 24) & 0xffffff);
-            if ((pg >> 48) & 1) { finished = true; break; }
-            const int left = w.max_iters - it_done;
-            const int limit = left < h->opt.run_ahead ? (left > 1 ? left : 1) : h->opt.run_ahead;
-            if (t - td < limit) break;
-            if (final_after != t && t - td < h->opt.run_ahead) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
-            if (h->stop && *h->stop) h->hstat->stop = 1;
-            if (now_ms() - t_start > 60000.0) {
-                std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
-                return MOVBA_ERR_HIP;
-            }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        if (finished) break;
-        if (h->stop && *h->stop) h->hstat->stop = 1;
-        if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
-        { ScopedEvents ev(h, KC_PCG); HIP_TRY(rows_kernel ? launch_pcg_rows(w, nrowent, pp, t, s) : launch_pcg(w, pp, t, s)); }
+    auto queue_solve = [&]() -> int {
+        ScopedEvents ev(h, KC_PCG);
+        if (direct) HIP_TRY(launch_dense_solve(w, s));
+        else HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, s));
+        return MOVBA_OK;
+    };
+    auto queue_tail = [&]() -> int {
         { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
+        return MOVBA_OK;
+    };
+    // The device parked the solve (k_pcg_rows gave up on trial `td`): every trial set queued behind has turned into no-ops.
+    // Queue the direct solver for that trial (its schur partials are still in place) and carry on in direct mode.
+    auto answer_pause = [&]() -> int {
+        pauses_seen = h->hstat->pause_seq;
+        direct = true;
+        t = (int)(h->hstat->progress & 0xffffff);
+        int rq = queue_solve(); if (rq != MOVBA_OK) return rq;
+        rq = queue_tail(); if (rq != MOVBA_OK) return rq;
+        ++t;
+        final_after = -1;
+        return MOVBA_OK;
+    };
+    for (;;) {
+        for (; t < max_trials; ++t) {
+            // stay at most run_ahead trial sets ahead of the device, and never further than the outer iterations that are
+            // left: with R iterations to go at most R more trials run unless one is rejected, so the sets queued beyond that
+            // would almost always be no-op launches (~5 us each) at the end of the solve
+            // (k_decide publishes trials_done, it and done as one word)
+            bool finished = false, paused = false;
+            for (;;) {
+                const uint64_t pg = h->hstat->progress;
+                const int td = (int)(pg & 0xffffff), it_done = (int)((pg >> 24) & 0xffffff);
+                if ((pg >> 48) & 1) { finished = true; break; }
+                if (h->hstat->pause_seq != pauses_seen) { paused = true; break; }
+                const int left = w.max_iters - it_done;
+                const int limit = left < h->opt.run_ahead ? (left > 1 ? left : 1) : h->opt.run_ahead;
+                if (t - td < limit) break;
+                if (final_after != t && t - td < h->opt.run_ahead) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
+                if (h->stop && *h->stop) h->hstat->stop = 1;
+                if (now_ms() - t_start > 60000.0) {
+                    std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
+                    return MOVBA_ERR_HIP;
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (finished) break;
+            if (paused) { const int rq = answer_pause(); if (rq != MOVBA_OK) return rq; --t; continue; }
+            if (h->stop && *h->stop) h->hstat->stop = 1;
+            if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
+            { const int rq = queue_solve(); if (rq != MOVBA_OK) return rq; }
+            { const int rq = queue_tail(); if (rq != MOVBA_OK) return rq; }
+        }
+        if (final_after != t) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
+        HIP_TRY(hipStreamSynchronize(s));
+        // a park that happened behind the last queued set is only seen now
+        if (h->hstat->pause_seq == pauses_seen) break;
+        const int rq = answer_pause(); if (rq != MOVBA_OK) return rq;
     }
-    if (final_after != t) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
-    HIP_TRY(hipStreamSynchronize(s));
     harvest_events(h);
 #ifdef MOVBA_CLOCK_STAMP
     std::fprintf(stderr, "libmovba[stamp]: k_pcg_rows %llu shader cycles in %llu x 10 ns -> %.3f GHz\n", h->ctrl_host->dbg_cycles,
@@ -674,6 +711,7 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     res->status = pre;
     res->iters_done = 0; res->n_solves = 0; res->n_outliers = 0; res->pcg_iters = 0; res->last_rejected = 0;
     res->lambda = 0; res->cost0 = 0; res->cost = 0; res->n_trace = 0;
+    res->n_direct = 0; res->direct_from = -1; res->n_chol_fail = 0; res->n_pcg_giveups = 0;
     if (pre != MOVBA_OK) return pre;
     const double t0 = now_ms();
     const DevWindow &w = h->win;
@@ -701,6 +739,7 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     for (int e = 0; e < w.E; ++e) n_out += sg[o_out + e] != 0;
     res->iters_done = c.iters_done; res->n_solves = c.n_solves; res->n_outliers = n_out;
     res->pcg_iters = c.pcg_total_iters; res->last_rejected = c.last_rejected;
+    res->n_direct = c.n_direct; res->direct_from = c.direct_from; res->n_chol_fail = c.n_chol_fail; res->n_pcg_giveups = c.n_pause;
     res->lambda = c.lambda; res->cost0 = c.cost0; res->cost = c.F0;
     res->n_trace = c.n_trace;
     for (int k = 0; k < c.n_trace && k < MOVBA_MAX_TRACE; ++k) {

@@ -1,0 +1,412 @@
+// Direct solve of the reduced camera system: dense blocked Cholesky over several launches.
+//
+// The reference's step is an exact sparse Cholesky (LinearSolverCSparse, selected at
+// /root/reference/src/Optimizer.cc:535; a failed factorisation rejects the LM trial).  The product's first choice for
+// windows of up to 80 free keyframes is the on-chip PCG (pcg_kernel.hip); this file is the exact path behind it:
+//   * every window with more free keyframes than k_pcg_rows holds on chip (any number: S lives in HBM / L2 here),
+//   * every trial from the first one whose PCG broke down or ran into its iteration cap (weakly constrained windows,
+//     where an iterative solve at any tolerance departs from the exact step).
+// S = Hpp + lambda I - sum B Dinv B^T is laid out densely in 48 x 48 tiles (8 pose blocks; lower block triangle), with the
+// right-hand side as one more block row, so that forward substitution is part of the factorisation (Cholesky of
+// [[S, b], [b^T, .]] leaves L^-1 b in the last row).  One launch per block column j (right-looking with a one-column
+// look-ahead by redundancy):
+//     step(j):  tile (I, K), K > j   <- tile (I, K) - L(I, j-1) L(K, j-1)^T        (trailing update with the previous column)
+//               tile (I, j)          <- the same update, then  L(I, j) = tile (I, j) L(j, j)^-T, where EVERY workgroup of
+//                                       column j updates and factors the diagonal tile (j, j) for itself: no workgroup
+//                                       waits for another inside a launch, and column j is final when the launch ends.
+// The 48 x 48 x 48 tile products run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: the one GEMM-shaped piece of the
+// path); the 48 sequential pivots of a column are one workgroup barrier each, with the panel in registers.
+// Then one workgroup solves L^T x = y backwards and applies the pose increments (VertexSE3Expmap::oplusImpl).
+// Fixed summation order everywhere: results are bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include "device_math.h"
+#include "device_types.h"
+#include "kernels.h"
+
+namespace movba {
+
+namespace {
+
+constexpr int NB = kDenseNB;
+constexpr int LD = NB + 1;              // LDS row stride: 49 doubles, conflict-free for the MFMA operand reads (rows x k)
+constexpr int kStepThreads = 256;
+constexpr int kBackThreads = 1024;
+
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t tile_off(int I, int J) { return ((size_t)I * (I + 1) / 2 + J) * (NB * NB); }
+
+// global tile (row-major NB x NB) -> LDS image with row stride LD
+__device__ __forceinline__ void load_tile(const double *__restrict__ g, double *sm, int tid)
+{
+    const double2 *g2 = reinterpret_cast<const double2 *>(g);
+    for (int e = tid; e < NB * NB / 2; e += kStepThreads) {
+        const double2 v = g2[e];
+        const int r = (2 * e) / NB, c = (2 * e) - r * NB;
+        sm[r * LD + c] = v.x; sm[r * LD + c + 1] = v.y;
+    }
+}
+
+// One wave's share of  C -= A B^T  for 48 x 48 tiles: MFMA tile (mt, nt) of 16 x 16, k = 48 in 12 steps of 4.
+// Operand maps of v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// C/D: col = lane & 15, row = (lane >> 4) + 4 reg.  A is negated on the way in, so D = C - A B^T.
+__device__ __forceinline__ dbl4 tile_mfma(const double *As, const double *Bs, int mt, int nt, int lane, dbl4 c)
+{
+    const double *ap = As + (mt * 16 + (lane & 15)) * LD + (lane >> 4);
+    const double *bp = Bs + (nt * 16 + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll
+    for (int k = 0; k < NB; k += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-ap[k], bp[k], c, 0, 0, 0);
+    return c;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dense_assemble: S (damped) and b_S from the schur work-item partials into the tile layout; one workgroup per tile.
+// Same item order as the PCG's own assembly, so both solvers see the same matrix to the last bit.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense_assemble(DevWindow w)
+{
+    const Ctrl *c = w.ctrl;
+    if (c->done == 1) return;
+    const DenseSys &ds = w.dense;
+    const int tid = threadIdx.x;
+    // tile (I, J) of the lower block triangle from the linear block index
+    int I = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= (int)blockIdx.x) ++I;
+    while (I * (I + 1) / 2 > (int)blockIdx.x) --I;
+    const int J = (int)blockIdx.x - I * (I + 1) / 2;
+    if (J >= ds.ntile) return;                                  // the corner tile behind the right-hand side is never read
+    if (blockIdx.x == 0 && tid == 0) *ds.fail = 0;
+    const double lambda = c->lambda;
+    const int nf = w.nfree, n = ds.n;
+    const double *part = w.part;
+    double *dst = ds.tiles + tile_off(I, J);
+    if (I == ds.ntile) {
+        // right-hand side b_S = b_p - sum B Dinv b_l in row 0, zeros below
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int r = e / NB, cc = e - r * NB, gc = J * NB + cc;
+            double v = 0.0;
+            if (r == 0 && gc < n) {
+                const int bj = gc / 6, a = gc - bj * 6;
+                double bb = 0.0, cb = 0.0;
+                for (int itx = w.pair_item_start[bj]; itx < w.pair_item_start[bj + 1]; ++itx) {
+                    bb += part[(size_t)itx * kPartStride + 63 + a];
+                    cb += part[(size_t)itx * kPartStride + 36 + a];
+                }
+                w.bp[gc] = bb;
+                v = bb - cb;
+            }
+            dst[e] = v;
+        }
+        return;
+    }
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int r = e / NB, cc = e - r * NB;
+        const int gr = I * NB + r, gc = J * NB + cc;
+        double v = 0.0;
+        if (gr >= n || gc >= n) v = (gr == gc) ? 1.0 : 0.0;        // padding rows: identity
+        else {
+            const int bi = gr / 6, a = gr - bi * 6, bj = gc / 6, b = gc - bj * 6;
+            // upper-triangle pair (lo <= hi) holds S_lo,hi row-major; the lower block is its transpose
+            const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
+            const int pr = ds.pid[(size_t)lo * nf + hi];
+            if (pr >= 0) {
+                const int k = bi <= bj ? a * 6 + b : b * 6 + a;
+                double sacc = 0.0;
+                for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx) sacc += part[(size_t)itx * kPartStride + k];
+                v = -sacc;
+                if (bi == bj) {
+                    const int u = 42 + (a <= b ? ut6(a, b) : ut6(b, a));
+                    double hpp = 0.0;
+                    for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx) hpp += part[(size_t)itx * kPartStride + u];
+                    v = (hpp + (a == b ? lambda : 0.0)) - sacc;
+                }
+            }
+        }
+        dst[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_chol_step: block column j (see the header).  Workgroups [0, nfin) finalise tiles (j + b, j); the rest apply the
+// previous column to the trailing tiles (only launched for j > 0).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStepThreads) void k_chol_step(DevWindow w, int j)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const Ctrl *c = w.ctrl;
+    if (c->done == 1) return;
+    const DenseSys &ds = w.dense;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = ds.ntile, m = nt - j, nfin = m + 1;
+    double *As = sm, *Bs = sm + NB * LD;            // L(I, j-1), L(K, j-1)
+    double *Ps = Bs + NB * LD;                      // finalising workgroups: the 96 x 48 panel [D; U]
+
+    if ((int)blockIdx.x >= nfin) {
+        // ---- trailing tile (I, K), K > j:  tile -= L(I, j-1) L(K, j-1)^T, C kept in registers in the MFMA layout ----
+        int t = (int)blockIdx.x - nfin, cc = 1;
+        while (t >= m - cc + 1) { t -= m - cc + 1; ++cc; }
+        const int K = j + cc, I = K + t;
+        load_tile(ds.tiles + tile_off(I, j - 1), As, tid);
+        load_tile(ds.tiles + tile_off(K, j - 1), Bs, tid);
+        double *C = ds.tiles + tile_off(I, K);
+        dbl4 acc[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = wv + 4 * u;                   // MFMA tiles dealt round-robin to the four waves
+            if (q < 9) {
+                const int mt = q / 3, ntc = q - mt * 3;
+                const double *cp = C + (mt * 16 + (lane >> 4)) * NB + ntc * 16 + (lane & 15);
+                acc[u] = dbl4{ cp[0], cp[4 * NB], cp[8 * NB], cp[12 * NB] };
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int q = wv + 4 * u;
+            if (q < 9) {
+                const int mt = q / 3, ntc = q - mt * 3;
+                acc[u] = tile_mfma(As, Bs, mt, ntc, lane, acc[u]);
+                double *cp = C + (mt * 16 + (lane >> 4)) * NB + ntc * 16 + (lane & 15);
+                cp[0] = acc[u].x; cp[4 * NB] = acc[u].y; cp[8 * NB] = acc[u].z; cp[12 * NB] = acc[u].w;
+            }
+        }
+        return;
+    }
+
+    // ---- finalising workgroup of tile (I, j) ----
+    const int I = j + (int)blockIdx.x;
+    const bool diag = I == j;
+    // panel rows 0..47 = D = tile (j, j), rows 48..95 = U = tile (I, j) (unused for the diagonal workgroup)
+    load_tile(ds.tiles + tile_off(j, j), Ps, tid);
+    if (!diag) load_tile(ds.tiles + tile_off(I, j), Ps + NB * LD, tid);
+    if (j > 0) {
+        load_tile(ds.tiles + tile_off(j, j - 1), Bs, tid);
+        if (!diag) load_tile(ds.tiles + tile_off(I, j - 1), As, tid);
+    }
+    __syncthreads();
+    if (j > 0) {
+        // D -= L(j, j-1) L(j, j-1)^T  (MFMA tiles 0..8),  U -= L(I, j-1) L(j, j-1)^T  (tiles 9..17), dealt round-robin to the waves
+        const int ntiles = diag ? 9 : 18;
+        dbl4 acc[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int q = wv + 4 * u;
+            if (q < ntiles) {
+                const int half = q >= 9, qq = q - 9 * half, mt = qq / 3, ntc = qq - mt * 3;
+                const double *pp = Ps + (half * NB + mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
+                acc[u] = dbl4{ pp[0], pp[4 * LD], pp[8 * LD], pp[12 * LD] };
+                acc[u] = tile_mfma(half ? As : Bs, Bs, mt, ntc, lane, acc[u]);
+            }
+        }
+        __syncthreads();                            // every wave has read its C tiles (and the operands) before anyone writes
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int q = wv + 4 * u;
+            if (q < ntiles) {
+                const int half = q >= 9, qq = q - 9 * half, mt = qq / 3, ntc = qq - mt * 3;
+                double *pp = Ps + (half * NB + mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
+                pp[0] = acc[u].x; pp[4 * LD] = acc[u].y; pp[8 * LD] = acc[u].z; pp[12 * LD] = acc[u].w;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- factor D and solve U L^T = U in one sweep over the 48 pivots.  Thread (tr, tc) owns the 3 x 3 elements rows
+    // 3 tr.., columns 3 tc.. of D and of U, in registers; per pivot k:  p_rc -= p_rk p_ck / p_kk  for c > k (r > k in D),
+    // then column k + 1 is published to LDS for the next pivot: one barrier per pivot.  L = P / sqrt(pivot) at the end. ----
+    const int tr = tid >> 4, tc = tid & 15;
+    double vd[3][3], vu[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            vd[a][b] = Ps[(3 * tr + a) * LD + 3 * tc + b];
+            vu[a][b] = diag ? 0.0 : Ps[(NB + 3 * tr + a) * LD + 3 * tc + b];
+        }
+    bool bad = false;
+    for (int k = 0; k < NB; ++k) {
+        double piv = Ps[k * LD + k];
+        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
+        const double rinv = 1.0 / piv;
+        double ck[3], dr[3], ur[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) ck[b] = Ps[(3 * tc + b) * LD + k] * rinv;           // p_ck / p_kk, rows c of D
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { dr[a] = Ps[(3 * tr + a) * LD + k]; ur[a] = Ps[(NB + 3 * tr + a) * LD + k]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = 3 * tr + a, cidx = 3 * tc + b;
+                if (cidx > k) {
+                    if (r >= cidx) vd[a][b] -= dr[a] * ck[b];          // lower triangle of D (r >= c > k)
+                    if (!diag) vu[a][b] -= ur[a] * ck[b];
+                }
+            }
+        // publish column k + 1 (its owner threads: tc == (k + 1) / 3)
+        if (k + 1 < NB && tc == (k + 1) / 3) {
+            const int b = (k + 1) - 3 * tc;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double d0 = b == 0 ? vd[a][0] : (b == 1 ? vd[a][1] : vd[a][2]);
+                const double u0 = b == 0 ? vu[a][0] : (b == 1 ? vu[a][1] : vu[a][2]);
+                Ps[(3 * tr + a) * LD + k + 1] = d0;
+                if (!diag) Ps[(NB + 3 * tr + a) * LD + k + 1] = u0;
+            }
+        }
+        __syncthreads();
+    }
+    if (bad && tid == 0) *ds.fail = 1;
+    // ---- L = P / sqrt(pivot of the column); the diagonal workgroup leaves L(j, j) in diagL, the others L(I, j) in place ----
+    double rs[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { const double p = Ps[(3 * tc + b) * LD + 3 * tc + b]; rs[b] = (p > 0.0 && isfinite(p)) ? 1.0 / sqrt(p) : 1.0; }
+    if (diag) {
+        double *out = ds.diagL + (size_t)j * NB * NB;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = 3 * tr + a, cidx = 3 * tc + b;
+                out[r * NB + cidx] = r >= cidx ? vd[a][b] * rs[b] : 0.0;
+            }
+    } else {
+        double *out = ds.tiles + tile_off(I, j);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) out[(3 * tr + a) * NB + 3 * tc + b] = vu[a][b] * rs[b];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dense_backsolve: one workgroup.  y = L^-1 b sits in row 0 of block row `ntile`; solves L^T x = y from the last
+// block column up, then writes the increment, the pose part of computeScale() and the trial poses exactly like the PCG
+// kernels' epilogue, and releases a parked solve (Ctrl::done 2 -> 0).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    Ctrl *c = w.ctrl;
+    if (c->done == 1) return;
+    const DenseSys &ds = w.dense;
+    const int tid = threadIdx.x;
+    const int nt = ds.ntile, n = ds.n, npad = nt * NB;
+    double *x = sm;                                 // npad
+    double *Ls = x + npad;                          // NB x LD: diagonal factor of the current block column
+    double *ps = Ls + NB * LD;                      // 21 x NB partial sums
+    double *red = ps + 21 * NB;                     // 16
+    constexpr int G = 21;                           // row groups of the column sums: 21 x 48 = 1008 threads
+    const int g = tid / NB, cc = tid - g * NB;
+    const bool fail = *ds.fail != 0;
+    const double lambda = c->lambda;
+    for (int J = nt - 1; J >= 0; --J) {
+        // diagonal factor -> LDS, partial sums of  sum_{I > J} L(I, J)^T x_I  over the row groups
+        for (int e = tid; e < NB * NB; e += kBackThreads) { const int r = e / NB, q = e - r * NB; Ls[r * LD + q] = ds.diagL[(size_t)J * NB * NB + e]; }
+        double s = 0.0;
+        if (g < G) {
+            const int rows = (nt - 1 - J) * NB;
+            for (int rr = g; rr < rows; rr += G) {
+                const int I = J + 1 + rr / NB, r = rr - (rr / NB) * NB;
+                s += ds.tiles[tile_off(I, J) + r * NB + cc] * x[I * NB + r];
+            }
+            ps[g * NB + cc] = s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // wave 0: s_c = y_c - (sums in group order), then the 48-step back substitution of L(J, J)^T x = s
+            double sv = 0.0;
+            if (tid < NB) {
+                double acc = 0.0;
+                for (int q = 0; q < G; ++q) acc += ps[q * NB + tid];
+                sv = ds.tiles[tile_off(nt, J) + tid] - acc;
+            }
+            for (int k = NB - 1; k >= 0; --k) {
+                const double xk = readlane_f64(sv, k) / Ls[k * LD + k];
+                if (tid == k) sv = xk;
+                else if (tid < k) sv -= Ls[k * LD + tid] * xk;
+            }
+            if (tid < NB) x[J * NB + tid] = sv;
+        }
+        __syncthreads();
+    }
+    // ---- outputs ----
+    double sc = 0.0;
+    for (int idx = tid; idx < n; idx += kBackThreads) {
+        const double xv = fail ? 0.0 : x[idx];
+        w.xp[idx] = xv;
+        sc += xv * (lambda * xv + w.bp[idx]);
+        x[idx] = xv;
+    }
+    const double scs = block_reduce<kBackThreads / 64, false>(sc, red);
+    const int cur = c->cur;
+    const DevState &S0 = w.st[cur];
+    const DevState &S1 = w.st[cur ^ 1];
+    for (int i = tid; i < w.NP; i += kBackThreads) {
+        double T[7], Tn[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) T[k] = S0.pose[7 * i + k];
+        const int h = w.hidx[i];
+        if (h >= 0) {
+            double u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[k] = x[6 * h + k];
+            se3_oplus(u, T, Tn);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) Tn[k] = T[k];
+        }
+        double R[9];
+        quat_to_R(Tn, R);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) S1.pose[7 * i + k] = Tn[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
+        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
+    }
+    if (tid == 0) {
+        w.scale_part[w.n_pt_blocks] = scs;
+        c->pcg_fail = fail ? 1 : 0;
+        c->pcg_last_iters = -1;                     // trace marker: this trial was solved directly
+        c->n_direct += 1;
+        if (fail) c->n_chol_fail += 1;
+        if (c->done == 2) c->done = 0;              // the solve was parked for this: the kernels behind run again
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+size_t dense_tiles_doubles(int nfree)
+{
+    const size_t nt = ((size_t)6 * nfree + NB - 1) / NB;
+    return (nt + 1) * (nt + 2) / 2 * (size_t)(NB * NB);
+}
+
+int dense_ntile(int nfree) { return (6 * nfree + NB - 1) / NB; }
+
+hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s)
+{
+    const int nt = w.dense.ntile;
+    hipLaunchKernelGGL(k_dense_assemble, dim3((nt + 1) * (nt + 2) / 2), dim3(256), 0, s, w);
+    const size_t lds = (size_t)(4 * NB * LD) * sizeof(double);
+    for (int j = 0; j < nt; ++j) {
+        const int m = nt - j;
+        int grid = m + 1;
+        if (j > 0) for (int cc = 1; cc < m; ++cc) grid += m - cc + 1;
+        hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(kStepThreads), lds, s, w, j);
+    }
+    const size_t lds_b = ((size_t)nt * NB + NB * LD + 21 * NB + 16) * sizeof(double);
+    hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(kBackThreads), lds_b, s, w);
+    return hipGetLastError();
+}
+
+hipError_t configure_dense_kernels()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_backsolve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
+}  // namespace movba

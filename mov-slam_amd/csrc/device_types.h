@@ -49,6 +49,11 @@ struct Ctrl {
     int32_t it, qmax, cur, done;
     int32_t n_solves, last_rejected, iters_done, n_trace;
     int32_t pcg_fail, pcg_last_iters, pcg_total_iters, n_outliers;
+    // reduced-solve bookkeeping: solver_mode 0 = PCG (k_pcg_rows), 1 = direct (dense Cholesky, dense_solve.hip); sticky from
+    // the first trial whose PCG broke down or ran into its iteration cap.  done == 2 parks the solve until the host has
+    // queued the direct kernels for that trial (HostStatus::pause_seq).
+    int32_t solver_mode, n_pause, n_direct, n_chol_fail;
+    int32_t direct_from, pad_c[3];      // n_solves at the switch to the direct solver (-1: never)
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
     unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8], dbg_wseg[8][8];
 };
@@ -61,11 +66,25 @@ struct HostStatus {
     // one), bit 48 done
     volatile uint64_t progress;
     volatile int32_t stop;      // host -> device: forceStopFlag seen by the host poll
-    int32_t pad;
+    // device -> host: number of times the solve has parked itself (Ctrl::done == 2) because the PCG failed and the direct
+    // kernels for the trial must be queued; the host answers each increment once
+    volatile int32_t pause_seq;
     static constexpr uint64_t pack(int trials_done, int it, int done)
     {
         return (uint64_t)(uint32_t)trials_done | ((uint64_t)(uint32_t)it << 24) | ((uint64_t)(done ? 1 : 0) << 48);
     }
+};
+
+// Dense form of the reduced system for the direct solver (dense_solve.hip): lower block triangle in tiles of kDenseNB x
+// kDenseNB doubles (row-major inside a tile), tile (I, J), I >= J, at index I (I + 1) / 2 + J.  Row tile `ntile` carries
+// the right-hand side in its first row (forward substitution by augmentation: it leaves the factorisation as L^-1 b).
+constexpr int kDenseNB = 48;        // 8 pose blocks
+struct DenseSys {
+    double *tiles;
+    double *diagL;              // ntile x NB x NB: Cholesky factors of the diagonal tiles
+    const int32_t *pid;         // nfree x nfree: pair id of block (i <= j) or -1
+    int32_t *fail;              // != 0: a pivot was not positive (the trial is rejected like a failed CSparse factorisation)
+    int32_t ntile, n;           // column tiles; unknowns (6 nfree)
 };
 
 struct DevWindow {
@@ -116,6 +135,9 @@ struct DevWindow {
     // outputs (caller edge order)
     double *out_chi2;
     uint8_t *out_outlier;
+    // direct solver
+    DenseSys dense;
+    int32_t direct_only, lds_poses;     // no on-chip PCG for this window (size); keyframe poses fit the point kernels' LDS staging
 };
 
 // Device view of the structure pass (struct_kernels.hip)

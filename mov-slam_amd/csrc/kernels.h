@@ -15,18 +15,25 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s);
-size_t pcg_lds_bytes(int nfree);
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s);
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s);
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s);
-hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s);
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s);
 hipError_t launch_decide(const DevWindow &w, hipStream_t s);
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s);
 // destinations of k_export in the host's pinned staging buffer (device view; null = not wanted), as 64-bit words
 struct ExportDst { unsigned long long *poses, *points, *chi2, *outlier; };
 hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s);
+
+// direct solver (dense_solve.hip): assemble + one launch per block column + back substitution / pose update
+hipError_t configure_dense_kernels();
+hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s);
+size_t dense_tiles_doubles(int nfree);
+int dense_ntile(int nfree);
+// the point kernels stage every keyframe's rotation in LDS up to this many bytes; larger windows read them through L2
+constexpr size_t kPointLdsLimit = 150 * 1024;
+size_t point_lds_need(int NP, int nfree);
 
 }  // namespace movba

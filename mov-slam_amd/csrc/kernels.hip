@@ -47,6 +47,8 @@ __global__ void k_init_pose(DevWindow w)
         c->it = 0; c->qmax = 0; c->cur = 0; c->done = (w.max_iters <= 0) ? 1 : 0;
         c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
+        c->solver_mode = w.direct_only ? 1 : 0; c->n_pause = 0; c->n_direct = 0; c->n_chol_fail = 0;
+        c->direct_from = w.direct_only ? 0 : -1;
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         w.ac_prev[kCoarseDim * kCoarseDim + 1] = -1.0;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
@@ -73,7 +75,9 @@ __global__ void k_init_pose(DevWindow w)
 //                   trial point X + x_l, then the same evaluation at the trial state cur^1
 // Pose rotations/translations and the pose increments are staged in LDS.
 // --------------------------------------------------------------------------------
-template <bool BACKSUB, bool STEREO>
+// LDSP: the keyframe rotations (and, for BACKSUB, the pose increments and hessian indices) are staged in LDS; windows
+// with more keyframes than fit (~850) read them through L2 instead (same arithmetic, same results).
+template <bool BACKSUB, bool STEREO, bool LDSP>
 __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -86,10 +90,16 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     const DevState &S1 = w.st[dst];
 
     double *sRt = sm;                               // NP x 12 at dst
-    double *sR0 = sm + 12 * w.NP;                   // NP x 9 at cur   (BACKSUB)
-    double *sxp = sR0 + (BACKSUB ? 9 * w.NP : 0);   // nfree x 6       (BACKSUB)
-    double *red = sxp + (BACKSUB ? 6 * w.nfree : 0);// 4
+    double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 9 at cur   (BACKSUB)
+    double *sxp = sR0 + ((BACKSUB && LDSP) ? 9 * w.NP : 0);   // nfree x 6       (BACKSUB)
+    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4
     int *shidx = reinterpret_cast<int *>(red + 4);  // NP              (BACKSUB)
+    // where the pose data is read from: the LDS images, or the state buffers themselves
+    const double *pRt = LDSP ? sRt : S1.Rt;
+    const double *pR0 = LDSP ? sR0 : S0.Rt;
+    constexpr int kR0Stride = LDSP ? 9 : 12;
+    const double *pxp = LDSP ? sxp : w.xp;
+    const int *phidx = LDSP ? shidx : w.hidx;
 
     // ---- everything this lane needs from HBM is requested before the LDS staging barrier, so that the
     //      point / edge gathers and the pose staging overlap instead of queueing behind each other ----
@@ -127,30 +137,32 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
         pur[k] = (STEREO && in) ? w.obs_r[g] : -1.0;
     }
 
-    for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
-    if (BACKSUB) {
-        for (int k = threadIdx.x; k < 9 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[(k / 9) * 12 + (k % 9)];
-        for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
-        for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
+    if (LDSP) {
+        for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+        if (BACKSUB) {
+            for (int k = threadIdx.x; k < 9 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[(k / 9) * 12 + (k % 9)];
+            for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
+            for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     double scale = 0.0;
     if (BACKSUB) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         // x_l's right-hand side: sum over the free observers of B_il^T xp_i, rebuilt from the cached (Xc, w)
         auto back_edge = [&](int g, int ip, const double4 &rc, double ur) {
-            const int h = shidx[ip];
+            const int h = phidx[ip];
             if (h < 0) return;
             const double x = rc.x, y = rc.y, z = rc.z, wg = rc.w;
             const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
             const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
-            const double *xp = sxp + 6 * h;
+            const double *xp = pxp + 6 * h;
             // t = J_c xp  (rows of -Jpi [ -[Xc]x | I ])
             const double t0 = (a02 * y) * xp[0] + (a00 * z - a02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + a02 * xp[5];
             const double t1 = (-a11 * z + a12 * y) * xp[0] + (-a12 * x) * xp[1] + (a11 * x) * xp[2] + a11 * xp[4] + a12 * xp[5];
             const double g0 = wg * t0, g1 = wg * t1;
-            const double *R = sR0 + 9 * ip;
+            const double *R = pR0 + kR0Stride * ip;
             // J_p = -Jpi R : rows p0 = a00 R0 + a02 R2, p1 = a11 R1 + a12 R2
             a0 += (a00 * R[0] + a02 * R[6]) * g0 + (a11 * R[3] + a12 * R[6]) * g1;
             a1 += (a00 * R[1] + a02 * R[7]) * g0 + (a11 * R[4] + a12 * R[7]) * g1;
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, v0 = 0, v1 = 0, v2 = 0, F = 0.0;
     const double dsqr = w.huber_delta * w.huber_delta;
     auto eval_edge = [&](int g, int ip, int sl, const double2 &ob, double om, double ur) {
-        const double *R = sRt + 12 * ip;
+        const double *R = pRt + 12 * ip;
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
         const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
@@ -617,218 +629,6 @@ __global__ __launch_bounds__(64) void k_lambda_init(DevWindow w)
 }
 
 // --------------------------------------------------------------------------------
-// k_pcg: single workgroup.  Assembles the upper blocks of S = Hpp + lambda I - sum B Dinv B^T
-// and b_S = b_p - sum B Dinv b_l from the work-item partials (fixed order), then solves
-// S x_p = b_S with block-Jacobi preconditioned conjugate gradients (replaces the
-// LinearSolverCSparse Cholesky selected at /root/reference/src/Optimizer.cc:535), and
-// applies VertexSE3Expmap::oplusImpl to produce the trial poses.
-// --------------------------------------------------------------------------------
-constexpr int kPcgThreads = 1024;
-constexpr int kPcgWaves = kPcgThreads / 64;
-
-__global__ __launch_bounds__(kPcgThreads) void k_pcg(DevWindow w, PcgParams pp, int trial)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    Ctrl *c = w.ctrl;
-    if (c->done) return;
-    const int tid = threadIdx.x;
-    const int nf = w.nfree, n = 6 * nf;
-    const int cur = c->cur;
-    const double lambda = c->lambda;
-    const double *partials = w.part;
-    double *x = sm, *r = x + n, *z = r + n, *p = z + n, *Ap = p + n;
-    double *minv = Ap + n;                  // nf x 36
-    double *red0 = minv + 36 * nf;          // kPcgWaves
-    double *red1 = red0 + kPcgWaves;        // kPcgWaves
-    int *flags = reinterpret_cast<int *>(red1 + kPcgWaves);   // [0] = failure
-    if (tid == 0) flags[0] = 0;
-
-    // ---- assemble S blocks and right-hand side ----
-    for (int idx = tid; idx < w.npairs * 36; idx += kPcgThreads) {
-        const int pr = idx / 36, k = idx - pr * 36;
-        double s = 0.0;
-        for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
-            s += partials[(size_t)itx * kPartStride + k];
-        double v = -s;
-        if (pr < nf) {
-            const int a = k / 6, b = k - a * 6;
-            const int u = a <= b ? ut6(a, b) : ut6(b, a);
-            double hpp = 0.0;
-            for (int itx = w.pair_item_start[pr]; itx < w.pair_item_start[pr + 1]; ++itx)
-                hpp += partials[(size_t)itx * kPartStride + 42 + u];
-            v += hpp + (a == b ? lambda : 0.0);
-        }
-        w.blocks[idx] = v;
-    }
-    for (int idx = tid; idx < n; idx += kPcgThreads) {
-        const int i = idx / 6, a = idx - i * 6;
-        double cc = 0.0, bb = 0.0;
-        for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx) {
-            cc += partials[(size_t)itx * kPartStride + 36 + a];
-            bb += partials[(size_t)itx * kPartStride + 63 + a];
-        }
-        w.bp[idx] = bb;
-        r[idx] = bb - cc;
-        x[idx] = 0.0;
-    }
-    __syncthreads();
-
-    // ---- block-Jacobi preconditioner: inverse of the 6x6 diagonal blocks (Cholesky) ----
-    for (int i = tid; i < nf; i += kPcgThreads) {
-        double L[36], Li[36];
-        const double *B = w.blocks + (size_t)i * 36;
-#pragma unroll
-        for (int k = 0; k < 36; ++k) L[k] = B[k];
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double d = L[j * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
-            if (!(d > 0.0)) ok = false;
-            d = sqrt(d);
-            L[j * 6 + j] = d;
-#pragma unroll
-            for (int q = j + 1; q < 6; ++q) {
-                double s = L[q * 6 + j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) s -= L[q * 6 + k] * L[j * 6 + k];
-                L[q * 6 + j] = s / d;
-            }
-        }
-        // Li = L^-1 (lower), Minv = Li^T Li
-#pragma unroll
-        for (int col = 0; col < 6; ++col) {
-#pragma unroll
-            for (int row = 0; row < 6; ++row) {
-                if (row < col) { Li[row * 6 + col] = 0.0; continue; }
-                double s = (row == col) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = col; k < row; ++k) s -= L[row * 6 + k] * Li[k * 6 + col];
-                Li[row * 6 + col] = s / L[row * 6 + row];
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s += (k >= a && k >= b) ? Li[k * 6 + a] * Li[k * 6 + b] : 0.0;
-                minv[i * 36 + a * 6 + b] = s;
-            }
-        if (!ok) flags[0] = 1;
-    }
-    __syncthreads();
-
-    // z = Minv r ; p = z ; rz = r.z
-    double part = 0.0;
-    for (int idx = tid; idx < n; idx += kPcgThreads) {
-        const int i = idx / 6, a = idx - i * 6;
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s += minv[i * 36 + a * 6 + k] * r[i * 6 + k];
-        z[idx] = s; p[idx] = s;
-        part += r[idx] * s;
-    }
-    double rz = block_reduce<kPcgWaves, false>(part, red0);
-    const double rz0 = rz;
-    const double thresh = pp.rel_tol * pp.rel_tol * rz0;
-    int iters = 0;
-    bool fail = flags[0] != 0 || !(rz0 >= 0.0) || !isfinite(rz0);
-
-    if (!fail && rz0 > 0.0) {
-        for (iters = 1; iters <= pp.max_iters; ++iters) {
-            // ---- Ap = S p (symmetric block mat-vec over the per-row gather lists), p.Ap ----
-            double dp = 0.0;
-            for (int row = tid >> 2; row < n; row += kPcgThreads / 4) {
-                const int sub = tid & 3;
-                const int i = row / 6, a = row - i * 6;
-                double s = 0.0;
-                for (int e = w.row_ptr[i] + sub; e < w.row_ptr[i + 1]; e += 4) {
-                    const RowEnt re = w.row_ent[e];
-                    if (re.block < 0) continue;                     // padding entry
-                    const double *B = w.blocks + (size_t)re.block * 36;
-                    const double *pv = p + 6 * re.col;
-                    if (!re.transposed) {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) s += B[a * 6 + k] * pv[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) s += B[k * 6 + a] * pv[k];
-                    }
-                }
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                if (sub == 0) { Ap[row] = s; dp += p[row] * s; }
-            }
-            const double pAp = block_reduce<kPcgWaves, false>(dp, red0);
-            if (!(pAp > 0.0) || !isfinite(pAp)) { fail = true; break; }
-            const double alpha = rz / pAp;
-            for (int idx = tid; idx < n; idx += kPcgThreads) { x[idx] += alpha * p[idx]; r[idx] -= alpha * Ap[idx]; }
-            __syncthreads();
-            double pr2 = 0.0;
-            for (int idx = tid; idx < n; idx += kPcgThreads) {
-                const int i = idx / 6, a = idx - i * 6;
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s += minv[i * 36 + a * 6 + k] * r[i * 6 + k];
-                z[idx] = s;
-                pr2 += r[idx] * s;
-            }
-            const double rzn = block_reduce<kPcgWaves, false>(pr2, red1);
-            if (!isfinite(rzn)) { fail = true; break; }
-            if (rzn <= thresh) break;
-            const double beta = rzn / rz;
-            rz = rzn;
-            for (int idx = tid; idx < n; idx += kPcgThreads) p[idx] = z[idx] + beta * p[idx];
-            __syncthreads();
-        }
-        if (iters > pp.max_iters) iters = pp.max_iters;
-    }
-
-    // ---- outputs: increment, pose part of computeScale(), trial poses ----
-    double sc = 0.0;
-    for (int idx = tid; idx < n; idx += kPcgThreads) {
-        const double xv = fail ? 0.0 : x[idx];
-        w.xp[idx] = xv;
-        sc += xv * (lambda * xv + w.bp[idx]);
-        x[idx] = xv;
-    }
-    const double scs = block_reduce<kPcgWaves, false>(sc, red0);
-    const DevState &S0 = w.st[cur];
-    const DevState &S1 = w.st[cur ^ 1];
-    for (int i = tid; i < w.NP; i += kPcgThreads) {
-        double T[7], Tn[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) T[k] = S0.pose[7 * i + k];
-        const int h = w.hidx[i];
-        if (h >= 0) {
-            double u[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) u[k] = x[6 * h + k];
-            se3_oplus(u, T, Tn);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) Tn[k] = T[k];
-        }
-        double R[9];
-        quat_to_R(Tn, R);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) S1.pose[7 * i + k] = Tn[k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
-        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
-    }
-    if (tid == 0) {
-        w.scale_part[w.n_pt_blocks] = scs;
-        c->pcg_fail = fail ? 1 : 0;
-        c->pcg_last_iters = iters;
-        c->pcg_total_iters += iters;
-    }
-}
-
-// --------------------------------------------------------------------------------
 // k_decide: one wave.  The accept/reject logic and lambda schedule of
 // OptimizationAlgorithmLevenberg::solve plus the loop conditions of
 // SparseOptimizer::optimize, restated as a state machine that
@@ -980,14 +780,15 @@ __global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
 // --------------------------------------------------------------------------------
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
+    if (!w.lds_poses) return 4 * sizeof(double) + 16;
     size_t d = 12 * (size_t)w.NP + (backsub ? 9 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
     return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
-size_t pcg_lds_bytes(int nfree)
+// the largest LDS image the point kernels would stage for this window (decides DevWindow::lds_poses)
+size_t point_lds_need(int NP, int nfree)
 {
-    const size_t n = 6 * (size_t)nfree;
-    return (5 * n + 36 * (size_t)nfree + 2 * kPcgWaves) * sizeof(double) + 16;
+    return (21 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s)
@@ -1001,8 +802,11 @@ hipError_t launch_init(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 {
-    if (w.stereo) hipLaunchKernelGGL((k_point<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
-    else hipLaunchKernelGGL((k_point<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    if (!w.lds_poses) {
+        if (w.stereo) hipLaunchKernelGGL((k_point<false, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+        else hipLaunchKernelGGL((k_point<false, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<false, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    else hipLaunchKernelGGL((k_point<false, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
     return hipGetLastError();
 }
 
@@ -1026,16 +830,13 @@ hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_pcg(const DevWindow &w, const PcgParams &pp, int trial, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_pcg, dim3(1), dim3(kPcgThreads), pcg_lds_bytes(w.nfree), s, w, pp, trial);
-    return hipGetLastError();
-}
-
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
 {
-    if (w.stereo) hipLaunchKernelGGL((k_point<true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-    else hipLaunchKernelGGL((k_point<true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    if (!w.lds_poses) {
+        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
     return hipGetLastError();
 }
 
@@ -1063,13 +864,11 @@ hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
 hipError_t configure_kernels(int nfree_max_lds_bytes)
 {
     (void)nfree_max_lds_bytes;
-    // allow the PCG workgroup and the point kernels to use more than the default 64 KiB of LDS
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    if (e != hipSuccess) return e;
-    const void *pk[4] = { reinterpret_cast<const void *>(k_point<true, false>), reinterpret_cast<const void *>(k_point<false, false>),
-                          reinterpret_cast<const void *>(k_point<true, true>), reinterpret_cast<const void *>(k_point<false, true>) };
+    // allow the point kernels to use more than the default 64 KiB of LDS
+    const void *pk[4] = { reinterpret_cast<const void *>(k_point<true, false, true>), reinterpret_cast<const void *>(k_point<false, false, true>),
+                          reinterpret_cast<const void *>(k_point<true, true, true>), reinterpret_cast<const void *>(k_point<false, true, true>) };
     for (const void *f : pk) {
-        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -528,12 +528,28 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
             }
             SEG_STAMP(6);
         }
-        if (iters > pp.max_iters) iters = pp.max_iters;
     }
+    const bool capped = iters > pp.max_iters;
+    if (capped) iters = pp.max_iters;
     __syncthreads();
+    // ---- no answer from the PCG (a diagonal block was not positive definite, the recurrence broke down, or the cap was
+    // reached before the tolerance: a weakly constrained window, where an iterative solve departs from the exact step
+    // anyway): park the solve (Ctrl::done = 2 turns every kernel queued behind into a no-op) and tell the host, which
+    // queues the direct solver (dense_solve.hip) for this trial and for every later one.  fail / capped are workgroup-uniform.
+    if (fail || capped) {
+        if (tid == 0) {
+            c->pcg_last_iters = iters;
+            c->pcg_total_iters += iters;
+            c->solver_mode = 1; c->direct_from = c->n_solves;
+            c->n_pause += 1;
+            c->done = 2;
+            __hip_atomic_store(&w.hstat->pause_seq, c->n_pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
 
     // ---- outputs: increment, pose part of computeScale(), trial poses (VertexSE3Expmap::oplusImpl) ----
-    const double xv = (fail || !owner) ? 0.0 : x_r;
+    const double xv = owner ? x_r : 0.0;
     if (owner) { w.xp[row] = xv; p_lds[row] = xv; }
     {
         const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + w.bp[row]) : 0.0);
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
 #endif
     if (tid == 0) {
         w.scale_part[w.n_pt_blocks] = scs;
-        c->pcg_fail = fail ? 1 : 0;
+        c->pcg_fail = 0;
         c->pcg_last_iters = iters;
         c->pcg_total_iters += iters;
 #ifdef MOVBA_CLOCK_STAMP

@@ -47,7 +47,8 @@ class LbaResult(C.Structure):
                 ("n_trace", C.c_int32),
                 ("tr_lambda", C.c_double * MAX_TRACE), ("tr_f0", C.c_double * MAX_TRACE),
                 ("tr_f1", C.c_double * MAX_TRACE), ("tr_rho", C.c_double * MAX_TRACE),
-                ("tr_accept", C.c_int32 * MAX_TRACE), ("tr_pcg_iters", C.c_int32 * MAX_TRACE)]
+                ("tr_accept", C.c_int32 * MAX_TRACE), ("tr_pcg_iters", C.c_int32 * MAX_TRACE),
+                ("n_direct", C.c_int32), ("direct_from", C.c_int32), ("n_chol_fail", C.c_int32), ("n_pcg_giveups", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -202,6 +203,7 @@ class Solver:
         n = r.n_trace
         out.update(status=rc, iters_done=r.iters_done, n_solves=r.n_solves, n_outliers=r.n_outliers,
                    pcg_iters=r.pcg_iters, last_rejected=r.last_rejected, lam=r.lambda_, cost0=r.cost0, cost=r.cost,
+                   n_direct=r.n_direct, direct_from=r.direct_from, n_chol_fail=r.n_chol_fail, n_pcg_giveups=r.n_pcg_giveups,
                    trace=dict(lam=np.array(r.tr_lambda[:n]), f0=np.array(r.tr_f0[:n]), f1=np.array(r.tr_f1[:n]),
                               rho=np.array(r.tr_rho[:n]), accept=np.array(r.tr_accept[:n]),
                               pcg=np.array(r.tr_pcg_iters[:n])))

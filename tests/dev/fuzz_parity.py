@@ -13,9 +13,9 @@ s = capi.Solver()
 worst = dict(dq=0.0, dt=0.0, pt=0.0, outl=0)
 bad = 0
 for it in range(n):
-    K = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 12, 15, 16, 17, 20, 24, 31, 40, 50, 64, 79, 81, 95]))
+    K = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 12, 15, 16, 17, 20, 24, 31, 40, 50, 64, 79, 81, 95, 130]))
     F = int(rng.integers(1, 6))
-    P = int(rng.choice([200, 600, 1500, 5000]))
+    P = int(rng.choice([30, 80, 200, 600, 1500, 5000]))
     lo = int(rng.integers(2, 5)); hi = int(min(K + F, lo + rng.integers(0, 12)))
     stereo = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
     seed = int(rng.integers(1, 10 ** 6))
@@ -23,10 +23,12 @@ for it in range(n):
         w = synth.make_window(K, F, P, seed=seed, run_lo=lo, run_hi=max(lo, hi), stereo_frac=stereo)
     except Exception as e:          # degenerate generator input
         continue
-    # keyframes held by a handful of observations make the reduced system rank-deficient up to the LM damping: the iterative
-    # solve then runs into its cap (limits); such windows are reported separately
+    # keyframes held by a handful of observations make the reduced system rank-deficient up to the LM damping: the PCG gives
+    # up there and the direct solver takes over; they are held to SURVEY 8(d)'s float32-map tolerance (two exact solvers differ
+    # by cond(S) * eps in the weak directions) and counted as mismatches like every other window when they exceed it
     per_kf = np.bincount(w.edge_pose, minlength=w.n_poses)[w.pose_fixed == 0]
     weak = per_kf.min() < 12 if len(per_kf) else True
+    tol_q, tol_t, tol_p = (1e-6, 1e-6, 1e-4) if weak else (1e-8, 1e-8, 1e-6)
     ro = oracle.solve(w)
     try:
         rg = s.solve(w)
@@ -39,14 +41,13 @@ for it in range(n):
     guard = np.abs(ro['chi2'] - w.chi2_gate) <= 1e-6
     outl = int(((ro['outlier'] != rg['outlier']) & ~guard).sum())
     same = np.array_equal(ro['trace']['accept'], rg['trace']['accept'])
-    ok = dq < 1e-8 and dt < 1e-8 and pt < 1e-6 and outl == 0 and same and ro['n_solves'] == rg['n_solves']
+    ok = dq < tol_q and dt < tol_t and pt < tol_p and outl == 0 and same and ro['n_solves'] == rg['n_solves']
     worst['dq'] = max(worst['dq'], dq); worst['dt'] = max(worst['dt'], dt); worst['pt'] = max(worst['pt'], pt); worst['outl'] += outl
-    if ok and (dt > 1e-9 or dq > 1e-10):
+    if ok and not weak and (dt > 1e-9 or dq > 1e-10):
         print(f"[{it}] close to tolerance: K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} pcg {rg['pcg_iters']} per trial {rg['trace']['pcg'].tolist()}", flush=True)
-    if not ok and weak:
-        print(f"[{it}] under-constrained window (min {per_kf.min()} observations per keyframe) departs: K={K} F={F} P={P} dq {dq:.2e} dt {dt:.2e} pcg {rg['pcg_iters']}", flush=True)
-    elif not ok:
+    if not ok:
         bad += 1
+        print(f"[{it}] weak={weak} direct_from={rg['direct_from']} n_direct={rg['n_direct']} chol_fail={rg['n_chol_fail']}", flush=True)
         print(f"[{it}] MISMATCH K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} outl {outl} accept_same {same} solves {ro['n_solves']}/{rg['n_solves']} pcg {rg['pcg_iters']}", flush=True)
 print(f"{n} windows, {bad} mismatches; worst dq {worst['dq']:.2e} dt {worst['dt']:.2e} pt {worst['pt']:.2e}")
 sys.exit(1 if bad else 0)

@@ -18,7 +18,7 @@ def test_library_exports_every_symbol_declared_in_header(built_lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(built_lib.EXPORTS) == declared
-    assert lib.movba_version() == 1
+    assert lib.movba_version() == 2
     assert built_lib.status_string(0) == "ok" and built_lib.status_string(-2) == "HIP runtime error"
 
 
