@@ -35,6 +35,16 @@ constexpr int kBackThreads = 1024;
 
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
+// 1 / p by v_rcp_f64 and two Newton steps (~1 ulp): the IEEE division sequence is several hundred cycles of dependent
+// instructions, and the pivot loops below are latency chains with one of these per link
+__device__ __forceinline__ double fast_rcp(double p)
+{
+    double r = __builtin_amdgcn_rcp(p);
+    r = r * (2.0 - p * r);
+    r = r * (2.0 - p * r);
+    return r;
+}
+
 __device__ __forceinline__ size_t tile_off(int I, int J) { return ((size_t)I * (I + 1) / 2 + J) * (NB * NB); }
 
 // global tile (row-major NB x NB) -> LDS image with row stride LD
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(DevWindow w, int j)
     for (int k = 0; k < NB; ++k) {
         double piv = Ps[k * LD + k];
         if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
-        const double rinv = 1.0 / piv;
+        const double rinv = fast_rcp(piv);
         double ck[3], dr[3], ur[3];
 #pragma unroll
         for (int b = 0; b < 3; ++b) ck[b] = Ps[(3 * tc + b) * LD + k] * rinv;           // p_ck / p_kk, rows c of D
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
     double *Ls = x + npad;                          // NB x LD: diagonal factor of the current block column
     double *ps = Ls + NB * LD;                      // 21 x NB partial sums
     double *red = ps + 21 * NB;                     // 16
+    double *rdiag = red + 16;                       // NB: reciprocals of the diagonal of the current factor
     constexpr int G = 21;                           // row groups of the column sums: 21 x 48 = 1008 threads
     const int g = tid / NB, cc = tid - g * NB;
     const bool fail = *ds.fail != 0;
@@ -315,6 +326,7 @@ __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
             }
             ps[g * NB + cc] = s;
         }
+        if (tid >= kBackThreads - NB) { const int k = tid - (kBackThreads - NB); rdiag[k] = fast_rcp(ds.diagL[(size_t)J * NB * NB + k * NB + k]); }
         __syncthreads();
         if (tid < 64) {
             // wave 0: s_c = y_c - (sums in group order), then the 48-step back substitution of L(J, J)^T x = s
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
                 sv = ds.tiles[tile_off(nt, J) + tid] - acc;
             }
             for (int k = NB - 1; k >= 0; --k) {
-                const double xk = readlane_f64(sv, k) / Ls[k * LD + k];
+                const double xk = readlane_f64(sv, k) * rdiag[k];
                 if (tid == k) sv = xk;
                 else if (tid < k) sv -= Ls[k * LD + tid] * xk;
             }
@@ -397,7 +409,7 @@ hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s)
         if (j > 0) for (int cc = 1; cc < m; ++cc) grid += m - cc + 1;
         hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(kStepThreads), lds, s, w, j);
     }
-    const size_t lds_b = ((size_t)nt * NB + NB * LD + 21 * NB + 16) * sizeof(double);
+    const size_t lds_b = ((size_t)nt * NB + NB * LD + 21 * NB + 16 + NB) * sizeof(double);
     hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(kBackThreads), lds_b, s, w);
     return hipGetLastError();
 }

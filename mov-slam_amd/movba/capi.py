@@ -219,6 +219,25 @@ class Solver:
             out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
         return self._pack(r, out, rc)
 
+    def prepare(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
+        """Descriptor and result buffers built once for repeated solve_prepared() calls: what a C++ caller that keeps its
+        flattened arrays and result buffers does (nothing is allocated or converted per call)."""
+        d, keep = make_desc(w, flags, stop, max_iters, max_trials)
+        r, out = self._alloc_result(d)
+        self._prep = (d, keep, r, out)
+
+    def solve_prepared(self, pack=True):
+        """movba_lba_solve on the prepared buffers; pack=False returns only the status (results stay in the buffers)."""
+        d, keep, r, out = self._prep
+        rc = lib().movba_lba_solve(self._h, C.byref(d), C.byref(r))
+        if rc < 0:
+            raise MovbaError(f"movba_lba_solve: {status_string(rc)}")
+        if not pack:
+            return rc
+        if rc != OK:
+            out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
+        return self._pack(r, dict(out), rc)
+
     def upload(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
         rc = lib().movba_lba_upload(self._h, C.byref(d))

@@ -18,12 +18,23 @@ POINT_TOL = 1e-6    # m
 GUARD = 1e-6
 
 
-def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL):
+def noise_floor_trial(o):
+    """First trial whose accept / reject decision the oracle takes on rounding noise: |F0 - F1| <= 1e-9 F0 (the robust cost
+    is a sum over all edges; a solve that has converged to machine precision keeps running, g2o has no convergence test, and
+    the sign of F0 - F1 is then arbitrary).  Decisions from there on are a guard band, like |chi2 - 5| <= 1e-6 for the flags."""
+    f0, f1 = o["trace"]["f0"], o["trace"]["f1"]
+    k = np.flatnonzero(np.abs(f0 - f1) <= 1e-9 * np.abs(f0))
+    return int(k[0]) if len(k) else len(f0)
+
+
+def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_guard=False):
     assert r["status"] == o["status"] == 0
-    assert r["n_solves"] == o["n_solves"] and r["iters_done"] == o["iters_done"]
-    assert np.array_equal(r["trace"]["accept"], o["trace"]["accept"])
-    np.testing.assert_allclose(r["trace"]["lam"], o["trace"]["lam"], rtol=1e-7)
-    np.testing.assert_allclose(r["trace"]["f1"], o["trace"]["f1"], rtol=1e-8)
+    k0 = noise_floor_trial(o) if noise_guard else len(o["trace"]["accept"])
+    if k0 == len(o["trace"]["accept"]):
+        assert r["n_solves"] == o["n_solves"] and r["iters_done"] == o["iters_done"]
+    assert np.array_equal(r["trace"]["accept"][:k0], o["trace"]["accept"][:k0])
+    np.testing.assert_allclose(r["trace"]["lam"][:k0], o["trace"]["lam"][:k0], rtol=1e-7)
+    np.testing.assert_allclose(r["trace"]["f1"][:k0], o["trace"]["f1"][:k0], rtol=1e-6 if noise_guard else 1e-8)
     assert quat_angle(r["poses"][:, :4], o["poses"][:, :4]).max() < rot
     assert np.abs(r["poses"][:, 4:] - o["poses"][:, 4:]).max() < trans
     assert np.abs(r["points"] - o["points"]).max() < point
@@ -169,10 +180,17 @@ def test_weakly_constrained_windows(solver, oracle_mod, K, F, P, lo, hi, seed):
     definition hardly move the cost)."""
     w = synth.make_window(K, F, P, seed=seed, run_lo=lo, run_hi=hi)
     r, o = solver.solve(w), oracle_mod.solve(w)
-    assert r["status"] == o["status"] == 0
-    assert np.array_equal(r["trace"]["accept"], o["trace"]["accept"]) and r["n_solves"] == o["n_solves"]
-    np.testing.assert_allclose(r["trace"]["f1"], o["trace"]["f1"], rtol=1e-6)
-    check_against(r, o, w, **WEAK_TOL)
+    check_against(r, o, w, noise_guard=True, **WEAK_TOL)
+    assert r["n_direct"] > 0 or r["pcg_iters"] < 200 * r["n_solves"]
+
+
+def test_converged_window_keeps_deciding_on_rounding_noise(solver, oracle_mod):
+    """130 keyframes over 30 points (fuzz seed 894021): the cost reaches its floor in trial 6, the remaining trials decide
+    on |F0 - F1| ~ 1e-11: the accept trace is compared up to there, the final state in full."""
+    w = synth.make_window(130, 3, 30, seed=894021, run_lo=4, run_hi=5)
+    r, o = solver.solve(w), oracle_mod.solve(w)
+    assert noise_floor_trial(o) < o["n_solves"]
+    check_against(r, o, w, noise_guard=True, **WEAK_TOL)
 @pytest.mark.parametrize("frac", [1.0, 0.4])
 def test_stereo_edges(solver, oracle_mod, frac):
     """g2o::EdgeStereoSE3ProjectXYZ (src/Optimizer.cc:673-705): 3-row edges, all-stereo and mixed with monocular ones."""
