@@ -143,6 +143,13 @@ int  movba_lba_reset(movba_handle *h);                                /* restore
 int  movba_lba_run(movba_handle *h);                                  /* LM loop on device; returns after stream sync */
 int  movba_lba_download(movba_handle *h, movba_lba_result *res);      /* D2H + caller edge order */
 
+/* movba_lba_run on the resident windows of n handles at once (multi-session serving: several independent windows on one
+ * GPU): every kernel of an LM trial is one launch over the concatenated windows, with per-window LM state, so each window
+ * takes exactly the steps of its solo run and returns bit-identical results; download each handle as usual.  The handles
+ * must have been created on the same device and the same stream, and hold either stereo or monocular windows.  Windows
+ * that end before the solve (MOVBA_EMPTY / MOVBA_NO_FIXED / stop flag up) report that through their own download. */
+int  movba_lba_run_batch(movba_handle *const *handles, int32_t n);
+
 /* Copy the optimised poses (n_poses x 7 f64) into a caller-owned DEVICE buffer on the
  * handle's stream — what the RCCL all-gather of independent windows sends. */
 int  movba_lba_export_poses_device(movba_handle *h, void *dst_device, int64_t capacity_bytes);

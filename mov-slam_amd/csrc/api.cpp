@@ -69,6 +69,9 @@ struct movba_handle {
     bool rows_kernel = false;
     char *scratch = nullptr;            // structure-pass temporaries (struct_kernels.hip)
     size_t scratch_cap = 0;
+    // movba_lba_run_batch (kept by the first handle of a batch): device views, PCG plans and block prefixes of the windows
+    char *batch_host = nullptr, *batch_dev = nullptr;
+    size_t batch_cap = 0;
     // pose-only scratch
     char *pose_arena = nullptr;
     size_t pose_cap = 0;
@@ -234,6 +237,8 @@ void movba_destroy(movba_handle *h)
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->arena) (void)hipFree(h->arena);
     if (h->pose_arena) (void)hipFree(h->pose_arena);
+    if (h->batch_dev) (void)hipFree(h->batch_dev);
+    if (h->batch_host) (void)hipHostFree(h->batch_host);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->stage) (void)hipHostFree(h->stage);
     if (h->hstat) (void)hipHostFree((void *)h->hstat);
@@ -576,43 +581,37 @@ int movba_lba_reset(movba_handle *h)
     return MOVBA_OK;
 }
 
-int movba_lba_run(movba_handle *h)
-{
-    if (!h) return MOVBA_ERR_ARG;
-    if (!h->uploaded) return MOVBA_ERR_STATE;
-    HIP_TRY(hipSetDevice(h->device));
-    h->ran = false; h->run_status = MOVBA_OK;
-    if (h->early_status != MOVBA_OK) { h->ran = true; return h->early_status; }
-    // early return before the solve (src/Optimizer.cc:749-751); not sticky: the next run looks at the flag again
-    if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
-    // (a registered export buffer too small for this window is ignored rather than overrun)
-    h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
-    const DevWindow &w = h->win;
-    hipStream_t s = h->stream;
-    h->hstat->progress = 0; h->hstat->stop = 0;
+}  // extern "C"
 
-    {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
-        ScopedEvents ev(h, KC_SETUP);
-        HIP_TRY(launch_init(w, s));
-        HIP_TRY(launch_linearize(w, s));
-        if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, 0, s));
-        HIP_TRY(launch_lambda_init(w, s));
-    }
+namespace {
+
+// PCG parameters of the handle's resident window for a run
+PcgParams run_pcg_params(const movba_handle *h)
+{
     PcgParams pp = h->pp;
     pp.rel_tol = h->opt.pcg_rel_tol;
     // PCG cap: past ~200 iterations the direct solver is cheaper than carrying on, and a system that slow to converge is
     // one whose iterative answer would depart from the exact step anyway (see the park in k_pcg_rows)
     pp.max_iters = h->opt.pcg_max_iters > 0 ? h->opt.pcg_max_iters : 200;
-    const int nrowent = (int)h->st.row_ent.size();
     // 1: coarse level built beside the solve, one trial old; 2: small window (<= one keyframe per wave), built first and fresh
     bool one_row_per_wave = true;
     for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) one_row_per_wave &= pp.wave_row0[wv + 1] - pp.wave_row0[wv] <= 1;
     pp.use_coarse = (h->opt.pcg_coarse && h->rows_kernel) ? (one_row_per_wave ? 2 : 1) : 0;
+    return pp;
+}
+
+// The LM trial loop of the handle's window on its own stream, from the state the device is in: a fresh window (after the
+// setup launches), or one that parked itself during a batched run (its pause is then the first thing answered).
+int lm_loop(movba_handle *h, bool parked)
+{
+    const DevWindow &w = h->win;
+    hipStream_t s = h->stream;
+    PcgParams pp = run_pcg_params(h);
+    const int nrowent = (int)h->st.row_ent.size();
     // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
     bool direct = !h->rows_kernel;
     int pauses_seen = 0;
-    h->hstat->pause_seq = 0;
-
+    if (!parked) h->hstat->pause_seq = 0;
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
     const double t_start = now_ms();
     // k_finalize + the Ctrl read-back are queued speculatively behind a trial that is likely the last one, so that the
@@ -685,6 +684,37 @@ int movba_lba_run(movba_handle *h)
         const int rq = answer_pause(); if (rq != MOVBA_OK) return rq;
     }
     harvest_events(h);
+    return MOVBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int movba_lba_run(movba_handle *h)
+{
+    if (!h) return MOVBA_ERR_ARG;
+    if (!h->uploaded) return MOVBA_ERR_STATE;
+    HIP_TRY(hipSetDevice(h->device));
+    h->ran = false; h->run_status = MOVBA_OK;
+    if (h->early_status != MOVBA_OK) { h->ran = true; return h->early_status; }
+    // early return before the solve (src/Optimizer.cc:749-751); not sticky: the next run looks at the flag again
+    if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
+    // (a registered export buffer too small for this window is ignored rather than overrun)
+    h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
+    const DevWindow &w = h->win;
+    hipStream_t s = h->stream;
+    h->hstat->progress = 0; h->hstat->stop = 0;
+
+    {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
+        ScopedEvents ev(h, KC_SETUP);
+        HIP_TRY(launch_init(w, s));
+        HIP_TRY(launch_linearize(w, s));
+        if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, 0, s));
+        HIP_TRY(launch_lambda_init(w, s));
+    }
+    const int rl = lm_loop(h, false);
+    if (rl != MOVBA_OK) return rl;
 #ifdef MOVBA_CLOCK_STAMP
     std::fprintf(stderr, "libmovba[stamp]: k_pcg_rows %llu shader cycles in %llu x 10 ns -> %.3f GHz\n", h->ctrl_host->dbg_cycles,
                  h->ctrl_host->dbg_ticks, h->ctrl_host->dbg_ticks ? 0.1 * (double)h->ctrl_host->dbg_cycles / (double)h->ctrl_host->dbg_ticks : 0.0);
@@ -699,6 +729,151 @@ int movba_lba_run(movba_handle *h)
     std::fprintf(stderr, "\n");
 #endif
     h->ran = true;
+    return MOVBA_OK;
+}
+
+// Optimizer::LocalBundleAdjustment's solve on n resident windows at once (multi-session serving; BASELINE cfg5's windows when
+// they share a GPU): every kernel of a trial is ONE launch over the concatenated windows — the point and schur grids of a
+// single 50-keyframe window leave most of the chip idle, and its PCG occupies 2 of 256 CUs — with per-window LM state, so
+// each window takes exactly the steps (and produces exactly the bits) of its solo movba_lba_run.
+int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
+{
+    if (!hs || n < 1) return MOVBA_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return MOVBA_ERR_ARG;
+        if (!hs[i]->uploaded) return MOVBA_ERR_STATE;
+        if (hs[i]->device != hs[0]->device || hs[i]->stream != hs[0]->stream) {
+            std::fprintf(stderr, "libmovba: the handles of a batch must share one device and one stream\n");
+            return MOVBA_ERR_ARG;
+        }
+        for (int k = 0; k < i; ++k) if (hs[k] == hs[i]) return MOVBA_ERR_ARG;
+    }
+    movba_handle *h0 = hs[0];
+    HIP_TRY(hipSetDevice(h0->device));
+    hipStream_t s = h0->stream;
+    // windows that return before the solve (nothing to do, no fixed keyframe, stop flag up) and windows without an on-chip
+    // PCG (they take the direct solver's per-window launches) stay out of the batched launches
+    std::vector<movba_handle *> act, solo;
+    for (int i = 0; i < n; ++i) {
+        movba_handle *h = hs[i];
+        h->ran = false; h->run_status = MOVBA_OK;
+        if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
+        if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
+        if (!h->rows_kernel) { solo.push_back(h); continue; }
+        act.push_back(h);
+    }
+    const int na = (int)act.size();
+    if (na > 0) {
+        bool stereo = act[0]->win.stereo != 0, ldsp = true, overflow = false;
+        for (movba_handle *h : act) {
+            if ((h->win.stereo != 0) != stereo) {
+                std::fprintf(stderr, "libmovba: a batch holds either stereo or monocular windows, not both\n");
+                return MOVBA_ERR_ARG;
+            }
+            ldsp &= h->win.lds_poses != 0; overflow |= h->pp.overflow != 0;
+        }
+        // ---- device views, PCG plans and block prefixes ----
+        Carver c;
+        const size_t o_win = c.take<DevWindow>(na), o_pp = c.take<PcgParams>(na);
+        const size_t o_bp = c.take<int32_t>(na + 1), o_bs = c.take<int32_t>(na + 1), o_bf = c.take<int32_t>(na + 1), o_bi = c.take<int32_t>(na + 1);
+        if (c.off > h0->batch_cap) {
+            HIP_TRY(hipStreamSynchronize(s));
+            if (h0->batch_dev) { HIP_TRY(hipFree(h0->batch_dev)); h0->batch_dev = nullptr; }
+            if (h0->batch_host) { HIP_TRY(hipHostFree(h0->batch_host)); h0->batch_host = nullptr; }
+            h0->batch_cap = 0;
+            const size_t cap = align_up(2 * c.off, 1 << 16);
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h0->batch_host), cap, hipHostMallocDefault));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h0->batch_dev), cap));
+            h0->batch_cap = cap;
+        }
+        HIP_TRY(hipStreamSynchronize(s));           // the previous batch's H2D copy of this buffer has landed
+        char *bh = h0->batch_host;
+        DevWindow *wins = reinterpret_cast<DevWindow *>(bh + o_win);
+        PcgParams *pps = reinterpret_cast<PcgParams *>(bh + o_pp);
+        int32_t *bp = reinterpret_cast<int32_t *>(bh + o_bp), *bs = reinterpret_cast<int32_t *>(bh + o_bs);
+        int32_t *bf = reinterpret_cast<int32_t *>(bh + o_bf), *bi = reinterpret_cast<int32_t *>(bh + o_bi);
+        bp[0] = bs[0] = bf[0] = bi[0] = 0;
+        size_t lds_lin = 0, lds_back = 0, lds_pcg = 0;
+        int max_trials = 0, max_iters = 0, run_ahead = h0->opt.run_ahead;
+        for (int i = 0; i < na; ++i) {
+            movba_handle *h = act[i];
+            h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
+            h->hstat->progress = 0; h->hstat->stop = 0; h->hstat->pause_seq = 0;
+            wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
+            pps[i] = run_pcg_params(h);
+            const DevWindow &w = h->win;
+            bp[i + 1] = bp[i] + w.n_pt_blocks;
+            bs[i + 1] = bs[i] + (w.nitems > 0 ? schur_blocks(w) : 0);
+            bf[i + 1] = bf[i] + (w.E + 255) / 256;
+            const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;
+            int nb = (work + 255) / 256; nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+            bi[i + 1] = bi[i] + nb;
+            lds_lin = std::max(lds_lin, point_lds_bytes_for(w, false, ldsp)); lds_back = std::max(lds_back, point_lds_bytes_for(w, true, ldsp));
+            lds_pcg = std::max(lds_pcg, pcg_rows_lds_bytes(w.nfree, (int)h->st.row_ent.size()));
+            max_trials = std::max(max_trials, (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials);
+            max_iters = std::max(max_iters, w.max_iters);
+        }
+        HIP_TRY(hipMemcpyAsync(h0->batch_dev, bh, c.off, hipMemcpyHostToDevice, s));
+        BatchDev b{};
+        char *bd = h0->batch_dev;
+        b.wins = reinterpret_cast<const DevWindow *>(bd + o_win); b.pps = reinterpret_cast<const PcgParams *>(bd + o_pp);
+        b.blk_point = reinterpret_cast<const int32_t *>(bd + o_bp); b.blk_schur = reinterpret_cast<const int32_t *>(bd + o_bs);
+        b.blk_final = reinterpret_cast<const int32_t *>(bd + o_bf); b.blk_init = reinterpret_cast<const int32_t *>(bd + o_bi);
+        b.n = na;
+        const int nb_point = bp[na], nb_schur = bs[na], nb_final = bf[na], nb_init = bi[na];
+
+        // ---- setup: state 0, first linearisation, lambda_0 and F0 of every window ----
+        HIP_TRY(launch_init_batch(b, nb_init, s));
+        HIP_TRY(launch_point_batch(b, nb_point, false, stereo, ldsp, lds_lin, s));
+        if (nb_schur > 0) HIP_TRY(launch_schur_batch(b, nb_schur, 1, stereo, s));
+        HIP_TRY(launch_lambda_init_batch(b, s));
+
+        // ---- trial sets, the host a bounded number of sets ahead of the slowest window still running ----
+        const double t_start = now_ms();
+        int t = 0, final_after = -1;
+        for (; t < max_trials; ++t) {
+            bool finished = false;
+            for (;;) {
+                int td_min = 1 << 30, it_min = 1 << 30, running = 0;
+                for (movba_handle *h : act) {
+                    const uint64_t pg = h->hstat->progress;
+                    if (((pg >> 48) & 1) || h->hstat->pause_seq != 0) continue;      // done, or parked for the direct solver
+                    ++running;
+                    td_min = std::min(td_min, (int)(pg & 0xffffff)); it_min = std::min(it_min, (int)((pg >> 24) & 0xffffff));
+                }
+                if (running == 0) { finished = true; break; }
+                const int left = max_iters - it_min;
+                const int limit = left < run_ahead ? (left > 1 ? left : 1) : run_ahead;
+                if (t - td_min < limit) break;
+                if (final_after != t && t - td_min < run_ahead) { HIP_TRY(launch_finalize_batch(b, nb_final, s)); final_after = t; }
+                for (movba_handle *h : act) if (h->stop && *h->stop) h->hstat->stop = 1;
+                if (now_ms() - t_start > 60000.0) {
+                    std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
+                    return MOVBA_ERR_HIP;
+                }
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (finished) break;
+            for (movba_handle *h : act) if (h->stop && *h->stop) h->hstat->stop = 1;
+            if (nb_schur > 0) HIP_TRY(launch_schur_batch(b, nb_schur, 0, stereo, s));
+            HIP_TRY(launch_pcg_rows_batch(b, overflow, lds_pcg, t, s));
+            HIP_TRY(launch_point_batch(b, nb_point, true, stereo, ldsp, lds_back, s));
+            HIP_TRY(launch_decide_batch(b, s));
+        }
+        if (final_after != t) HIP_TRY(launch_finalize_batch(b, nb_final, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        // windows whose PCG gave up parked themselves: each finishes on the direct solver from where it stands
+        for (movba_handle *h : act) {
+            if (h->hstat->pause_seq != 0 && !((h->hstat->progress >> 48) & 1)) {
+                const int rl = lm_loop(h, true);
+                if (rl != MOVBA_OK) return rl;
+            }
+            h->ran = true;
+        }
+    }
+    for (movba_handle *h : solo) { const int rc = movba_lba_run(h); if (rc < 0) return rc; }
     return MOVBA_OK;
 }
 

@@ -161,4 +161,13 @@ struct PcgParams {
     int32_t use_coarse;         // k_pcg_rows: add the aggregate coarse-level correction to block-Jacobi (1: lagged, 2: fresh)
 };
 
+// Batched launches over n resident windows (movba_lba_run_batch): device arrays of the windows' views and PCG plans, and
+// per kernel the prefix of the windows' block counts (n + 1 entries each).
+struct BatchDev {
+    const DevWindow *wins;
+    const PcgParams *pps;
+    const int32_t *blk_point, *blk_schur, *blk_final, *blk_init;
+    int32_t n, pad;
+};
+
 }  // namespace movba

@@ -27,6 +27,18 @@ hipError_t launch_finalize(const DevWindow &w, hipStream_t s);
 struct ExportDst { unsigned long long *poses, *points, *chi2, *outlier; };
 hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s);
 
+// batched launches over the concatenated windows of a BatchDev (movba_lba_run_batch)
+hipError_t launch_init_batch(const BatchDev &b, int nblk, hipStream_t s);
+hipError_t launch_point_batch(const BatchDev &b, int nblk, bool backsub, bool stereo, bool ldsp, size_t lds, hipStream_t s);
+size_t point_lds_bytes_for(const DevWindow &w, bool backsub, bool ldsp);
+int schur_blocks(const DevWindow &w);
+hipError_t launch_schur_batch(const BatchDev &b, int nblk, int mode, bool stereo, hipStream_t s);
+hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s);
+hipError_t launch_decide_batch(const BatchDev &b, hipStream_t s);
+hipError_t launch_finalize_batch(const BatchDev &b, int nblk, hipStream_t s);
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, size_t lds, int trial, hipStream_t s);
+size_t pcg_rows_lds_bytes(int nfree, int nrowent);
+
 // direct solver (dense_solve.hip): assemble + one launch per block column + back substitution / pose update
 hipError_t configure_dense_kernels();
 hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s);

@@ -31,14 +31,14 @@ namespace movba {
 // k_init_pose: uploaded poses -> state 0 (normalised like SE3Quat's constructor), Rt cache; uploaded points -> state 0
 // (in the same launch: a separate device-to-device copy costs a launch gap of its own at the start of every solve)
 // --------------------------------------------------------------------------------
-__global__ void k_init_pose(DevWindow w)
+__device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int nblk)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = bid * blockDim.x + threadIdx.x;
     {
         const double2 *src = reinterpret_cast<const double2 *>(w.point0);
         double2 *dst = reinterpret_cast<double2 *>(w.st[0].point);
         const int n2 = (3 * w.P) >> 1;
-        for (int k = i; k < n2; k += gridDim.x * blockDim.x) dst[k] = src[k];
+        for (int k = i; k < n2; k += nblk * blockDim.x) dst[k] = src[k];
         if (i == 0 && ((3 * w.P) & 1)) w.st[0].point[3 * w.P - 1] = w.point0[3 * w.P - 1];
     }
     if (i == 0) {
@@ -68,6 +68,8 @@ __global__ void k_init_pose(DevWindow w)
     w.st[0].Rt[12 * i + 9] = q[4]; w.st[0].Rt[12 * i + 10] = q[5]; w.st[0].Rt[12 * i + 11] = q[6];
 }
 
+__global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim.x); }
+
 // --------------------------------------------------------------------------------
 // k_point<BACKSUB>: 8 lanes per map point, edges of a point are contiguous.
 //   BACKSUB=false : evaluate errors + linearise (Hll, bl, per-edge Xc/weight) at state cur
@@ -78,7 +80,7 @@ __global__ void k_init_pose(DevWindow w)
 // LDSP: the keyframe rotations (and, for BACKSUB, the pose increments and hessian indices) are staged in LDS; windows
 // with more keyframes than fit (~850) read them through L2 instead (same arithmetic, same results).
 template <bool BACKSUB, bool STEREO, bool LDSP>
-__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
+__device__ __forceinline__ void point_body(const DevWindow &w, int bid)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = w.ctrl;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     // ---- everything this lane needs from HBM is requested before the LDS staging barrier, so that the
     //      point / edge gathers and the pose staging overlap instead of queueing behind each other ----
     const int sub = threadIdx.x & (kPointGroup - 1);
-    const int l = blockIdx.x * kPointsPerBlock + (threadIdx.x / kPointGroup);
+    const int l = bid * kPointsPerBlock + (threadIdx.x / kPointGroup);
     const bool valid = l < w.P;
     int begin = 0, end = 0;
     if (valid) { begin = w.pt_start[l]; end = w.pt_start[l + 1]; }
@@ -274,12 +276,37 @@ __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w)
     const double Fsum = block_reduce<kPointBlock / 64, false>(F, red);
     if (BACKSUB) {
         const double ssum = block_reduce<kPointBlock / 64, false>(scale, red);
-        if (threadIdx.x == 0) w.scale_part[blockIdx.x] = ssum;
+        if (threadIdx.x == 0) w.scale_part[bid] = ssum;
     } else {
         const double m = block_reduce<kPointBlock / 64, true>(hmax, red);
-        if (threadIdx.x == 0) w.hmax_part[blockIdx.x] = m;
+        if (threadIdx.x == 0) w.hmax_part[bid] = m;
     }
-    if (threadIdx.x == 0) S1.Fpart[blockIdx.x] = Fsum;
+    if (threadIdx.x == 0) S1.Fpart[bid] = Fsum;
+}
+
+template <bool BACKSUB, bool STEREO, bool LDSP>
+__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w) { point_body<BACKSUB, STEREO, LDSP>(w, blockIdx.x); }
+
+// Batched launches (movba_lba_run_batch): one grid over the concatenated windows; `pre` is the prefix of the windows'
+// block counts for this kernel.  Every window runs exactly the code of its solo launch, so results are bit-identical.
+__device__ __forceinline__ int batch_window(const int32_t *pre, int n, int b)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= b) lo = mid; else hi = mid - 1; }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
+template <bool BACKSUB, bool STEREO, bool LDSP>
+__global__ __launch_bounds__(kPointBlock) void k_point_b(BatchDev b)
+{
+    const int wi = batch_window(b.blk_point, b.n, blockIdx.x);
+    point_body<BACKSUB, STEREO, LDSP>(b.wins[wi], blockIdx.x - b.blk_point[wi]);
+}
+
+__global__ void k_init_pose_b(BatchDev b)
+{
+    const int wi = batch_window(b.blk_init, b.n, blockIdx.x);
+    init_pose_body(b.wins[wi], blockIdx.x - b.blk_init[wi], b.blk_init[wi + 1] - b.blk_init[wi]);
 }
 
 // partial-slot of each of the 54 sums of a diagonal work item (layout in device_types.h) and, for the
@@ -450,7 +477,7 @@ constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
 
 // HPP_ONLY: diagonal pairs only, Hpp and b_p only (one launch per solve, seeds lambda)
 template <int NR, bool HPP_ONLY>
-__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
+__device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
 {
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long wst[5];
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
     // XCD-aware launch schedule (structure.cpp): workgroups b, b+8, ... share an XCD (and its L2) and take the slots of
     // that XCD's segment in order.  The slot is fetched together with the LM state (one scalar round trip).
     constexpr int ipw = kSchurWaves / kSchurWPI;            // kSchurWPI waves share one work item
-    const int wg = (blockIdx.x & 7) * (w.sched_per_xcd / ipw) + (blockIdx.x >> 3);
+    const int wg = (bid & 7) * (w.sched_per_xcd / ipw) + (bid >> 3);
     const SchedItem it = w.sched[wg * ipw + wv / kSchurWPI];
     const Ctrl *c = w.ctrl;
     if (c->done) return;
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
 #ifdef MOVBA_CLOCK_STAMP
     WSTAMP(4);
     if (!HPP_ONLY && lane == 0 && c->n_solves == 3) {        // one launch: per-wave stamps (100 MHz ticks), read back through out_chi2
-        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 8 * (size_t)(blockIdx.x * kSchurWaves + wv);
+        unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 8 * (size_t)(bid * kSchurWaves + wv);
         for (int k = 0; k < 5; ++k) dbg[k] = wst[k];
         dbg[5] = (unsigned long long)(wend - wbeg);
         dbg[6] = (unsigned long long)is_diag | ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 8) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 40);
@@ -586,11 +613,21 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w)
 #endif
 }
 
+template <int NR, bool HPP_ONLY>
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w) { schur_body<NR, HPP_ONLY>(w, blockIdx.x); }
+
+template <int NR, bool HPP_ONLY>
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur_b(BatchDev b)
+{
+    const int wi = batch_window(b.blk_schur, b.n, blockIdx.x);
+    schur_body<NR, HPP_ONLY>(b.wins[wi], blockIdx.x - b.blk_schur[wi]);
+}
+
 // --------------------------------------------------------------------------------
 // k_lambda_init: OptimizationAlgorithmLevenberg::computeLambdaInit — tau * max |H_jj| over
 // the free pose and point diagonals (tau = 1e-5), and the initial robust cost F0.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_lambda_init(DevWindow w)
+__device__ __forceinline__ void lambda_init_body(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
     if (c->done) return;
@@ -628,13 +665,16 @@ __global__ __launch_bounds__(64) void k_lambda_init(DevWindow w)
     }
 }
 
+__global__ __launch_bounds__(64) void k_lambda_init(DevWindow w) { lambda_init_body(w); }
+__global__ __launch_bounds__(64) void k_lambda_init_b(BatchDev b) { lambda_init_body(b.wins[blockIdx.x]); }
+
 // --------------------------------------------------------------------------------
 // k_decide: one wave.  The accept/reject logic and lambda schedule of
 // OptimizationAlgorithmLevenberg::solve plus the loop conditions of
 // SparseOptimizer::optimize, restated as a state machine that
 // advances by one trial per launch.  Publishes progress to pinned host memory.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_decide(DevWindow w)
+__device__ __forceinline__ void decide_body(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
     const int lane = threadIdx.x;
@@ -714,15 +754,18 @@ __global__ __launch_bounds__(64) void k_decide(DevWindow w)
     __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ __launch_bounds__(64) void k_decide(DevWindow w) { decide_body(w); }
+__global__ __launch_bounds__(64) void k_decide_b(BatchDev b) { decide_body(b.wins[blockIdx.x]); }
+
 // --------------------------------------------------------------------------------
 // k_finalize: chi2 / outlier flags in caller edge order (src/Optimizer.cc:757-775).
 // With the stale-error quirk the chi2 of a rejected last trial is reported, as g2o leaves
 // it in the edges; the depth test always uses the final estimates.
 // --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(DevWindow w)
+__device__ __forceinline__ void finalize_body(const DevWindow &w, int bid, int nblk)
 {
     const Ctrl *c = w.ctrl;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = bid * blockDim.x + threadIdx.x;
     int bad = 0;
     if (g < w.E) {
         const int cur = c->cur;
@@ -741,17 +784,24 @@ __global__ __launch_bounds__(256) void k_finalize(DevWindow w)
     // made this kernel four times longer than its memory traffic)
     // the controller state goes to the host's pinned copy from here: a separate small device-to-host copy behind the last
     // kernel costs more than these few hundred stores across the bus
-    if (blockIdx.x == 0) {
+    if (bid == 0) {
         static_assert(sizeof(Ctrl) % 8 == 0, "copied as 64-bit words");
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(c);
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(w.ctrl_out);
         for (int k = threadIdx.x; k < (int)(sizeof(Ctrl) / 8); k += blockDim.x) dst[k] = src[k];
     }
     // final poses into the caller's registered device buffer (movba_lba_set_pose_export: what the all-gather sends)
-    if (w.pose_export && blockIdx.x == gridDim.x - 1) {
+    if (w.pose_export && bid == nblk - 1) {
         const double *src = w.st[c->cur].pose;
         for (int k = threadIdx.x; k < 7 * w.NP; k += blockDim.x) w.pose_export[k] = src[k];
     }
+}
+
+__global__ __launch_bounds__(256) void k_finalize(DevWindow w) { finalize_body(w, blockIdx.x, gridDim.x); }
+__global__ __launch_bounds__(256) void k_finalize_b(BatchDev b)
+{
+    const int wi = batch_window(b.blk_final, b.n, blockIdx.x);
+    finalize_body(b.wins[wi], blockIdx.x - b.blk_final[wi], b.blk_final[wi + 1] - b.blk_final[wi]);
 }
 
 // --------------------------------------------------------------------------------
@@ -861,12 +911,75 @@ hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---- batched launches (movba_lba_run_batch).  stereo / lds_poses are properties of the whole batch (api.cpp checks) ----
+hipError_t launch_init_batch(const BatchDev &b, int nblk, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_init_pose_b, dim3(nblk), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_point_batch(const BatchDev &b, int nblk, bool backsub, bool stereo, bool ldsp, size_t lds, hipStream_t s)
+{
+    const dim3 g(nblk), t(kPointBlock);
+#define MOVBA_PB(B, S, L) hipLaunchKernelGGL((k_point_b<B, S, L>), g, t, lds, s, b)
+    if (backsub) {
+        if (stereo) { if (ldsp) MOVBA_PB(true, true, true); else MOVBA_PB(true, true, false); }
+        else { if (ldsp) MOVBA_PB(true, false, true); else MOVBA_PB(true, false, false); }
+    } else {
+        if (stereo) { if (ldsp) MOVBA_PB(false, true, true); else MOVBA_PB(false, true, false); }
+        else { if (ldsp) MOVBA_PB(false, false, true); else MOVBA_PB(false, false, false); }
+    }
+#undef MOVBA_PB
+    return hipGetLastError();
+}
+
+size_t point_lds_bytes_for(const DevWindow &w, bool backsub, bool ldsp)
+{
+    DevWindow v = w; v.lds_poses = ldsp ? 1 : 0;
+    return point_lds_bytes(v, backsub);
+}
+
+int schur_blocks(const DevWindow &w) { return 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI)); }
+
+hipError_t launch_schur_batch(const BatchDev &b, int nblk, int mode, bool stereo, hipStream_t s)
+{
+    const dim3 g(nblk), t(kSchurWaves * 64);
+    if (mode == 1) {
+        if (stereo) hipLaunchKernelGGL((k_schur_b<3, true>), g, t, 0, s, b);
+        else hipLaunchKernelGGL((k_schur_b<2, true>), g, t, 0, s, b);
+    } else {
+        if (stereo) hipLaunchKernelGGL((k_schur_b<3, false>), g, t, 0, s, b);
+        else hipLaunchKernelGGL((k_schur_b<2, false>), g, t, 0, s, b);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lambda_init_b, dim3(b.n), dim3(64), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_decide_batch(const BatchDev &b, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_decide_b, dim3(b.n), dim3(64), 0, s, b);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_batch(const BatchDev &b, int nblk, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize_b, dim3(nblk), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
 hipError_t configure_kernels(int nfree_max_lds_bytes)
 {
     (void)nfree_max_lds_bytes;
     // allow the point kernels to use more than the default 64 KiB of LDS
-    const void *pk[4] = { reinterpret_cast<const void *>(k_point<true, false, true>), reinterpret_cast<const void *>(k_point<false, false, true>),
-                          reinterpret_cast<const void *>(k_point<true, true, true>), reinterpret_cast<const void *>(k_point<false, true, true>) };
+    const void *pk[8] = { reinterpret_cast<const void *>(k_point<true, false, true>), reinterpret_cast<const void *>(k_point<false, false, true>),
+                          reinterpret_cast<const void *>(k_point<true, true, true>), reinterpret_cast<const void *>(k_point<false, true, true>),
+                          reinterpret_cast<const void *>(k_point_b<true, false, true>), reinterpret_cast<const void *>(k_point_b<false, false, true>),
+                          reinterpret_cast<const void *>(k_point_b<true, true, true>), reinterpret_cast<const void *>(k_point_b<false, true, true>) };
     for (const void *f : pk) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;

@@ -84,8 +84,9 @@ __device__ __forceinline__ double s_block_elem(const double *part, int pr, int i
 
 // OVERFLOW: some wave's gather list does not fit its 64 VGPR-resident pairs; the tail is multiplied from an L2 copy of S
 // (a separate instantiation: its extra live values must not cost the common case registers)
+// role 0: the solving workgroup, role 1: the coarse-level builder of the same launch
 template <bool OVERFLOW>
-__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial)
+__device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParams &pp, int trial, int role)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     if (fresh) {
         coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false);
         __syncthreads();
-    } else if (blockIdx.x == 1) {   // second workgroup: coarse level of THIS trial's matrix, for the next trial
+    } else if (role == 1) {         // second workgroup: coarse level of THIS trial's matrix, for the next trial
         coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true);
         return;
     }
@@ -598,6 +599,20 @@ __global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int 
     }
 }
 
+template <bool OVERFLOW>
+__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW>(w, pp, trial, blockIdx.x); }
+
+// batched: workgroups 2 i and 2 i + 1 are the solver and the coarse builder of window i (a window in fresh-coarse mode
+// has no builder: its second workgroup returns at once)
+template <bool OVERFLOW>
+__global__ __launch_bounds__(kT) void k_pcg_rows_b(BatchDev b, int trial)
+{
+    const int wi = blockIdx.x >> 1, role = blockIdx.x & 1;
+    const PcgParams &pp = b.pps[wi];
+    if (role == 1 && pp.use_coarse != 1) return;
+    pcg_rows_body<OVERFLOW>(b.wins[wi], pp, trial, role);
+}
+
 size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
@@ -652,11 +667,22 @@ hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp,
     return hipGetLastError();
 }
 
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, size_t lds, int trial, hipStream_t s)
+{
+    if (overflow) hipLaunchKernelGGL(k_pcg_rows_b<true>, dim3(2 * b.n), dim3(kT), lds, s, b, trial);
+    else hipLaunchKernelGGL(k_pcg_rows_b<false>, dim3(2 * b.n), dim3(kT), lds, s, b, trial);
+    return hipGetLastError();
+}
+
 hipError_t configure_pcg_rows()
 {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    const void *fs[4] = { reinterpret_cast<const void *>(k_pcg_rows<false>), reinterpret_cast<const void *>(k_pcg_rows<true>),
+                          reinterpret_cast<const void *>(k_pcg_rows_b<false>), reinterpret_cast<const void *>(k_pcg_rows_b<true>) };
+    for (const void *f : fs) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace movba

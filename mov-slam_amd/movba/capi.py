@@ -82,7 +82,7 @@ class PoseResult(C.Structure):
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
            "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
            "movba_lba_export_poses_device", "movba_lba_set_pose_export", "movba_get_profile", "movba_reset_profile",
-           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask"]
+           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch"]
 
 _lib = None
 
@@ -112,6 +112,7 @@ def lib():
         L.movba_set_profile_mask.argtypes = [C.c_void_p, C.c_int32]
         L.movba_structure_probe.argtypes = [C.POINTER(LbaDesc), C.POINTER(StructureInfo), _i, _i]
         L.movba_pose_opt.argtypes = [C.c_void_p, C.POINTER(PoseDesc), C.POINTER(PoseResult)]
+        L.movba_lba_run_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
         _lib = L
     return _lib
 
@@ -163,6 +164,15 @@ def structure_probe(w):
                 pcg_overflow=bool(info.pcg_overflow), pcg_max_wave_entries=info.pcg_max_wave_entries,
                 n_row_entries=info.n_row_entries, n_sched_slots=info.n_sched_slots, sched_items=info.sched_items,
                 sched_max_permille=info.sched_max_permille, slots_ok=bool(info.slots_ok), perm=perm, free_index=fidx)
+
+
+def run_batch(solvers) -> int:
+    """movba_lba_run_batch over the resident windows of `solvers` (created on one stream); download each as usual."""
+    arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    rc = lib().movba_lba_run_batch(arr, len(solvers))
+    if rc < 0:
+        raise MovbaError(f"movba_lba_run_batch: {status_string(rc)}")
+    return rc
 
 
 class Solver:

@@ -459,3 +459,79 @@ def test_raised_stop_flag_is_not_sticky_in_the_phased_api(solver, built_lib):
     r = solver.download()
     assert r["status"] == 0 and r["n_solves"] >= 10
     assert np.array_equal(r["poses"], solver.solve(w)["poses"])
+
+
+def _shared_stream_solvers(built_lib, n, **kw):
+    import torch
+    st = torch.cuda.Stream(device=0)
+    return st, [built_lib.Solver(device=0, stream=st.cuda_stream, **kw) for _ in range(n)]
+
+
+def test_batched_run_is_bit_identical_to_solo_runs(built_lib, oracle_mod):
+    """movba_lba_run_batch: eight resident windows of different shapes, every kernel of a trial one launch over all of them.
+    Each window must take exactly the steps of its solo run (same accept trace, same PCG iteration counts, same bits)."""
+    import torch
+    shapes = [(10, 2, 2000, 2, 6), (50, 10, 20000, 2, 10), (8, 2, 200, 2, 6), (24, 3, 3000, 2, 8), (40, 4, 3000, 10, 30),
+              (3, 1, 60, 2, 3), (64, 5, 8000, 2, 9), (17, 2, 900, 3, 7)]
+    ws = [synth.make_window(K, F, P, seed=4000 + i, run_lo=lo, run_hi=hi) for i, (K, F, P, lo, hi) in enumerate(shapes)]
+    st, solvers = _shared_stream_solvers(built_lib, len(ws))
+    try:
+        solo = [s.solve(w) for s, w in zip(solvers, ws)]
+        for s, w in zip(solvers, ws):
+            s.upload(w)
+        assert built_lib.run_batch(solvers) == 0
+        for s, w, a in zip(solvers, ws, solo):
+            b = s.download()
+            for k in ("poses", "points", "chi2", "outlier"):
+                assert np.array_equal(a[k], b[k]), k
+            assert np.array_equal(a["trace"]["pcg"], b["trace"]["pcg"]) and np.array_equal(a["trace"]["accept"], b["trace"]["accept"])
+            assert a["n_solves"] == b["n_solves"] and a["lam"] == b["lam"]
+        check_against(solvers[1].download(), oracle_mod.solve(ws[1]), ws[1])
+        # a second batch over a subset, in another order, on the same handles
+        sub = [solvers[4], solvers[0], solvers[6]]
+        assert built_lib.run_batch(sub) == 0
+        for s, i in zip(sub, (4, 0, 6)):
+            assert np.array_equal(s.download()["poses"], solo[i]["poses"])
+    finally:
+        for s in solvers:
+            s.close()
+
+
+def test_batched_run_with_windows_that_leave_the_batch(built_lib, oracle_mod):
+    """A batch may hold windows that do not take the batched kernels to the end: one whose PCG gives up (it parks itself and
+    finishes on the direct solver), one beyond the on-chip PCG (direct solver throughout), an empty one, one without a
+    fixed keyframe and one whose stop flag is up; the others are not disturbed."""
+    ws = [synth.cfg("cfg2"), synth.make_window(50, 2, 30, seed=101, run_lo=2, run_hi=6), synth.make_window(90, 6, 4000, seed=9, run_lo=2, run_hi=8),
+          synth.cfg("small"), synth.cfg("small"), synth.cfg("small"), synth.make_window(12, 3, 1500, seed=58, run_lo=2, run_hi=7)]
+    for f in ("edge_pose", "edge_point", "obs", "inv_sigma2"):
+        setattr(ws[3], f, getattr(ws[3], f)[:0])                      # empty
+    ws[4].pose_fixed = np.zeros_like(ws[4].pose_fixed)              # no fixed keyframe
+    st, solvers = _shared_stream_solvers(built_lib, len(ws))
+    try:
+        stop = np.ones(1, np.uint8)
+        solo = [s.solve(w, stop=stop if i == 5 else None) for i, (s, w) in enumerate(zip(solvers, ws))]
+        for i, (s, w) in enumerate(zip(solvers, ws)):
+            s.upload(w, stop=stop if i == 5 else None)
+        assert built_lib.run_batch(solvers) == 0
+        res = [s.download() for s in solvers]
+        assert [r["status"] for r in res] == [0, 0, 0, built_lib.EMPTY, built_lib.NO_FIXED, built_lib.STOPPED, 0]
+        for a, b in zip(solo, res):
+            assert a["status"] == b["status"]
+            for k in ("poses", "points", "chi2", "outlier"):
+                assert np.array_equal(a[k], b[k]), k
+        assert res[1]["n_pcg_giveups"] == 1 and res[1]["n_direct"] > 0 and res[2]["direct_from"] == 0
+        check_against(res[0], oracle_mod.solve(ws[0]), ws[0])
+        check_against(res[1], oracle_mod.solve(ws[1]), ws[1], noise_guard=True, **WEAK_TOL)
+    finally:
+        for s in solvers:
+            s.close()
+
+
+def test_batch_rejects_handles_on_different_streams(built_lib):
+    a, b = built_lib.Solver(), built_lib.Solver()              # private streams
+    try:
+        w = synth.cfg("small"); a.upload(w); b.upload(w)
+        with pytest.raises(built_lib.MovbaError):
+            built_lib.run_batch([a, b])
+    finally:
+        a.close(); b.close()
