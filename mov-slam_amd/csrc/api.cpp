@@ -26,6 +26,8 @@ using namespace movba;
 
 namespace {
 
+constexpr int kPhaseEvents = 16;
+constexpr int kMaxGroups = 4;
 enum KernelClass { KC_SCHUR = 0, KC_PCG, KC_BACKSUB, KC_DECIDE, KC_SETUP, KC_FINALIZE };
 const char *kKernelNames[MOVBA_NKERNELS] = { "k_schur", "k_pcg", "k_point<backsub>", "k_decide", "setup(init+linearize+lambda)", "k_finalize" };
 
@@ -72,6 +74,9 @@ struct movba_handle {
     // movba_lba_run_batch (kept by the first handle of a batch): device views, PCG plans and block prefixes of the windows
     char *batch_host = nullptr, *batch_dev = nullptr;
     size_t batch_cap = 0;
+    hipStream_t batch_streams[kMaxGroups] = {};   // extra streams of a batched run (groups of windows run out of phase); [0] unused
+    hipEvent_t batch_ev[kMaxGroups + 1] = {};     // [0]: fork from the callers' stream, [g]: join of group g
+    hipEvent_t batch_phase_ev[kMaxGroups][kPhaseEvents] = {};   // ring: end of group g's schur launch of trial t (t mod 16)
     // pose-only scratch
     char *pose_arena = nullptr;
     size_t pose_cap = 0;
@@ -237,6 +242,9 @@ void movba_destroy(movba_handle *h)
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->arena) (void)hipFree(h->arena);
     if (h->pose_arena) (void)hipFree(h->pose_arena);
+    for (hipStream_t st : h->batch_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : h->batch_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &ring : h->batch_phase_ev) for (hipEvent_t e : ring) if (e) (void)hipEventDestroy(e);
     if (h->batch_dev) (void)hipFree(h->batch_dev);
     if (h->batch_host) (void)hipHostFree(h->batch_host);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -457,11 +465,11 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
         o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
-        o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);
+        o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);       // erecA
         o_st[b][6] = 0;  o_st[b][7] = c.take<double>(E);
         o_st[b][8] = c.take<double>(nb);
         o_st[b][9] = 0;
-        o_st[b][10] = c.take<double>(8 * (size_t)E);
+        o_st[b][10] = c.take<double>((stereo ? 4 : 2) * (size_t)E);                                  // erecB
     }
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
     const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
@@ -552,10 +560,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         DevState &S = w.st[b];
         S.pose = reinterpret_cast<double *>(a + o_st[b][0]); S.Rt = reinterpret_cast<double *>(a + o_st[b][1]);
         S.point = reinterpret_cast<double *>(a + o_st[b][2]); S.Hll = reinterpret_cast<double *>(a + o_st[b][3]);
-        S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.rec = reinterpret_cast<double *>(a + o_st[b][5]);
+        S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.erecA = reinterpret_cast<double *>(a + o_st[b][5]);
         S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
-        S.erec = reinterpret_cast<double *>(a + o_st[b][10]);
+        S.erecB = reinterpret_cast<double *>(a + o_st[b][10]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c); w.blocks_ov = reinterpret_cast<double *>(a + o_blocks_ov);
@@ -772,10 +780,37 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             }
             ldsp &= h->win.lds_poses != 0; overflow |= h->pp.overflow != 0;
         }
-        // ---- device views, PCG plans and block prefixes ----
+        // Groups of windows on streams of their own, out of phase: a group's PCG launch keeps 2 CUs per window busy for most
+        // of a trial while its point / schur launches fill the chip for the rest, so the PCG of one group runs beside the
+        // streaming kernels of the others.  Each window's own kernels still run in its solo order on one stream.
+        int ngroups = na >= 8 ? 4 : (na >= 2 ? 2 : 1);
+        if (const char *eg = std::getenv("MOVBA_BATCH_GROUPS")) ngroups = std::max(1, std::min(std::min(kMaxGroups, na), std::atoi(eg)));
+        if (ngroups > 1 && !h0->batch_ev[0]) {
+            for (hipEvent_t &e : h0->batch_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto &ring : h0->batch_phase_ev) for (hipEvent_t &e : ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        for (int g = 1; g < ngroups; ++g)
+            if (!h0->batch_streams[g]) HIP_TRY(hipStreamCreateWithFlags(&h0->batch_streams[g], hipStreamNonBlocking));
+        struct Group {
+            std::vector<movba_handle *> hs;
+            hipStream_t s = nullptr;
+            BatchDev b{};
+            int nb_point = 0, nb_schur = 0, nb_final = 0, nb_init = 0, max_trials = 0, max_iters = 0;
+            size_t lds_lin = 0, lds_back = 0, lds_pcg = 0;
+            int t = 0, final_after = -1;
+            bool finished = false;
+        } grp[kMaxGroups];
+        for (int i = 0; i < na; ++i) grp[(int)((int64_t)i * ngroups / na)].hs.push_back(act[i]);
+        grp[0].s = s;
+        for (int g = 1; g < ngroups; ++g) grp[g].s = h0->batch_streams[g];
+        // ---- device views, PCG plans and block prefixes of both groups in one buffer ----
         Carver c;
-        const size_t o_win = c.take<DevWindow>(na), o_pp = c.take<PcgParams>(na);
-        const size_t o_bp = c.take<int32_t>(na + 1), o_bs = c.take<int32_t>(na + 1), o_bf = c.take<int32_t>(na + 1), o_bi = c.take<int32_t>(na + 1);
+        size_t o_win[kMaxGroups], o_pp[kMaxGroups], o_bp[kMaxGroups], o_bs[kMaxGroups], o_bf[kMaxGroups], o_bi[kMaxGroups];
+        for (int g = 0; g < ngroups; ++g) {
+            const size_t m = grp[g].hs.size();
+            o_win[g] = c.take<DevWindow>(m); o_pp[g] = c.take<PcgParams>(m);
+            o_bp[g] = c.take<int32_t>(m + 1); o_bs[g] = c.take<int32_t>(m + 1); o_bf[g] = c.take<int32_t>(m + 1); o_bi[g] = c.take<int32_t>(m + 1);
+        }
         if (c.off > h0->batch_cap) {
             HIP_TRY(hipStreamSynchronize(s));
             if (h0->batch_dev) { HIP_TRY(hipFree(h0->batch_dev)); h0->batch_dev = nullptr; }
@@ -787,83 +822,106 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             h0->batch_cap = cap;
         }
         HIP_TRY(hipStreamSynchronize(s));           // the previous batch's H2D copy of this buffer has landed
-        char *bh = h0->batch_host;
-        DevWindow *wins = reinterpret_cast<DevWindow *>(bh + o_win);
-        PcgParams *pps = reinterpret_cast<PcgParams *>(bh + o_pp);
-        int32_t *bp = reinterpret_cast<int32_t *>(bh + o_bp), *bs = reinterpret_cast<int32_t *>(bh + o_bs);
-        int32_t *bf = reinterpret_cast<int32_t *>(bh + o_bf), *bi = reinterpret_cast<int32_t *>(bh + o_bi);
-        bp[0] = bs[0] = bf[0] = bi[0] = 0;
-        size_t lds_lin = 0, lds_back = 0, lds_pcg = 0;
-        int max_trials = 0, max_iters = 0, run_ahead = h0->opt.run_ahead;
-        for (int i = 0; i < na; ++i) {
-            movba_handle *h = act[i];
-            h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
-            h->hstat->progress = 0; h->hstat->stop = 0; h->hstat->pause_seq = 0;
-            wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
-            pps[i] = run_pcg_params(h);
-            const DevWindow &w = h->win;
-            bp[i + 1] = bp[i] + w.n_pt_blocks;
-            bs[i + 1] = bs[i] + (w.nitems > 0 ? schur_blocks(w) : 0);
-            bf[i + 1] = bf[i] + (w.E + 255) / 256;
-            const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;
-            int nb = (work + 255) / 256; nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
-            bi[i + 1] = bi[i] + nb;
-            lds_lin = std::max(lds_lin, point_lds_bytes_for(w, false, ldsp)); lds_back = std::max(lds_back, point_lds_bytes_for(w, true, ldsp));
-            lds_pcg = std::max(lds_pcg, pcg_rows_lds_bytes(w.nfree, (int)h->st.row_ent.size()));
-            max_trials = std::max(max_trials, (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials);
-            max_iters = std::max(max_iters, w.max_iters);
+        char *bh = h0->batch_host, *bd = h0->batch_dev;
+        const int run_ahead = h0->opt.run_ahead;
+        for (int g = 0; g < ngroups; ++g) {
+            Group &G = grp[g];
+            const int m = (int)G.hs.size();
+            DevWindow *wins = reinterpret_cast<DevWindow *>(bh + o_win[g]);
+            PcgParams *pps = reinterpret_cast<PcgParams *>(bh + o_pp[g]);
+            int32_t *bp = reinterpret_cast<int32_t *>(bh + o_bp[g]), *bs = reinterpret_cast<int32_t *>(bh + o_bs[g]);
+            int32_t *bf = reinterpret_cast<int32_t *>(bh + o_bf[g]), *bi = reinterpret_cast<int32_t *>(bh + o_bi[g]);
+            bp[0] = bs[0] = bf[0] = bi[0] = 0;
+            for (int i = 0; i < m; ++i) {
+                movba_handle *h = G.hs[i];
+                h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
+                h->hstat->progress = 0; h->hstat->stop = 0; h->hstat->pause_seq = 0;
+                wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
+                pps[i] = run_pcg_params(h);
+                const DevWindow &w = h->win;
+                bp[i + 1] = bp[i] + w.n_pt_blocks;
+                bs[i + 1] = bs[i] + (w.nitems > 0 ? schur_blocks(w) : 0);
+                bf[i + 1] = bf[i] + (w.E + 255) / 256;
+                const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;
+                int nb = (work + 255) / 256; nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+                bi[i + 1] = bi[i] + nb;
+                G.lds_lin = std::max(G.lds_lin, point_lds_bytes_for(w, false, ldsp)); G.lds_back = std::max(G.lds_back, point_lds_bytes_for(w, true, ldsp));
+                G.lds_pcg = std::max(G.lds_pcg, pcg_rows_lds_bytes(w.nfree, (int)h->st.row_ent.size()));
+                G.max_trials = std::max(G.max_trials, (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials);
+                G.max_iters = std::max(G.max_iters, w.max_iters);
+            }
+            G.nb_point = bp[m]; G.nb_schur = bs[m]; G.nb_final = bf[m]; G.nb_init = bi[m];
+            G.b.wins = reinterpret_cast<const DevWindow *>(bd + o_win[g]); G.b.pps = reinterpret_cast<const PcgParams *>(bd + o_pp[g]);
+            G.b.blk_point = reinterpret_cast<const int32_t *>(bd + o_bp[g]); G.b.blk_schur = reinterpret_cast<const int32_t *>(bd + o_bs[g]);
+            G.b.blk_final = reinterpret_cast<const int32_t *>(bd + o_bf[g]); G.b.blk_init = reinterpret_cast<const int32_t *>(bd + o_bi[g]);
+            G.b.n = m;
         }
-        HIP_TRY(hipMemcpyAsync(h0->batch_dev, bh, c.off, hipMemcpyHostToDevice, s));
-        BatchDev b{};
-        char *bd = h0->batch_dev;
-        b.wins = reinterpret_cast<const DevWindow *>(bd + o_win); b.pps = reinterpret_cast<const PcgParams *>(bd + o_pp);
-        b.blk_point = reinterpret_cast<const int32_t *>(bd + o_bp); b.blk_schur = reinterpret_cast<const int32_t *>(bd + o_bs);
-        b.blk_final = reinterpret_cast<const int32_t *>(bd + o_bf); b.blk_init = reinterpret_cast<const int32_t *>(bd + o_bi);
-        b.n = na;
-        const int nb_point = bp[na], nb_schur = bs[na], nb_final = bf[na], nb_init = bi[na];
-
+        HIP_TRY(hipMemcpyAsync(bd, bh, c.off, hipMemcpyHostToDevice, s));
+        if (ngroups > 1) {                          // the other streams start behind the uploads and this copy
+            HIP_TRY(hipEventRecord(h0->batch_ev[0], s));
+            for (int g = 1; g < ngroups; ++g) HIP_TRY(hipStreamWaitEvent(grp[g].s, h0->batch_ev[0], 0));
+        }
         // ---- setup: state 0, first linearisation, lambda_0 and F0 of every window ----
-        HIP_TRY(launch_init_batch(b, nb_init, s));
-        HIP_TRY(launch_point_batch(b, nb_point, false, stereo, ldsp, lds_lin, s));
-        if (nb_schur > 0) HIP_TRY(launch_schur_batch(b, nb_schur, 1, stereo, s));
-        HIP_TRY(launch_lambda_init_batch(b, s));
-
-        // ---- trial sets, the host a bounded number of sets ahead of the slowest window still running ----
+        for (int g = 0; g < ngroups; ++g) {
+            Group &G = grp[g];
+            HIP_TRY(launch_init_batch(G.b, G.nb_init, G.s));
+            HIP_TRY(launch_point_batch(G.b, G.nb_point, false, stereo, ldsp, G.lds_lin, G.s));
+            if (G.nb_schur > 0) HIP_TRY(launch_schur_batch(G.b, G.nb_schur, 1, stereo, G.s));
+            HIP_TRY(launch_lambda_init_batch(G.b, G.s));
+        }
+        // ---- trial sets: each group a bounded number of sets ahead of its slowest window still running ----
         const double t_start = now_ms();
-        int t = 0, final_after = -1;
-        for (; t < max_trials; ++t) {
-            bool finished = false;
-            for (;;) {
+        for (;;) {
+            bool all_finished = true;
+            for (int g = 0; g < ngroups; ++g) {
+                Group &G = grp[g];
+                if (G.finished) continue;
                 int td_min = 1 << 30, it_min = 1 << 30, running = 0;
-                for (movba_handle *h : act) {
+                for (movba_handle *h : G.hs) {
                     const uint64_t pg = h->hstat->progress;
                     if (((pg >> 48) & 1) || h->hstat->pause_seq != 0) continue;      // done, or parked for the direct solver
                     ++running;
                     td_min = std::min(td_min, (int)(pg & 0xffffff)); it_min = std::min(it_min, (int)((pg >> 24) & 0xffffff));
+                    if (h->stop && *h->stop) h->hstat->stop = 1;
                 }
-                if (running == 0) { finished = true; break; }
-                const int left = max_iters - it_min;
+                if (running == 0 || G.t >= G.max_trials) {
+                    if (G.final_after != G.t) { HIP_TRY(launch_finalize_batch(G.b, G.nb_final, G.s)); G.final_after = G.t; }
+                    G.finished = true;
+                    continue;
+                }
+                all_finished = false;
+                const int left = G.max_iters - it_min;
                 const int limit = left < run_ahead ? (left > 1 ? left : 1) : run_ahead;
-                if (t - td_min < limit) break;
-                if (final_after != t && t - td_min < run_ahead) { HIP_TRY(launch_finalize_batch(b, nb_final, s)); final_after = t; }
-                for (movba_handle *h : act) if (h->stop && *h->stop) h->hstat->stop = 1;
-                if (now_ms() - t_start > 60000.0) {
-                    std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
-                    return MOVBA_ERR_HIP;
+                if (G.t - td_min >= limit) {
+                    if (G.final_after != G.t && G.t - td_min < run_ahead) { HIP_TRY(launch_finalize_batch(G.b, G.nb_final, G.s)); G.final_after = G.t; }
+                    continue;
                 }
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
+                // keep the groups out of phase: group g's schur launch of trial t starts when group g-1's has ended (otherwise
+                // the streams drift into lockstep, all in their PCG at once with the chip idle: rocprofv3 trace); group g-1's
+                // launch of that trial must therefore be queued first
+                if (g > 0 && !grp[g - 1].finished && grp[g - 1].t <= G.t) continue;
+                if (g > 0 && grp[g - 1].t > G.t) HIP_TRY(hipStreamWaitEvent(G.s, h0->batch_phase_ev[g - 1][G.t % kPhaseEvents], 0));
+                if (G.nb_schur > 0) HIP_TRY(launch_schur_batch(G.b, G.nb_schur, 0, stereo, G.s));
+                if (g + 1 < ngroups) HIP_TRY(hipEventRecord(h0->batch_phase_ev[g][G.t % kPhaseEvents], G.s));
+                HIP_TRY(launch_pcg_rows_batch(G.b, overflow, G.lds_pcg, G.t, G.s));
+                HIP_TRY(launch_point_batch(G.b, G.nb_point, true, stereo, ldsp, G.lds_back, G.s));
+                HIP_TRY(launch_decide_batch(G.b, G.s));
+                G.t += 1;
             }
-            if (finished) break;
-            for (movba_handle *h : act) if (h->stop && *h->stop) h->hstat->stop = 1;
-            if (nb_schur > 0) HIP_TRY(launch_schur_batch(b, nb_schur, 0, stereo, s));
-            HIP_TRY(launch_pcg_rows_batch(b, overflow, lds_pcg, t, s));
-            HIP_TRY(launch_point_batch(b, nb_point, true, stereo, ldsp, lds_back, s));
-            HIP_TRY(launch_decide_batch(b, s));
+            if (all_finished) break;
+            if (now_ms() - t_start > 60000.0) {
+                std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
+                return MOVBA_ERR_HIP;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
         }
-        if (final_after != t) HIP_TRY(launch_finalize_batch(b, nb_final, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        for (int g = 1; g < ngroups; ++g) {         // the callers' stream ends behind the others
+            HIP_TRY(hipEventRecord(h0->batch_ev[g], grp[g].s));
+            HIP_TRY(hipStreamWaitEvent(s, h0->batch_ev[g], 0));
+        }
+        HIP_TRY(hipStreamSynchronize(s));           // (every group was finalised behind its last trial set, in stream order)
         // windows whose PCG gave up parked themselves: each finishes on the direct solver from where it stands
         for (movba_handle *h : act) {
             if (h->hstat->pause_seq != 0 && !((h->hstat->progress >> 48) & 1)) {

@@ -35,10 +35,11 @@ struct DevState {
     double *point;   // P x 3
     double *Hll;     // P x 6   (xx xy xz yy yz zz), undamped
     double *bl;      // P x 3
-    double *rec;     // E x 4   (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2), point-major: back-substitution and the depth test
     double *chi2;    // E
     double *Fpart;   // n_pt_blocks robust-cost partials of this state
-    double *erec;    // E_free x 8, POSE-major (DevWindow::slot): (Xc.x Xc.y Xc.z w | -w e0, -w e1, -w e2, stereo flag) for k_schur
+    // per-edge records of the edges of FREE keyframes, POSE-major (DevWindow::slot), written by k_point for k_schur:
+    double *erecA;   // E_free x 4: camera-frame point and weight (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2): everything both Jacobians need
+    double *erecB;   // weighted residual: E_free x 2 (-w e0, -w e1), stereo windows E_free x 4 (-w e0, -w e1, -w e2, stereo flag)
 };
 
 // LM controller state, lives in HBM; every kernel reads it, k_decide/k_pcg/k_lambda_init write it.

@@ -92,14 +92,13 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     const DevState &S1 = w.st[dst];
 
     double *sRt = sm;                               // NP x 12 at dst
-    double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 9 at cur   (BACKSUB)
-    double *sxp = sR0 + ((BACKSUB && LDSP) ? 9 * w.NP : 0);   // nfree x 6       (BACKSUB)
+    double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 12 at cur  (BACKSUB)
+    double *sxp = sR0 + ((BACKSUB && LDSP) ? 12 * w.NP : 0);  // nfree x 6       (BACKSUB)
     double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4
     int *shidx = reinterpret_cast<int *>(red + 4);  // NP              (BACKSUB)
     // where the pose data is read from: the LDS images, or the state buffers themselves
     const double *pRt = LDSP ? sRt : S1.Rt;
     const double *pR0 = LDSP ? sR0 : S0.Rt;
-    constexpr int kR0Stride = LDSP ? 9 : 12;
     const double *pxp = LDSP ? sxp : w.xp;
     const int *phidx = LDSP ? shidx : w.hidx;
 
@@ -123,7 +122,6 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     // the lane's first two edges (a point with more than 16 observations takes the loop further down)
     constexpr int kPre = 2;
     int pg[kPre], pip[kPre], psl[kPre];
-    double4 prc[kPre];
     double2 pob[kPre];
     double pom[kPre], pur[kPre];
 #pragma unroll
@@ -133,7 +131,6 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         const bool in = pg[k] < end;
         pip[k] = in ? w.g_pose[g] : 0;
         psl[k] = in ? w.slot[g] : -1;
-        prc[k] = (BACKSUB && in) ? *reinterpret_cast<const double4 *>(S0.rec + 4 * g) : make_double4(0, 0, 1, 0);
         pob[k] = in ? *reinterpret_cast<const double2 *>(w.obs + 2 * g) : make_double2(0, 0);
         pom[k] = in ? w.isig[g] : 0.0;
         pur[k] = (STEREO && in) ? w.obs_r[g] : -1.0;
@@ -142,7 +139,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     if (LDSP) {
         for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
         if (BACKSUB) {
-            for (int k = threadIdx.x; k < 9 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[(k / 9) * 12 + (k % 9)];
+            for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[k];
             for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
             for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
         }
@@ -153,10 +150,24 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     if (BACKSUB) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         // x_l's right-hand side: sum over the free observers of B_il^T xp_i, rebuilt from the cached (Xc, w)
-        auto back_edge = [&](int g, int ip, const double4 &rc, double ur) {
+        // (the camera-frame point and the robust weight of the edge at the CURRENT state are recomputed from the staged pose,
+        //  the point and the observation — the same expressions that produced Hll / bl — instead of being read back from a
+        //  per-edge record: this kernel is bound by memory, not arithmetic)
+        const double dsq0 = w.huber_delta * w.huber_delta;
+        auto back_edge = [&](int g, int ip, const double2 &ob, double om, double ur) {
             const int h = phidx[ip];
             if (h < 0) return;
-            const double x = rc.x, y = rc.y, z = rc.z, wg = rc.w;
+            const double *R = pR0 + 12 * ip;
+            const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
+            const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
+            const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
+            const double e0 = ob.x - (w.fx * x / z + w.cx);
+            const double e1 = ob.y - (w.fy * y / z + w.cy);
+            double chi2 = e0 * (om * e0) + e1 * (om * e1);
+            if (STEREO && ur >= 0.0) { const double e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
+            double rho1 = 1.0;
+            if (w.huber_delta > 0.0 && !(chi2 <= dsq0)) rho1 = w.huber_delta / sqrt(chi2);
+            const double wg = rho1 * om;
             const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
             const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
             const double *xp = pxp + 6 * h;
@@ -164,7 +175,6 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const double t0 = (a02 * y) * xp[0] + (a00 * z - a02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + a02 * xp[5];
             const double t1 = (-a11 * z + a12 * y) * xp[0] + (-a12 * x) * xp[1] + (a11 * x) * xp[2] + a11 * xp[4] + a12 * xp[5];
             const double g0 = wg * t0, g1 = wg * t1;
-            const double *R = pR0 + kR0Stride * ip;
             // J_p = -Jpi R : rows p0 = a00 R0 + a02 R2, p1 = a11 R1 + a12 R2
             a0 += (a00 * R[0] + a02 * R[6]) * g0 + (a11 * R[3] + a12 * R[6]) * g1;
             a1 += (a00 * R[1] + a02 * R[7]) * g0 + (a11 * R[4] + a12 * R[7]) * g1;
@@ -180,9 +190,9 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         };
 #pragma unroll
         for (int k = 0; k < kPre; ++k)
-            if (pg[k] < end) back_edge(pg[k], pip[k], prc[k], pur[k]);
+            if (pg[k] < end) back_edge(pg[k], pip[k], pob[k], pom[k], pur[k]);
         for (int g = begin + sub + kPointGroup * kPre; g < end; g += kPointGroup)
-            back_edge(g, w.g_pose[g], *reinterpret_cast<const double4 *>(S0.rec + 4 * g), STEREO ? w.obs_r[g] : -1.0);
+            back_edge(g, w.g_pose[g], *reinterpret_cast<const double2 *>(w.obs + 2 * g), w.isig[g], STEREO ? w.obs_r[g] : -1.0);
 #pragma unroll
         for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
             a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
@@ -228,12 +238,11 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         }
         const double wg = rho1 * om;
         const double r0 = -wg * e0, r1 = -wg * e1;
-        *reinterpret_cast<double4 *>(S1.rec + 4 * g) = make_double4(x, y, z, wg);
         S1.chi2[g] = chi2;
-        if (sl >= 0) {      // pose-major copy for the schur pass (edges of free keyframes): one 64-byte record
-            double4 *er = reinterpret_cast<double4 *>(S1.erec + 8 * (size_t)sl);
-            er[0] = make_double4(x, y, z, wg);
-            er[1] = make_double4(r0, r1, STEREO ? -wg * e2 : 0.0, (STEREO && st) ? 1.0 : 0.0);
+        if (sl >= 0) {      // pose-major records for the schur pass (edges of free keyframes): (Xc, w) and the weighted residual
+            *reinterpret_cast<double4 *>(S1.erecA + 4 * (size_t)sl) = make_double4(x, y, z, wg);
+            if (STEREO) *reinterpret_cast<double4 *>(S1.erecB + 4 * (size_t)sl) = make_double4(r0, r1, -wg * e2, st ? 1.0 : 0.0);
+            else *reinterpret_cast<double2 *>(S1.erecB + 2 * (size_t)sl) = make_double2(r0, r1);
         }
         F += rho0;
         const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
@@ -353,6 +362,8 @@ __device__ __forceinline__ double wave_reduce(double (&v)[NV], double *strip, in
 // Jacobian rows of one edge from its cached camera-frame point: P = J_point rows (-Jpi R), C = J_pose rows
 // (-Jpi [ -[Xc]x | I ]).  NR = 2: monocular edge (src/OptimizableTypes.cpp:158-180); NR = 3 adds the stereo row of
 // g2o::EdgeStereoSE3ProjectXYZ (built at src/Optimizer.cc:673-705), zeroed for the monocular edges of a mixed window.
+// (A division-free variant on normalised records (x / z, y / z, 1 / z) with the structural zeros of C skipped was 20 %
+//  SLOWER, solo and batched: the kernel then needs all 256 registers and the compiler schedules its gathers worse.)
 template <int NR>
 __device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y, double z, const double R[9], bool stereo,
                                           double (&P)[NR][3], double (&C)[NR][6])
@@ -533,8 +544,9 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
             double4 rc[B], rq[B]; double2 h[B][3]; double bl[B][3];
 #pragma unroll
             for (int u = 0; u < B; ++u) {
-                const double4 *er = reinterpret_cast<const double4 *>(S0.erec + 8 * (size_t)en[u].x);
-                rc[u] = er[0]; rq[u] = er[1];
+                rc[u] = *reinterpret_cast<const double4 *>(S0.erecA + 4 * (size_t)en[u].x);
+                if (NR == 3) rq[u] = *reinterpret_cast<const double4 *>(S0.erecB + 4 * (size_t)en[u].x);
+                else { const double2 t2 = *reinterpret_cast<const double2 *>(S0.erecB + 2 * (size_t)en[u].x); rq[u] = make_double4(t2.x, t2.y, 0.0, 0.0); }
                 if (HPP_ONLY) { h[u][0] = h[u][1] = h[u][2] = make_double2(0.0, 0.0); bl[u][0] = bl[u][1] = bl[u][2] = 0.0; continue; }
                 const int l = en[u].z;
                 const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
@@ -572,11 +584,10 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
             double4 ri[B], rj[B]; double2 h[B][3]; bool sti[B], stj[B];
 #pragma unroll
             for (int u = 0; u < B; ++u) {
-                const double4 *ei = reinterpret_cast<const double4 *>(S0.erec + 8 * (size_t)en[u].x);
-                const double4 *ej = reinterpret_cast<const double4 *>(S0.erec + 8 * (size_t)en[u].y);
-                ri[u] = ei[0]; rj[u] = ej[0];
+                ri[u] = *reinterpret_cast<const double4 *>(S0.erecA + 4 * (size_t)en[u].x);
+                rj[u] = *reinterpret_cast<const double4 *>(S0.erecA + 4 * (size_t)en[u].y);
                 sti[u] = false; stj[u] = false;
-                if (NR == 3) { sti[u] = S0.erec[8 * (size_t)en[u].x + 7] != 0.0; stj[u] = S0.erec[8 * (size_t)en[u].y + 7] != 0.0; }
+                if (NR == 3) { sti[u] = S0.erecB[4 * (size_t)en[u].x + 3] != 0.0; stj[u] = S0.erecB[4 * (size_t)en[u].y + 3] != 0.0; }
                 const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * en[u].z);
                 h[u][0] = hp[0]; h[u][1] = hp[1]; h[u][2] = hp[2];
             }
@@ -771,7 +782,10 @@ __device__ __forceinline__ void finalize_body(const DevWindow &w, int bid, int n
         const int cur = c->cur;
         const int sel = ((w.flags & MOVBA_FLAG_STALE_ERROR_QUIRK) && c->last_rejected) ? (cur ^ 1) : cur;
         const double chi2 = w.st[sel].chi2[g];
-        const double zc = w.st[cur].rec[4 * g + 2];
+        // isDepthPositive() at the final estimates (include/OptimizableTypes.h:111-116)
+        const double *Rz = w.st[cur].Rt + 12 * w.g_pose[g];
+        const double *Xf = w.st[cur].point + 3 * w.g_point[g];
+        const double zc = Rz[6] * Xf[0] + Rz[7] * Xf[1] + Rz[8] * Xf[2] + Rz[11];
         bad = (chi2 > w.chi2_gate) || !(zc > 0.0);
         const int e = w.perm ? w.perm[g] : g;          // null: the caller's edges were already grouped by map point
 #ifdef MOVBA_CLOCK_STAMP
@@ -831,14 +845,14 @@ __global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
     if (!w.lds_poses) return 4 * sizeof(double) + 16;
-    size_t d = 12 * (size_t)w.NP + (backsub ? 9 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
+    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
     return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
 // the largest LDS image the point kernels would stage for this window (decides DevWindow::lds_poses)
 size_t point_lds_need(int NP, int nfree)
 {
-    return (21 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
+    return (24 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
 import torch
 from movba import capi, synth, shard
 st = torch.cuda.Stream(device=0)
-for n in (1, 2, 4, 8, 16):
+for n in [int(v) for v in sys.argv[1:]] or (1, 2, 4, 8, 16):
     ws = [synth.make_window(50, 10, 20000, shard.window_seed(i), run_lo=2, run_hi=10) for i in range(n)]
     solvers = [capi.Solver(device=0, stream=st.cuda_stream) for _ in range(n)]
     for s, w in zip(solvers, ws):
