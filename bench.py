@@ -197,6 +197,56 @@ def main():
             out["config"]["resident_window"] = {"lm_iterations_per_s": res["n_solves"] * args.steps / tr_,
                                                 "ms_per_window_solve": 1e3 * tr_ / args.steps,
                                                 "note": "movba_lba_run only; no structure pass, H2D or D2H in the region"}
+        if world == 1:
+            # for information only (never `value`): movba_lba_run_batch over 8 resident cfg5-shaped windows on this one GPU
+            # (multi-session serving): one launch per kernel over all windows, groups of windows out of phase on streams
+            try:
+                nb = 8
+                bws = [synth.make_window(shape[0], shape[1], shape[2], shard.window_seed(i), run_lo=shape[3], run_hi=shape[4]) for i in range(nb)]
+                bsolvers = [capi.Solver(device=local_rank, stream=stream.cuda_stream) for _ in range(nb)]
+                for bs_, bw_ in zip(bsolvers, bws):
+                    bs_.upload(bw_)
+                capi.run_batch(bsolvers); capi.run_batch(bsolvers)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    capi.run_batch(bsolvers)
+                torch.cuda.synchronize(dev)
+                tb = (time.perf_counter() - t1) / 5
+                lm = sum(bs_.download()["n_solves"] for bs_ in bsolvers)
+                one = out["config"]["resident_window"]["ms_per_window_solve"] * 1e-3
+                out["config"]["batched_windows"] = {"n": nb, "ms_per_batch": 1e3 * tb, "window_solves_per_s": nb / tb,
+                                                    "lm_iterations_per_s": lm / tb, "vs_one_resident_window_at_a_time": nb * one / tb,
+                                                    "note": "resident windows (seeds 2000-2007), bit-identical to their solo solves"}
+                for bs_ in bsolvers:
+                    bs_.close()
+            except Exception as exc:                        # context only
+                out["config"]["batched_windows"] = {"error": str(exc)}
+        if world == 1:
+            # for information only: host-side cost of the Optimizer.h adapter around the solve on this window (mock map classes,
+            # mov-slam_amd/host/adapter_test): window selection + flattening, and the write-back under the map mutex
+            try:
+                import struct, subprocess, tempfile
+                host = os.path.join(ROOT, "mov-slam_amd", "host")
+                exe = os.path.join(host, "adapter_test")
+                if not os.path.exists(exe):
+                    subprocess.check_call(["make", "-C", host, "-s"])
+                with tempfile.TemporaryDirectory() as tmp:
+                    fin, fout = os.path.join(tmp, "w.bin"), os.path.join(tmp, "o.bin")
+                    wf = w
+                    with open(fin, "wb") as fh:
+                        fh.write(struct.pack("4i", wf.n_poses, wf.n_points, wf.n_edges, 0))
+                        for arr, dt in ((wf.pose_fixed, np.uint8), (wf.poses, np.float64), (wf.points, np.float64), (wf.edge_pose, np.int32),
+                                        (wf.edge_point, np.int32), (wf.obs, np.float64)):
+                            fh.write(np.ascontiguousarray(arr, dt).tobytes())
+                    subprocess.check_call([exe, "lba", fin, fout])
+                    raw = open(fout, "rb").read()
+                    tm = struct.unpack_from("3d", raw, len(raw) - 24)
+                out["config"]["adapter_host_ms"] = {"extraction": tm[0], "solve_call_first_on_fresh_handle": tm[1], "write_back": tm[2],
+                                                    "note": "Optimizer::LocalBundleAdjustment over mock KeyFrame/MapPoint classes: one GetObservations() "
+                                                            "copy per point, normal/depth stored from the GPU result"}
+            except Exception as exc:                        # context only
+                out["config"]["adapter_host_ms"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle                       # CPU baseline leg: the oracle as the timed "port"
             oracle.build(force=True)                        # -march=native of THIS box's host cores

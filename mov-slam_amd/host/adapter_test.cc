@@ -10,6 +10,8 @@
 
 using namespace MOV_SLAM;
 
+extern "C" void movba_adapter_last_timing(double out[3]);
+
 template <typename T> static std::vector<T> rd(FILE *f, size_t n)
 {
     std::vector<T> v(n);
@@ -55,6 +57,7 @@ static int run_lba(const char *in, const char *out, bool global)
         const int idx = (int)k.mvKeysUn.size();
         k.mvKeysUn.push_back(kp); k.mvuRight.push_back(obs_right.empty() ? -1.f : (float)obs_right[e]); k.mvpMapPoints.push_back(&mps[el[e]]);
         mps[el[e]].mObservations[&k] = std::make_tuple(idx, -1);
+        if (!mps[el[e]].mpRefKF) mps[el[e]].mpRefKF = &k;           // the keyframe that created the point
     }
     // the newest free keyframe is the one LocalMapping passes in; every other free keyframe is covisible
     KeyFrame *pKF = nullptr;
@@ -66,6 +69,7 @@ static int run_lba(const char *in, const char *out, bool global)
 
     int num_fixedKF = 0, num_OptKF = 0, num_MPs = 0, num_edges = 0;
     bool stop = false;
+    MapPoint::nObservationCopies() = 0;
     if (global) Optimizer::GlobalBundleAdjustemnt(&map, 10, &stop, kfs[0].mnId, true);
     else Optimizer::LocalBundleAdjustment(pKF, &stop, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
 
@@ -88,7 +92,21 @@ static int run_lba(const char *in, const char *out, bool global)
     for (int l = 0; l < P; ++l) nnorm += mps[l].nNormalUpdates;
     const int32_t tail[2] = { nposes, nnorm };
     fwrite(tail, sizeof(int32_t), 2, o);
+    // what UpdateNormalAndDepth (or the adapter's own normal / depth pass) left in the points, and the accessor traffic
+    int ncenter = 0;
+    for (int i = 0; i < NP; ++i) ncenter += kfs[i].nCenterReads;
+    const int32_t counts[2] = { (int32_t)MapPoint::nObservationCopies(), ncenter };
+    fwrite(counts, sizeof(int32_t), 2, o);
+    for (int l = 0; l < P; ++l) {
+        const float v[5] = { mps[l].mNormalVector(0), mps[l].mNormalVector(1), mps[l].mNormalVector(2), mps[l].mfMinDistance, mps[l].mfMaxDistance };
+        fwrite(v, sizeof(float), 5, o);
+    }
+    double tm[3] = { 0, 0, 0 };
+    if (!global) movba_adapter_last_timing(tm);
+    fwrite(tm, sizeof(double), 3, o);
     fclose(o);
+    if (std::getenv("MOVBA_ADAPTER_TIMING"))
+        std::fprintf(stderr, "adapter: extraction %.3f ms, solve call %.3f ms, write-back %.3f ms (NP=%d P=%d E=%d)\n", tm[0], tm[1], tm[2], NP, P, E);
     return 0;
 }
 

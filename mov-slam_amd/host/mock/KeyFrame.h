@@ -10,6 +10,23 @@ class KeyFrame {
 public:
     Sophus::SE3f GetPose() { return mTcw; }
     void SetPose(const Sophus::SE3f &T) { mTcw = T; ++nPoseSets; }
+    // KeyFrame.h:155: mOw = Twc.translation() = -Rcw^T tcw, in float like Sophus::SE3f::inverse()
+    Eigen::Vector3f GetCameraCenter() {
+        ++nCenterReads;
+        const float x = mTcw.q.qx, y = mTcw.q.qy, z = mTcw.q.qz, w = mTcw.q.qw;
+        const float R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                             2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                             2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y) };
+        const Eigen::Vector3f &t = mTcw.t;
+        return Eigen::Vector3f(-(R[0] * t(0) + R[3] * t(1) + R[6] * t(2)), -(R[1] * t(0) + R[4] * t(1) + R[7] * t(2)),
+                               -(R[2] * t(0) + R[5] * t(1) + R[8] * t(2)));
+    }
+    Eigen::Vector3f GetRightCameraCenter() { return GetCameraCenter(); }
+    const int NLeft = -1, NRight = -1;                       // KeyFrame.h:452 (no fisheye rig in this fork)
+    const int mnScaleLevels = 8;                             // KeyFrame.h:335
+    const std::vector<float> mvScaleFactors = std::vector<float>{1.f, 1.2f, 1.44f, 1.728f, 2.0736f, 2.48832f, 2.985984f, 3.5831808f};
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+    int nCenterReads = 0;
     std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return mvCovisible; }
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
     void EraseMapPointMatch(MapPoint *pMP) {
@@ -28,4 +45,33 @@ public:
     Sophus::SE3f mTcw; std::vector<KeyFrame *> mvCovisible; std::vector<MapPoint *> mvpMapPoints;
     bool mbBad = false; Map *mpMap = nullptr; int nPoseSets = 0;
 };
+// MapPoint::UpdateNormalAndDepth as the reference computes it (MapPoint.cc:362-435): the mean of the unit viewing rays of
+// all observers, and the scale-invariance distances from the reference keyframe.  Defined here because it needs KeyFrame.
+inline void MapPoint::UpdateNormalAndDepth()
+{
+    ++nNormalUpdates;
+    if (mbBad) return;
+    const std::map<KeyFrame *, std::tuple<int, int>> observations = mObservations;
+    KeyFrame *pRefKF = mpRefKF;
+    const Eigen::Vector3f Pos = mWorldPos;
+    if (observations.empty()) return;
+    Eigen::Vector3f normal; normal.setZero();
+    int n = 0;
+    for (auto mit = observations.begin(); mit != observations.end(); ++mit) {
+        KeyFrame *pKF = mit->first;
+        const int leftIndex = std::get<0>(mit->second), rightIndex = std::get<1>(mit->second);
+        if (leftIndex != -1) { const Eigen::Vector3f normali = Pos - pKF->GetCameraCenter(); normal = normal + normali / normali.norm(); n++; }
+        if (rightIndex != -1) { const Eigen::Vector3f normali = Pos - pKF->GetRightCameraCenter(); normal = normal + normali / normali.norm(); n++; }
+    }
+    const Eigen::Vector3f PC = Pos - pRefKF->GetCameraCenter();
+    const float dist = PC.norm();
+    const std::tuple<int, int> indexes = observations.count(pRefKF) ? observations.at(pRefKF) : std::make_tuple(0, -1);
+    const int leftIndex = std::get<0>(indexes);
+    const int level = pRefKF->mvKeysUn[leftIndex].octave;                    // NLeft == -1
+    const float levelScaleFactor = pRefKF->mvScaleFactors[level];
+    const int nLevels = pRefKF->mnScaleLevels;
+    mfMaxDistance = dist * levelScaleFactor;
+    mfMinDistance = mfMaxDistance / pRefKF->mvScaleFactors[nLevels - 1];
+    mNormalVector = normal / n;
+}
 }  // namespace MOV_SLAM

@@ -10,15 +10,30 @@ class MapPoint {
 public:
     void SetWorldPos(const Eigen::Vector3f &p) { mWorldPos = p; }
     Eigen::Vector3f GetWorldPos() { return mWorldPos; }
-    std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { return mObservations; }
-    void EraseObservation(KeyFrame *pKF) { mObservations.erase(pKF); ++nErased; }
+    std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { ++nObservationCopies(); return mObservations; }
+    static long &nObservationCopies() { static long n = 0; return n; }      // test plumbing: std::map copies handed out
+    KeyFrame *GetReferenceKeyFrame() { return mpRefKF; }                     // MapPoint.h:87
+    Eigen::Vector3f GetNormal() { return mNormalVector; }
+    void SetNormalVector(const Eigen::Vector3f &n) { mNormalVector = n; }     // MapPoint.h:85
+#ifdef MOVBA_MAPPOINT_HAS_SET_DISTANCES
+    // the accessor INTEGRATION.md asks MoV-SLAM's MapPoint.h to gain (the reference can only set these inside UpdateNormalAndDepth)
+    void SetMinMaxDistance(float mn, float mx) { mfMinDistance = mn; mfMaxDistance = mx; }
+#endif
+    void UpdateNormalAndDepth();                                             // MapPoint.cc:362-435, restated on the mock types below
+    // MapPoint.cc:171-209: the reference keyframe moves on when its observation goes; <= 2 observations left: bad point
+    void EraseObservation(KeyFrame *pKF) {
+        if (!mObservations.count(pKF)) return;
+        mObservations.erase(pKF); ++nErased;
+        if (mpRefKF == pKF && !mObservations.empty()) mpRefKF = mObservations.begin()->first;
+        if (mObservations.size() <= 2) mbBad = true;
+    }
     bool isBad() { return mbBad; }
-    void UpdateNormalAndDepth() { ++nNormalUpdates; }
     Map *GetMap() { return mpMap; }
     long unsigned int mnId = 0, mnBALocalForKF = ~0ul, mnBAGlobalForKF = 0;
     Eigen::Vector3f mPosGBA;
     // test plumbing
     Eigen::Vector3f mWorldPos; std::map<KeyFrame *, std::tuple<int, int>> mObservations;
     bool mbBad = false; Map *mpMap = nullptr; int nErased = 0, nNormalUpdates = 0;
+    KeyFrame *mpRefKF = nullptr; Eigen::Vector3f mNormalVector; float mfMinDistance = 0.f, mfMaxDistance = 0.f;
 };
 }  // namespace MOV_SLAM

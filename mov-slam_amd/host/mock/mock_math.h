@@ -14,6 +14,12 @@ struct Vector3f {
     float operator()(int i) const { return v[i]; }
     float &operator()(int i) { return v[i]; }
     float x() const { return v[0]; } float y() const { return v[1]; } float z() const { return v[2]; }
+    // the float arithmetic MapPoint::UpdateNormalAndDepth uses (MapPoint.cc:380-431)
+    Vector3f operator-(const Vector3f &o) const { return Vector3f(v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]); }
+    Vector3f operator+(const Vector3f &o) const { return Vector3f(v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]); }
+    Vector3f operator/(float s) const { return Vector3f(v[0] / s, v[1] / s, v[2] / s); }
+    float norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+    void setZero() { v[0] = v[1] = v[2] = 0.f; }
 };
 struct Quaternionf {
     float qx, qy, qz, qw;

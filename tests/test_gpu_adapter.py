@@ -53,16 +53,20 @@ def _read_out(path, w):
     poses = np.frombuffer(b, np.float32, 7 * w.n_poses, off).reshape(-1, 7); off += 28 * w.n_poses
     points = np.frombuffer(b, np.float32, 3 * w.n_points, off).reshape(-1, 3); off += 12 * w.n_points
     erased = np.frombuffer(b, np.int32, 2 * hd[3], off).reshape(-1, 2); off += 8 * hd[3]
-    tail = struct.unpack_from("2i", b, off)
+    tail = struct.unpack_from("2i", b, off); off += 8
+    counts = struct.unpack_from("2i", b, off); off += 8
+    nd = np.frombuffer(b, np.float32, 5 * w.n_points, off).reshape(-1, 5); off += 20 * w.n_points
+    timing = struct.unpack_from("3d", b, off)
     return dict(num_fixedKF=hd[0], num_OptKF=hd[1], num_edges=hd[2], n_erased=hd[3], change_idx=hd[4],
-                poses=poses, points=points, erased=erased, n_pose_sets=tail[0], n_normal_updates=tail[1])
+                poses=poses, points=points, erased=erased, n_pose_sets=tail[0], n_normal_updates=tail[1],
+                n_observation_copies=counts[0], n_center_reads=counts[1], normals=nd[:, :3], dist=nd[:, 3:], timing_ms=timing)
 
 
 def _check_map(out, o, w, moved):
     assert quat_angle(out["poses"][:, :4].astype(np.float64), _f32_pose(o["poses"])[:, :4]).max() < 2e-6
     np.testing.assert_allclose(out["poses"][:, 4:], o["poses"][:, 4:].astype(np.float32), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(out["points"], o["points"].astype(np.float32), rtol=2e-6, atol=2e-6)
-    assert out["n_pose_sets"] == moved and out["n_normal_updates"] == w.n_points
+    assert out["n_pose_sets"] == moved and out["n_normal_updates"] == w.n_points     # BundleAdjustment keeps the reference's per-point update
 
 
 def _local_subwindow(w):
@@ -104,7 +108,19 @@ def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tm
     np.testing.assert_allclose(out["poses"][:, 4:], exp_poses[:, 4:].astype(np.float32), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(out["points"], exp_points.astype(np.float32), rtol=2e-6, atol=2e-6)
     assert out["n_pose_sets"] == K                    # SetPose on the local keyframes only (Optimizer.cc:822-829)
-    assert out["n_normal_updates"] == int(local_pt.sum())
+    # ONE std::map copy per local map point for the whole call (the reference takes three), the camera centres
+    # read once per window keyframe, and normal / depth stored from the GPU result without MapPoint::UpdateNormalAndDepth
+    assert out["n_observation_copies"] == int(local_pt.sum())
+    assert out["n_normal_updates"] == 0 and out["n_center_reads"] == int(used_pose.sum())
+    # ... with exactly what UpdateNormalAndDepth computes: the same run with the reference's per-point update
+    env = dict(os.environ, MOVBA_ADAPTER_REFERENCE_NORMALS="1")
+    fout2 = str(tmp_path / "o2.bin")
+    subprocess.check_call([adapter_bin, "lba", fin, fout2], env=env)
+    ref = _read_out(fout2, w)
+    assert ref["n_normal_updates"] == int(local_pt.sum()) and ref["n_center_reads"] > out["n_center_reads"]
+    assert np.array_equal(out["normals"], ref["normals"]) and np.array_equal(out["dist"], ref["dist"])
+    assert np.array_equal(out["poses"], ref["poses"]) and np.array_equal(out["points"], ref["points"])
+    assert np.abs(np.linalg.norm(out["normals"][local_pt], axis=1)).max() <= 1.0 + 1e-6 and (out["dist"][local_pt, 1] > out["dist"][local_pt, 0]).all()
     # erased (KeyFrame, MapPoint) pairs == the oracle's outliers in edge order, up to the chi2 guard band
     ep, el = w.edge_pose[keep_e], w.edge_point[keep_e]
     want = set(map(tuple, np.stack([ep, el], 1)[o["outlier"] == 1]))
