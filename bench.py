@@ -203,7 +203,8 @@ def main():
             try:
                 nb = 8
                 bws = [synth.make_window(shape[0], shape[1], shape[2], shard.window_seed(i), run_lo=shape[3], run_hi=shape[4]) for i in range(nb)]
-                bsolvers = [capi.Solver(device=local_rank, stream=stream.cuda_stream) for _ in range(nb)]
+                bstream = torch.cuda.Stream(device=dev)     # the handles of a batch share one (non-default) stream
+                bsolvers = [capi.Solver(device=local_rank, stream=bstream.cuda_stream) for _ in range(nb)]
                 for bs_, bw_ in zip(bsolvers, bws):
                     bs_.upload(bw_)
                 capi.run_batch(bsolvers); capi.run_batch(bsolvers)

@@ -110,6 +110,9 @@ typedef struct {
                                  * with HIP events on the handle's stream; 0x3f = all          */
     int32_t pcg_coarse;         /* 0 = default (two-level: block-Jacobi + aggregate coarse level),
                                  * -1 = block-Jacobi only                                       */
+    int32_t host_wait;          /* how the calling thread waits for the device between queueing trials:
+                                 * 0 = spin on the progress word (default, lowest latency), 1 = sched_yield() between
+                                 * looks (for a LocalMapping thread that shares its core with Tracking)            */
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */
@@ -196,7 +199,15 @@ typedef struct {
     double chi2_gate;           /* threshold^2                                                */
     int32_t rounds;             /* 4                                                          */
     int32_t its_per_round;      /* 10                                                         */
+    /* Hypothesis stage in front of the LM, so that the result does not depend on pose0 (the reference calls
+     * cv::solvePnPRansac with useExtrinsicGuess = false, Optimizer.cc:437): ransac_iters minimal P3P samples
+     * (iterationCount of PoseOptimization, 50 by default), drawn from ransac_seed; every candidate pose is scored on
+     * all matches at chi2_gate and the best one starts the LM when it has at least 4 inliers.  0: LM from pose0. */
+    int32_t ransac_iters;       /* <= MOVBA_MAX_RANSAC_ITERS                                  */
+    uint32_t ransac_seed;
 } movba_pose_desc;
+
+#define MOVBA_MAX_RANSAC_ITERS 256
 
 typedef struct {
     double   pose[7];
@@ -204,9 +215,14 @@ typedef struct {
     double  *chi2;              /* n out or NULL                                              */
     int32_t  n_inliers;         /* return value of PoseOptimization (Optimizer.cc:458)        */
     int32_t  status;
+    int32_t  ransac_inliers;    /* inliers of the best hypothesis (0: stage off, or no candidate with >= 4)  */
+    int32_t  pad;
+    double   ransac_pose[7];    /* the pose the LM started from                               */
 } movba_pose_result;
 
 int  movba_pose_opt(movba_handle *h, const movba_pose_desc *desc, movba_pose_result *res);
+/* The minimal samples movba_pose_opt draws for (n matches, n_hyp, seed): n_hyp x 3 distinct match indices.  Host only. */
+int  movba_pose_ransac_samples(int32_t n, int32_t n_hyp, uint32_t seed, int32_t *out);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 // Replaces, behind Optimizer::LocalBundleAdjustment (/root/reference/src/Optimizer.cc:461-841),
 // the g2o objects set up at :532-545 and driven at :754-755, and the gate at :757-775.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -98,6 +99,16 @@ struct movba_handle {
 namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// between two looks at the device's progress word: spin (lowest latency: the LM chain is ~100 us per trial), or give the
+// core away (movba_options::host_wait = 1: the LocalMapping thread then does not starve a Tracking thread it shares a core with)
+inline void host_relax(int mode)
+{
+    if (mode == 1) { sched_yield(); return; }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
 
 struct Carver {
     size_t off = 0;
@@ -203,13 +214,14 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     movba_handle *h = new (std::nothrow) movba_handle();
     if (!h) return MOVBA_ERR_HIP;
     h->device = device;
-    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0;
     if (opt) {
         if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
         if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
         if (opt->run_ahead > 0) h->opt.run_ahead = opt->run_ahead;
         h->opt.profile = opt->profile;
         if (opt->pcg_coarse < 0) h->opt.pcg_coarse = 0;
+        h->opt.host_wait = opt->host_wait == 1 ? 1 : 0;
     }
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
     if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
@@ -674,9 +686,7 @@ int lm_loop(movba_handle *h, bool parked)
                     std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
                     return MOVBA_ERR_HIP;
                 }
-#if defined(__x86_64__)
-                __builtin_ia32_pause();
-#endif
+                host_relax(h->opt.host_wait);
             }
             if (finished) break;
             if (paused) { const int rq = answer_pause(); if (rq != MOVBA_OK) return rq; --t; continue; }
@@ -783,7 +793,8 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
         // Groups of windows on streams of their own, out of phase: a group's PCG launch keeps 2 CUs per window busy for most
         // of a trial while its point / schur launches fill the chip for the rest, so the PCG of one group runs beside the
         // streaming kernels of the others.  Each window's own kernels still run in its solo order on one stream.
-        int ngroups = na >= 8 ? 4 : (na >= 2 ? 2 : 1);
+        // (two by default: with more streams than hardware queues left to the process the groups fall back into lockstep)
+        int ngroups = na >= 2 ? 2 : 1;
         if (const char *eg = std::getenv("MOVBA_BATCH_GROUPS")) ngroups = std::max(1, std::min(std::min(kMaxGroups, na), std::atoi(eg)));
         if (ngroups > 1 && !h0->batch_ev[0]) {
             for (hipEvent_t &e : h0->batch_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -913,9 +924,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
                 return MOVBA_ERR_HIP;
             }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
+            host_relax(h0->opt.host_wait);
         }
         for (int g = 1; g < ngroups; ++g) {         // the callers' stream ends behind the others
             HIP_TRY(hipEventRecord(h0->batch_ev[g], grp[g].s));
@@ -1043,11 +1052,28 @@ int movba_reset_profile(movba_handle *h)
 // ---------------------------------------------------------------------------------------
 // Optimizer::PoseOptimization (/root/reference/src/Optimizer.cc:397-459)
 // ---------------------------------------------------------------------------------------
+// minimal samples of the hypothesis stage: n_hyp triples of distinct match indices from a xorshift32 stream (the same
+// function feeds the oracle in the tests, so both sides score the same hypotheses)
+extern "C" int movba_pose_ransac_samples(int32_t n, int32_t n_hyp, uint32_t seed, int32_t *out)
+{
+    if (n < 3 || n_hyp < 0 || !out) return MOVBA_ERR_ARG;
+    uint32_t x = seed ? seed : 0x9E3779B9u;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+    for (int h = 0; h < n_hyp; ++h) {
+        int32_t a = (int32_t)(next() % (uint32_t)n), b, c;
+        do { b = (int32_t)(next() % (uint32_t)n); } while (b == a);
+        do { c = (int32_t)(next() % (uint32_t)n); } while (c == a || c == b);
+        out[3 * h] = a; out[3 * h + 1] = b; out[3 * h + 2] = c;
+    }
+    return MOVBA_OK;
+}
+
 extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_pose_result *res)
 {
     if (!h || !d || !res) return MOVBA_ERR_ARG;
-    res->status = MOVBA_ERR_ARG; res->n_inliers = 0;
+    res->status = MOVBA_ERR_ARG; res->n_inliers = 0; res->ransac_inliers = 0;
     const int n = d->n;
+    const int n_hyp = d->ransac_iters > 0 ? std::min(d->ransac_iters, (int32_t)MOVBA_MAX_RANSAC_ITERS) : 0;
     if (n < 0 || (n && (!d->Xw || !d->obs)) || d->rounds < 1 || d->its_per_round < 1) return MOVBA_ERR_ARG;
     for (int k = 0; k < 7; ++k) res->pose[k] = d->pose0[k];
     // fewer than 4 matches: the reference returns 0 without touching the frame (Optimizer.cc:415-418)
@@ -1055,10 +1081,13 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     HIP_TRY(hipSetDevice(h->device));
     Carver c;
     const size_t o_X = c.take<double>(3 * (size_t)n), o_obs = c.take<double>(2 * (size_t)n), o_is = c.take<double>(n);
+    const size_t o_samp = c.take<int32_t>(3 * (size_t)n_hyp + 1);
     const size_t h2d = c.off;
-    const size_t o_chi = c.take<double>(n), o_pose = c.take<double>(8), o_lvl = c.take<uint8_t>(n);
+    const size_t o_chi = c.take<double>(n), o_pose = c.take<double>(16), o_lvl = c.take<uint8_t>(n);
+    const size_t d2h_end = c.off;
+    const size_t o_cand = c.take<uint8_t>(pose_ransac_bytes(n_hyp) + 16);
     const size_t total = c.off;
-    const bool staged = pose_opt_staged_lds_bytes(n) <= 150 * 1024;
+    const bool staged = pose_opt_staged_lds_bytes(n, n_hyp) <= 150 * 1024;
     if (!staged && total > h->pose_cap) {
         if (h->pose_arena) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->pose_arena)); h->pose_arena = nullptr; h->pose_cap = 0; }
         const size_t cap = align_up(2 * total, 1 << 16);
@@ -1072,21 +1101,25 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)n);
     double *isg = reinterpret_cast<double *>(sg + o_is);
     for (int i = 0; i < n; ++i) isg[i] = d->inv_sigma2 ? d->inv_sigma2[i] : 1.0;
+    if (n_hyp > 0) (void)movba_pose_ransac_samples(n, n_hyp, d->ransac_seed, reinterpret_cast<int32_t *>(sg + o_samp));
     // staged (up to ~3 000 matches): the kernel reads the pinned buffer itself and writes its results back into it
     if (!staged) HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
     PoseDev p{};
-    p.n = n; p.rounds = d->rounds; p.its = d->its_per_round;
+    p.n = n; p.rounds = d->rounds; p.its = d->its_per_round; p.n_hyp = n_hyp;
     p.fx = d->fx; p.fy = d->fy; p.cx = d->cx; p.cy = d->cy; p.huber_delta = d->huber_delta; p.chi2_gate = d->chi2_gate;
     for (int k = 0; k < 7; ++k) p.pose0[k] = d->pose0[k];
     char *a = staged ? h->stage_dev : h->pose_arena;
     p.Xw = reinterpret_cast<double *>(a + o_X); p.obs = reinterpret_cast<double *>(a + o_obs); p.isig = reinterpret_cast<double *>(a + o_is);
     p.chi2 = reinterpret_cast<double *>(a + o_chi); p.pose_out = reinterpret_cast<double *>(a + o_pose); p.level1 = reinterpret_cast<uint8_t *>(a + o_lvl);
+    p.samples = reinterpret_cast<const int32_t *>(a + o_samp); p.cand = reinterpret_cast<double *>(a + o_cand);
     HIP_TRY(launch_pose_opt(p, staged, h->stream));
-    if (!staged) HIP_TRY(hipMemcpyAsync(sg + o_chi, a + o_chi, total - o_chi, hipMemcpyDeviceToHost, h->stream));
+    if (!staged) HIP_TRY(hipMemcpyAsync(sg + o_chi, a + o_chi, d2h_end - o_chi, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double *po = reinterpret_cast<const double *>(sg + o_pose);
     for (int k = 0; k < 7; ++k) res->pose[k] = po[k];
     res->n_inliers = (int32_t)po[7];
+    res->ransac_inliers = n_hyp > 0 ? (int32_t)po[8] : 0;
+    for (int k = 0; k < 7; ++k) res->ransac_pose[k] = n_hyp > 0 ? po[9 + k] : d->pose0[k];
     if (res->outlier) std::memcpy(res->outlier, sg + o_lvl, (size_t)n);
     if (res->chi2) std::memcpy(res->chi2, sg + o_chi, sizeof(double) * (size_t)n);
     res->status = MOVBA_OK;

@@ -164,6 +164,149 @@ __device__ bool solve6(const double Hu[21], double lambda, const double b[6], do
     return ok;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hypothesis stage in front of the LM: RANSAC over minimal P3P solves, so that the result does not depend on the pose the
+// caller's Frame happens to hold.  The reference's PoseOptimization IS a RANSAC-PnP (cv::solvePnPRansac with
+// useExtrinsicGuess = false, /root/reference/src/Optimizer.cc:437; USAC_MAGSAC over P3P): it recovers from a stale
+// Frame pose (mState == RECENTLY_LOST, Tracking.cc:806) and from match sets dominated by outliers.  OpenCV's arithmetic is
+// not in the reference tree; this is the classical scheme it implements: H minimal samples (host-drawn, seeded), the
+// Grunert three-point solution of each (Haralick et al. 1994, eq. for the quartic in v = s3 / s1), every candidate pose
+// scored on all matches by its inlier count at the caller's reprojection threshold (ties: truncated cost), the best one
+// starts the LM.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Cplx { double re, im; };
+__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return Cplx{ a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; }
+__device__ __forceinline__ Cplx csub(Cplx a, Cplx b) { return Cplx{ a.re - b.re, a.im - b.im }; }
+__device__ __forceinline__ Cplx cdiv(Cplx a, Cplx b)
+{
+    const double d = b.re * b.re + b.im * b.im;
+    return Cplx{ (a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d };
+}
+
+// all four roots of z^4 + c3 z^3 + c2 z^2 + c1 z + c0 (Durand-Kerner, fixed iteration count: deterministic)
+__device__ void quartic_roots(double c3, double c2, double c1, double c0, Cplx z[4])
+{
+    // Fujiwara bound: every root lies within 2 max(|c3|, |c2|^1/2, |c1|^1/3, |c0|^1/4)
+    const double rb = 2.0 * fmax(fmax(fabs(c3), sqrt(fabs(c2))), fmax(cbrt(fabs(c1)), sqrt(sqrt(fabs(c0))))) + 1e-300;
+    const double r0 = 0.5 * rb;
+    z[0] = Cplx{ r0 * 0.9210609940028851, r0 * 0.3894183423086505 };      // radius r0, angles 0.4 + k pi / 2
+    z[1] = Cplx{ -z[0].im, z[0].re }; z[2] = Cplx{ -z[0].re, -z[0].im }; z[3] = Cplx{ z[0].im, -z[0].re };
+    for (int it = 0; it < 80; ++it) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Cplx x = z[k];
+            // p(x) by Horner
+            Cplx pv = Cplx{ x.re + c3, x.im };
+            pv = cmul(pv, x); pv.re += c2;
+            pv = cmul(pv, x); pv.re += c1;
+            pv = cmul(pv, x); pv.re += c0;
+            Cplx den = Cplx{ 1.0, 0.0 };
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (j != k) den = cmul(den, csub(x, z[j]));
+            if (den.re * den.re + den.im * den.im > 0.0) z[k] = csub(x, cdiv(pv, den));
+        }
+    }
+}
+
+__device__ __forceinline__ void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// orthonormal frame of a point triple: e1 along P2 - P1, e3 normal to the triangle, e2 = e3 x e1; false when degenerate
+__device__ bool triple_frame(const double P1[3], const double P2[3], const double P3[3], double F[9])
+{
+    double d1[3] = { P2[0] - P1[0], P2[1] - P1[1], P2[2] - P1[2] }, d2[3] = { P3[0] - P1[0], P3[1] - P1[1], P3[2] - P1[2] };
+    const double n1 = sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]);
+    if (!(n1 > 0.0)) return false;
+    d1[0] /= n1; d1[1] /= n1; d1[2] /= n1;
+    double e3[3];
+    cross3(d1, d2, e3);
+    const double n3 = sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    if (!(n3 > 1e-12 * n1)) return false;
+    e3[0] /= n3; e3[1] /= n3; e3[2] /= n3;
+    double e2[3];
+    cross3(e3, d1, e2);
+    // columns e1 e2 e3
+    F[0] = d1[0]; F[3] = d1[1]; F[6] = d1[2]; F[1] = e2[0]; F[4] = e2[1]; F[7] = e2[2]; F[2] = e3[0]; F[5] = e3[1]; F[8] = e3[2];
+    return true;
+}
+
+// Grunert's P3P: world points X[3][3], unit bearings j[3][3] -> up to 4 poses (R row-major, t) with X_cam = R X + t
+__device__ int p3p_grunert(const double X[3][3], const double j[3][3], double Rs[4][9], double ts[4][3])
+{
+    auto d2 = [](const double *a, const double *b) { const double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2]; return x * x + y * y + z * z; };
+    const double a2 = d2(X[1], X[2]), b2 = d2(X[0], X[2]), c2 = d2(X[0], X[1]);
+    if (!(b2 > 0.0) || !(a2 > 0.0) || !(c2 > 0.0)) return 0;
+    const double ca = j[1][0] * j[2][0] + j[1][1] * j[2][1] + j[1][2] * j[2][2];
+    const double cb = j[0][0] * j[2][0] + j[0][1] * j[2][1] + j[0][2] * j[2][2];
+    const double cg = j[0][0] * j[1][0] + j[0][1] * j[1][1] + j[0][2] * j[1][2];
+    const double q = (a2 - c2) / b2, pp = (a2 + c2) / b2;
+    const double A4 = (q - 1.0) * (q - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (q * (1.0 - q) * cb - (1.0 - pp) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (q * q - 1.0 + 2.0 * q * q * cb * cb + 2.0 * (b2 - c2) / b2 * ca * ca - 4.0 * pp * ca * cb * cg + 2.0 * (b2 - a2) / b2 * cg * cg);
+    const double A1 = 4.0 * (-q * (1.0 + q) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - pp) * ca * cg);
+    const double A0 = (1.0 + q) * (1.0 + q) - 4.0 * a2 / b2 * cg * cg;
+    const double mx = fmax(fmax(fabs(A4), fabs(A3)), fmax(fmax(fabs(A2), fabs(A1)), fabs(A0)));
+    if (!(fabs(A4) > 1e-12 * mx) || !isfinite(mx)) return 0;
+    const double c3 = A3 / A4, c2q = A2 / A4, c1 = A1 / A4, c0 = A0 / A4;
+    Cplx z[4];
+    quartic_roots(c3, c2q, c1, c0, z);
+    double Fw[9];
+    if (!triple_frame(X[0], X[1], X[2], Fw)) return 0;
+    int ns = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!(fabs(z[k].im) <= 1e-6 * (1.0 + fabs(z[k].re)))) continue;
+        double v = z[k].re;
+        for (int it = 0; it < 2; ++it) {            // polish on the real quartic
+            const double f = (((v + c3) * v + c2q) * v + c1) * v + c0, df = ((4.0 * v + 3.0 * c3) * v + 2.0 * c2q) * v + c1;
+            if (df != 0.0) v -= f / df;
+        }
+        if (!(v > 0.0)) continue;
+        const double den = 2.0 * (cg - v * ca);
+        if (!(fabs(den) > 1e-12)) continue;
+        const double u = ((q - 1.0) * v * v - 2.0 * q * cb * v + 1.0 + q) / den;
+        if (!(u > 0.0)) continue;
+        const double dd = 1.0 + v * v - 2.0 * v * cb;
+        if (!(dd > 0.0)) continue;
+        const double s1 = sqrt(b2 / dd), s2 = u * s1, s3 = v * s1;
+        const double P1[3] = { s1 * j[0][0], s1 * j[0][1], s1 * j[0][2] }, P2[3] = { s2 * j[1][0], s2 * j[1][1], s2 * j[1][2] },
+                     P3[3] = { s3 * j[2][0], s3 * j[2][1], s3 * j[2][2] };
+        double Fc[9];
+        if (!triple_frame(P1, P2, P3, Fc)) continue;
+        // R = Fc Fw^T
+        double *R = Rs[ns];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = Fc[r * 3] * Fw[c * 3] + Fc[r * 3 + 1] * Fw[c * 3 + 1] + Fc[r * 3 + 2] * Fw[c * 3 + 2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ts[ns][r] = P1[r] - (R[r * 3] * X[0][0] + R[r * 3 + 1] * X[0][1] + R[r * 3 + 2] * X[0][2]);
+        ++ns;
+    }
+    return ns;
+}
+
+// rotation matrix (row-major) -> unit quaternion (x, y, z, w), w >= 0 (Eigen's conversion, as in oplus above)
+__device__ void R2q(const double m[9], double q[4])
+{
+    double t = m[0] + m[4] + m[8];
+    if (t > 0.0) {
+        t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {
+        t = sqrt(m[0] - m[4] - m[8] + 1.0); q[0] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
+    } else if (m[4] > m[0] && m[4] >= m[8]) {
+        t = sqrt(m[4] - m[8] - m[0] + 1.0); q[1] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
+    } else {
+        t = sqrt(m[8] - m[0] - m[4] + 1.0); q[2] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
+    }
+    qnorm(q);
+}
+
 }  // namespace
 
 // STAGED: the matches are read ONCE from where the host left them (its pinned staging buffer, across the bus) into LDS,
@@ -190,11 +333,83 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 #pragma unroll
     for (int k = 0; k < 7; ++k) pose0[k] = p.pose0[k];
     qnorm(pose0);
+    for (int i = tid; i < p.n; i += kT) level1[i] = 0;
+    __syncthreads();
+    if (p.n_hyp > 0) {
+        // ---- hypothesis stage (see the header of the P3P block): thread h solves sample h, then every wave scores candidates ----
+        double *cand = STAGED ? reinterpret_cast<double *>(level1 + (((size_t)p.n + 15) & ~(size_t)15)) : p.cand;   // n_hyp x 4 x 12 poses, then x 2 scores
+        double *score = cand + (size_t)p.n_hyp * 48;
+        int *nsol = reinterpret_cast<int *>(score + (size_t)p.n_hyp * 8);
+        for (int h = tid; h < p.n_hyp; h += kT) {
+            double X[3][3], jb[3][3];
+            bool okh = true;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int i = p.samples[3 * h + m];
+                okh &= i >= 0 && i < p.n;
+                const int ii = okh ? i : 0;
+                X[m][0] = Xw[3 * ii]; X[m][1] = Xw[3 * ii + 1]; X[m][2] = Xw[3 * ii + 2];
+                const double bx = (obs[2 * ii] - p.cx) / p.fx, by = (obs[2 * ii + 1] - p.cy) / p.fy;
+                const double nn = 1.0 / sqrt(bx * bx + by * by + 1.0);
+                jb[m][0] = bx * nn; jb[m][1] = by * nn; jb[m][2] = nn;
+            }
+            double Rs[4][9], ts[4][3];
+            const int ns = okh ? p3p_grunert(X, jb, Rs, ts) : 0;
+            nsol[h] = ns;
+            for (int k = 0; k < ns; ++k) {
+                double *c = cand + ((size_t)h * 4 + k) * 12;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) c[e] = Rs[k][e];
+                c[9] = ts[k][0]; c[10] = ts[k][1]; c[11] = ts[k][2];
+            }
+        }
+        __syncthreads();
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int cidx = wv; cidx < 4 * p.n_hyp; cidx += kW) {
+            double cnt = 0.0, cst = 0.0;
+            if ((cidx & 3) < nsol[cidx >> 2]) {
+                const double *R = cand + (size_t)cidx * 12;
+                for (int i = lane; i < p.n; i += 64) {
+                    const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
+                    const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
+                    const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
+                    const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
+                    const double om = isig[i];
+                    const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
+                    const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+                    const bool in = (z > 0.0) && (chi2 <= p.chi2_gate);
+                    cnt += in ? 1.0 : 0.0; cst += in ? chi2 : p.chi2_gate;
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); cst += __shfl_xor(cst, o, 64); }
+            } else { cnt = -1.0; cst = DBL_MAX; }
+            if (lane == 0) { score[2 * cidx] = cnt; score[2 * cidx + 1] = cst; }
+        }
+        __syncthreads();
+        // best candidate: most inliers, then lowest truncated cost, then lowest index; every thread scans the same table
+        int best = -1; double bc = 3.5, bs = DBL_MAX;                   // a pose needs at least 4 inliers to replace the caller's
+        for (int cidx = 0; cidx < 4 * p.n_hyp; ++cidx) {
+            const double cnt = score[2 * cidx], cst = score[2 * cidx + 1];
+            if (cnt > bc || (cnt == bc && best >= 0 && cst < bs)) { best = cidx; bc = cnt; bs = cst; }
+        }
+        if (best >= 0) {
+            const double *R = cand + (size_t)best * 12;
+            double Rm[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) Rm[e] = R[e];
+            R2q(Rm, pose0);
+            pose0[4] = R[9]; pose0[5] = R[10]; pose0[6] = R[11];
+        }
+        if (tid == 0) {
+            p.pose_out[8] = best >= 0 ? bc : 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) p.pose_out[9 + k] = pose0[k];
+        }
+        __syncthreads();
+    }
     double pose[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) pose[k] = pose0[k];
-    for (int i = tid; i < p.n; i += kT) level1[i] = 0;
-    __syncthreads();
 
     // robust cost of the active matches at a pose
     auto cost = [&](const double T[7], bool robust) {
@@ -333,7 +548,8 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     }
 }
 
-size_t pose_opt_staged_lds_bytes(int n) { return (size_t)n * 6 * sizeof(double) + (((size_t)n + 15) & ~(size_t)15); }
+size_t pose_ransac_bytes(int n_hyp) { return n_hyp > 0 ? (size_t)n_hyp * (48 + 8) * sizeof(double) + (size_t)n_hyp * sizeof(int) + 16 : 0; }
+size_t pose_opt_staged_lds_bytes(int n, int n_hyp) { return (size_t)n * 6 * sizeof(double) + (((size_t)n + 15) & ~(size_t)15) + pose_ransac_bytes(n_hyp); }
 
 hipError_t configure_pose_kernels()
 {
@@ -342,7 +558,7 @@ hipError_t configure_pose_kernels()
 
 hipError_t launch_pose_opt(const PoseDev &p, bool staged, hipStream_t s)
 {
-    if (staged) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kT), pose_opt_staged_lds_bytes(p.n), s, p);
+    if (staged) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kT), pose_opt_staged_lds_bytes(p.n, p.n_hyp), s, p);
     else hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(kT), 0, s, p);
     return hipGetLastError();
 }

@@ -36,6 +36,7 @@ namespace MOV_SLAM
     namespace
     {
         const float delta = 5.0f;      // chi2 gate and squared Huber threshold, as the file-static at Optimizer.cc:52
+        const uint32_t kPoseRansacSeed = 20221105u;              // fixed: PoseOptimization is reproducible call to call
 
         // One device handle per calling thread: LocalMapping's thread runs LocalBundleAdjustment while the
         // tracking thread runs PoseOptimization (System.cc:128-129), and a handle is single-threaded.
@@ -60,6 +61,34 @@ namespace MOV_SLAM
         };
         thread_local ThreadHandle tls_handle;
 
+        // KeyFrame* -> vertex index, open addressing (one lookup per observation: std::unordered_map's node chasing was a
+        // third of the extraction time on a 50-keyframe window)
+        struct KfIndex
+        {
+            std::vector<KeyFrame *> key;
+            std::vector<int32_t> val;
+            size_t mask = 0;
+            static size_t hash(const KeyFrame *p) { return (size_t)((reinterpret_cast<uintptr_t>(p) >> 4) * 0x9E3779B97F4A7C15ull >> 20); }
+            void build(const std::vector<KeyFrame *> &kfs)
+            {
+                size_t cap = 16;
+                while (cap < 2 * kfs.size() + 2) cap <<= 1;
+                key.assign(cap, nullptr); val.assign(cap, -1); mask = cap - 1;
+                for (size_t i = 0; i < kfs.size(); ++i)
+                {
+                    size_t h = hash(kfs[i]) & mask;
+                    while (key[h]) h = (h + 1) & mask;
+                    key[h] = kfs[i]; val[h] = (int32_t)i;
+                }
+            }
+            int32_t find(const KeyFrame *p) const       // -1: no vertex
+            {
+                size_t h = hash(p) & mask;
+                while (key[h]) { if (key[h] == p) return val[h]; h = (h + 1) & mask; }
+                return -1;
+            }
+        };
+
         // One entry of a MapPoint's observation map, copied ONCE per point and call (MapPoint::GetObservations() hands out a
         // std::map copy under the point's mutex, MapPoint.cc:211-215: the reference takes two per point before the solve and
         // UpdateNormalAndDepth a third one after it).
@@ -67,6 +96,7 @@ namespace MOV_SLAM
         {
             KeyFrame *kf;
             int left, right;
+            int32_t vertex;                         // index of the keyframe's vertex in the window (-1: none), filled by push_point
         };
 
         // Flattened window in the layout of movba_lba_desc, plus the bookkeeping to write results back.
@@ -129,8 +159,7 @@ namespace MOV_SLAM
 
         // One MapPoint vertex and its edges (Optimizer.cc:623-705 / :142-190) from the point's observation list.
         // Returns the number of edges added.
-        int push_point(Flat &f, MapPoint *pMP, const ObsRef *ob, const ObsRef *ob_end, const std::unordered_map<KeyFrame *, int32_t> &kfIndex,
-                       Map *pCurrentMap, bool requireSameMap)
+        int push_point(Flat &f, MapPoint *pMP, ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex, Map *pCurrentMap, bool requireSameMap)
         {
             const Eigen::Vector3f wp = pMP->GetWorldPos();
             const int32_t pid = (int32_t)f.mps.size();
@@ -138,10 +167,11 @@ namespace MOV_SLAM
             for (; ob != ob_end; ++ob)
             {
                 KeyFrame *pKFi = ob->kf;
+                const int32_t vertex = kfIndex.find(pKFi);
+                ob->vertex = vertex;
                 if (pKFi->isBad() || (requireSameMap && pKFi->GetMap() != pCurrentMap))
                     continue;
-                const std::unordered_map<KeyFrame *, int32_t>::const_iterator vit = kfIndex.find(pKFi);
-                if (vit == kfIndex.end())
+                if (vertex < 0)
                     continue;                                   // observer without a vertex
                 const int leftIndex = ob->left;
                 if (leftIndex == -1)
@@ -167,7 +197,7 @@ namespace MOV_SLAM
                 else
                     for (int k = 0; k < 4; ++k)
                         if (f.cam[k] != (double)pKFi->mpCamera->getParameter(k)) f.cam_mixed = true;
-                f.edge_pose.push_back(vit->second);
+                f.edge_pose.push_back(vertex);
                 f.edge_point.push_back(pid);
                 f.obs.push_back(kpUn.pt.x); f.obs.push_back(kpUn.pt.y);
                 f.inv_sigma2.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
@@ -185,12 +215,12 @@ namespace MOV_SLAM
         }
 
         // the same from a fresh copy of the point's observations (BundleAdjustment: one copy per point)
-        int push_point(Flat &f, MapPoint *pMP, const std::unordered_map<KeyFrame *, int32_t> &kfIndex, Map *pCurrentMap, bool requireSameMap)
+        int push_point(Flat &f, MapPoint *pMP, const KfIndex &kfIndex, Map *pCurrentMap, bool requireSameMap)
         {
             const std::map<KeyFrame *, std::tuple<int, int>> observations = pMP->GetObservations();
             const size_t o0 = f.obs_all.size();
             for (std::map<KeyFrame *, std::tuple<int, int>>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit)
-                f.obs_all.push_back(ObsRef{mit->first, std::get<0>(mit->second), std::get<1>(mit->second)});
+                f.obs_all.push_back(ObsRef{mit->first, std::get<0>(mit->second), std::get<1>(mit->second), -1});
             const int n = push_point(f, pMP, f.obs_all.data() + o0, f.obs_all.data() + f.obs_all.size(), kfIndex, pCurrentMap, requireSameMap);
             f.obs_all.resize(o0);
             return n;
@@ -308,8 +338,8 @@ namespace MOV_SLAM
             push_pose(f, pKF, pKF->mnId == pMap->GetInitKFid());
         }
         sort_poses(f);
-        std::unordered_map<KeyFrame *, int32_t> kfIndex;
-        for (size_t i = 0; i < f.kfs.size(); ++i) kfIndex[f.kfs[i]] = (int32_t)i;
+        KfIndex kfIndex;
+        kfIndex.build(f.kfs);
 
         // MapPoints without any edge are left out of the problem (vbNotIncludedMP, Optimizer.cc:273-281)
         std::vector<bool> vbNotIncludedMP(vpMP.size(), true);
@@ -410,7 +440,7 @@ namespace MOV_SLAM
             f.obs_start.push_back(f.obs_all.size());
             const std::map<KeyFrame *, std::tuple<int, int>> observations = pMP->GetObservations();
             for (std::map<KeyFrame *, std::tuple<int, int>>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit)
-                f.obs_all.push_back(ObsRef{mit->first, std::get<0>(mit->second), std::get<1>(mit->second)});
+                f.obs_all.push_back(ObsRef{mit->first, std::get<0>(mit->second), std::get<1>(mit->second), -1});
         }
         f.obs_start.push_back(f.obs_all.size());
 
@@ -445,8 +475,8 @@ namespace MOV_SLAM
             pCurrentMap->msFixedKFs.insert(pKFi->mnId);
         }
         sort_poses(f);
-        std::unordered_map<KeyFrame *, int32_t> kfIndex;
-        for (size_t i = 0; i < f.kfs.size(); ++i) kfIndex[f.kfs[i]] = (int32_t)i;
+        KfIndex kfIndex;
+        kfIndex.build(f.kfs);
 
         int nEdges = 0;
         std::vector<MapPoint *> edgeless;                        // vertices g2o would keep but never move
@@ -503,7 +533,7 @@ namespace MOV_SLAM
             pMPi->EraseObservation(pKFi);
         }
         for (KeyFrame *pKFi : lLocalKeyFrames)                  // local keyframes only, the fixed init KF included
-            pKFi->SetPose(pose_to_se3f(&s.poses[7 * kfIndex[pKFi]]));
+            pKFi->SetPose(pose_to_se3f(&s.poses[7 * kfIndex.find(pKFi)]));
 #ifdef MOVBA_MAPPOINT_HAS_SET_DISTANCES
         // MapPoint::UpdateNormalAndDepth (MapPoint.cc:362-435) copies the observation map once more and locks every observer
         // for its camera centre: with P points that is as expensive as the solve.  Its arithmetic needs only what is already
@@ -550,15 +580,14 @@ namespace MOV_SLAM
                     if (erased)
                         continue;                               // EraseObservation removed it before the update
                     any = true;
-                    const std::unordered_map<KeyFrame *, int32_t>::const_iterator vit = kfIndex.find(ob->kf);
-                    if (vit == kfIndex.end() || ob->right != -1) { fallback = true; break; }
+                    if (ob->vertex < 0 || ob->right != -1) { fallback = true; break; }
                     if (ob->left != -1)
                     {
-                        const Eigen::Vector3f normali = Pos - Ow[vit->second];
+                        const Eigen::Vector3f normali = Pos - Ow[ob->vertex];
                         normal = normal + normali / normali.norm();
                         n++;
                     }
-                    if (ob->kf == pRefKF) { refLeft = ob->left; refIdx = vit->second; }
+                    if (ob->kf == pRefKF) { refLeft = ob->left; refIdx = ob->vertex; }
                 }
                 if (!fallback && !any)
                     continue;                                   // observations.empty(): nothing is updated
@@ -592,7 +621,10 @@ namespace MOV_SLAM
     int Optimizer::PoseOptimization(Frame *pFrame, const bool isLost, const int iterationCount, const double reprojectionError,
                                     const double reprojectErrorLost, const double confidence, const int algorithm)
     {
-        (void)confidence; (void)algorithm;                      // RANSAC parameters of cv::solvePnPRansac: not used by the LM path
+        // `confidence` (early termination of the sampling) and `algorithm` (which OpenCV sampler / scorer: 38 = USAC_MAGSAC)
+        // steer cv::solvePnPRansac's internals; the hypothesis stage here always draws iterationCount minimal samples and
+        // scores them by inlier count at the reprojection threshold
+        (void)confidence; (void)algorithm;
         // ---- gather 3D-2D matches (Optimizer.cc:404-413) ----
         std::vector<double> Xw, obs;
         std::vector<int> indx;
@@ -628,6 +660,11 @@ namespace MOV_SLAM
         d.chi2_gate = (double)repError * (double)repError;
         d.rounds = 4;
         d.its_per_round = std::max(1, std::min(10, iterationCount / 4));
+        // cv::solvePnPRansac(..., useExtrinsicGuess = false, iterationCount, repError, ...) (Optimizer.cc:437): the result must
+        // not depend on the pose the Frame holds (stale after tracking loss, Tracking.cc:806): iterationCount P3P hypotheses
+        // scored on the GPU, the best one starts the LM
+        d.ransac_iters = std::max(0, iterationCount);
+        d.ransac_seed = kPoseRansacSeed;
         std::vector<uint8_t> outl(indx.size(), 1);
         movba_pose_result r{};
         r.outlier = outl.data(); r.chi2 = nullptr;

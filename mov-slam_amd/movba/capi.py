@@ -53,7 +53,7 @@ class LbaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
-                ("profile", C.c_int32), ("pcg_coarse", C.c_int32)]
+                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -72,17 +72,18 @@ class PoseDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("Xw", _d), ("obs", _d), ("inv_sigma2", _d),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("pose0", C.c_double * 7), ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
-                ("rounds", C.c_int32), ("its_per_round", C.c_int32)]
+                ("rounds", C.c_int32), ("its_per_round", C.c_int32), ("ransac_iters", C.c_int32), ("ransac_seed", C.c_uint32)]
 
 
 class PoseResult(C.Structure):
-    _fields_ = [("pose", C.c_double * 7), ("outlier", _u), ("chi2", _d), ("n_inliers", C.c_int32), ("status", C.c_int32)]
+    _fields_ = [("pose", C.c_double * 7), ("outlier", _u), ("chi2", _d), ("n_inliers", C.c_int32), ("status", C.c_int32),
+                ("ransac_inliers", C.c_int32), ("pad", C.c_int32), ("ransac_pose", C.c_double * 7)]
 
 
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
            "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
            "movba_lba_export_poses_device", "movba_lba_set_pose_export", "movba_get_profile", "movba_reset_profile",
-           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch"]
+           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch", "movba_pose_ransac_samples"]
 
 _lib = None
 
@@ -113,6 +114,7 @@ def lib():
         L.movba_structure_probe.argtypes = [C.POINTER(LbaDesc), C.POINTER(StructureInfo), _i, _i]
         L.movba_pose_opt.argtypes = [C.c_void_p, C.POINTER(PoseDesc), C.POINTER(PoseResult)]
         L.movba_lba_run_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+        L.movba_pose_ransac_samples.argtypes = [C.c_int32, C.c_int32, C.c_uint32, _i]
         _lib = L
     return _lib
 
@@ -166,6 +168,15 @@ def structure_probe(w):
                 sched_max_permille=info.sched_max_permille, slots_ok=bool(info.slots_ok), perm=perm, free_index=fidx)
 
 
+def ransac_samples(n: int, n_hyp: int, seed: int) -> np.ndarray:
+    """The minimal samples movba_pose_opt draws (host only): (n_hyp, 3) match indices."""
+    out = np.zeros((n_hyp, 3), np.int32)
+    rc = lib().movba_pose_ransac_samples(n, n_hyp, seed, _p(out, _i))
+    if rc != OK:
+        raise MovbaError(f"movba_pose_ransac_samples: {status_string(rc)}")
+    return out
+
+
 def run_batch(solvers) -> int:
     """movba_lba_run_batch over the resident windows of `solvers` (created on one stream); download each as usual."""
     arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
@@ -179,9 +190,9 @@ class Solver:
     """One handle = one device + one stream (movba_create / movba_destroy)."""
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
-                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True):
+                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0):
         self._h = C.c_void_p()
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1)
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()
@@ -295,7 +306,7 @@ class Solver:
     def set_profile_mask(self, mask: int):
         lib().movba_set_profile_mask(self._h, mask)
 
-    def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None) -> dict:
+    def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None, ransac_iters=0, ransac_seed=1) -> dict:
         Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
         n = len(Xw)
         d = PoseDesc()
@@ -306,9 +317,11 @@ class Solver:
         d.fx, d.fy, d.cx, d.cy = cam
         d.pose0 = (C.c_double * 7)(*pose0)
         d.huber_delta, d.chi2_gate, d.rounds, d.its_per_round = huber_delta, chi2_gate, rounds, its
+        d.ransac_iters, d.ransac_seed = ransac_iters, ransac_seed
         outl = np.zeros(n, np.uint8); chi2 = np.zeros(n)
         r = PoseResult(); r.outlier = _p(outl, _u); r.chi2 = _p(chi2, _d)
         rc = lib().movba_pose_opt(self._h, C.byref(d), C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_pose_opt: {status_string(rc)}")
-        return dict(status=rc, n_inliers=r.n_inliers, pose=np.array(r.pose[:]), outlier=outl, chi2=chi2)
+        return dict(status=rc, n_inliers=r.n_inliers, pose=np.array(r.pose[:]), outlier=outl, chi2=chi2,
+                    ransac_inliers=r.ransac_inliers, ransac_pose=np.array(r.ransac_pose[:]))

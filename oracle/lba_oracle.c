@@ -847,6 +847,168 @@ int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
 
 /* OpenMP build only (liblba_oracle_omp.so): number of threads of the all-cores timing variant; returns what is in force
  * (1 in the serial library). */
+/* ---------------------------------------------------------------------------------------------
+ * Hypothesis stage of PoseOptimization: RANSAC over minimal P3P solves (the classical scheme behind
+ * cv::solvePnPRansac, which the reference calls with useExtrinsicGuess = false at src/Optimizer.cc:437;
+ * OpenCV's own arithmetic is not in the reference tree).  Plain restatement of the same algorithm the
+ * kernel runs: Grunert's three-point solution (Haralick et al. 1994: quartic in v = s3 / s1), every
+ * candidate scored on all matches by its inlier count at chi2_gate, ties by truncated cost, then index.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct { double re, im; } cplx_t;
+static cplx_t c_mul(cplx_t a, cplx_t b) { cplx_t r = { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; return r; }
+static cplx_t c_sub(cplx_t a, cplx_t b) { cplx_t r = { a.re - b.re, a.im - b.im }; return r; }
+static cplx_t c_div(cplx_t a, cplx_t b)
+{
+    const double d = b.re * b.re + b.im * b.im;
+    cplx_t r = { (a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d };
+    return r;
+}
+
+static void quartic_roots(double c3, double c2, double c1, double c0, cplx_t z[4])
+{
+    const double rb = 2.0 * fmax(fmax(fabs(c3), sqrt(fabs(c2))), fmax(cbrt(fabs(c1)), sqrt(sqrt(fabs(c0))))) + 1e-300;
+    const double r0 = 0.5 * rb;
+    z[0].re = r0 * 0.9210609940028851; z[0].im = r0 * 0.3894183423086505;
+    z[1].re = -z[0].im; z[1].im = z[0].re; z[2].re = -z[0].re; z[2].im = -z[0].im; z[3].re = z[0].im; z[3].im = -z[0].re;
+    for (int it = 0; it < 80; ++it)
+        for (int k = 0; k < 4; ++k) {
+            const cplx_t x = z[k];
+            cplx_t pv = { x.re + c3, x.im };
+            pv = c_mul(pv, x); pv.re += c2;
+            pv = c_mul(pv, x); pv.re += c1;
+            pv = c_mul(pv, x); pv.re += c0;
+            cplx_t den = { 1.0, 0.0 };
+            for (int j = 0; j < 4; ++j) if (j != k) den = c_mul(den, c_sub(x, z[j]));
+            if (den.re * den.re + den.im * den.im > 0.0) z[k] = c_sub(x, c_div(pv, den));
+        }
+}
+
+static void cross3(const double a[3], const double b[3], double o[3])
+{
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+static int triple_frame(const double P1[3], const double P2[3], const double P3[3], double F[9])
+{
+    double d1[3] = { P2[0] - P1[0], P2[1] - P1[1], P2[2] - P1[2] }, d2[3] = { P3[0] - P1[0], P3[1] - P1[1], P3[2] - P1[2] };
+    const double n1 = sqrt(d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2]);
+    if (!(n1 > 0.0)) return 0;
+    d1[0] /= n1; d1[1] /= n1; d1[2] /= n1;
+    double e3[3], e2[3];
+    cross3(d1, d2, e3);
+    const double n3 = sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    if (!(n3 > 1e-12 * n1)) return 0;
+    e3[0] /= n3; e3[1] /= n3; e3[2] /= n3;
+    cross3(e3, d1, e2);
+    F[0] = d1[0]; F[3] = d1[1]; F[6] = d1[2]; F[1] = e2[0]; F[4] = e2[1]; F[7] = e2[2]; F[2] = e3[0]; F[5] = e3[1]; F[8] = e3[2];
+    return 1;
+}
+
+static double dist2(const double *a, const double *b)
+{
+    const double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+    return x * x + y * y + z * z;
+}
+
+static int p3p_grunert(double X[3][3], double j[3][3], double Rs[4][9], double ts[4][3])
+{
+    const double a2 = dist2(X[1], X[2]), b2 = dist2(X[0], X[2]), c2 = dist2(X[0], X[1]);
+    if (!(b2 > 0.0) || !(a2 > 0.0) || !(c2 > 0.0)) return 0;
+    const double ca = j[1][0] * j[2][0] + j[1][1] * j[2][1] + j[1][2] * j[2][2];
+    const double cb = j[0][0] * j[2][0] + j[0][1] * j[2][1] + j[0][2] * j[2][2];
+    const double cg = j[0][0] * j[1][0] + j[0][1] * j[1][1] + j[0][2] * j[1][2];
+    const double q = (a2 - c2) / b2, pp = (a2 + c2) / b2;
+    const double A4 = (q - 1.0) * (q - 1.0) - 4.0 * c2 / b2 * ca * ca;
+    const double A3 = 4.0 * (q * (1.0 - q) * cb - (1.0 - pp) * ca * cg + 2.0 * c2 / b2 * ca * ca * cb);
+    const double A2 = 2.0 * (q * q - 1.0 + 2.0 * q * q * cb * cb + 2.0 * (b2 - c2) / b2 * ca * ca - 4.0 * pp * ca * cb * cg + 2.0 * (b2 - a2) / b2 * cg * cg);
+    const double A1 = 4.0 * (-q * (1.0 + q) * cb + 2.0 * a2 / b2 * cg * cg * cb - (1.0 - pp) * ca * cg);
+    const double A0 = (1.0 + q) * (1.0 + q) - 4.0 * a2 / b2 * cg * cg;
+    const double mx = fmax(fmax(fabs(A4), fabs(A3)), fmax(fmax(fabs(A2), fabs(A1)), fabs(A0)));
+    if (!(fabs(A4) > 1e-12 * mx) || !isfinite(mx)) return 0;
+    const double c3 = A3 / A4, c2q = A2 / A4, c1 = A1 / A4, c0 = A0 / A4;
+    cplx_t z[4];
+    quartic_roots(c3, c2q, c1, c0, z);
+    double Fw[9];
+    if (!triple_frame(X[0], X[1], X[2], Fw)) return 0;
+    int ns = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!(fabs(z[k].im) <= 1e-6 * (1.0 + fabs(z[k].re)))) continue;
+        double v = z[k].re;
+        for (int it = 0; it < 2; ++it) {
+            const double f = (((v + c3) * v + c2q) * v + c1) * v + c0, df = ((4.0 * v + 3.0 * c3) * v + 2.0 * c2q) * v + c1;
+            if (df != 0.0) v -= f / df;
+        }
+        if (!(v > 0.0)) continue;
+        const double den = 2.0 * (cg - v * ca);
+        if (!(fabs(den) > 1e-12)) continue;
+        const double u = ((q - 1.0) * v * v - 2.0 * q * cb * v + 1.0 + q) / den;
+        if (!(u > 0.0)) continue;
+        const double dd = 1.0 + v * v - 2.0 * v * cb;
+        if (!(dd > 0.0)) continue;
+        const double s1 = sqrt(b2 / dd), s2 = u * s1, s3 = v * s1;
+        const double P1[3] = { s1 * j[0][0], s1 * j[0][1], s1 * j[0][2] }, P2[3] = { s2 * j[1][0], s2 * j[1][1], s2 * j[1][2] },
+                     P3[3] = { s3 * j[2][0], s3 * j[2][1], s3 * j[2][2] };
+        double Fc[9];
+        if (!triple_frame(P1, P2, P3, Fc)) continue;
+        double *R = Rs[ns];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) R[r * 3 + c] = Fc[r * 3] * Fw[c * 3] + Fc[r * 3 + 1] * Fw[c * 3 + 1] + Fc[r * 3 + 2] * Fw[c * 3 + 2];
+        for (int r = 0; r < 3; ++r) ts[ns][r] = P1[r] - (R[r * 3] * X[0][0] + R[r * 3 + 1] * X[0][1] + R[r * 3 + 2] * X[0][2]);
+        ++ns;
+    }
+    return ns;
+}
+
+/* Best pose over n_hyp minimal samples (n_hyp x 3 match indices).  pose_out = pb->pose0 (normalised) when no candidate
+ * reaches 4 inliers.  Returns the inlier count of the pose returned (0 in that case). */
+int lba_oracle_pose_ransac(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double pose_out[7])
+{
+    const int n = pb->n;
+    double best_cnt = 3.5, best_cost = DBL_MAX, bestR[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, bestt[3] = { 0, 0, 0 };
+    int have = 0;
+    for (int h = 0; h < n_hyp; ++h) {
+        double X[3][3], jb[3][3];
+        int okh = 1;
+        for (int m = 0; m < 3; ++m) {
+            const int i = samples[3 * h + m];
+            if (i < 0 || i >= n) { okh = 0; break; }
+            for (int k = 0; k < 3; ++k) X[m][k] = pb->Xw[3 * i + k];
+            const double bx = (pb->obs[2 * i] - pb->cx) / pb->fx, by = (pb->obs[2 * i + 1] - pb->cy) / pb->fy;
+            const double nn = 1.0 / sqrt(bx * bx + by * by + 1.0);
+            jb[m][0] = bx * nn; jb[m][1] = by * nn; jb[m][2] = nn;
+        }
+        double Rs[4][9], ts[4][3];
+        const int ns = okh ? p3p_grunert(X, jb, Rs, ts) : 0;
+        for (int k = 0; k < ns; ++k) {
+            const double *R = Rs[k], *t = ts[k];
+            double cnt = 0.0, cst = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const double *Xi = pb->Xw + 3 * i;
+                const double x = R[0] * Xi[0] + R[1] * Xi[1] + R[2] * Xi[2] + t[0];
+                const double y = R[3] * Xi[0] + R[4] * Xi[1] + R[5] * Xi[2] + t[1];
+                const double z = R[6] * Xi[0] + R[7] * Xi[1] + R[8] * Xi[2] + t[2];
+                const double om = pb->inv_sigma2 ? pb->inv_sigma2[i] : 1.0;
+                const double e0 = pb->obs[2 * i] - (pb->fx * x / z + pb->cx), e1 = pb->obs[2 * i + 1] - (pb->fy * y / z + pb->cy);
+                const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+                const int in = (z > 0.0) && (chi2 <= pb->chi2_gate);
+                cnt += in ? 1.0 : 0.0; cst += in ? chi2 : pb->chi2_gate;
+            }
+            if (cnt > best_cnt || (cnt == best_cnt && have && cst < best_cost)) {
+                best_cnt = cnt; best_cost = cst; have = 1;
+                memcpy(bestR, R, sizeof bestR); memcpy(bestt, t, sizeof bestt);
+            }
+        }
+    }
+    memcpy(pose_out, pb->pose0, 7 * sizeof(double));
+    lba_oracle_se3_normalize(pose_out);
+    if (!have) return 0;
+    R_to_quat(bestR, pose_out);
+    pose_out[4] = bestt[0]; pose_out[5] = bestt[1]; pose_out[6] = bestt[2];
+    lba_oracle_se3_normalize(pose_out);
+    return (int)best_cnt;
+}
+
+
 int lba_oracle_set_threads(int n)
 {
 #ifdef _OPENMP

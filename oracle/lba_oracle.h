@@ -123,6 +123,11 @@ typedef struct {
 int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
                         uint8_t *outlier, double *chi2);
 
+/* Hypothesis stage of PoseOptimization (RANSAC over P3P, see lba_oracle.c): best pose over n_hyp minimal samples
+ * (n_hyp x 3 match indices), scored at pb->chi2_gate; pose_out = normalised pb->pose0 and 0 when no candidate has
+ * >= 4 inliers.  Returns the inlier count of the returned pose. */
+int lba_oracle_pose_ransac(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double pose_out[7]);
+
 /* threads of the OpenMP timing variant (liblba_oracle_omp.so); the serial library always answers 1 */
 int lba_oracle_set_threads(int n);
 

@@ -172,6 +172,23 @@ def pose_opt(Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_
     return dict(n_inliers=ninl, pose=pose, outlier=outl, chi2=chi2)
 
 
+def pose_ransac(Xw, obs, pose0, cam, chi2_gate, samples, inv_sigma2=None) -> dict:
+    """Hypothesis stage of PoseOptimization: best P3P pose over the given minimal samples ((H, 3) match indices)."""
+    n = len(Xw)
+    Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
+    isg = np.ones(n) if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float64)
+    samples = np.ascontiguousarray(samples, np.int32)
+    pb = _PoseProblem()
+    pb.n = n; pb.Xw = _p(Xw, _d); pb.obs = _p(obs, _d); pb.inv_sigma2 = _p(isg, _d)
+    pb.fx, pb.fy, pb.cx, pb.cy = cam
+    pb.pose0 = (C.c_double * 7)(*pose0)
+    pb.huber_delta, pb.chi2_gate, pb.rounds, pb.its_per_round = 0.0, chi2_gate, 0, 0
+    pose = np.zeros(7)
+    L = lib(); L.lba_oracle_pose_ransac.restype = C.c_int
+    cnt = L.lba_oracle_pose_ransac(C.byref(pb), C.c_int(len(samples)), _p(samples, _i), _p(pose, _d))
+    return dict(n_inliers=cnt, pose=pose)
+
+
 def se3_exp(u):
     out = np.zeros(7); lib().lba_oracle_se3_exp(_p(np.ascontiguousarray(u, np.float64), _d), _p(out, _d)); return out
 

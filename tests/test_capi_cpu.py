@@ -25,7 +25,7 @@ def test_library_exports_every_symbol_declared_in_header(built_lib):
 def test_ctypes_struct_sizes_match_header_layout(built_lib):
     # int32 x3 (+pad) | 7 pointers | 6 doubles | 2 int32 + u32 (+pad) | pointer
     assert ctypes.sizeof(built_lib.LbaDesc) == 16 + 7 * 8 + 6 * 8 + 16 + 8 + 16
-    assert ctypes.sizeof(built_lib.Options) == 24
+    assert ctypes.sizeof(built_lib.Options) == 32
     assert ctypes.sizeof(built_lib.StructureInfo) == 64
 
 

@@ -120,7 +120,9 @@ def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tm
     assert ref["n_normal_updates"] == int(local_pt.sum()) and ref["n_center_reads"] > out["n_center_reads"]
     assert np.array_equal(out["normals"], ref["normals"]) and np.array_equal(out["dist"], ref["dist"])
     assert np.array_equal(out["poses"], ref["poses"]) and np.array_equal(out["points"], ref["points"])
-    assert np.abs(np.linalg.norm(out["normals"][local_pt], axis=1)).max() <= 1.0 + 1e-6 and (out["dist"][local_pt, 1] > out["dist"][local_pt, 0]).all()
+    live = out["dist"][:, 1] > 0                       # (points left with <= 2 observations went bad: never updated)
+    assert live.sum() > 0.8 * local_pt.sum() and not live[~local_pt].any()
+    assert np.linalg.norm(out["normals"][live], axis=1).max() <= 1.0 + 1e-6 and (out["dist"][live, 1] > out["dist"][live, 0]).all()
     # erased (KeyFrame, MapPoint) pairs == the oracle's outliers in edge order, up to the chi2 guard band
     ep, el = w.edge_pose[keep_e], w.edge_point[keep_e]
     want = set(map(tuple, np.stack([ep, el], 1)[o["outlier"] == 1]))
@@ -190,7 +192,12 @@ def test_pose_optimization_through_the_adapter(adapter_bin, oracle_mod, tmp_path
     pose = np.frombuffer(b, np.float32, 7, 4)
     outl = np.frombuffer(b, np.uint8, n + 3, 32)
     rep = 8.0 if is_lost else 5.0                    # reprojectErrorLost / reprojectionError defaults (Optimizer.h:55)
-    o = oracle_mod.pose_opt(f["Xw"], f["obs"], pose0, f["cam"], rep, rep * rep, rounds=4, its=10)
+    # iterationCount = 50 P3P hypotheses from the adapter's fixed seed, then the LM from the best of them
+    from movba import capi
+    samples = capi.ransac_samples(n, 50, 20221105)
+    o_r = oracle_mod.pose_ransac(f["Xw"], f["obs"], pose0, f["cam"], rep * rep, samples)
+    assert o_r["n_inliers"] >= 0.8 * (~f["is_outlier"]).sum()
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], o_r["pose"], f["cam"], rep, rep * rep, rounds=4, its=10)
     assert ninl == o["n_inliers"]
     assert np.abs(pose.astype(np.float64) - _f32_pose(o["pose"])).max() < 2e-6
     assert np.array_equal(outl[:n], o["outlier"]) and (outl[n:] == 1).all()   # slots without a MapPoint stay "outlier"

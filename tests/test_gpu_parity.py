@@ -535,3 +535,62 @@ def test_batch_rejects_handles_on_different_streams(built_lib):
             built_lib.run_batch([a, b])
     finally:
         a.close(); b.close()
+
+
+def _far_off_pose(truth, deg, shift):
+    ax = np.array([0.3, 0.9, 0.3]); ax /= np.linalg.norm(ax)
+    R = synth._rodrigues(np.deg2rad(deg) * ax) @ synth.R_from_quat(truth[:4])
+    p = truth.copy(); p[:4] = synth.quat_from_R(R); p[4:] += shift
+    return p
+
+
+@pytest.mark.parametrize("outlier_frac,hub", [(0.10, 5.0), (0.55, 5.0), (0.55, 8.0)])
+def test_pose_optimization_hypothesis_stage_does_not_depend_on_the_start_pose(solver, oracle_mod, built_lib, outlier_frac, hub):
+    """cv::solvePnPRansac(useExtrinsicGuess = false) at Optimizer.cc:437 ignores the pose the Frame holds: with the P3P
+    hypothesis stage on, a start pose 150 degrees / 3 m off and a match set with more outliers than inliers give the same
+    result as a good start, equal to the oracle's (same samples), and recover the generating inliers.  The LM alone, from
+    that start, does not."""
+    f = synth.make_frame(n=500, seed=1001, outlier_frac=outlier_frac)
+    n = len(f["Xw"]); gate = hub * hub
+    bad0 = _far_off_pose(f["truth"], 150.0, np.array([2.0, -1.5, 1.7]))
+    samples = built_lib.ransac_samples(n, 50, 7)
+    o_r = oracle_mod.pose_ransac(f["Xw"], f["obs"], bad0, f["cam"], gate, samples)
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], o_r["pose"], f["cam"], hub, gate)
+    r = solver.pose_opt(f["Xw"], f["obs"], bad0, f["cam"], hub, gate, ransac_iters=50, ransac_seed=7)
+    assert r["status"] == 0 and r["ransac_inliers"] == o_r["n_inliers"] >= 0.9 * (~f["is_outlier"]).sum()
+    assert np.abs(r["ransac_pose"] - o_r["pose"]).max() < 1e-7
+    assert r["n_inliers"] == o["n_inliers"] and np.abs(r["pose"] - o["pose"]).max() < 1e-8
+    mism = r["outlier"] != o["outlier"]
+    assert (np.abs(o["chi2"][mism] - gate) <= GUARD).all()
+    # the generating inliers are recovered (noise 0.5 px against a 5 / 8 px threshold), the pose is the true one
+    assert ((r["outlier"] == 1) == f["is_outlier"]).mean() > 0.99
+    assert np.abs(r["pose"][4:] - f["truth"][4:]).max() < 0.03 and quat_angle(r["pose"][None, :4], f["truth"][None, :4]).max() < 2e-3
+    # same answer from a good start pose: the stage makes the result independent of it
+    r2 = solver.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], hub, gate, ransac_iters=50, ransac_seed=7)
+    assert np.array_equal(r2["pose"], r["pose"]) and np.array_equal(r2["outlier"], r["outlier"])
+    # without it the LM from the far-off pose stays lost
+    r3 = solver.pose_opt(f["Xw"], f["obs"], bad0, f["cam"], hub, gate)
+    assert r3["n_inliers"] < 0.5 * r["n_inliers"] or np.abs(r3["pose"][4:] - f["truth"][4:]).max() > 0.5
+
+
+def test_pose_optimization_hypothesis_stage_beyond_the_lds_staging_limit(solver, oracle_mod, built_lib):
+    f = synth.make_frame(n=4000, seed=77, outlier_frac=0.4)
+    bad0 = _far_off_pose(f["truth"], 150.0, np.array([2.0, -1.5, 1.7]))
+    samples = built_lib.ransac_samples(4000, 64, 3)
+    o_r = oracle_mod.pose_ransac(f["Xw"], f["obs"], bad0, f["cam"], 25.0, samples)
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], o_r["pose"], f["cam"], 5.0, 25.0)
+    r = solver.pose_opt(f["Xw"], f["obs"], bad0, f["cam"], 5.0, 25.0, ransac_iters=64, ransac_seed=3)
+    assert r["ransac_inliers"] == o_r["n_inliers"] and r["n_inliers"] == o["n_inliers"]
+    assert np.abs(r["pose"] - o["pose"]).max() < 1e-8
+
+
+def test_host_wait_yield_mode_gives_the_same_result(built_lib, solver):
+    w = synth.cfg("cfg2")
+    s = built_lib.Solver(host_wait=1)
+    try:
+        a = s.solve(w)
+    finally:
+        s.close()
+    b = solver.solve(w)
+    for k in ("poses", "points", "chi2", "outlier"):
+        assert np.array_equal(a[k], b[k]), k

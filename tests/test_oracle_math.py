@@ -154,3 +154,24 @@ def test_pose_only_oracle_recovers_pose(oracle_mod):
     assert (r["outlier"][f["is_outlier"]] == 1).all()
     assert r["outlier"][~f["is_outlier"]].mean() < 0.01
     assert r["n_inliers"] == int((r["outlier"] == 0).sum())
+
+
+def test_pose_ransac_p3p_recovers_the_generating_pose_from_any_start(oracle_mod, built_lib):
+    """Hypothesis stage of PoseOptimization in the oracle: Grunert P3P over 50 seeded minimal samples on a frame with 55 %
+    gross outliers; the start pose plays no role; the noise-free three-point problem is solved exactly."""
+    from movba import synth
+    f = synth.make_frame(n=500, seed=1001, outlier_frac=0.55)
+    samples = built_lib.ransac_samples(500, 50, 7)
+    assert samples.shape == (50, 3) and (samples >= 0).all() and (samples < 500).all()
+    assert all(len(set(r)) == 3 for r in samples.tolist())
+    r = oracle_mod.pose_ransac(f["Xw"], f["obs"], np.array([0, 0, 0, 1.0, 5, 5, 5]), f["cam"], 25.0, samples)
+    assert r["n_inliers"] == int((~f["is_outlier"]).sum())
+    assert np.abs(r["pose"] - f["truth"]).max() < 0.05
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], r["pose"], f["cam"], 5.0, 25.0)
+    assert ((o["outlier"] == 1) == f["is_outlier"]).all() and np.abs(o["pose"] - f["truth"]).max() < 0.01
+    # exact data: the three sampled points alone fix the pose to rounding
+    g = synth.make_frame(n=60, seed=5, outlier_frac=0.0, pix_sigma=0.0)
+    Rt = synth.R_from_quat(g["truth"][:4]); Xc = g["Xw"] @ Rt.T + g["truth"][4:]
+    obs = np.stack([320 * Xc[:, 0] / Xc[:, 2] + 320, 320 * Xc[:, 1] / Xc[:, 2] + 240], 1)
+    e = oracle_mod.pose_ransac(g["Xw"], obs, g["pose0"], g["cam"], 1e-6, built_lib.ransac_samples(60, 8, 1))
+    assert e["n_inliers"] == 60 and np.abs(e["pose"] - g["truth"]).max() < 1e-6
