@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational extras (resident / batched / adapter runs): profiling passes")
     args = ap.parse_args()
 
     import numpy as np
@@ -183,7 +184,8 @@ def main():
         out["config"]["timed_region"] = ("movba_lba_solve: host arrays in -> structure pass, H2D, all launches, D2H -> results in "
                                          "host memory (SURVEY 8d); identical region for cpu_baseline")
         out["config"]["host_phase_ms_per_step"] = {k: prof[k] / args.steps for k in ("structure_ms", "upload_ms", "download_ms")}
-        if world == 1:
+        extras = world == 1 and not args.no_extras
+        if extras:
             # for information only (never `value`): the LM loop alone with the window already resident in HBM
             # (movba_lba_upload once, then movba_lba_run per step)
             solver.set_profile_mask(0)
@@ -197,7 +199,7 @@ def main():
             out["config"]["resident_window"] = {"lm_iterations_per_s": res["n_solves"] * args.steps / tr_,
                                                 "ms_per_window_solve": 1e3 * tr_ / args.steps,
                                                 "note": "movba_lba_run only; no structure pass, H2D or D2H in the region"}
-        if world == 1:
+        if extras:
             # for information only (never `value`): movba_lba_run_batch over 8 resident cfg5-shaped windows on this one GPU
             # (multi-session serving): one launch per kernel over all windows, groups of windows out of phase on streams
             try:
@@ -223,7 +225,7 @@ def main():
                     bs_.close()
             except Exception as exc:                        # context only
                 out["config"]["batched_windows"] = {"error": str(exc)}
-        if world == 1:
+        if extras:
             # for information only: host-side cost of the Optimizer.h adapter around the solve on this window (mock map classes,
             # mov-slam_amd/host/adapter_test): window selection + flattening, and the write-back under the map mutex
             try:
