@@ -12,6 +12,10 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -38,6 +42,51 @@ double now_ms()
 }
 
 struct EventPair { hipEvent_t a, b; int cls; };
+
+// One helper thread per handle: copies the caller's big arrays into the pinned staging buffer while the calling thread
+// runs the grouping / validation pass over the edges (both are memory-bound single-thread loops of ~0.1 ms at cfg3).
+// Sleeps on a condition variable between uploads.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    int state = 0;              // 0 idle, 1 job posted, 2 job done
+    bool quit = false;
+    void post(std::function<void()> j)
+    {
+        if (!th.joinable())
+            th = std::thread([this] {
+                std::unique_lock<std::mutex> lk(m);
+                for (;;) {
+                    cv.wait(lk, [&] { return state == 1 || quit; });
+                    if (quit) return;
+                    std::function<void()> jb = std::move(job);
+                    lk.unlock();
+                    jb();
+                    lk.lock();
+                    state = 2;
+                    cv.notify_all();
+                }
+            });
+        { std::lock_guard<std::mutex> lk(m); job = std::move(j); state = 1; }
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return state != 1; });
+        state = 0;
+    }
+    ~Worker()
+    {
+        if (th.joinable()) {
+            { std::lock_guard<std::mutex> lk(m); quit = true; }
+            cv.notify_all();
+            th.join();
+        }
+    }
+};
 
 }  // namespace
 
@@ -81,6 +130,7 @@ struct movba_handle {
     // pose-only scratch
     char *pose_arena = nullptr;
     size_t pose_cap = 0;
+    Worker packer;                      // helper thread of movba_lba_upload
     // profiling
     std::vector<EventPair> ev_used;
     std::vector<hipEvent_t> ev_pool;
@@ -321,40 +371,64 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     static const bool lap_on = std::getenv("MOVBA_TIME_UPLOAD") != nullptr;
     double lap_t = t0;
     auto lap = [&](const char *what) { if (lap_on) { const double t = now_ms(); std::fprintf(stderr, "libmovba[upload]: %-28s %.3f ms\n", what, t - lap_t); lap_t = t; } };
+    // ---- edge region of the arena, laid out from the caller's counts alone so that the helper thread can start copying the
+    // caller's big arrays (observations, information, initial estimates: 3/4 of the region) into the pinned staging buffer
+    // while this thread runs the grouping / validation pass.  Its H2D copies are queued as soon as it is packed, so that
+    // the transfer runs while the pair structure is still being worked out ----
+    if (d->n_poses < 0 || d->n_points < 0 || d->n_edges < 0) return MOVBA_ERR_ARG;
+    if ((d->n_poses && (!d->poses || !d->pose_fixed)) || (d->n_points && !d->points)) return MOVBA_ERR_ARG;
+    if (d->n_edges && (!d->edge_pose || !d->edge_point || !d->obs || !d->inv_sigma2)) return MOVBA_ERR_ARG;
+    const int NP = d->n_poses, P = d->n_points, E = d->n_edges;
+    Carver c;
+    // (what the device structure pass reads comes first: it is copied ahead of the rest)
+    const size_t o_gpose = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1), o_hidx = c.take<int32_t>(NP);
+    const size_t edge_a_bytes = c.off;
+    const size_t o_gpoint = c.take<int32_t>(E);
+    const size_t o_free = c.take<int32_t>(NP + 1);
+    const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
+    const size_t o_obsr = c.take<double>(d->obs_right ? E : 0);
+    const size_t o_slot = c.take<int32_t>(E);
+    const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
+    const size_t edge_bytes_grouped = c.off;
+    const size_t o_perm = c.take<int32_t>(E);                   // only travels when the caller's edges are not grouped by point
+    const size_t edge_bytes_max = c.off;
+    const size_t nf_dev = (size_t)std::min(NP, 80);             // the device structure pass takes windows of up to 80 free keyframes
+    const size_t misc_bytes = (nf_dev * nf_dev + 8) * sizeof(int32_t) * 2 + 4096;        // counts back / pair ids out (device structure pass)
+    int rc2 = ensure_stage(h, edge_bytes_max + misc_bytes); if (rc2) return rc2;
+    // first sizing of the arena: room for the states and pair lists too, so that it is not reallocated a moment later
+    if (edge_bytes_max > h->arena_cap) { rc2 = ensure_arena(h, 10 * edge_bytes_max); if (rc2) return rc2; }
+    HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
+    char *sg = h->stage;
+    bool stereo = false;
+    // helper: straight copies of the caller's arrays (valid as they are when the edges come grouped by map point, the
+    // reference's own order; an ungrouped window has them permuted again below) and the scan for stereo observations
+    h->packer.post([=, &stereo]() {
+        std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)E);
+        std::memcpy(sg + o_isig, d->inv_sigma2, sizeof(double) * (size_t)E);
+        if (d->obs_right) {
+            std::memcpy(sg + o_obsr, d->obs_right, sizeof(double) * (size_t)E);
+            bool st = false;
+            for (int e = 0; e < E && !st; ++e) st = d->obs_right[e] >= 0.0;
+            stereo = st;
+        }
+        std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
+        std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+    });
     int rc = build_basic(*d, h->st);
     lap("build_basic");
+    h->packer.wait();
+    lap("wait for the packing thread");
     if (rc < 0) return rc;
     const Structure &s = h->st;
     h->stop = d->stop;
     if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
     else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
     if (h->early_status != MOVBA_OK) { h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK; }
-    const int NP = s.NP, P = s.P, E = s.E, nf = s.nfree;
+    const int nf = s.nfree;
     const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
-
-    // ---- edge region of the arena: everything known after the O(E) grouping pass.  It is packed and its H2D copy queued
-    // NOW, so that the transfer runs while the pair structure is still being worked out ----
-    Carver c;
-    // (what the device structure pass reads comes first: it is copied ahead of the rest)
-    const size_t o_gpose = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1), o_hidx = c.take<int32_t>(NP);
-    const size_t edge_a_bytes = c.off;
-    const size_t o_gpoint = c.take<int32_t>(E);
-    const size_t o_perm = c.take<int32_t>(s.already_grouped ? 0 : E), o_free = c.take<int32_t>(nf + 1);
-    const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
-    bool stereo = false;
-    if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
-    const size_t o_obsr = c.take<double>(stereo ? E : 0);
-    const size_t o_slot = c.take<int32_t>(E);
-    const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
-    const size_t edge_bytes = c.off;
+    const size_t edge_bytes = s.already_grouped ? edge_bytes_grouped : edge_bytes_max;
     const int nbins = nf * nf;
-    const size_t misc_bytes = (size_t)(nbins + 8) * sizeof(int32_t) * 2 + 4096;         // counts back / pair ids out (device structure pass)
-    int rc2 = ensure_stage(h, edge_bytes + misc_bytes); if (rc2) return rc2;
-    // first sizing of the arena: room for the states and pair lists too, so that it is not reallocated a moment later
-    if (edge_bytes > h->arena_cap) { rc2 = ensure_arena(h, 10 * edge_bytes); if (rc2) return rc2; }
-    HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
-    char *sg = h->stage;
-    auto pack_edges = [&]() {
+    auto pack_edges = [&](bool raw_too) {
         std::memcpy(sg + o_gpose, s.g_pose.data(), sizeof(int32_t) * E);
         std::memcpy(sg + o_gpoint, s.g_point.data(), sizeof(int32_t) * E);
         std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
@@ -364,22 +438,24 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
         double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
         double *obr = reinterpret_cast<double *>(sg + o_obsr);
-        if (s.already_grouped) {        // the reference's own edge order: straight copies
-            std::memcpy(obs, d->obs, sizeof(double) * 2 * (size_t)E);
-            std::memcpy(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
-            if (stereo) std::memcpy(obr, d->obs_right, sizeof(double) * (size_t)E);
-        } else {
+        if (!s.already_grouped) {       // the helper's straight copies are in caller order: permute into grouped order
             for (int g = 0; g < E; ++g) {
                 const int e = s.perm[g];
                 obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
             }
-            if (stereo) for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
+            if (d->obs_right) for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
+        } else if (raw_too) {
+            std::memcpy(obs, d->obs, sizeof(double) * 2 * (size_t)E);
+            std::memcpy(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
+            if (d->obs_right) std::memcpy(obr, d->obs_right, sizeof(double) * (size_t)E);
         }
-        std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
-        std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+        if (raw_too) {
+            std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
+            std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+        }
     };
-    pack_edges();
-    lap("pack edge region");
+    pack_edges(false);
+    lap("pack derived arrays");
     const double t_up0 = now_ms();
     HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_a_bytes, hipMemcpyHostToDevice, h->stream));
     const uint64_t arena_gen_at_edge_copy = h->arena_gen;
@@ -469,16 +545,18 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
     const size_t o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
-    const size_t o_ent_h2d = dev_structure ? 0 : c.take<Int4>((size_t)s.nentries + 1);       // host-built entry lists travel with the pair region
+    const size_t noff = (size_t)(s.nentries - s.E_free);                                     // off-diagonal entries (the diagonal ones are their slot)
+    const size_t o_ent_h2d = dev_structure ? 0 : c.take<int32_t>(3 * noff + 4);              // host-built entry lists travel with the pair region
     const size_t h2d = c.off;
     // ---- device-only region ----
-    const size_t o_ent = dev_structure ? c.take<Int4>((size_t)s.nentries + 1) : o_ent_h2d;
+    const size_t o_ent = dev_structure ? c.take<int32_t>(3 * noff + 4) : o_ent_h2d;
+    const size_t o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
     size_t o_st[2][11];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
         o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
         o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);       // erecA
-        o_st[b][6] = 0;  o_st[b][7] = c.take<double>(E);
+        o_st[b][6] = 0;  o_st[b][7] = 0;
         o_st[b][8] = c.take<double>(nb);
         o_st[b][9] = 0;
         o_st[b][10] = c.take<double>((stereo ? 4 : 2) * (size_t)E);                                  // erecB
@@ -508,11 +586,15 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         // has landed; the edge region is packed again only to keep the buffer self-consistent
         rc2 = ensure_stage(h, h2d + misc_bytes); if (rc2) return rc2;
         sg = h->stage;
-        pack_edges();
+        pack_edges(true);
     }
 
     // ---- pack the pair region ----
-    if (!dev_structure) std::memcpy(sg + o_ent_h2d, s.entries.data(), sizeof(Int4) * (size_t)s.nentries);
+    if (!dev_structure && noff) {
+        int32_t *eh = reinterpret_cast<int32_t *>(sg + o_ent_h2d);
+        std::memcpy(eh, s.ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s.ent_j.data(), sizeof(int32_t) * noff);
+        std::memcpy(eh + 2 * noff, s.ent_l.data(), sizeof(int32_t) * noff);
+    }
     std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
     std::memcpy(sg + o_sched, s.sched.data(), sizeof(SchedItem) * s.sched.size());
     std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
@@ -531,12 +613,15 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     lap("carve + pack pair region");
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
-    HIP_TRY(hipMemcpyAsync(h->arena + edge_bytes, sg + edge_bytes, h2d - edge_bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->arena + edge_bytes_max, sg + edge_bytes_max, h2d - edge_bytes_max, hipMemcpyHostToDevice, h->stream));
     if (dev_structure) {
-        sd.entries = reinterpret_cast<Int4 *>(h->arena + o_ent);
+        int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
+        sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff; sd.n_diag = s.E_free;
         sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
         HIP_TRY(launch_struct_fill(sd, h->stream));
     }
+    HIP_TRY(launch_slot_point(reinterpret_cast<const int32_t *>(h->arena + o_slot), reinterpret_cast<const int32_t *>(h->arena + o_gpoint),
+                              reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
     // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were
     // copied to the staging buffer already (the next upload synchronises before it refills it)
     lap("pair H2D + fill kernel (queued)");
@@ -554,9 +639,14 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = s.already_grouped ? nullptr : reinterpret_cast<int32_t *>(a + o_perm);
     w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
-    w.obs_r = reinterpret_cast<double *>(a + o_obsr); w.bf = d->bf; w.stereo = stereo ? 1 : 0;
+    w.obs_r = d->obs_right ? reinterpret_cast<double *>(a + o_obsr) : nullptr; w.bf = d->bf; w.stereo = stereo ? 1 : 0;
     w.slot = reinterpret_cast<int32_t *>(a + o_slot);
-    w.entries = reinterpret_cast<Int4 *>(a + o_ent); w.items = reinterpret_cast<Item *>(a + o_items);
+    {
+        const int32_t *ed = reinterpret_cast<const int32_t *>(a + o_ent);
+        w.ent_i = ed; w.ent_j = ed + noff; w.ent_l = ed + 2 * noff;
+        w.slot_point = reinterpret_cast<const int32_t *>(a + o_slotpt); w.n_diag = s.E_free;
+    }
+    w.items = reinterpret_cast<Item *>(a + o_items);
     w.sched = reinterpret_cast<SchedItem *>(a + o_sched); w.sched_per_xcd = s.sched_per_xcd;
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
@@ -573,7 +663,6 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.pose = reinterpret_cast<double *>(a + o_st[b][0]); S.Rt = reinterpret_cast<double *>(a + o_st[b][1]);
         S.point = reinterpret_cast<double *>(a + o_st[b][2]); S.Hll = reinterpret_cast<double *>(a + o_st[b][3]);
         S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.erecA = reinterpret_cast<double *>(a + o_st[b][5]);
-        S.chi2 = reinterpret_cast<double *>(a + o_st[b][7]);
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
         S.erecB = reinterpret_cast<double *>(a + o_st[b][10]);
     }

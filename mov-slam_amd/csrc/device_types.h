@@ -35,7 +35,6 @@ struct DevState {
     double *point;   // P x 3
     double *Hll;     // P x 6   (xx xy xz yy yz zz), undamped
     double *bl;      // P x 3
-    double *chi2;    // E
     double *Fpart;   // n_pt_blocks robust-cost partials of this state
     // per-edge records of the edges of FREE keyframes, POSE-major (DevWindow::slot), written by k_point for k_schur:
     double *erecA;   // E_free x 4: camera-frame point and weight (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2): everything both Jacobians need
@@ -101,7 +100,11 @@ struct DevWindow {
     double bf;              // KeyFrame::mbf
     int32_t stereo, pad2;   // window has >= 1 stereo edge: 3-row kernels
     const int32_t *slot;    // E: pose-major slot of a grouped edge (-1: edge of a fixed pose)
-    const Int4 *entries;    // (slot of the edge of pose i, slot of the edge of pose j, map point, 0)
+    // k_schur entry lists.  Diagonal pair of free pose h: its entry k IS pose-major slot k (the diagonal pairs come first
+    // and list every edge of the pose in slot order), only the map point of a slot is stored.  Off-diagonal pairs: entry k
+    // of the global numbering at k - n_diag in three arrays (slot of the edge of pose i, of pose j, map point): 12 bytes.
+    const int32_t *ent_i, *ent_j, *ent_l, *slot_point;
+    int32_t n_diag, pad5;   // entries of the diagonal pairs = edges of free poses
     const Item *items;
     const SchedItem *sched; // k_schur launch schedule: 8 x sched_per_xcd slots (structure.h)
     int32_t sched_per_xcd, pad3;
@@ -151,7 +154,8 @@ struct StructDev {
     const int32_t *pid;         // nfree^2 -> pair id        (fill)
     const int32_t *pair_ptr;    // npairs+1                   (fill)
     const int32_t *slot;        // E: pose-major slot of a grouped edge (fill)
-    Int4 *entries;              //                            (fill)
+    int32_t *ent_i, *ent_j, *ent_l;     // off-diagonal entry lists (fill)
+    int32_t n_diag, pad6;
 };
 
 struct PcgParams {

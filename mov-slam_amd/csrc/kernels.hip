@@ -238,7 +238,6 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         }
         const double wg = rho1 * om;
         const double r0 = -wg * e0, r1 = -wg * e1;
-        S1.chi2[g] = chi2;
         if (sl >= 0) {      // pose-major records for the schur pass (edges of free keyframes): (Xc, w) and the weighted residual
             *reinterpret_cast<double4 *>(S1.erecA + 4 * (size_t)sl) = make_double4(x, y, z, wg);
             if (STEREO) *reinterpret_cast<double4 *>(S1.erecB + 4 * (size_t)sl) = make_double4(r0, r1, -wg * e2, st ? 1.0 : 0.0);
@@ -537,10 +536,11 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
         for (int k = 0; k < 6; ++k) { ca[k] = 0.0; ba[k] = 0.0; }
         for (int base = wbeg; base < wend; base += 64 * B) {
             Int4 en[B]; bool ok[B];
+            // the diagonal pair of keyframe i lists ALL its edges in map-point order and the diagonal pairs come first: entry k
+            // IS pose-major slot k (no entry list to read: the record loads do not wait for one), its map point comes from
+            // slot_point; the record loads of a wave are contiguous
 #pragma unroll
-            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; en[u] = w.entries[min(kk, wend - 1)]; }
-            // the diagonal pair of keyframe i lists ALL its edges in map-point order = consecutive pose-major records:
-            // the record loads of a wave are contiguous 64-byte lines
+            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; const int k = min(kk, wend - 1); en[u] = Int4{ k, k, w.slot_point[k], 0 }; }
             double4 rc[B], rq[B]; double2 h[B][3]; double bl[B][3];
 #pragma unroll
             for (int u = 0; u < B; ++u) {
@@ -579,7 +579,11 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
         for (int base = wbeg; base < wend; base += 64 * B) {
             Int4 en[B]; bool ok[B];
 #pragma unroll
-            for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; en[u] = w.entries[min(kk, wend - 1)]; }
+            for (int u = 0; u < B; ++u) {
+                const int kk = base + lane + 64 * u; ok[u] = kk < wend;
+                const int k = min(kk, wend - 1) - w.n_diag;
+                en[u] = Int4{ w.ent_i[k], w.ent_j[k], w.ent_l[k], 0 };
+            }
             // edges of keyframe i (and of j) shared with the other one, in map-point order: ascending pose-major records
             double4 ri[B], rj[B]; double2 h[B][3]; bool sti[B], stj[B];
 #pragma unroll
@@ -781,7 +785,24 @@ __device__ __forceinline__ void finalize_body(const DevWindow &w, int bid, int n
     if (g < w.E) {
         const int cur = c->cur;
         const int sel = ((w.flags & MOVBA_FLAG_STALE_ERROR_QUIRK) && c->last_rejected) ? (cur ^ 1) : cur;
-        const double chi2 = w.st[sel].chi2[g];
+        // e->chi2() of the edge at state `sel`, recomputed here once instead of being stored by every trial's point pass
+        // (the trial state of a rejected last trial is still in the other buffer: poses from the solver's epilogue, points
+        // from the back-substitution)
+        double chi2;
+        {
+            const double *Rs = w.st[sel].Rt + 12 * w.g_pose[g];
+            const double *Xs = w.st[sel].point + 3 * w.g_point[g];
+            const double x = Rs[0] * Xs[0] + Rs[1] * Xs[1] + Rs[2] * Xs[2] + Rs[9];
+            const double y = Rs[3] * Xs[0] + Rs[4] * Xs[1] + Rs[5] * Xs[2] + Rs[10];
+            const double z = Rs[6] * Xs[0] + Rs[7] * Xs[1] + Rs[8] * Xs[2] + Rs[11];
+            const double om = w.isig[g];
+            const double e0 = w.obs[2 * g] - (w.fx * x / z + w.cx), e1 = w.obs[2 * g + 1] - (w.fy * y / z + w.cy);
+            chi2 = e0 * (om * e0) + e1 * (om * e1);
+            if (w.stereo) {
+                const double ur = w.obs_r[g];
+                if (ur >= 0.0) { const double e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
+            }
+        }
         // isDepthPositive() at the final estimates (include/OptimizableTypes.h:111-116)
         const double *Rz = w.st[cur].Rt + 12 * w.g_pose[g];
         const double *Xf = w.st[cur].point + 3 * w.g_point[g];

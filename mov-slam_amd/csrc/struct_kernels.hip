@@ -56,14 +56,16 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
         for (int a = begin; a < end; ++a) {
             const int ha = sd.hidx[sd.g_pose[a]];
             if (ha < 0) continue;
-            for (int b = a; b < end; ++b) {
+            for (int b = a + 1; b < end; ++b) {              // (a, a): diagonal entries are their slot, nothing to store
                 const int hb = sd.hidx[sd.g_pose[b]];
-                if (hb < 0 || (b != a && hb == ha)) continue;
+                if (hb < 0 || hb == ha) continue;
                 const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
                 const int bin = lo * nf + hi;
-                const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)bin * sd.nchunks + chunk] + __popcll(masks[bin] & lower);
+                const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)bin * sd.nchunks + chunk] + __popcll(masks[bin] & lower) - sd.n_diag;
                 // pose-major slots of the two edges, the one of the lower hessian index first
-                sd.entries[pos] = (ha <= hb) ? Int4{ sd.slot[a], sd.slot[b], l, 0 } : Int4{ sd.slot[b], sd.slot[a], l, 0 };
+                sd.ent_i[pos] = (ha <= hb) ? sd.slot[a] : sd.slot[b];
+                sd.ent_j[pos] = (ha <= hb) ? sd.slot[b] : sd.slot[a];
+                sd.ent_l[pos] = l;
             }
         }
     }
@@ -88,6 +90,19 @@ __global__ __launch_bounds__(64) void k_struct_scan(StructDev sd)
         carry += __shfl(incl, 63, 64);
     }
     if (lane == 0) sd.cnt[bin] = carry;
+}
+
+// map point of every pose-major slot (what a diagonal schur entry needs besides its slot)
+__global__ __launch_bounds__(256) void k_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < E) { const int sl = slot[g]; if (sl >= 0) slot_point[sl] = g_point[g]; }
+}
+
+hipError_t launch_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s)
+{
+    if (E > 0) hipLaunchKernelGGL(k_slot_point, dim3((E + 255) / 256), dim3(256), 0, s, slot, g_point, slot_point, E);
+    return hipGetLastError();
 }
 
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)

@@ -16,7 +16,7 @@ int build_basic(const movba_lba_desc& d, Structure& s)
     // would be paid in page faults every time)
     s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0;
     s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.sched.clear(); s.sched_per_xcd = 0; s.row_ent.clear();
-    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.entries.clear();
+    s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.ent_i.clear(); s.ent_j.clear(); s.ent_l.clear(); s.E_free = 0;
     s.NP = NP; s.P = P; s.E = E;
 
     // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization).  ONE pass over the caller's
@@ -66,6 +66,7 @@ int build_basic(const movba_lba_desc& d, Structure& s)
         if (d.pose_fixed[i]) { s.n_fixed++; continue; }
         if (s.pose_edges[i] > 0) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); pstart[i] = run; run += s.pose_edges[i]; }
     }
+    s.E_free = run;
     for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
     s.slot.resize(E);
     {
@@ -122,6 +123,8 @@ int finish_pairs(Structure& s, const int32_t* cnt)
     for (int p = 0; p < s.npairs; ++p) s.pair_ptr[p + 1] = s.pair_ptr[p] + cnt[(size_t)s.pair_i[p] * nf + s.pair_j[p]];
     s.nentries = s.pair_ptr[s.npairs];
     if (s.nentries > (int64_t)0x7fffffff) return MOVBA_ERR_ARG;
+    // the diagonal pair of a free pose lists each of its edges once, in slot order: diagonal entry k is slot k (structure.h)
+    if (nf > 0 && s.pair_ptr[nf] != (int64_t)s.E_free) return MOVBA_ERR_ARG;
 
     // ---- work items: chunks of a pair's entries ----
     s.items.clear();
@@ -209,16 +212,21 @@ int build_structure(const movba_lba_desc& d, Structure& s)
         }
     const int rp = finish_pairs(s, cnt.data());
     if (rp != MOVBA_OK) return rp;
-    s.entries.resize((size_t)s.nentries);
+    // off-diagonal entries only: diagonal entry k is slot k (structure.h)
+    if (s.pair_ptr[nf] != s.E_free) return MOVBA_ERR_ARG;
+    const size_t noff = (size_t)(s.nentries - s.E_free);
+    s.ent_i.resize(noff); s.ent_j.resize(noff); s.ent_l.resize(noff);
     {
         std::vector<int32_t> cur(s.npairs);
-        for (int p = 0; p < s.npairs; ++p) cur[p] = (int32_t)s.pair_ptr[p];
-        Int4 *ent = s.entries.data();
+        for (int p = 0; p < s.npairs; ++p) cur[p] = (int32_t)(s.pair_ptr[p] - s.E_free);
         for (int l = 0; l < P; ++l)
             for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
                 const int32_t *prow = &s.pid[(size_t)fe_h[a] * nf];
                 const int32_t ga = fe_g[a];
-                for (int b = a; b < fe_start[l + 1]; ++b) ent[cur[prow[fe_h[b]]]++] = Int4{ s.slot[ga], s.slot[fe_g[b]], l, 0 };
+                for (int b = a + 1; b < fe_start[l + 1]; ++b) {
+                    const int32_t pos = cur[prow[fe_h[b]]]++;
+                    s.ent_i[pos] = s.slot[ga]; s.ent_j[pos] = s.slot[fe_g[b]]; s.ent_l[pos] = l;
+                }
             }
     }
     return MOVBA_OK;

@@ -40,7 +40,11 @@ struct Structure {
     std::vector<int64_t> pair_ptr;          // npairs+1: first entry of every pair
     std::vector<int32_t> pid;               // nfree x nfree: pair id of (i <= j) or -1
     std::vector<int32_t> slot;          // E: pose-major position of a grouped edge among the edges of FREE poses (-1: fixed pose)
-    std::vector<Int4> entries;          // nentries: (pose-major slot of the edge of i, of the edge of j, map point, 0)
+    // entry lists of the OFF-diagonal pairs only (host builder; entry k of the global numbering sits at k - E_free):
+    // pose-major slot of the edge of pose i, of the edge of pose j, map point.  The diagonal pair of free pose h lists all
+    // its edges in slot order, and the diagonal pairs come first: diagonal entry k IS slot k, nothing is stored for it.
+    std::vector<int32_t> ent_i, ent_j, ent_l;
+    int E_free = 0;                     // edges of free poses = entries of the diagonal pairs
     std::vector<Item> items;            // nitems
     // k_schur launch schedule: 8 segments (one per XCD) of sched_per_xcd slots
     std::vector<SchedItem> sched;
