@@ -148,7 +148,7 @@ struct DevWindow {
 struct StructDev {
     int32_t P, nfree, nchunks, pad;
     const int32_t *g_pose, *pt_start, *hidx;
-    int32_t *cntw;              // nfree^2 x nchunks: per-chunk counts, then their exclusive scan
+    int32_t *cntw;              // nchunks x nfree^2: per-chunk counts, then their exclusive scan over the chunks
     int32_t *cnt;               // nfree^2: entries per pair bin
     int32_t *error;             // set when a keyframe observes a point twice
     const int32_t *pid;         // nfree^2 -> pair id        (fill)

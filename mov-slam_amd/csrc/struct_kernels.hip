@@ -49,8 +49,10 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!FILL) {
-        // per-chunk counts, bin-major so that one wave can scan a bin's chunks with coalesced loads
-        for (int b = lane; b < nbins; b += 64) sd.cntw[(size_t)b * sd.nchunks + chunk] = __popcll(masks[b]);
+        // per-chunk counts, chunk-major: the wave's nbins values leave as contiguous lines (bin-major, every lane wrote a
+        // line of its own: 24 MB of write traffic for 3 MB of counts at cfg3), and the fill pass finds its chunk's row in one
+        // 10 KB stretch
+        for (int b = lane; b < nbins; b += 64) sd.cntw[(size_t)chunk * nbins + b] = __popcll(masks[b]);
     } else {
         const unsigned long long lower = bit - 1ull;
         for (int a = begin; a < end; ++a) {
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
                 if (hb < 0 || hb == ha) continue;
                 const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
                 const int bin = lo * nf + hi;
-                const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)bin * sd.nchunks + chunk] + __popcll(masks[bin] & lower) - sd.n_diag;
+                const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)chunk * nbins + bin] + __popcll(masks[bin] & lower) - sd.n_diag;
                 // pose-major slots of the two edges, the one of the lower hessian index first
                 sd.ent_i[pos] = (ha <= hb) ? sd.slot[a] : sd.slot[b];
                 sd.ent_j[pos] = (ha <= hb) ? sd.slot[b] : sd.slot[a];
@@ -71,25 +73,26 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
     }
 }
 
-// exclusive scan of every bin's per-chunk counts (in place) and the bin totals; one wave per bin
+// exclusive scan over the chunks of every bin's counts (in place) and the bin totals; one lane per bin (coalesced across
+// bins), the chunks walked in order with 8 loads in flight
 __global__ __launch_bounds__(64) void k_struct_scan(StructDev sd)
 {
-    const int bin = blockIdx.x, lane = threadIdx.x;
-    int32_t *row = sd.cntw + (size_t)bin * sd.nchunks;
+    const int nbins = sd.nfree * sd.nfree;
+    const int bin = blockIdx.x * 64 + threadIdx.x;
+    if (bin >= nbins) return;
+    int32_t *col = sd.cntw + bin;
     int carry = 0;
-    for (int c0 = 0; c0 < sd.nchunks; c0 += 64) {
-        const int c = c0 + lane;
-        const int v = c < sd.nchunks ? row[c] : 0;
-        int incl = v;
+    for (int c0 = 0; c0 < sd.nchunks; c0 += 8) {
+        int v[8];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
+        for (int u = 0; u < 8; ++u) v[u] = c0 + u < sd.nchunks ? col[(size_t)(c0 + u) * nbins] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (c0 + u < sd.nchunks) col[(size_t)(c0 + u) * nbins] = carry;
+            carry += v[u];
         }
-        if (c < sd.nchunks) row[c] = carry + incl - v;
-        carry += __shfl(incl, 63, 64);
     }
-    if (lane == 0) sd.cnt[bin] = carry;
+    sd.cnt[bin] = carry;
 }
 
 // map point of every pose-major slot (what a diagonal schur entry needs besides its slot)
@@ -109,7 +112,7 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
 {
     const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree;
     hipLaunchKernelGGL(k_struct_pairs<false>, dim3(sd.nchunks), dim3(64), lds, s, sd);
-    hipLaunchKernelGGL(k_struct_scan, dim3(sd.nfree * sd.nfree), dim3(64), 0, s, sd);
+    hipLaunchKernelGGL(k_struct_scan, dim3((sd.nfree * sd.nfree + 63) / 64), dim3(64), 0, s, sd);
     return hipGetLastError();
 }
 
