@@ -18,6 +18,8 @@
 
 namespace movba {
 
+constexpr int kDegCap = 16;     // observers per point whose hessian indices are cached in LDS (longer tracks read the rest from memory)
+
 // bins[b] |= bit of this lane, for every unordered couple of free observers (a <= b) of the lane's point
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
@@ -34,11 +36,16 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
     int begin = 0, end = 0;
     if (l < sd.P) { begin = sd.pt_start[l]; end = sd.pt_start[l + 1]; }
     const unsigned long long bit = 1ull << lane;
+    // the hessian indices of the lane's first kDegCap observers, gathered ONCE into LDS (the pair loops below would
+    // otherwise repeat the dependent g_pose -> hidx loads d^2 / 2 times per point: the kernel was a chain of memory round trips)
+    int *hcache = reinterpret_cast<int *>(masks + nbins) + lane * kDegCap;
+    for (int k = 0; k < kDegCap && begin + k < end; ++k) hcache[k] = sd.hidx[sd.g_pose[begin + k]];
+    auto hof = [&](int e) { const int k = e - begin; return k < kDegCap ? hcache[k] : sd.hidx[sd.g_pose[e]]; };
     for (int a = begin; a < end; ++a) {
-        const int ha = sd.hidx[sd.g_pose[a]];
+        const int ha = hof(a);
         if (ha < 0) continue;
         for (int b = a; b < end; ++b) {
-            const int hb = sd.hidx[sd.g_pose[b]];
+            const int hb = hof(b);
             if (hb < 0) continue;
             if (b != a && hb == ha) { *sd.error = 1; continue; }          // same keyframe observing a point twice
             const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
@@ -56,43 +63,60 @@ __global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
     } else {
         const unsigned long long lower = bit - 1ull;
         for (int a = begin; a < end; ++a) {
-            const int ha = sd.hidx[sd.g_pose[a]];
+            const int ha = hof(a);
             if (ha < 0) continue;
+            const int sa = sd.slot[a];
             for (int b = a + 1; b < end; ++b) {              // (a, a): diagonal entries are their slot, nothing to store
-                const int hb = sd.hidx[sd.g_pose[b]];
+                const int hb = hof(b);
                 if (hb < 0 || hb == ha) continue;
                 const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
                 const int bin = lo * nf + hi;
                 const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)chunk * nbins + bin] + __popcll(masks[bin] & lower) - sd.n_diag;
                 // pose-major slots of the two edges, the one of the lower hessian index first
-                sd.ent_i[pos] = (ha <= hb) ? sd.slot[a] : sd.slot[b];
-                sd.ent_j[pos] = (ha <= hb) ? sd.slot[b] : sd.slot[a];
+                const int sb = sd.slot[b];
+                sd.ent_i[pos] = (ha <= hb) ? sa : sb;
+                sd.ent_j[pos] = (ha <= hb) ? sb : sa;
                 sd.ent_l[pos] = l;
             }
         }
     }
 }
 
-// exclusive scan over the chunks of every bin's counts (in place) and the bin totals; one lane per bin (coalesced across
-// bins), the chunks walked in order with 8 loads in flight
-__global__ __launch_bounds__(64) void k_struct_scan(StructDev sd)
+// exclusive scan over the chunks of every bin's counts (in place) and the bin totals.  A workgroup takes 64 bins (one per
+// lane: coalesced across bins) and cuts the chunks into 16 segments, one per wave: segment sums, a 16-step prefix through
+// LDS, then the running prefixes written back; 8 loads in flight per lane in both passes.
+__global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
 {
+    __shared__ int seg_tot[16][64];
     const int nbins = sd.nfree * sd.nfree;
-    const int bin = blockIdx.x * 64 + threadIdx.x;
-    if (bin >= nbins) return;
-    int32_t *col = sd.cntw + bin;
-    int carry = 0;
-    for (int c0 = 0; c0 < sd.nchunks; c0 += 8) {
+    const int tx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + tx;
+    const bool live = bin < nbins;
+    const int L = (sd.nchunks + 15) / 16, c_beg = sy * L, c_end = min(sd.nchunks, c_beg + L);
+    int32_t *col = sd.cntw + (live ? bin : 0);
+    int sum = 0;
+    for (int c0 = c_beg; c0 < c_end && live; c0 += 8) {
         int v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = c0 + u < sd.nchunks ? col[(size_t)(c0 + u) * nbins] : 0;
+        for (int u = 0; u < 8; ++u) v[u] = c0 + u < c_end ? col[(size_t)(c0 + u) * nbins] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    seg_tot[sy][tx] = sum;
+    __syncthreads();
+    int carry = 0, total = 0;
+    for (int q = 0; q < 16; ++q) { const int t = seg_tot[q][tx]; carry += q < sy ? t : 0; total += t; }
+    for (int c0 = c_beg; c0 < c_end && live; c0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = c0 + u < c_end ? col[(size_t)(c0 + u) * nbins] : 0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (c0 + u < sd.nchunks) col[(size_t)(c0 + u) * nbins] = carry;
+            if (c0 + u < c_end) col[(size_t)(c0 + u) * nbins] = carry;
             carry += v[u];
         }
     }
-    sd.cnt[bin] = carry;
+    if (live && sy == 0) sd.cnt[bin] = total;
 }
 
 // map point of every pose-major slot (what a diagonal schur entry needs besides its slot)
@@ -110,15 +134,15 @@ hipError_t launch_slot_point(const int32_t *slot, const int32_t *g_point, int32_
 
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
 {
-    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree;
+    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree + sizeof(int) * 64 * kDegCap;
     hipLaunchKernelGGL(k_struct_pairs<false>, dim3(sd.nchunks), dim3(64), lds, s, sd);
-    hipLaunchKernelGGL(k_struct_scan, dim3((sd.nfree * sd.nfree + 63) / 64), dim3(64), 0, s, sd);
+    hipLaunchKernelGGL(k_struct_scan, dim3((sd.nfree * sd.nfree + 63) / 64), dim3(1024), 0, s, sd);
     return hipGetLastError();
 }
 
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s)
 {
-    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree;
+    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree + sizeof(int) * 64 * kDegCap;
     hipLaunchKernelGGL(k_struct_pairs<true>, dim3(sd.nchunks), dim3(64), lds, s, sd);
     return hipGetLastError();
 }
