@@ -436,6 +436,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const uint64_t arena_gen_at_post = h->arena_gen;
     hipError_t raw_copy_err = hipSuccess;
     h->packer.post([=, &stereo, &raw_copy_err]() {
+        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_edges otherwise)
+        std::memcpy(sg + o_gpose, d->edge_pose, sizeof(int32_t) * (size_t)E);
+        std::memcpy(sg + o_gpoint, d->edge_point, sizeof(int32_t) * (size_t)E);
         std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)E);
         std::memcpy(sg + o_isig, d->inv_sigma2, sizeof(double) * (size_t)E);
         if (d->obs_right) {
@@ -468,8 +471,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t edge_bytes = s.already_grouped ? edge_bytes_grouped : edge_bytes_max;
     const int nbins = nf * nf;
     auto pack_edges = [&](bool raw_too) {
-        std::memcpy(sg + o_gpose, s.g_pose.data(), sizeof(int32_t) * E);
-        std::memcpy(sg + o_gpoint, s.g_point.data(), sizeof(int32_t) * E);
+        if (!s.already_grouped || raw_too) {         // (grouped order: the helper thread copied the caller's index arrays)
+            std::memcpy(sg + o_gpose, s.gp, sizeof(int32_t) * E);
+            std::memcpy(sg + o_gpoint, s.gl, sizeof(int32_t) * E);
+        }
         std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
         if (!s.already_grouped) std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
         std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);

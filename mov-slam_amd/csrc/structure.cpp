@@ -37,15 +37,16 @@ int build_basic(const movba_lba_desc& d, Structure& s)
         s.already_grouped = grouped;      // identity permutation iff the caller's edges are in ascending point order
     }
     for (int l = 0; l < P; ++l) s.pt_start[l + 2] += s.pt_start[l + 1];
-    s.g_pose.resize(E); s.g_point.resize(E);
     if (s.already_grouped) {
         // the reference's own edge order (map points in list order, Optimizer.cc:623-672): identity permutation
         // (perm stays empty: the upload path copies the per-edge arrays as they are)
         s.perm.clear();
-        if (E) { std::memcpy(s.g_pose.data(), d.edge_pose, sizeof(int32_t) * E); std::memcpy(s.g_point.data(), d.edge_point, sizeof(int32_t) * E); }
+        // (no copy either: gp / gl alias the caller's arrays, valid for the duration of the upload call, which is their only use)
+        s.gp = d.edge_pose; s.gl = d.edge_point;
         s.pt_start.erase(s.pt_start.begin());       // counts were accumulated one slot late for the counting sort
     } else {
         s.perm.resize(E);
+        s.g_pose.resize(E); s.g_point.resize(E);
         for (int e = 0; e < E; ++e) {
             const int pos = s.pt_start[d.edge_point[e] + 1]++;
             s.perm[pos] = e;
@@ -55,6 +56,7 @@ int build_basic(const movba_lba_desc& d, Structure& s)
             s.g_pose[g] = d.edge_pose[s.perm[g]];
             s.g_point[g] = d.edge_point[s.perm[g]];
         }
+        s.gp = s.g_pose.data(); s.gl = s.g_point.data();
     }
     s.hidx.assign(NP, -1);
     // pose-major slots: the edges of free pose h occupy [pstart[h], pstart[h+1]) in ascending map-point order, so the
@@ -70,7 +72,7 @@ int build_basic(const movba_lba_desc& d, Structure& s)
     for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
     s.slot.resize(E);
     {
-        const int32_t *gp = s.g_pose.data();
+        const int32_t *gp = s.gp;
         int32_t *sl = s.slot.data(), *ps = pstart.data();
         for (int g = 0; g < E; ++g) { const int i = gp[g]; const int v = ps[i]; sl[g] = v; ps[i] = v + (v >= 0); }
     }
@@ -87,7 +89,7 @@ static int free_lists(const Structure& s, std::vector<int32_t>& fe_start, std::v
     for (int l = 0; l < P; ++l) {
         const size_t base = fe_h.size();
         for (int g = s.pt_start[l]; g < s.pt_start[l + 1]; ++g) {
-            const int h = s.hidx[s.g_pose[g]];
+            const int h = s.hidx[s.gp[g]];
             if (h < 0) continue;
             // insertion keeps the (usually already ascending) list sorted and stable
             size_t pos = fe_h.size();

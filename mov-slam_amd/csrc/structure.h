@@ -34,7 +34,8 @@ struct Structure {
     std::vector<int32_t> perm;          // E: grouped position -> caller edge; EMPTY when the caller's order is already grouped (identity)
     std::vector<int32_t> pose_edges, pose_slot0;   // scratch of build_basic: edges per pose, first pose-major slot of a free pose
     std::vector<int32_t> pt_start;      // P+1
-    std::vector<int32_t> g_pose, g_point;   // E (grouped order)
+    std::vector<int32_t> g_pose, g_point;   // E (grouped order); left empty when the caller's order is already grouped:
+    const int32_t *gp = nullptr, *gl = nullptr;   // the grouped arrays to read: the caller's own, or the two vectors above
     std::vector<int32_t> pair_i, pair_j;    // npairs (hessian indices, i <= j); pair k<nfree is (k,k)
     std::vector<int32_t> pair_item_start;   // npairs+1
     std::vector<int64_t> pair_ptr;          // npairs+1: first entry of every pair
