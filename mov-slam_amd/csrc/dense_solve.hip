@@ -70,6 +70,63 @@ __device__ __forceinline__ dbl4 tile_mfma(const double *As, const double *Bs, in
     return c;
 }
 
+// The single-wave panel sweeps of k_chol_step (see there), K a compile-time constant so that a panel row stays in
+// registers.  DiagSweep<0>::run factors D: pivot K publishes column K of D in T[K][.] (one ds_write, broadcast reads back:
+// LDS operations of one wave execute in order, no barrier) and its reciprocal pivot in rinvb[K].  RowSweep<0>::run then
+// solves a row of U against it from the same table: u_c -= (u_K / p_KK) T[K][c], no cross-lane traffic at all.
+// (Both sweeps in one pass made the compiler sink the whole U chain behind the D chain and keep every broadcast value for
+//  it: two thousand spilled registers.  The table in LDS is that hand-off done on purpose.)
+template <int K>
+struct DiagSweep {
+    static __device__ __forceinline__ void run(double (&d)[NB], double *T, double *rinvb, double *pivb, volatile int *prog, int lane, bool &bad)
+    {
+        double *cb = T + K * 64;
+        cb[lane] = d[K];                            // column K of D, one value per lane
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double piv = cb[K];
+        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
+        const double rinv = fast_rcp(piv);
+        // column K and its reciprocal pivot are in LDS: the row sweep of the second wave may take pivot K (LDS operations of a
+        // wave are performed in order, so whoever sees the counter sees what was written before it)
+        if (lane == 0) { pivb[K] = piv; rinvb[K] = rinv; *prog = K + 1; }
+        const double td = d[K] * rinv;
+#pragma unroll
+        for (int c = K + 1; c < NB; ++c) d[c] -= td * cb[c];
+        __builtin_amdgcn_sched_barrier(0);
+        DiagSweep<K + 1>::run(d, T, rinvb, pivb, prog, lane, bad);
+    }
+};
+template <>
+struct DiagSweep<NB> {
+    static __device__ __forceinline__ void run(double (&)[NB], double *, double *, double *, volatile int *, int, bool &) {}
+};
+template <int K>
+struct RowSweep {
+    static __device__ __forceinline__ void run(double (&u)[NB], const double *T, const double *rinvb, const volatile int *prog)
+    {
+        // wait for pivot K of the factorisation running beside this sweep (bounded: the first wave always gets through
+        // its 48 pivots, whatever their values)
+        for (int guard = 0; *prog <= K && guard < (1 << 20); ++guard) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // (the table address is made to depend on u[K] through an opaque zero: left alone, the compiler hoists the reads of the
+        //  whole table — 1 128 values, none of which depends on the u chain — to the top of the sweep and spills them)
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2hiint(u[K])));
+        const double *cb = T + K * 64 + z;
+        const double tu = u[K] * rinvb[K + z];
+#pragma unroll
+        for (int c = K + 1; c < NB; ++c) u[c] -= tu * cb[c];
+        __builtin_amdgcn_sched_barrier(0);
+        RowSweep<K + 1>::run(u, T, rinvb, prog);
+    }
+};
+template <>
+struct RowSweep<NB> {
+    static __device__ __forceinline__ void run(double (&)[NB], const double *, const double *, const volatile int *) {}
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -224,71 +281,63 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(DevWindow w, int j)
         }
         __syncthreads();
     }
-    // ---- factor D and solve U L^T = U in one sweep over the 48 pivots.  Thread (tr, tc) owns the 3 x 3 elements rows
-    // 3 tr.., columns 3 tc.. of D and of U, in registers; per pivot k:  p_rc -= p_rk p_ck / p_kk  for c > k (r > k in D),
-    // then column k + 1 is published to LDS for the next pivot: one barrier per pivot.  L = P / sqrt(pivot) at the end. ----
-    const int tr = tid >> 4, tc = tid & 15;
-    double vd[3][3], vu[3][3];
+    // ---- factor D, then solve U L^T = U, each by ONE wave with a panel row per lane in registers (lane r < 48: row r).
+    // Pivot k of the factorisation:  p_rc -= (p_rk / p_kk) p_ck  for c > k; column k of D (the p_ck) is published in an
+    // LDS table, T[k][.], and read back as broadcasts: no workgroup barrier inside the sweep, against 48 barriers and a
+    // chain of LDS round trips per pivot with the panel spread over four waves (40 us per launch).  The upper triangle
+    // of D is carried along as its symmetric image (same formula), so nothing is masked.  Wave 1 then runs the rows of
+    // U through the same table (no cross-lane traffic at all).  L = P / sqrt(pivot) at the end. ----
+    double *T = As;                                 // 48 x 64 doubles: As and Bs (adjacent, 2 x 48 x 49) are free now
+    double *pivb = As + NB * 64, *rinvb = pivb + 64;
+    volatile int *prog = reinterpret_cast<volatile int *>(rinvb + 64);       // pivots published so far (NB + 1: column scales too)
+    static_assert(NB * 64 + 130 <= 2 * NB * LD, "the column table fits the two operand tiles");
+    __syncthreads();                                // every wave is done with As / Bs as MFMA operands
+    if (tid == 0) *prog = 0;
+    __syncthreads();
+    if (wv == 0) {
+        bool bad = false;
+        const int r = lane < NB ? lane : NB - 1;    // lanes 48..63 shadow row 47 (their results are never stored)
+        double d[NB];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < NB; ++c) d[c] = Ps[r * LD + c];
+        DiagSweep<0>::run(d, T, rinvb, pivb, prog, lane, bad);  // pivots 0..47, fully unrolled (register indices are static)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // 1 / sqrt(pivot) of every column, once (lane c), then the rows back into the panel image for the coalesced store
+        if (lane < NB) { const double p = pivb[lane]; pivb[lane] = (p > 0.0 && isfinite(p)) ? 1.0 / sqrt(p) : 1.0; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane == 0) *prog = NB + 1;
+        if (lane < NB) {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            vd[a][b] = Ps[(3 * tr + a) * LD + 3 * tc + b];
-            vu[a][b] = diag ? 0.0 : Ps[(NB + 3 * tr + a) * LD + 3 * tc + b];
+            for (int c = 0; c < NB; ++c) Ps[lane * LD + c] = c <= lane ? d[c] * pivb[c] : 0.0;
         }
-    bool bad = false;
-    for (int k = 0; k < NB; ++k) {
-        double piv = Ps[k * LD + k];
-        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
-        const double rinv = fast_rcp(piv);
-        double ck[3], dr[3], ur[3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) ck[b] = Ps[(3 * tc + b) * LD + k] * rinv;           // p_ck / p_kk, rows c of D
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { dr[a] = Ps[(3 * tr + a) * LD + k]; ur[a] = Ps[(NB + 3 * tr + a) * LD + k]; }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int r = 3 * tr + a, cidx = 3 * tc + b;
-                if (cidx > k) {
-                    if (r >= cidx) vd[a][b] -= dr[a] * ck[b];          // lower triangle of D (r >= c > k)
-                    if (!diag) vu[a][b] -= ur[a] * ck[b];
-                }
-            }
-        // publish column k + 1 (its owner threads: tc == (k + 1) / 3)
-        if (k + 1 < NB && tc == (k + 1) / 3) {
-            const int b = (k + 1) - 3 * tc;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double d0 = b == 0 ? vd[a][0] : (b == 1 ? vd[a][1] : vd[a][2]);
-                const double u0 = b == 0 ? vu[a][0] : (b == 1 ? vu[a][1] : vu[a][2]);
-                Ps[(3 * tr + a) * LD + k + 1] = d0;
-                if (!diag) Ps[(NB + 3 * tr + a) * LD + k + 1] = u0;
-            }
-        }
-        __syncthreads();
+        if (bad && lane == 0) *ds.fail = 1;
     }
-    if (bad && tid == 0) *ds.fail = 1;
-    // ---- L = P / sqrt(pivot of the column); the diagonal workgroup leaves L(j, j) in diagL, the others L(I, j) in place ----
-    double rs[3];
+    if (wv == 1 && !diag) {                         // beside the factorisation, a few pivots behind it
+        const int r = lane < NB ? lane : NB - 1;
+        double u[NB];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) { const double p = Ps[(3 * tc + b) * LD + 3 * tc + b]; rs[b] = (p > 0.0 && isfinite(p)) ? 1.0 / sqrt(p) : 1.0; }
-    if (diag) {
-        double *out = ds.diagL + (size_t)j * NB * NB;
+        for (int c = 0; c < NB; ++c) u[c] = Ps[(NB + r) * LD + c];
+        RowSweep<0>::run(u, T, rinvb, prog);
+        for (int guard = 0; *prog <= NB && guard < (1 << 20); ++guard) __builtin_amdgcn_s_sleep(1);        // the column scales
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane < NB) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const int r = 3 * tr + a, cidx = 3 * tc + b;
-                out[r * NB + cidx] = r >= cidx ? vd[a][b] * rs[b] : 0.0;
-            }
-    } else {
-        double *out = ds.tiles + tile_off(I, j);
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) out[(3 * tr + a) * NB + 3 * tc + b] = vu[a][b] * rs[b];
+            for (int c = 0; c < NB; ++c) Ps[(NB + lane) * LD + c] = u[c] * pivb[c];
+        }
+    }
+    __syncthreads();
+    // ---- the diagonal workgroup leaves L(j, j) in diagL, the others L(I, j) in place ----
+    {
+        double2 *out = reinterpret_cast<double2 *>(diag ? ds.diagL + (size_t)j * NB * NB : ds.tiles + tile_off(I, j));
+        const double *src = diag ? Ps : Ps + NB * LD;
+        for (int e = tid; e < NB * NB / 2; e += kStepThreads) {
+            const int r = (2 * e) / NB, c = (2 * e) - r * NB;
+            out[e] = make_double2(src[r * LD + c], src[r * LD + c + 1]);
+        }
     }
 }
 
@@ -336,10 +385,15 @@ __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
                 for (int q = 0; q < G; ++q) acc += ps[q * NB + tid];
                 sv = ds.tiles[tile_off(nt, J) + tid] - acc;
             }
+            // (row k of the factor and its reciprocal diagonal are fetched one step ahead: the chain per step is
+            //  readlane -> multiply -> fused update, not an LDS round trip)
+            double lk = tid < NB ? Ls[(NB - 1) * LD + tid] : 0.0, rk = rdiag[NB - 1];
             for (int k = NB - 1; k >= 0; --k) {
-                const double xk = readlane_f64(sv, k) * rdiag[k];
+                const double lcur = lk, rcur = rk;
+                if (k > 0) { lk = tid < NB ? Ls[(k - 1) * LD + tid] : 0.0; rk = rdiag[k - 1]; }
+                const double xk = readlane_f64(sv, k) * rcur;
                 if (tid == k) sv = xk;
-                else if (tid < k) sv -= Ls[k * LD + tid] * xk;
+                else if (tid < k) sv -= lcur * xk;
             }
             if (tid < NB) x[J * NB + tid] = sv;
         }
