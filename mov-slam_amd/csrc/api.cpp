@@ -620,6 +620,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     const int ntile = dense_ntile(nf);
     const size_t o_dtiles = c.take<double>(dense_tiles_doubles(nf)), o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1), o_dfail = c.take<int32_t>(4);
+    const size_t o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
     const size_t total = c.off;
 
     rc2 = ensure_arena(h, total); if (rc2) return rc2;
@@ -724,7 +725,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
     w.dense.pid = reinterpret_cast<const int32_t *>(a + o_pid); w.dense.fail = reinterpret_cast<int32_t *>(a + o_dfail);
-    w.dense.ntile = ntile; w.dense.n = 6 * nf;
+    w.dense.ntile = ntile; w.dense.n = 6 * nf; w.dense.xsol = reinterpret_cast<double *>(a + o_dx);
     w.direct_only = h->rows_kernel ? 0 : 1;
     w.lds_poses = point_lds_need(NP, nf) <= kPointLdsLimit ? 1 : 0;
     h->uploaded = true;

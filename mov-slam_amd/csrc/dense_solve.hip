@@ -32,6 +32,7 @@ constexpr int NB = kDenseNB;
 constexpr int LD = NB + 1;              // LDS row stride: 49 doubles, conflict-free for the MFMA operand reads (rows x k)
 constexpr int kStepThreads = 256;
 constexpr int kBackThreads = 1024;
+constexpr int kBackStepsFrom = 12;      // block columns beyond which the back substitution takes one launch per block row
 
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
@@ -363,6 +364,57 @@ __global__ __launch_bounds__(kStepThreads) void k_chol_step(DevWindow w, int j)
 // block column up, then writes the increment, the pose part of computeScale() and the trial poses exactly like the PCG
 // kernels' epilogue, and releases a parked solve (Ctrl::done 2 -> 0).
 // ---------------------------------------------------------------------------------------------------------------------
+// k_back_step: back substitution of block row I for large systems, one launch per block row from the last one up
+// (right-looking: y_J -= L(I, J)^T x_I for every J < I, one workgroup each).  Every workgroup solves the 48 x 48 triangular
+// system L(I, I)^T x_I = y_I for itself first (one wave, ~1 us), so none waits for another; workgroup I stores x_I.
+// One workgroup streaming the whole factor (k_dense_backsolve's loop) takes 1.1 ms at 400 free keyframes; this takes 50
+// launches of a few microseconds.
+__global__ __launch_bounds__(256) void k_back_step(DevWindow w, int I)
+{
+    __shared__ double Ls[NB * LD], rdiag[NB], xs[NB], ps[5 * NB];
+    const Ctrl *c = w.ctrl;
+    if (c->done == 1) return;
+    const DenseSys &ds = w.dense;
+    const int tid = threadIdx.x, nt = ds.ntile, J = blockIdx.x;
+    for (int e = tid; e < NB * NB; e += 256) { const int r = e / NB, q = e - r * NB; Ls[r * LD + q] = ds.diagL[(size_t)I * NB * NB + e]; }
+    if (tid < NB) rdiag[tid] = fast_rcp(ds.diagL[(size_t)I * NB * NB + tid * NB + tid]);
+    // this workgroup's tile of the factor is requested before the substitution, so that it arrives behind it
+    const int g = tid / NB, cc = tid - g * NB;      // 5 row groups x 48 columns = 240 threads
+    double lv[10];
+    const bool upd = J < I && g < 5;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) { const int r = g + 5 * q; lv[q] = (upd && r < NB) ? ds.tiles[tile_off(I, J) + r * NB + cc] : 0.0; }
+    __syncthreads();
+    if (tid < 64) {
+        double sv = tid < NB ? ds.tiles[tile_off(nt, I) + tid] : 0.0;
+        double lk = tid < NB ? Ls[(NB - 1) * LD + tid] : 0.0, rk = rdiag[NB - 1];
+        for (int k = NB - 1; k >= 0; --k) {
+            const double lcur = lk, rcur = rk;
+            if (k > 0) { lk = tid < NB ? Ls[(k - 1) * LD + tid] : 0.0; rk = rdiag[k - 1]; }
+            const double xk = readlane_f64(sv, k) * rcur;
+            if (tid == k) sv = xk;
+            else if (tid < k) sv -= lcur * xk;
+        }
+        if (tid < NB) { xs[tid] = sv; if (J == I) ds.xsol[I * NB + tid] = sv; }
+    }
+    __syncthreads();
+    if (J == I) return;
+    if (upd) {
+        double sacc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { const int r = g + 5 * q; if (r < NB) sacc += lv[q] * xs[r]; }
+        ps[g * NB + cc] = sacc;
+    }
+    __syncthreads();
+    if (tid < NB) {
+        double *y = ds.tiles + tile_off(nt, J);
+        y[tid] -= (((ps[tid] + ps[NB + tid]) + ps[2 * NB + tid]) + ps[3 * NB + tid]) + ps[4 * NB + tid];
+    }
+}
+
+// PRESOLVED: the solution was left in DenseSys::xsol by the k_back_step launches (large systems); otherwise this
+// workgroup runs the whole back substitution itself.
+template <bool PRESOLVED>
 __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -380,7 +432,11 @@ __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
     const int g = tid / NB, cc = tid - g * NB;
     const bool fail = *ds.fail != 0;
     const double lambda = c->lambda;
-    for (int J = nt - 1; J >= 0; --J) {
+    if (PRESOLVED) {
+        for (int idx = tid; idx < npad; idx += kBackThreads) x[idx] = ds.xsol[idx];
+        __syncthreads();
+    }
+    for (int J = PRESOLVED ? -1 : nt - 1; J >= 0; --J) {
         // diagonal factor -> LDS, partial sums of  sum_{I > J} L(I, J)^T x_I  over the row groups
         for (int e = tid; e < NB * NB; e += kBackThreads) { const int r = e / NB, q = e - r * NB; Ls[r * LD + q] = ds.diagL[(size_t)J * NB * NB + e]; }
         double s = 0.0;
@@ -481,7 +537,10 @@ hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s)
         hipLaunchKernelGGL(k_chol_step, dim3(grid), dim3(kStepThreads), lds, s, w, j);
     }
     const size_t lds_b = ((size_t)nt * NB + NB * LD + 21 * NB + 16 + NB) * sizeof(double);
-    hipLaunchKernelGGL(k_dense_backsolve, dim3(1), dim3(kBackThreads), lds_b, s, w);
+    if (nt > kBackStepsFrom) {
+        for (int I = nt - 1; I >= 0; --I) hipLaunchKernelGGL(k_back_step, dim3(I + 1), dim3(256), 0, s, w, I);
+        hipLaunchKernelGGL(k_dense_backsolve<true>, dim3(1), dim3(kBackThreads), lds_b, s, w);
+    } else hipLaunchKernelGGL(k_dense_backsolve<false>, dim3(1), dim3(kBackThreads), lds_b, s, w);
     return hipGetLastError();
 }
 
@@ -489,7 +548,9 @@ hipError_t configure_dense_kernels()
 {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_chol_step), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_backsolve), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_backsolve<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_backsolve<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
 }
 
 }  // namespace movba

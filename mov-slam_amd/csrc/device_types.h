@@ -82,6 +82,7 @@ constexpr int kDenseNB = 48;        // 8 pose blocks
 struct DenseSys {
     double *tiles;
     double *diagL;              // ntile x NB x NB: Cholesky factors of the diagonal tiles
+    double *xsol;               // ntile x NB: solution of the multi-launch back substitution (large systems)
     const int32_t *pid;         // nfree x nfree: pair id of block (i <= j) or -1
     int32_t *fail;              // != 0: a pivot was not positive (the trial is rejected like a failed CSparse factorisation)
     int32_t ntile, n;           // column tiles; unknowns (6 nfree)
