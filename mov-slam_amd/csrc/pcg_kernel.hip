@@ -369,7 +369,9 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // (A_c^-1 v_c)[own row crow], v_c = rcg (all aggregates, visible after a workgroup barrier): valid in lanes with cq == 0.
     // A_c^-1 sits in LDS rounded to fp32: as a preconditioner the inverse needs no more (same CG iteration counts), and
     // this product reads all 96 x 96 entries every iteration: in fp64 that was more LDS traffic than the rest of the
-    // iteration together.
+    // iteration together.  The vector side and the row sums stay fp64: z_c is carried by the recurrence z_c -= alpha u_c,
+    // which is only consistent while u_c is an exact linear image of s (fp32 sums put 1e-7 |u_c| of noise into z_c, more
+    // than z_c itself once the residual has dropped 7 digits: tried, the solve then ends 1e-8 off the oracle's poses).
     auto coarse_rows = [&]() {
         const float4 *arow = reinterpret_cast<const float4 *>(Acf + (wv * kPA + crow) * kNC + cq * 24);
         const double2 *rcv = reinterpret_cast<const double2 *>(rcg + cq * 24);
