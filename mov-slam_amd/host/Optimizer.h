@@ -7,10 +7,12 @@
 // KeyFrame / MapPoint graph and runs the solve on the GPU through the C-ABI in include/movba.h.
 //
 // Differences from the reference header, both invisible to the callers:
-//   * no g2o / Eigen solver headers are pulled in (the arithmetic they provided now lives in
-//     libmovba.so);
+//   * the g2o solver headers the reference header pulled in (:27-36) are included only where they exist
+//     (__has_include: inside the reference tree they do, so whoever relied on getting them through
+//     this header still does; in this repository they do not, and nothing here needs them: the
+//     arithmetic they provided lives in libmovba.so);
 //   * the KeyFrameAndPose typedef (it names g2o::Sim3 and is used nowhere in the reference's
-//     sources) is only declared when MOVBA_HAVE_G2O_SIM3 is defined.
+//     sources) is declared when the sim3 header was found or MOVBA_HAVE_G2O_SIM3 is defined.
 #ifndef OPTIMIZER_H
 #define OPTIMIZER_H
 
@@ -19,10 +21,29 @@
 #include "KeyFrame.h"
 #include "Frame.h"
 
+#include <math.h>
+
+#include <map>
 #include <set>
 #include <utility>
 #include <vector>
 
+#if defined(__has_include)
+#if __has_include("g2o/types/sim3/types_seven_dof_expmap.h") && __has_include("g2o/core/block_solver.h")
+#include "g2o/types/sim3/types_seven_dof_expmap.h"
+#include "g2o/core/sparse_block_matrix.h"
+#include "g2o/core/block_solver.h"
+#include "g2o/core/optimization_algorithm_levenberg.h"
+#include "g2o/core/optimization_algorithm_gauss_newton.h"
+#include "g2o/solvers/eigen/linear_solver_eigen.h"
+#include "g2o/types/sba/types_six_dof_expmap.h"
+#include "g2o/core/robust_kernel_impl.h"
+#include "g2o/solvers/dense/linear_solver_dense.h"
+#ifndef MOVBA_HAVE_G2O_SIM3
+#define MOVBA_HAVE_G2O_SIM3 1
+#endif
+#endif
+#endif
 #ifdef MOVBA_HAVE_G2O_SIM3
 #include "g2o/types/sim3/types_seven_dof_expmap.h"
 #endif
