@@ -450,10 +450,14 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     char *const arena_at_post = h->arena;
     const uint64_t arena_gen_at_post = h->arena_gen;
     hipError_t raw_copy_err = hipSuccess;
-    h->packer.post([=, &stereo, &raw_copy_err]() {
+    std::atomic<int> idx_ready{0};
+    // (every way out of this function waits for the helper first: it reads the caller's arrays and writes to this frame)
+    struct HelperGuard { Worker &w; ~HelperGuard() { w.wait(); } } helper_guard{h->packer};
+    h->packer.post([=, &stereo, &raw_copy_err, &idx_ready]() {
         // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_edges otherwise)
         std::memcpy(sg + o_gpose, d->edge_pose, sizeof(int32_t) * (size_t)E);
         std::memcpy(sg + o_gpoint, d->edge_point, sizeof(int32_t) * (size_t)E);
+        idx_ready.store(1, std::memory_order_release);       // what the structure pass on the device waits for
         std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)E);
         std::memcpy(sg + o_isig, d->inv_sigma2, sizeof(double) * (size_t)E);
         if (d->obs_right) {
@@ -470,30 +474,43 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         if (raw_copy_err == hipSuccess) raw_copy_err = hipMemcpyAsync(arena_at_post + raw_begin, sg + raw_begin, edge_bytes_grouped - raw_begin, hipMemcpyHostToDevice, h->copy_stream);
         if (raw_copy_err == hipSuccess) raw_copy_err = hipEventRecord(h->copy_event, h->copy_stream);
     });
-    int rc = build_basic(*d, h->st);
+    // (the pose-major slots are left for later: they are worked out while the device counts the pairs)
+    int rc = build_basic(*d, h->st, /*defer_slots=*/true);
     lap("build_basic");
-    h->packer.wait();
-    lap("wait for the packing thread");
-    if (raw_copy_err != hipSuccess) { std::fprintf(stderr, "libmovba: upload copy failed: %s\n", hipGetErrorString(raw_copy_err)); return MOVBA_ERR_HIP; }
-    if (rc < 0) { (void)hipStreamSynchronize(h->copy_stream); return rc; }
+    bool helper_done = false;
+    auto wait_helper = [&]() -> int {
+        if (helper_done) return MOVBA_OK;
+        h->packer.wait();
+        helper_done = true;
+        if (raw_copy_err != hipSuccess) { std::fprintf(stderr, "libmovba: upload copy failed: %s\n", hipGetErrorString(raw_copy_err)); return MOVBA_ERR_HIP; }
+        return MOVBA_OK;
+    };
+    if (rc < 0) { (void)wait_helper(); (void)hipStreamSynchronize(h->copy_stream); return rc; }
     const Structure &s = h->st;
     h->stop = d->stop;
     if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
     else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
-    if (h->early_status != MOVBA_OK) { h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK; }
+    if (h->early_status != MOVBA_OK) {
+        const int rw = wait_helper(); if (rw) return rw;
+        h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK;
+    }
     const int nf = s.nfree;
     const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
     const size_t edge_bytes = s.already_grouped ? edge_bytes_grouped : edge_bytes_max;
     const int nbins = nf * nf;
-    auto pack_edges = [&](bool raw_too) {
+    // what the device structure pass reads (first part of the edge region) ...
+    auto pack_a = [&](bool raw_too) {
         if (!s.already_grouped || raw_too) {         // (grouped order: the helper thread copied the caller's index arrays)
             std::memcpy(sg + o_gpose, s.gp, sizeof(int32_t) * E);
             std::memcpy(sg + o_gpoint, s.gl, sizeof(int32_t) * E);
         }
         std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
+        std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
+    };
+    // ... and the rest of the derived arrays
+    auto pack_b = [&](bool raw_too) {
         if (!s.already_grouped) std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
         std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
-        std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
         std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
         double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
         double *obr = reinterpret_cast<double *>(sg + o_obsr);
@@ -513,7 +530,18 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
             std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
         }
     };
-    pack_edges(false);
+    auto pack_edges = [&](bool raw_too) { pack_a(raw_too); pack_b(raw_too); };
+    bool slots_packed = false;
+    if (!s.already_grouped) {
+        // (rare: the helper's straight copies get permuted below, so it has to be through with them)
+        const int rw = wait_helper(); if (rw) return rw;
+        build_slots(h->st);
+        pack_edges(false);
+        slots_packed = true;
+    } else {
+        while (idx_ready.load(std::memory_order_acquire) == 0) host_relax(0);
+        pack_a(false);
+    }
     lap("pack derived arrays");
     const double t_up0 = now_ms();
     HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_a_bytes, hipMemcpyHostToDevice, h->stream));
@@ -521,6 +549,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     double upload_host_ms = now_ms() - t_up0;
     bool edge_b_queued = false;
     auto queue_edge_b = [&]() -> int {
+        { const int rw = wait_helper(); if (rw) return rw; }      // (its copy_event must have been recorded)
         // the rest of the derived arrays; the caller's arrays are already on their way on the copy stream: the solve's
         // kernels on this stream start behind them.  (Edges not grouped by point: the helper's straight copies were
         // permuted again by pack_edges, so that part travels once more, behind the first copy.)
@@ -539,6 +568,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (!dev_structure) {
         rc = build_structure(*d, h->st);
         if (rc < 0) return rc;
+        if (!slots_packed) { pack_b(false); slots_packed = true; }
     } else {
         const int nchunks = (s.P + 63) / 64;
         Carver sc;
@@ -563,9 +593,13 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         HIP_TRY(launch_struct_count(sd, h->stream));
         // cnt and the error word are adjacent in the scratch carve: one D2H copy
         HIP_TRY(hipMemcpyAsync(misc, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
+        // the pose-major slots, while the device counts
+        build_slots(h->st);
+        pack_b(false); slots_packed = true;
+        lap("edge H2D + count launches, slot pass");
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (*reinterpret_cast<const int32_t *>(misc + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
-        lap("edge H2D + count kernel + D2H");
+        lap("wait for the pair counts");
         // observations, point ids, slots and initial estimates cross the bus while the host lays out the pairs
         { const int rq = queue_edge_b(); if (rq) return rq; }
         rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
@@ -837,7 +871,10 @@ int lm_loop(movba_handle *h, bool parked)
                 if (final_after != t && t - td < h->opt.run_ahead) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
                 if (h->stop && *h->stop) h->hstat->stop = 1;
                 if (now_ms() - t_start > 60000.0) {
+                    // raise the device-side stop flag on the way out: whatever is still queued on the stream turns into
+                    // no-op launches as soon as a k_decide sees it, and the window has to be uploaded again
                     std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
+                    h->hstat->stop = 1; h->uploaded = false;
                     return MOVBA_ERR_HIP;
                 }
                 host_relax(h->opt.host_wait);
@@ -1078,6 +1115,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             if (all_finished) break;
             if (now_ms() - t_start > 60000.0) {
                 std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
+                for (movba_handle *h : act) { h->hstat->stop = 1; h->uploaded = false; }
                 return MOVBA_ERR_HIP;
             }
             host_relax(h0->opt.host_wait);
@@ -1260,6 +1298,8 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     }
     int rc = ensure_stage(h, total); if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // (a window uploaded on this handle and not run yet: its arrays may still be crossing the bus out of the staging buffer)
+    HIP_TRY(hipEventSynchronize(h->copy_event));
     char *sg = h->stage;
     std::memcpy(sg + o_X, d->Xw, sizeof(double) * 3 * (size_t)n);
     std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)n);

@@ -6,7 +6,7 @@
 
 namespace movba {
 
-int build_basic(const movba_lba_desc& d, Structure& s)
+int build_basic(const movba_lba_desc& d, Structure& s, bool defer_slots)
 {
     const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
     if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
@@ -24,26 +24,41 @@ int build_basic(const movba_lba_desc& d, Structure& s)
     s.pose_edges.assign(NP + 1, 0);
     s.pt_start.assign(P + 2, 0);
     {
-        int prev_l = -1;
+        // Grouped edges (the expected case) need no counting: the last edge of point l leaves its end offset in slot l (plain
+        // stores, no chain of dependent increments of one counter), and a running maximum fills the points nobody observes.
         bool grouped = true;
+        int prev_l = -1;
+        int32_t *pe = s.pose_edges.data(), *pend = s.pt_start.data() + 1;
+        const int32_t *ep = d.edge_pose, *el = d.edge_point;
         for (int e = 0; e < E; ++e) {
-            const int ip = d.edge_pose[e], l = d.edge_point[e];
-            if (ip < 0 || ip >= NP || l < 0 || l >= P) return MOVBA_ERR_ARG;
-            s.pose_edges[ip]++;
-            s.pt_start[l + 2]++;
+            const int ip = ep[e], l = el[e];
+            if ((unsigned)ip >= (unsigned)NP || (unsigned)l >= (unsigned)P) return MOVBA_ERR_ARG;
+            pe[ip]++;
+            pend[l] = e + 1;
             grouped &= l >= prev_l;
             prev_l = l;
         }
         s.already_grouped = grouped;      // identity permutation iff the caller's edges are in ascending point order
     }
-    for (int l = 0; l < P; ++l) s.pt_start[l + 2] += s.pt_start[l + 1];
+    if (s.already_grouped) {
+        for (int l = 0; l < P; ++l) {
+            const int b = s.pt_start[l], en = std::max(s.pt_start[l + 1], b);
+            s.pt_start[l + 1] = en;
+            s.max_degree = std::max(s.max_degree, en - b);
+        }
+        s.pt_start.pop_back();            // size P + 1
+    } else {
+        // counting sort by map point: counts accumulated one slot late, so that the scatter below can advance them in place
+        std::fill(s.pt_start.begin(), s.pt_start.end(), 0);
+        for (int e = 0; e < E; ++e) s.pt_start[d.edge_point[e] + 2]++;
+        for (int l = 0; l < P; ++l) { s.max_degree = std::max(s.max_degree, s.pt_start[l + 2]); s.pt_start[l + 2] += s.pt_start[l + 1]; }
+    }
     if (s.already_grouped) {
         // the reference's own edge order (map points in list order, Optimizer.cc:623-672): identity permutation
         // (perm stays empty: the upload path copies the per-edge arrays as they are)
         s.perm.clear();
         // (no copy either: gp / gl alias the caller's arrays, valid for the duration of the upload call, which is their only use)
         s.gp = d.edge_pose; s.gl = d.edge_point;
-        s.pt_start.erase(s.pt_start.begin());       // counts were accumulated one slot late for the counting sort
     } else {
         s.perm.resize(E);
         s.g_pose.resize(E); s.g_point.resize(E);
@@ -69,15 +84,17 @@ int build_basic(const movba_lba_desc& d, Structure& s)
         if (s.pose_edges[i] > 0) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); pstart[i] = run; run += s.pose_edges[i]; }
     }
     s.E_free = run;
-    for (int l = 0; l < P; ++l) s.max_degree = std::max(s.max_degree, s.pt_start[l + 1] - s.pt_start[l]);
-    s.slot.resize(E);
-    {
-        const int32_t *gp = s.gp;
-        int32_t *sl = s.slot.data(), *ps = pstart.data();
-        for (int g = 0; g < E; ++g) { const int i = gp[g]; const int v = ps[i]; sl[g] = v; ps[i] = v + (v >= 0); }
-    }
+    if (!defer_slots) build_slots(s);
     if (E == 0) return MOVBA_EMPTY;
     return MOVBA_OK;
+}
+
+void build_slots(Structure& s)
+{
+    s.slot.resize(s.E);
+    const int32_t *gp = s.gp;
+    int32_t *sl = s.slot.data(), *ps = s.pose_slot0.data();
+    for (int g = 0; g < s.E; ++g) { const int i = gp[g]; const int v = ps[i]; sl[g] = v; ps[i] = v + (v >= 0); }
 }
 
 // free observers of every point, flattened: (hessian index, grouped edge), ascending hessian index
@@ -148,50 +165,71 @@ int finish_pairs(Structure& s, const int32_t* cnt)
     // a contiguous run of rows shares its map points in one L2) and cut into 8 runs of equal estimated work, heavy
     // items first inside a run; the diagonal items (Hpp, b and the Schur diagonal: ~1.5x the work per entry) are
     // thereby spread over all XCDs instead of filling the first two. ----
+    // (this function sits between the device's pair counts and the solve's first launch: no allocations, no general sorts)
     {
         const int ipw = kSchurWaves / kSchurWPI;
-        std::vector<int32_t> order(s.nitems);
-        for (int k = 0; k < s.nitems; ++k) order[k] = k;
+        // items by block row, in item order inside a row: the diagonal pair's items, then those of the row's off-diagonal
+        // pairs (pairs are numbered diagonal first, then off-diagonal row-major, and items follow their pairs)
+        std::vector<int32_t>& order = s.tmp_order;
+        order.resize(s.nitems);
+        {
+            int n = 0, od = nf < s.npairs ? s.pair_item_start[nf] : s.nitems;
+            for (int i = 0; i < nf; ++i) {
+                for (int k = s.pair_item_start[i]; k < s.pair_item_start[i + 1]; ++k) order[n++] = k;
+                while (od < s.nitems && s.pair_i[s.items[od].pair] == i) order[n++] = od++;
+            }
+        }
         auto weight = [&](int k) { const Item& it = s.items[k]; return (int64_t)(it.end - it.begin) * (it.diag ? 3 : 2) + 128; };
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return s.pair_i[s.items[a].pair] < s.pair_i[s.items[b].pair]; });
         int64_t total = 0;
         for (int k = 0; k < s.nitems; ++k) total += weight(k);
-        std::vector<std::vector<int32_t>> seg(8);
-        int64_t acc = 0; int x = 0;
-        for (int k : order) {
-            while (x < 7 && acc >= (total * (x + 1)) / 8) ++x;
-            seg[x].push_back(k);
-            acc += weight(k);
+        // 8 runs of equal estimated work; inside a run the heavy items first (ties in row order: the keys are unique)
+        std::vector<uint64_t>& key = s.tmp_key;
+        key.resize(s.nitems);
+        int seg_begin[9];
+        {
+            int64_t acc = 0; int x = 0;
+            seg_begin[0] = 0;
+            for (int n = 0; n < s.nitems; ++n) {
+                while (x < 7 && acc >= (total * (x + 1)) / 8) seg_begin[++x] = n;
+                const int64_t wgt = weight(order[n]);
+                key[n] = ((uint64_t)(0x7fffffff - wgt) << 32) | (uint32_t)n;
+                acc += wgt;
+            }
+            while (x < 8) seg_begin[++x] = s.nitems;
         }
         size_t longest = 1;
-        for (auto& v : seg) {
-            std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return weight(a) > weight(b); });
-            longest = std::max(longest, v.size());
+        for (int g = 0; g < 8; ++g) {
+            std::sort(key.begin() + seg_begin[g], key.begin() + seg_begin[g + 1]);
+            longest = std::max(longest, (size_t)(seg_begin[g + 1] - seg_begin[g]));
         }
         s.sched_per_xcd = (int)((longest + ipw - 1) / ipw) * ipw;
         s.sched.assign((size_t)8 * s.sched_per_xcd, SchedItem{ 0, 0, -1, 0, 0, { 0, 0, 0 } });
         for (int g = 0; g < 8; ++g)
-            for (size_t k = 0; k < seg[g].size(); ++k) {
-                const Item& it = s.items[seg[g][k]];
-                s.sched[(size_t)g * s.sched_per_xcd + k] = SchedItem{ it.begin, it.end, (seg[g][k] << 1) | (it.diag ? 1 : 0),
-                                                                     s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], { 0, 0, 0 } };
+            for (int n = seg_begin[g]; n < seg_begin[g + 1]; ++n) {
+                const int item = order[(uint32_t)key[n]];
+                const Item& it = s.items[item];
+                s.sched[(size_t)g * s.sched_per_xcd + (n - seg_begin[g])] = SchedItem{ it.begin, it.end, (item << 1) | (it.diag ? 1 : 0),
+                                                                                      s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], { 0, 0, 0 } };
             }
     }
 
-    // ---- block-row gather lists for y = S x with S given by its upper blocks ----
-    std::vector<std::vector<RowEnt>> rows(nf);
-    for (int p = 0; p < s.npairs; ++p) {
-        const int i = s.pair_i[p], j = s.pair_j[p];
-        rows[i].push_back(RowEnt{ p, j, 0, 0 });
-        if (i != j) rows[j].push_back(RowEnt{ p, i, 1, 0 });
-    }
-    s.row_ptr.assign(nf + 1, 0);
-    s.row_ent.clear();
-    for (int i = 0; i < nf; ++i) {
-        std::sort(rows[i].begin(), rows[i].end(), [](const RowEnt& a, const RowEnt& b) { return a.col < b.col; });
-        if (rows[i].size() & 1) rows[i].push_back(RowEnt{ -1, 0, 0, 0 });      // lists are consumed in pairs; -1 = zero block
-        s.row_ptr[i + 1] = s.row_ptr[i] + (int32_t)rows[i].size();
-        s.row_ent.insert(s.row_ent.end(), rows[i].begin(), rows[i].end());
+    // ---- block-row gather lists for y = S x with S given by its upper blocks: row i lists, by ascending column, the
+    // transposed blocks (j, i), j < i, then the diagonal block, then the blocks (i, j), j > i; padded to an even length
+    // (lists are consumed in pairs; block -1 = zero block).  The off-diagonal pairs are numbered row-major, so walking them
+    // once per part fills every row in column order. ----
+    {
+        s.row_ptr.assign(nf + 1, 0);
+        for (int p = 0; p < s.npairs; ++p) {
+            s.row_ptr[s.pair_i[p] + 1]++;
+            if (p >= nf) s.row_ptr[s.pair_j[p] + 1]++;
+        }
+        for (int i = 0; i < nf; ++i) s.row_ptr[i + 1] = s.row_ptr[i] + ((s.row_ptr[i + 1] + 1) & ~1);
+        s.row_ent.assign((size_t)s.row_ptr[nf], RowEnt{ -1, 0, 0, 0 });
+        std::vector<int32_t>& cur = s.tmp_order;
+        cur.assign(s.row_ptr.begin(), s.row_ptr.begin() + nf);
+        for (int p = nf; p < s.npairs; ++p) s.row_ent[cur[s.pair_j[p]]++] = RowEnt{ p, s.pair_i[p], 1, 0 };
+        for (int i = 0; i < nf; ++i) s.row_ent[cur[i]++] = RowEnt{ i, i, 0, 0 };
+        for (int p = nf; p < s.npairs; ++p) s.row_ent[cur[s.pair_i[p]]++] = RowEnt{ p, s.pair_j[p], 0, 0 };
     }
     return MOVBA_OK;
 }

@@ -32,6 +32,7 @@ struct Structure {
     std::vector<int32_t> hidx;          // NP: hessian index or -1
     std::vector<int32_t> free_pose;     // nfree: pose index
     std::vector<int32_t> perm;          // E: grouped position -> caller edge; EMPTY when the caller's order is already grouped (identity)
+    std::vector<int32_t> tmp_order; std::vector<uint64_t> tmp_key;   // scratch of finish_pairs
     std::vector<int32_t> pose_edges, pose_slot0;   // scratch of build_basic: edges per pose, first pose-major slot of a free pose
     std::vector<int32_t> pt_start;      // P+1
     std::vector<int32_t> g_pose, g_point;   // E (grouped order); left empty when the caller's order is already grouped:
@@ -82,7 +83,9 @@ constexpr int kSchurChunk = MOVBA_SCHUR_EPW * kSchurWPI;       // entries per sc
 // entry filling, all on the host; the upload path normally runs only build_basic and finish_pairs on the host and
 // leaves counting / filling to the device (struct_kernels.hip).
 int build_structure(const movba_lba_desc& d, Structure& s);
-int build_basic(const movba_lba_desc& d, Structure& s);        // validation, grouping by point, hessian indices
+int build_basic(const movba_lba_desc& d, Structure& s, bool defer_slots = false);   // validation, grouping by point, hessian indices
+void build_slots(Structure& s);                               // pose-major slot of every grouped edge (the part of build_basic that defer_slots leaves out;
+                                                              // s.gp must still be valid: the caller's arrays, or s.g_pose)
 int finish_pairs(Structure& s, const int32_t* cnt);           // cnt[i*nfree+j] (i <= j) -> pairs, items, gather lists
 
 }  // namespace movba

@@ -594,3 +594,20 @@ def test_host_wait_yield_mode_gives_the_same_result(built_lib, solver):
     b = solver.solve(w)
     for k in ("poses", "points", "chi2", "outlier"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_pose_optimization_between_upload_and_run_on_one_handle(solver):
+    """Both entry points share the handle's pinned staging buffer: a PoseOptimization call between movba_lba_upload and
+    movba_lba_run must wait for the window's arrays to have left it (they cross the bus on the copy stream)."""
+    w = synth.cfg("cfg3")
+    ref = solver.solve(w)
+    f = synth.make_frame(n=4000, seed=5)                 # large enough to overwrite most of the staged window
+    p_ref = solver.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0)
+    assert solver.upload(w) == 0
+    p = solver.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0)
+    assert solver.run() == 0
+    r = solver.download()
+    np.testing.assert_array_equal(p["pose"], p_ref["pose"])
+    np.testing.assert_array_equal(r["poses"], ref["poses"])
+    np.testing.assert_array_equal(r["points"], ref["points"])
+    np.testing.assert_array_equal(r["outlier"], ref["outlier"])
