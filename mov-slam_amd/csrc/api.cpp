@@ -130,6 +130,8 @@ struct movba_handle {
     char *stage_dev = nullptr;          // device view of the pinned staging buffer (written by k_export)
     // current window
     bool uploaded = false, ran = false;
+    bool export_in_run = false;         // this run's results were written to the staging buffer behind its last kernel
+    bool export_hint = false;           // set by movba_lba_solve around its run: a download follows at once
     Structure st;
     DevWindow win{};
     size_t h2d_bytes = 0;
@@ -267,6 +269,29 @@ int ensure_stage(movba_handle *h, size_t bytes)
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->stage_dev), h->stage, 0));
     h->stage_cap = cap;
     return MOVBA_OK;
+}
+
+// where k_export leaves a window's results in the pinned staging buffer
+struct ExportLayout { size_t o_pose, o_pt, o_chi, o_out, end; };
+ExportLayout export_layout(const DevWindow &w)
+{
+    ExportLayout L;
+    L.o_pose = 0;
+    L.o_pt = align_up(sizeof(double) * 7 * (size_t)w.NP, 256);
+    L.o_chi = L.o_pt + align_up(sizeof(double) * 3 * (size_t)w.P, 256);
+    L.o_out = L.o_chi + align_up(sizeof(double) * (size_t)w.E, 256);
+    L.end = L.o_out + align_up((size_t)w.E + 8, 256);
+    return L;
+}
+
+ExportDst export_dst(char *stage_dev, const ExportLayout &L, bool poses, bool points, bool chi2)
+{
+    ExportDst dst;
+    dst.poses = poses ? reinterpret_cast<unsigned long long *>(stage_dev + L.o_pose) : nullptr;
+    dst.points = points ? reinterpret_cast<unsigned long long *>(stage_dev + L.o_pt) : nullptr;
+    dst.chi2 = chi2 ? reinterpret_cast<unsigned long long *>(stage_dev + L.o_chi) : nullptr;
+    dst.outlier = reinterpret_cast<unsigned long long *>(stage_dev + L.o_out);
+    return dst;
 }
 
 }  // namespace
@@ -827,6 +852,9 @@ int lm_loop(movba_handle *h, bool parked)
     int t = 0, final_after = -1;
     auto queue_finalize = [&]() -> int {
         { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }        // (also writes Ctrl to h->ctrl_host)
+        // ... and the results go across the bus into the staging buffer right behind it: movba_lba_download then finds them
+        // there instead of paying a launch and a stream synchronise of its own
+        if (h->export_in_run) HIP_TRY(launch_export(w, export_dst(h->stage_dev, export_layout(w), true, true, true), s));
         final_after = t;
         return MOVBA_OK;
     };
@@ -914,6 +942,9 @@ int movba_lba_run(movba_handle *h)
     const DevWindow &w = h->win;
     hipStream_t s = h->stream;
     h->hstat->progress = 0; h->hstat->stop = 0;
+    // (the staging buffer is free once the upload's copies, queued ahead of every kernel of the run, have left it; it is as
+    // large as the upload needed, which is more than the results take)
+    h->export_in_run = h->export_hint && export_layout(w).end <= h->stage_cap;
 
     {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
         ScopedEvents ev(h, KC_SETUP);
@@ -965,7 +996,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
     std::vector<movba_handle *> act, solo;
     for (int i = 0; i < n; ++i) {
         movba_handle *h = hs[i];
-        h->ran = false; h->run_status = MOVBA_OK;
+        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false;
         if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
         if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
         if (!h->rows_kernel) { solo.push_back(h); continue; }
@@ -1154,17 +1185,12 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     const Ctrl &c = *h->ctrl_host;
     const size_t nb_pose = sizeof(double) * 7 * (size_t)w.NP, nb_pt = sizeof(double) * 3 * (size_t)w.P, nb_chi = sizeof(double) * (size_t)w.E;
     char *sg = h->stage;
-    const size_t o_pose = 0, o_pt = align_up(nb_pose, 256), o_chi = o_pt + align_up(nb_pt, 256), o_out = o_chi + align_up(nb_chi, 256);
-    {
-        int rs = ensure_stage(h, o_out + align_up((size_t)w.E + 8, 256)); if (rs) return rs;
+    const ExportLayout L = export_layout(w);
+    const size_t o_pose = L.o_pose, o_pt = L.o_pt, o_chi = L.o_chi, o_out = L.o_out;
+    if (!h->export_in_run) {
+        int rs = ensure_stage(h, L.end); if (rs) return rs;
         sg = h->stage;
-        char *sd = h->stage_dev;
-        ExportDst dst;
-        dst.poses = res->poses ? reinterpret_cast<unsigned long long *>(sd + o_pose) : nullptr;
-        dst.points = res->points ? reinterpret_cast<unsigned long long *>(sd + o_pt) : nullptr;
-        dst.chi2 = res->chi2 ? reinterpret_cast<unsigned long long *>(sd + o_chi) : nullptr;
-        dst.outlier = reinterpret_cast<unsigned long long *>(sd + o_out);
-        HIP_TRY(launch_export(w, dst, h->stream));
+        HIP_TRY(launch_export(w, export_dst(h->stage_dev, L, res->poses != nullptr, res->points != nullptr, res->chi2 != nullptr), h->stream));
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     // out of the pinned buffer into the caller's arrays (handing half of it to the helper thread saved 20 us when the
@@ -1175,11 +1201,13 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     if (res->outlier) std::memcpy(res->outlier, sg + o_out, (size_t)w.E);
     int n_out = 0;
     {
+        // (flags are 0 / 1 bytes: eight at a time, summed by one multiplication)
         const uint8_t *of = reinterpret_cast<const uint8_t *>(sg + o_out);
-        int a0 = 0, a1 = 0, a2 = 0, a3 = 0, e = 0;
-        for (; e + 4 <= w.E; e += 4) { a0 += of[e] != 0; a1 += of[e + 1] != 0; a2 += of[e + 2] != 0; a3 += of[e + 3] != 0; }
-        for (; e < w.E; ++e) a0 += of[e] != 0;
-        n_out = a0 + a1 + a2 + a3;
+        uint64_t acc = 0;
+        int e = 0;
+        for (; e + 8 <= w.E; e += 8) { uint64_t v; std::memcpy(&v, of + e, 8); acc += (v * 0x0101010101010101ull) >> 56; }
+        for (; e < w.E; ++e) acc += of[e] != 0;
+        n_out = (int)acc;
     }
     res->iters_done = c.iters_done; res->n_solves = c.n_solves; res->n_outliers = n_out;
     res->pcg_iters = c.pcg_total_iters; res->last_rejected = c.last_rejected;
@@ -1200,7 +1228,9 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
     res->status = MOVBA_ERR_ARG;
     int rc = movba_lba_upload(h, desc);
     if (rc != MOVBA_OK) { res->status = rc; return rc; }
+    h->export_hint = true;
     rc = movba_lba_run(h);
+    h->export_hint = false;
     if (rc < 0) { res->status = rc; h->stop = nullptr; return rc; }
     rc = movba_lba_download(h, res);
     h->stop = nullptr;      // keep no caller pointer after the call returns
@@ -1300,6 +1330,7 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     HIP_TRY(hipStreamSynchronize(h->stream));
     // (a window uploaded on this handle and not run yet: its arrays may still be crossing the bus out of the staging buffer)
     HIP_TRY(hipEventSynchronize(h->copy_event));
+    h->export_in_run = false;        // (results a run may have left in the staging buffer are overwritten here: download exports again)
     char *sg = h->stage;
     std::memcpy(sg + o_X, d->Xw, sizeof(double) * 3 * (size_t)n);
     std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)n);

@@ -236,6 +236,7 @@ class Solver:
         rc = lib().movba_lba_solve(self._h, C.byref(d), C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_lba_solve: {status_string(rc)}")
+        self._keep = (d, keep)             # (download() may be called again on the solved window)
         if rc != OK:                       # silent early return: nothing written, echo the inputs
             out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
         return self._pack(r, out, rc)

@@ -611,3 +611,18 @@ def test_pose_optimization_between_upload_and_run_on_one_handle(solver):
     np.testing.assert_array_equal(r["poses"], ref["poses"])
     np.testing.assert_array_equal(r["points"], ref["points"])
     np.testing.assert_array_equal(r["outlier"], ref["outlier"])
+
+
+def test_download_again_after_the_staging_buffer_was_reused(solver):
+    """movba_lba_solve leaves its results in the pinned staging buffer behind the solve's last kernel; a later
+    PoseOptimization call on the handle overwrites that buffer, and a second movba_lba_download must export again."""
+    w = synth.cfg("cfg2")
+    r1 = solver.solve(w)
+    r2 = solver.download()                               # straight from the staging buffer
+    f = synth.make_frame(n=4000, seed=6)
+    solver.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0)
+    r3 = solver.download()                               # exported again from the resident window
+    for r in (r2, r3):
+        for k in ("poses", "points", "chi2", "outlier"):
+            np.testing.assert_array_equal(r[k], r1[k])
+        assert r["n_outliers"] == r1["n_outliers"] == int(r1["outlier"].sum())
