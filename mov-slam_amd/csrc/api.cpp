@@ -113,6 +113,7 @@ struct movba_handle {
                                         // handles of a device: every extra stream of the process competes for the few hardware queues,
                                         // and two streams of a batched run that land on one queue run in turns)
     hipEvent_t copy_event = nullptr;
+    hipEvent_t count_event = nullptr;   // the pair counts of the device structure pass have reached the host
     movba_options opt{};
     // device arena
     char *arena = nullptr;
@@ -345,6 +346,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     }
     if ((h->copy_stream = shared_copy_stream(device)) == nullptr ||
         hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
@@ -367,6 +369,7 @@ void movba_destroy(movba_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);        // shared: stays
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
+    if (h->count_event) (void)hipEventDestroy(h->count_event);
     harvest_events(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->arena) (void)hipFree(h->arena);
@@ -483,7 +486,16 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         std::memcpy(sg + o_gpose, d->edge_pose, sizeof(int32_t) * (size_t)E);
         std::memcpy(sg + o_gpoint, d->edge_point, sizeof(int32_t) * (size_t)E);
         idx_ready.store(1, std::memory_order_release);       // what the structure pass on the device waits for
+        // ... each part straight on to the device on the copy stream while the next one is being staged: most of the upload
+        // is across the bus before the calling thread has finished its pass over the edges (the solve's first kernels wait
+        // for copy_event, nothing else does)
+        raw_copy_err = hipSetDevice(h->device);
+        auto send = [&](size_t from, size_t to) {
+            if (raw_copy_err == hipSuccess && to > from)
+                raw_copy_err = hipMemcpyAsync(arena_at_post + from, sg + from, to - from, hipMemcpyHostToDevice, h->copy_stream);
+        };
         std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)E);
+        send(o_obs, o_isig);
         std::memcpy(sg + o_isig, d->inv_sigma2, sizeof(double) * (size_t)E);
         if (d->obs_right) {
             std::memcpy(sg + o_obsr, d->obs_right, sizeof(double) * (size_t)E);
@@ -493,10 +505,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         }
         std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
         std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
-        // ... and straight on to the device, on the copy stream: 3/4 of the upload is across the bus before the calling
-        // thread has finished its pass over the edges (the solve's first kernels wait for copy_event, nothing else does)
-        raw_copy_err = hipSetDevice(h->device);
-        if (raw_copy_err == hipSuccess) raw_copy_err = hipMemcpyAsync(arena_at_post + raw_begin, sg + raw_begin, edge_bytes_grouped - raw_begin, hipMemcpyHostToDevice, h->copy_stream);
+        send(o_isig, edge_bytes_grouped);
         if (raw_copy_err == hipSuccess) raw_copy_err = hipEventRecord(h->copy_event, h->copy_stream);
     });
     // (the pose-major slots are left for later: they are worked out while the device counts the pairs)
@@ -579,8 +588,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         // kernels on this stream start behind them.  (Edges not grouped by point: the helper's straight copies were
         // permuted again by pack_edges, so that part travels once more, behind the first copy.)
         HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, raw_begin - edge_a_bytes, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
-        if (!s.already_grouped) HIP_TRY(hipMemcpyAsync(h->arena + raw_begin, sg + raw_begin, edge_bytes - raw_begin, hipMemcpyHostToDevice, h->stream));
+        if (!s.already_grouped) {
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
+            HIP_TRY(hipMemcpyAsync(h->arena + raw_begin, sg + raw_begin, edge_bytes - raw_begin, hipMemcpyHostToDevice, h->stream));
+        }
         edge_b_queued = true;
         return MOVBA_OK;
     };
@@ -588,17 +599,39 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
     // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
     StructDev sd{};
-    const bool dev_structure = s.already_grouped && s.nfree > 0 && s.nfree <= 80 && !std::getenv("MOVBA_HOST_STRUCTURE");
-    size_t so_pid = 0, so_pptr = 0, so_cntw = 0, so_cnt = 0, so_err = 0;
+    // (on the device: up to 80 free keyframes, and as many keyframes in all as the kernels' LDS image has room for)
+    const bool dev_structure = s.already_grouped && s.nfree > 0 && s.nfree <= 80 && struct_lds_fits(s.nfree, NP) && !std::getenv("MOVBA_HOST_STRUCTURE");
+    size_t so_cntw = 0, so_cnt = 0, so_err = 0, so_ent0 = 0;
+    // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
+    // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
+    size_t noff = 0, o_ent = 0, o_slotpt = 0;
+    bool filled_early = false;
+    uint64_t fill_gen = 0;
+    auto launch_fill = [&]() -> int {
+        int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
+        sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff;
+        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
+        sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
+        sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
+        HIP_TRY(launch_struct_fill(sd, h->stream));
+        return MOVBA_OK;
+    };
+    auto launch_slotpt = [&]() -> int {
+        HIP_TRY(launch_slot_point(reinterpret_cast<const int32_t *>(h->arena + o_slot), reinterpret_cast<const int32_t *>(h->arena + o_gpoint),
+                                  reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
+        return MOVBA_OK;
+    };
     if (!dev_structure) {
         rc = build_structure(*d, h->st);
         if (rc < 0) return rc;
         if (!slots_packed) { pack_b(false); slots_packed = true; }
+        noff = (size_t)(s.nentries - s.E_free);
+        o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
     } else {
         const int nchunks = (s.P + 63) / 64;
         Carver sc;
         so_cnt = sc.take<int32_t>(nbins); so_err = sc.take<int32_t>(4);
-        so_pid = sc.take<int32_t>(nbins); so_pptr = sc.take<int32_t>(nbins + 1);
+        so_ent0 = sc.take<int32_t>(nbins);
         so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
         if (sc.off > h->scratch_cap) {
             if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
@@ -608,35 +641,48 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         }
         char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;    // tail of the staging buffer: the pair region is packed in front of it
         HIP_TRY(hipMemsetAsync(sa + so_err, 0, 16, h->stream));
-        sd.P = s.P; sd.nfree = nf; sd.nchunks = nchunks;
+        sd.P = s.P; sd.nfree = nf; sd.nchunks = nchunks; sd.NP = NP;
         // grouped edges, point ranges and hessian indices are read where the edge copy just put them
         sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
         sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
         sd.cntw = reinterpret_cast<int32_t *>(sa + so_cntw); sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt);
         sd.error = reinterpret_cast<int32_t *>(sa + so_err);
-        sd.pid = reinterpret_cast<int32_t *>(sa + so_pid); sd.pair_ptr = reinterpret_cast<int32_t *>(sa + so_pptr);
+        sd.ent0 = reinterpret_cast<int32_t *>(sa + so_ent0);
         HIP_TRY(launch_struct_count(sd, h->stream));
-        // cnt and the error word are adjacent in the scratch carve: one D2H copy
+        // cnt and the error word are adjacent in the scratch carve: one D2H copy; the host waits for exactly that copy, the
+        // stream goes on to the entry offsets of the fill kernel
         HIP_TRY(hipMemcpyAsync(misc, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipEventRecord(h->count_event, h->stream));
+        HIP_TRY(launch_struct_ptr(sd, h->stream));
         // the pose-major slots, while the device counts
         build_slots(h->st);
         pack_b(false); slots_packed = true;
         lap("edge H2D + count launches, slot pass");
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipEventSynchronize(h->count_event));
         if (*reinterpret_cast<const int32_t *>(misc + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
         lap("wait for the pair counts");
-        // observations, point ids, slots and initial estimates cross the bus while the host lays out the pairs
+        // slots, point ids, observations and initial estimates cross the bus, then the entry lists are filled, while the
+        // host lays out the pairs
         { const int rq = queue_edge_b(); if (rq) return rq; }
+        {
+            const int32_t *cnt = reinterpret_cast<const int32_t *>(misc);
+            int64_t n = 0;
+            for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) n += cnt[(size_t)i * nf + j];
+            if (n > (int64_t)0x7fffffff / 4) return MOVBA_ERR_ARG;
+            noff = (size_t)n;
+        }
+        o_ent = c.take<int32_t>(3 * noff + 4);
+        o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
+        if (c.off <= h->arena_cap && h->arena_gen == arena_gen_at_post) {
+            int rq = launch_fill(); if (rq) return rq;
+            rq = launch_slotpt(); if (rq) return rq;
+            filled_early = true; fill_gen = h->arena_gen;
+        }
+        lap("edge B H2D + fill kernel (queued)");
         rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
         lap("finish_pairs");
         if (rc < 0) return rc;
-        // pair ids / first entries for the fill kernel (launched once the arena is carved)
-        int32_t *pp32 = reinterpret_cast<int32_t *>(misc + nbins * sizeof(int32_t));
-        std::memcpy(misc, s.pid.data(), sizeof(int32_t) * nbins);
-        for (int p = 0; p <= s.npairs; ++p) pp32[p] = (int32_t)s.pair_ptr[p];
-        HIP_TRY(hipMemcpyAsync(sa + so_pid, misc, sizeof(int32_t) * nbins, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(sa + so_pptr, pp32, sizeof(int32_t) * (s.npairs + 1), hipMemcpyHostToDevice, h->stream));
-        lap("pid/pair_ptr H2D enqueue");
+        if ((size_t)(s.nentries - s.E_free) != noff) return MOVBA_ERR_ARG;
     }
     if (!edge_b_queued) { const int rq = queue_edge_b(); if (rq) return rq; }
     h->pp = PcgParams{};
@@ -644,7 +690,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     lap("pcg plan + coarse lists");
 
-    // ---- pair region (second H2D copy) ----
+    // ---- pair region (second H2D copy): packed in the staging buffer right behind the edge region, `hole` bytes before
+    // its place in the arena (the device-only arrays carved above sit in between) ----
+    const size_t pair_begin = c.off, hole = pair_begin - edge_bytes_max;
+    auto sp = [&](size_t o) { return sg + (o - hole); };
     const size_t o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<SchedItem>(s.sched.size() + 1);
     const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
     const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
@@ -668,12 +717,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
     const size_t o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
-    const size_t noff = (size_t)(s.nentries - s.E_free);                                     // off-diagonal entries (the diagonal ones are their slot)
-    const size_t o_ent_h2d = dev_structure ? 0 : c.take<int32_t>(3 * noff + 4);              // host-built entry lists travel with the pair region
+    if (!dev_structure) o_ent = c.take<int32_t>(3 * noff + 4);       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
     const size_t h2d = c.off;
     // ---- device-only region ----
-    const size_t o_ent = dev_structure ? c.take<int32_t>(3 * noff + 4) : o_ent_h2d;
-    const size_t o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
     size_t o_st[2][11];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
@@ -700,55 +746,49 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     rc2 = ensure_arena(h, total); if (rc2) return rc2;
     if (h->arena_gen != arena_gen_at_edge_copy) {
         // the arena was reallocated (told by its generation: the new allocation may sit at the old address): queue the
-        // edge region again (the staging copy is intact) and re-point the structure pass
+        // edge region again (the staging copy is intact); the fill below then runs on the new arena
         HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_bytes, hipMemcpyHostToDevice, h->stream));
-        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
-        sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
     }
-    if (h2d + misc_bytes > h->stage_cap) {
+    if (h2d - hole + misc_bytes > h->stage_cap) {
         // (rare: huge host-built entry lists) a bigger staging buffer: ensure_stage drains the stream first, so the edge copy
         // has landed; the edge region is packed again only to keep the buffer self-consistent
-        rc2 = ensure_stage(h, h2d + misc_bytes); if (rc2) return rc2;
+        rc2 = ensure_stage(h, h2d - hole + misc_bytes); if (rc2) return rc2;
         sg = h->stage;
         pack_edges(true);
     }
 
     // ---- pack the pair region ----
     if (!dev_structure && noff) {
-        int32_t *eh = reinterpret_cast<int32_t *>(sg + o_ent_h2d);
+        int32_t *eh = reinterpret_cast<int32_t *>(sp(o_ent));
         std::memcpy(eh, s.ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s.ent_j.data(), sizeof(int32_t) * noff);
         std::memcpy(eh + 2 * noff, s.ent_l.data(), sizeof(int32_t) * noff);
     }
-    std::memcpy(sg + o_items, s.items.data(), sizeof(Item) * (size_t)s.nitems);
-    std::memcpy(sg + o_sched, s.sched.data(), sizeof(SchedItem) * s.sched.size());
-    std::memcpy(sg + o_pi, s.pair_i.data(), sizeof(int32_t) * s.npairs);
-    std::memcpy(sg + o_pj, s.pair_j.data(), sizeof(int32_t) * s.npairs);
-    std::memcpy(sg + o_pis, s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
-    std::memcpy(sg + o_rowptr, s.row_ptr.data(), sizeof(int32_t) * (nf + 1));
-    std::memcpy(sg + o_rowent, s.row_ent.data(), sizeof(RowEnt) * s.row_ent.size());
-    if (!lane_plan.empty()) std::memcpy(sg + o_plan, lane_plan.data(), sizeof(int32_t) * lane_plan.size());
-    std::memcpy(sg + o_cg, s.cblk_g.data(), sizeof(int32_t) * ncb);
-    std::memcpy(sg + o_ch, s.cblk_h.data(), sizeof(int32_t) * ncb);
-    std::memcpy(sg + o_cp, s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
-    std::memcpy(sg + o_ce, s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
-    std::memcpy(sg + o_cij, s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
-    std::memcpy(sg + o_multi, s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
-    std::memcpy(sg + o_pid, s.pid.data(), sizeof(int32_t) * (size_t)nf * nf);
+    std::memcpy(sp(o_items), s.items.data(), sizeof(Item) * (size_t)s.nitems);
+    std::memcpy(sp(o_sched), s.sched.data(), sizeof(SchedItem) * s.sched.size());
+    std::memcpy(sp(o_pi), s.pair_i.data(), sizeof(int32_t) * s.npairs);
+    std::memcpy(sp(o_pj), s.pair_j.data(), sizeof(int32_t) * s.npairs);
+    std::memcpy(sp(o_pis), s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
+    std::memcpy(sp(o_rowptr), s.row_ptr.data(), sizeof(int32_t) * (nf + 1));
+    std::memcpy(sp(o_rowent), s.row_ent.data(), sizeof(RowEnt) * s.row_ent.size());
+    if (!lane_plan.empty()) std::memcpy(sp(o_plan), lane_plan.data(), sizeof(int32_t) * lane_plan.size());
+    std::memcpy(sp(o_cg), s.cblk_g.data(), sizeof(int32_t) * ncb);
+    std::memcpy(sp(o_ch), s.cblk_h.data(), sizeof(int32_t) * ncb);
+    std::memcpy(sp(o_cp), s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
+    std::memcpy(sp(o_ce), s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
+    std::memcpy(sp(o_cij), s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
+    std::memcpy(sp(o_multi), s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
+    std::memcpy(sp(o_pid), s.pid.data(), sizeof(int32_t) * (size_t)nf * nf);
     lap("carve + pack pair region");
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
-    HIP_TRY(hipMemcpyAsync(h->arena + edge_bytes_max, sg + edge_bytes_max, h2d - edge_bytes_max, hipMemcpyHostToDevice, h->stream));
-    if (dev_structure) {
-        int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
-        sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff; sd.n_diag = s.E_free;
-        sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
-        HIP_TRY(launch_struct_fill(sd, h->stream));
-    }
-    HIP_TRY(launch_slot_point(reinterpret_cast<const int32_t *>(h->arena + o_slot), reinterpret_cast<const int32_t *>(h->arena + o_gpoint),
-                              reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->arena + pair_begin, sg + edge_bytes_max, h2d - pair_begin, hipMemcpyHostToDevice, h->stream));
+    if (dev_structure && !(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_fill(); if (rq) return rq; }
+    if (!(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_slotpt(); if (rq) return rq; }
+    // the solve's kernels start behind the caller's arrays on the copy stream (the structure pass above did not need them)
+    HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
     // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were
     // copied to the staging buffer already (the next upload synchronises before it refills it)
-    lap("pair H2D + fill kernel (queued)");
+    lap("pair H2D (queued)");
     h->prof.upload_ms += now_ms() - t2 + upload_host_ms;
     h->h2d_bytes = h2d;
 

@@ -147,16 +147,15 @@ struct DevWindow {
 
 // Device view of the structure pass (struct_kernels.hip)
 struct StructDev {
-    int32_t P, nfree, nchunks, pad;
+    int32_t P, nfree, nchunks, NP;
     const int32_t *g_pose, *pt_start, *hidx;
     int32_t *cntw;              // nchunks x nfree^2: per-chunk counts, then their exclusive scan over the chunks
     int32_t *cnt;               // nfree^2: entries per pair bin
     int32_t *error;             // set when a keyframe observes a point twice
-    const int32_t *pid;         // nfree^2 -> pair id        (fill)
-    const int32_t *pair_ptr;    // npairs+1                   (fill)
+    int32_t *ent0;              // nfree^2: first off-diagonal entry of a pair bin (i < j; k_struct_ptr -> fill)
     const int32_t *slot;        // E: pose-major slot of a grouped edge (fill)
     int32_t *ent_i, *ent_j, *ent_l;     // off-diagonal entry lists (fill)
-    int32_t n_diag, pad6;
+    int32_t pad5, pad6;
 };
 
 struct PcgParams {

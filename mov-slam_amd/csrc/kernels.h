@@ -12,6 +12,8 @@ hipError_t configure_kernels(int unused);
 hipError_t configure_pcg_rows();
 hipError_t configure_struct_kernels();
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
+bool struct_lds_fits(int nfree, int NP);
+hipError_t launch_struct_ptr(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
 hipError_t launch_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);

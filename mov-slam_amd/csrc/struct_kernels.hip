@@ -4,10 +4,11 @@
 //
 // What it replaces in the reference is the part of g2o's BlockSolver::buildStructure that lays out the Hpl /
 // Hschur block pattern (called from optimizer.initializeOptimization(), /root/reference/src/Optimizer.cc:754);
-// on the host this pass cost as much as the whole GPU solve.
+// on the host this pass cost as much as the whole GPU solve.  The fill needs nothing from the host but the edges'
+// pose-major slots: it runs while the host lays out the pairs (finish_pairs) from the counts.
 //
-// One wave handles a chunk of 64 consecutive map points (one per lane).  For every pair bin (i * nf + j) the
-// wave builds, in LDS, the 64-bit mask of its points that contribute to the bin (atomic OR: the result does not
+// One workgroup handles a chunk of 64 consecutive map points (one per lane of each of its waves).  For every pair bin
+// (i * nf + j) it builds, in LDS, the 64-bit mask of its points that contribute to the bin (atomic OR: the result does not
 // depend on the order of the atomics).  The rank of a point inside its chunk is the popcount of the lower lanes'
 // bits, the offset of the chunk inside the pair's list is an exclusive scan of the per-chunk counts, so the entry
 // order (pair, then point) is exactly the host builder's and does not depend on scheduling.
@@ -20,65 +21,133 @@ namespace movba {
 
 constexpr int kDegCap = 16;     // observers per point whose hessian indices are cached in LDS (longer tracks read the rest from memory)
 
-// bins[b] |= bit of this lane, for every unordered couple of free observers (a <= b) of the lane's point
+// bins[b] |= bit of the point, for every unordered couple of free observers (a <= b) of the point.
+// One workgroup of kStructWaves waves per chunk: lane l of EVERY wave stands for point l of the chunk, and the waves deal the
+// point's couples among themselves (couple number mod kStructWaves): the kernel is a chain of LDS atomics and scattered
+// memory operations per couple, so a chunk's time is the longest chain of one lane (one wave per chunk: 39 us for the fill
+// at cfg3, with 313 waves on 256 CUs).
+constexpr int kStructWaves = 4;
+
+// LDS image of a chunk's workgroup: pair-bin masks, the caches of the points' first kDegCap observers (hessian index,
+// and for the fill their pose-major slot), the window's hessian-index table, and for the fill the chunk's row of scanned
+// counts and the bins' first entries.  Everything the couple loops look up is in LDS before they start: the dependent
+// global loads are pt_start -> (g_pose, slot), two round trips (five before: the launch boundary leaves the caches cold,
+// and the kernel was little more than that chain).
+__host__ __device__ inline size_t struct_lds_bytes(int nf, int NP, bool fill)
+{
+    const size_t nbins = (size_t)nf * nf;
+    return sizeof(unsigned long long) * nbins + sizeof(int) * (64 * kDegCap * (fill ? 2 : 1) + (size_t)NP + (fill ? 2 * nbins : 0));
+}
+
 template <bool FILL>
-__global__ __launch_bounds__(64) void k_struct_pairs(StructDev sd)
+__global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long masks[];     // nf x nf
-    const int lane = threadIdx.x;
+    constexpr int NT = 64 * kStructWaves;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int chunk = blockIdx.x;
     const int nf = sd.nfree, nbins = nf * nf;
-    for (int b = lane; b < nbins; b += 64) masks[b] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int *hcache_all = reinterpret_cast<int *>(masks + nbins);
+    int *scache_all = hcache_all + 64 * kDegCap;                            // (fill only)
+    int *htab = hcache_all + 64 * kDegCap * (FILL ? 2 : 1);                 // NP
+    int *cnt_row = htab + sd.NP, *ent0_row = cnt_row + nbins;               // (fill only)
     const int l = chunk * 64 + lane;
     int begin = 0, end = 0;
     if (l < sd.P) { begin = sd.pt_start[l]; end = sd.pt_start[l + 1]; }
+    for (int b = threadIdx.x; b < nbins; b += NT) masks[b] = 0ull;
+    for (int k = threadIdx.x; k < sd.NP; k += NT) htab[k] = sd.hidx[k];
+    if (FILL)
+        for (int b = threadIdx.x; b < nbins; b += NT) { cnt_row[b] = sd.cntw[(size_t)chunk * nbins + b]; ent0_row[b] = sd.ent0[b]; }
     const unsigned long long bit = 1ull << lane;
-    // the hessian indices of the lane's first kDegCap observers, gathered ONCE into LDS (the pair loops below would
-    // otherwise repeat the dependent g_pose -> hidx loads d^2 / 2 times per point: the kernel was a chain of memory round trips)
-    int *hcache = reinterpret_cast<int *>(masks + nbins) + lane * kDegCap;
-    for (int k = 0; k < kDegCap && begin + k < end; ++k) hcache[k] = sd.hidx[sd.g_pose[begin + k]];
-    auto hof = [&](int e) { const int k = e - begin; return k < kDegCap ? hcache[k] : sd.hidx[sd.g_pose[e]]; };
-    for (int a = begin; a < end; ++a) {
-        const int ha = hof(a);
-        if (ha < 0) continue;
-        for (int b = a; b < end; ++b) {
-            const int hb = hof(b);
-            if (hb < 0) continue;
-            if (b != a && hb == ha) { *sd.error = 1; continue; }          // same keyframe observing a point twice
-            const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
-            atomicOr(&masks[lo * nf + hi], bit);
-        }
+    int *hcache = hcache_all + lane * kDegCap, *scache = scache_all + lane * kDegCap;
+    int gp_reg[kDegCap / kStructWaves];
+#pragma unroll
+    for (int u = 0; u < kDegCap / kStructWaves; ++u) {
+        const int k = part + u * kStructWaves;
+        gp_reg[u] = begin + k < end ? sd.g_pose[begin + k] : -1;
+        if (FILL && begin + k < end) scache[k] = sd.slot[begin + k];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (!FILL) {
-        // per-chunk counts, chunk-major: the wave's nbins values leave as contiguous lines (bin-major, every lane wrote a
-        // line of its own: 24 MB of write traffic for 3 MB of counts at cfg3), and the fill pass finds its chunk's row in one
-        // 10 KB stretch
-        for (int b = lane; b < nbins; b += 64) sd.cntw[(size_t)chunk * nbins + b] = __popcll(masks[b]);
-    } else {
-        const unsigned long long lower = bit - 1ull;
-        for (int a = begin; a < end; ++a) {
-            const int ha = hof(a);
-            if (ha < 0) continue;
-            const int sa = sd.slot[a];
-            for (int b = a + 1; b < end; ++b) {              // (a, a): diagonal entries are their slot, nothing to store
-                const int hb = hof(b);
-                if (hb < 0 || hb == ha) continue;
-                const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
-                const int bin = lo * nf + hi;
-                const int pos = sd.pair_ptr[sd.pid[bin]] + sd.cntw[(size_t)chunk * nbins + bin] + __popcll(masks[bin] & lower) - sd.n_diag;
-                // pose-major slots of the two edges, the one of the lower hessian index first
-                const int sb = sd.slot[b];
-                sd.ent_i[pos] = (ha <= hb) ? sa : sb;
-                sd.ent_j[pos] = (ha <= hb) ? sb : sa;
-                sd.ent_l[pos] = l;
+    __syncthreads();                                                        // htab is in place
+#pragma unroll
+    for (int u = 0; u < kDegCap / kStructWaves; ++u) if (gp_reg[u] >= 0) hcache[part + u * kStructWaves] = htab[gp_reg[u]];
+    __syncthreads();
+    // The couples among a point's first kDegCap observers are walked with the observers' hessian indices (and slots) in
+    // registers and the couple loops fully unrolled: couple number k (in a fixed order) belongs to wave k mod kStructWaves.
+    // As loops over LDS-resident lists they cost ~100 cycles of LDS latency per couple and lane (8 of the count kernel's
+    // 16 us).  Observers past kDegCap (long tracks) take the generic loops below.
+    const int deg = end - begin, dcap = deg < kDegCap ? deg : kDegCap;
+    int hreg[kDegCap], sreg[kDegCap];
+#pragma unroll
+    for (int k = 0; k < kDegCap; ++k) { hreg[k] = k < dcap ? hcache[k] : -1; sreg[k] = (FILL && k < dcap) ? scache[k] : 0; }
+    auto hof = [&](int e) { const int k = e - begin; return k < kDegCap ? hcache[k] : htab[sd.g_pose[e]]; };
+    auto sof = [&](int e) { const int k = e - begin; return k < kDegCap ? scache[k] : sd.slot[e]; };
+    const unsigned long long lower = bit - 1ull;
+    // one couple (a <= b) of observers with hessian indices ha, hb >= 0
+    auto mark = [&](int ha, int hb, bool same_edge) {
+        if (!same_edge && hb == ha) { *sd.error = 1; return; }               // same keyframe observing a point twice
+        const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
+        atomicOr(&masks[lo * nf + hi], bit);
+    };
+    auto emit = [&](int ha, int hb, int sa, int sb) {
+        const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
+        const int bin = lo * nf + hi;
+        const int pos = ent0_row[bin] + cnt_row[bin] + __popcll(masks[bin] & lower);
+        // pose-major slots of the two edges, the one of the lower hessian index first
+        sd.ent_i[pos] = (ha <= hb) ? sa : sb;
+        sd.ent_j[pos] = (ha <= hb) ? sb : sa;
+        sd.ent_l[pos] = l;
+    };
+#if !defined(MOVBA_STRUCT_SKIP) || MOVBA_STRUCT_SKIP != 1
+    {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < kDegCap; ++a)
+#pragma unroll
+            for (int b = a; b < kDegCap; ++b, ++k)
+                if ((k & (kStructWaves - 1)) == part && hreg[a] >= 0 && hreg[b] >= 0) mark(hreg[a], hreg[b], a == b);
+        if (deg > kDegCap) {
+            int turn = 0;
+            for (int a = begin; a < end; ++a) {
+                const int ha = hof(a);
+                if (ha < 0) continue;
+                for (int b = max(a, begin + kDegCap); b < end; ++b) {
+                    const int hb = hof(b);
+                    if (hb < 0) continue;
+                    if ((turn++ & (kStructWaves - 1)) != part) continue;
+                    mark(ha, hb, a == b);
+                }
             }
         }
+    }
+#endif
+    __syncthreads();
+    if (!FILL) {
+        // per-chunk counts, chunk-major: the chunk's nbins values leave as contiguous lines, and the fill pass finds its
+        // chunk's row in one 10 KB stretch
+        for (int b = threadIdx.x; b < nbins; b += NT) sd.cntw[(size_t)chunk * nbins + b] = __popcll(masks[b]);
+    } else {
+#if !defined(MOVBA_STRUCT_SKIP) || MOVBA_STRUCT_SKIP != 2
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < kDegCap; ++a)
+#pragma unroll
+            for (int b = a + 1; b < kDegCap; ++b, ++k)            // (a, a): diagonal entries are their slot, nothing to store
+                if ((k & (kStructWaves - 1)) == part && hreg[a] >= 0 && hreg[b] >= 0 && hreg[a] != hreg[b]) emit(hreg[a], hreg[b], sreg[a], sreg[b]);
+        if (deg > kDegCap) {
+            int turn = 0;
+            for (int a = begin; a < end; ++a) {
+                const int ha = hof(a);
+                if (ha < 0) continue;
+                const int sa = sof(a);
+                for (int b = max(a + 1, begin + kDegCap); b < end; ++b) {
+                    const int hb = hof(b);
+                    if (hb < 0 || hb == ha) continue;
+                    if ((turn++ & (kStructWaves - 1)) != part) continue;
+                    emit(ha, hb, sa, sof(b));
+                }
+            }
+        }
+#endif
     }
 }
 
@@ -119,6 +188,32 @@ __global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
     if (live && sy == 0) sd.cnt[bin] = total;
 }
 
+// first off-diagonal entry of every pair bin: the pairs are numbered diagonal first, then the off-diagonal bins with
+// entries in row-major order (structure.cpp, finish_pairs), and the off-diagonal entry lists follow that order, so
+// ent0[bin] is the exclusive prefix sum of cnt over the bins (i, j), i < j, taken row-major.  One workgroup: every
+// thread sums a run of consecutive bins, the run totals are scanned through LDS.
+__global__ __launch_bounds__(1024) void k_struct_ptr(StructDev sd)
+{
+    __shared__ int tot[1024];
+    const int nf = sd.nfree, nbins = nf * nf;
+    const int per = (nbins + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(nbins, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += (b / nf < b % nf) ? sd.cnt[b] : 0;
+    tot[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele, inclusive
+        const int v = threadIdx.x >= d ? tot[threadIdx.x - d] : 0;
+        __syncthreads();
+        tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = tot[threadIdx.x] - sum;
+    for (int b = b0; b < b1; ++b) {
+        sd.ent0[b] = run;
+        run += (b / nf < b % nf) ? sd.cnt[b] : 0;
+    }
+}
+
 // map point of every pose-major slot (what a diagonal schur entry needs besides its slot)
 __global__ __launch_bounds__(256) void k_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E)
 {
@@ -134,24 +229,32 @@ hipError_t launch_slot_point(const int32_t *slot, const int32_t *g_point, int32_
 
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
 {
-    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree + sizeof(int) * 64 * kDegCap;
-    hipLaunchKernelGGL(k_struct_pairs<false>, dim3(sd.nchunks), dim3(64), lds, s, sd);
+    const size_t lds = struct_lds_bytes(sd.nfree, sd.NP, false);
+    hipLaunchKernelGGL(k_struct_pairs<false>, dim3(sd.nchunks), dim3(64 * kStructWaves), lds, s, sd);
     hipLaunchKernelGGL(k_struct_scan, dim3((sd.nfree * sd.nfree + 63) / 64), dim3(1024), 0, s, sd);
+    return hipGetLastError();
+}
+
+bool struct_lds_fits(int nfree, int NP) { return struct_lds_bytes(nfree, NP, true) <= 150 * 1024; }
+
+hipError_t launch_struct_ptr(const StructDev &sd, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_struct_ptr, dim3(1), dim3(1024), 0, s, sd);
     return hipGetLastError();
 }
 
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s)
 {
-    const size_t lds = sizeof(unsigned long long) * (size_t)sd.nfree * sd.nfree + sizeof(int) * 64 * kDegCap;
-    hipLaunchKernelGGL(k_struct_pairs<true>, dim3(sd.nchunks), dim3(64), lds, s, sd);
+    const size_t lds = struct_lds_bytes(sd.nfree, sd.NP, true);
+    hipLaunchKernelGGL(k_struct_pairs<true>, dim3(sd.nchunks), dim3(64 * kStructWaves), lds, s, sd);
     return hipGetLastError();
 }
 
 hipError_t configure_struct_kernels()
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_struct_pairs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_struct_pairs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_struct_pairs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_struct_pairs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
 }
 
 }  // namespace movba
