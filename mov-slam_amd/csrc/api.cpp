@@ -456,6 +456,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_gpoint = c.take<int32_t>(E);
     const size_t o_free = c.take<int32_t>(NP + 1);
     const size_t o_slot = c.take<int32_t>(E);
+    const size_t o_base = c.take<int32_t>(NP + 1);             // first pose-major slot of every keyframe (slots are completed on the device)
     // (the caller's own arrays, contiguous: they cross the bus on the copy stream, straight from the helper thread)
     const size_t raw_begin = c.off;
     const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
@@ -508,8 +509,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         send(o_isig, edge_bytes_grouped);
         if (raw_copy_err == hipSuccess) raw_copy_err = hipEventRecord(h->copy_event, h->copy_stream);
     });
-    // (the pose-major slots are left for later: they are worked out while the device counts the pairs)
-    int rc = build_basic(*d, h->st, /*defer_slots=*/true);
+    // (the pose-major slots are left to the device when the edges come grouped by point: the pass leaves each edge's rank
+    // among its keyframe's edges where the slots go)
+    int rc = build_basic(*d, h->st, reinterpret_cast<int32_t *>(sg + o_slot));
+    bool rank_mode = true;              // the staging buffer's slot array holds ranks; pose_slot0 the keyframes' first slots
     lap("build_basic");
     bool helper_done = false;
     auto wait_helper = [&]() -> int {
@@ -544,7 +547,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     // ... and the rest of the derived arrays
     auto pack_b = [&](bool raw_too) {
         if (!s.already_grouped) std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
-        std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
+        if (!rank_mode) std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
+        else std::memcpy(sg + o_base, s.pose_slot0.data(), sizeof(int32_t) * NP);
         std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
         double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
         double *obr = reinterpret_cast<double *>(sg + o_obsr);
@@ -569,7 +573,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (!s.already_grouped) {
         // (rare: the helper's straight copies get permuted below, so it has to be through with them)
         const int rw = wait_helper(); if (rw) return rw;
-        build_slots(h->st);
+        build_slots(h->st); rank_mode = false;
         pack_edges(false);
         slots_packed = true;
     } else {
@@ -617,13 +621,15 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         return MOVBA_OK;
     };
     auto launch_slotpt = [&]() -> int {
-        HIP_TRY(launch_slot_point(reinterpret_cast<const int32_t *>(h->arena + o_slot), reinterpret_cast<const int32_t *>(h->arena + o_gpoint),
-                                  reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
+        HIP_TRY(launch_slot_point(reinterpret_cast<int32_t *>(h->arena + o_slot), reinterpret_cast<const int32_t *>(h->arena + o_gpose),
+                                  rank_mode ? reinterpret_cast<const int32_t *>(h->arena + o_base) : nullptr,
+                                  reinterpret_cast<const int32_t *>(h->arena + o_gpoint), reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
         return MOVBA_OK;
     };
     if (!dev_structure) {
-        rc = build_structure(*d, h->st);
+        rc = build_structure(*d, h->st);         // (runs build_basic again, with the slots this time)
         if (rc < 0) return rc;
+        rank_mode = false;
         if (!slots_packed) { pack_b(false); slots_packed = true; }
         noff = (size_t)(s.nentries - s.E_free);
         o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
@@ -654,10 +660,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         HIP_TRY(hipMemcpyAsync(misc, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipEventRecord(h->count_event, h->stream));
         HIP_TRY(launch_struct_ptr(sd, h->stream));
-        // the pose-major slots, while the device counts
-        build_slots(h->st);
         pack_b(false); slots_packed = true;
-        lap("edge H2D + count launches, slot pass");
+        lap("edge H2D + count launches");
         HIP_TRY(hipEventSynchronize(h->count_event));
         if (*reinterpret_cast<const int32_t *>(misc + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
         lap("wait for the pair counts");
@@ -674,8 +678,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_ent = c.take<int32_t>(3 * noff + 4);
         o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
         if (c.off <= h->arena_cap && h->arena_gen == arena_gen_at_post) {
-            int rq = launch_fill(); if (rq) return rq;
-            rq = launch_slotpt(); if (rq) return rq;
+            int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
+            rq = launch_fill(); if (rq) return rq;
             filled_early = true; fill_gen = h->arena_gen;
         }
         lap("edge B H2D + fill kernel (queued)");
@@ -782,8 +786,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
     HIP_TRY(hipMemcpyAsync(h->arena + pair_begin, sg + edge_bytes_max, h2d - pair_begin, hipMemcpyHostToDevice, h->stream));
-    if (dev_structure && !(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_fill(); if (rq) return rq; }
     if (!(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_slotpt(); if (rq) return rq; }
+    if (dev_structure && !(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_fill(); if (rq) return rq; }
     // the solve's kernels start behind the caller's arrays on the copy stream (the structure pass above did not need them)
     HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
     // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were

@@ -15,7 +15,7 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
 bool struct_lds_fits(int nfree, int NP);
 hipError_t launch_struct_ptr(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
-hipError_t launch_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s);
+hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s);
 

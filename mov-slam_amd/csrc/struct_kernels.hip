@@ -214,16 +214,24 @@ __global__ __launch_bounds__(1024) void k_struct_ptr(StructDev sd)
     }
 }
 
-// map point of every pose-major slot (what a diagonal schur entry needs besides its slot)
-__global__ __launch_bounds__(256) void k_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E)
+// map point of every pose-major slot (what a diagonal schur entry needs besides its slot).  With `base` the slot array
+// arrives holding each edge's rank among its keyframe's edges (structure.h, build_basic): the slots are completed here.
+__global__ __launch_bounds__(256) void k_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g < E) { const int sl = slot[g]; if (sl >= 0) slot_point[sl] = g_point[g]; }
+    if (g >= E) return;
+    int sl = slot[g];
+    if (base) {
+        const int b = base[g_pose[g]];
+        sl = b >= 0 ? b + sl : -1;
+        slot[g] = sl;
+    }
+    if (sl >= 0) slot_point[sl] = g_point[g];
 }
 
-hipError_t launch_slot_point(const int32_t *slot, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s)
+hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s)
 {
-    if (E > 0) hipLaunchKernelGGL(k_slot_point, dim3((E + 255) / 256), dim3(256), 0, s, slot, g_point, slot_point, E);
+    if (E > 0) hipLaunchKernelGGL(k_slot_point, dim3((E + 255) / 256), dim3(256), 0, s, slot, g_pose, base, g_point, slot_point, E);
     return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@
 
 namespace movba {
 
-int build_basic(const movba_lba_desc& d, Structure& s, bool defer_slots)
+int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out)
 {
     const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
     if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
@@ -33,7 +33,8 @@ int build_basic(const movba_lba_desc& d, Structure& s, bool defer_slots)
         for (int e = 0; e < E; ++e) {
             const int ip = ep[e], l = el[e];
             if ((unsigned)ip >= (unsigned)NP || (unsigned)l >= (unsigned)P) return MOVBA_ERR_ARG;
-            pe[ip]++;
+            const int r = pe[ip]++;
+            if (rank_out) rank_out[e] = r;    // (the edge's rank among its keyframe's edges: slot = first slot of the keyframe + rank)
             pend[l] = e + 1;
             grouped &= l >= prev_l;
             prev_l = l;
@@ -84,7 +85,7 @@ int build_basic(const movba_lba_desc& d, Structure& s, bool defer_slots)
         if (s.pose_edges[i] > 0) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); pstart[i] = run; run += s.pose_edges[i]; }
     }
     s.E_free = run;
-    if (!defer_slots) build_slots(s);
+    if (!rank_out) build_slots(s);
     if (E == 0) return MOVBA_EMPTY;
     return MOVBA_OK;
 }

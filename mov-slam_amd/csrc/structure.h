@@ -83,9 +83,12 @@ constexpr int kSchurChunk = MOVBA_SCHUR_EPW * kSchurWPI;       // entries per sc
 // entry filling, all on the host; the upload path normally runs only build_basic and finish_pairs on the host and
 // leaves counting / filling to the device (struct_kernels.hip).
 int build_structure(const movba_lba_desc& d, Structure& s);
-int build_basic(const movba_lba_desc& d, Structure& s, bool defer_slots = false);   // validation, grouping by point, hessian indices
-void build_slots(Structure& s);                               // pose-major slot of every grouped edge (the part of build_basic that defer_slots leaves out;
-                                                              // s.gp must still be valid: the caller's arrays, or s.g_pose)
+// validation, grouping by point, hessian indices, pose-major slots.  With rank_out (E values) the slots are NOT built: every
+// edge's rank among the edges of its keyframe, in caller order, is stored there instead, and pose_slot0 keeps the first slot
+// of every free keyframe (-1: fixed or unobserved) — for edges already grouped by point, slot = pose_slot0[pose] + rank, which
+// the upload path leaves to the device; build_slots(s) completes the job on the host otherwise.
+int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out = nullptr);
+void build_slots(Structure& s);                               // (s.gp must still be valid: the caller's arrays, or s.g_pose)
 int finish_pairs(Structure& s, const int32_t* cnt);           // cnt[i*nfree+j] (i <= j) -> pairs, items, gather lists
 
 }  // namespace movba
