@@ -1,5 +1,6 @@
 """Randomised GPU-vs-oracle parity sweep over window shapes (run on a GPU box): free/fixed keyframe counts around every
-code-path boundary (one keyframe per wave, two rows per aggregate, VGPR overflow, generic PCG), track lengths, stereo."""
+code-path boundary (one keyframe per wave, two rows per aggregate, VGPR overflow, generic PCG), track lengths, stereo,
+unobserved map points, edges that do not arrive grouped by map point."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
@@ -23,6 +24,18 @@ for it in range(n):
         w = synth.make_window(K, F, P, seed=seed, run_lo=lo, run_hi=max(lo, hi), stereo_frac=stereo)
     except Exception as e:          # degenerate generator input
         continue
+    variant = int(rng.integers(0, 5))
+    if variant == 0 and w.n_edges > 40:                 # map points nobody observes: drop all edges of a few points
+        dead = rng.choice(w.n_points, size=max(1, w.n_points // 25), replace=False)
+        keep = ~np.isin(w.edge_point, dead)
+        kf_alive = np.bincount(w.edge_pose[keep], minlength=w.n_poses) > 0
+        if kf_alive.all():
+            w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[keep], w.edge_point[keep], w.obs[keep], w.inv_sigma2[keep]
+            if getattr(w, "obs_right", None) is not None: w.obs_right = w.obs_right[keep]
+    elif variant == 1:                                  # edges not grouped by map point (host structure pass, permuted arrays)
+        pm = rng.permutation(w.n_edges)
+        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[pm], w.edge_point[pm], w.obs[pm], w.inv_sigma2[pm]
+        if getattr(w, "obs_right", None) is not None: w.obs_right = w.obs_right[pm]
     # keyframes held by a handful of observations make the reduced system rank-deficient up to the LM damping: the PCG gives
     # up there and the direct solver takes over; they are held to SURVEY 8(d)'s float32-map tolerance (two exact solvers differ
     # by cond(S) * eps in the weak directions) and counted as mismatches like every other window when they exceed it
