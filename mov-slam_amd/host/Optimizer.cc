@@ -99,9 +99,20 @@ namespace MOV_SLAM
             int32_t vertex;                         // index of the keyframe's vertex in the window (-1: none), filled by push_point
         };
 
+        // What the edges of a window must agree on: ONE pinhole (and one stereo baseline) per window (see emit_point).
+        struct CamState
+        {
+            double cam[4] = {0, 0, 0, 0};
+            bool cam_set = false;
+            bool any_stereo = false;
+            double bf = 0.0;
+            bool cam_mixed = false;                 // keyframes with different intrinsics / baselines in one window
+            void reset() { cam_set = false; any_stereo = false; bf = 0.0; cam_mixed = false; }
+        };
+
         // Flattened window in the layout of movba_lba_desc, plus the bookkeeping to write results back.
         // One instance per calling thread, reused from call to call (the vectors keep their capacity).
-        struct Flat
+        struct Flat : CamState
         {
             std::vector<ObsRef> obs_all;            // observation lists of the local map points, back to back (map order)
             std::vector<size_t> obs_start;          // first observation of local map point k; one more entry at the end
@@ -111,9 +122,13 @@ namespace MOV_SLAM
                 obs_all.clear(); obs_start.clear(); point_edge0.clear();
                 kfs.clear(); fixed.clear(); poses.clear(); mps.clear(); points.clear(); edge_pose.clear(); edge_point.clear();
                 obs.clear(); inv_sigma2.clear(); edge_kf.clear(); edge_mp.clear(); obs_right.clear();
-                cam_set = false; any_stereo = false; bf = 0.0; cam_mixed = false;
+                reset();
             }
-            bool cam_mixed = false;                 // keyframes with different intrinsics / baselines in one window
+            void resize_edges(size_t n)
+            {
+                edge_pose.resize(n); edge_point.resize(n); obs.resize(2 * n); inv_sigma2.resize(n);
+                edge_kf.resize(n); edge_mp.resize(n); obs_right.resize(n);
+            }
             std::vector<KeyFrame *> kfs;            // vertex order: ascending mnId (g2o's hessian order)
             std::vector<uint8_t> fixed;
             std::vector<double> poses;
@@ -123,11 +138,7 @@ namespace MOV_SLAM
             std::vector<double> obs, inv_sigma2;
             std::vector<KeyFrame *> edge_kf;        // vpEdgeKFMono
             std::vector<MapPoint *> edge_mp;        // vpMapPointEdgeMono
-            double cam[4] = {0, 0, 0, 0};
-            bool cam_set = false;
             std::vector<double> obs_right;          // mvuRight of stereo observations, -1 for monocular ones
-            bool any_stereo = false;
-            double bf = 0.0;
         };
 
         void push_pose(Flat &f, KeyFrame *pKF, bool isFixed)
@@ -157,13 +168,13 @@ namespace MOV_SLAM
             f.kfs.swap(g.kfs); f.fixed.swap(g.fixed); f.poses.swap(g.poses);
         }
 
-        // One MapPoint vertex and its edges (Optimizer.cc:623-705 / :142-190) from the point's observation list.
-        // Returns the number of edges added.
-        int push_point(Flat &f, MapPoint *pMP, ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex, Map *pCurrentMap, bool requireSameMap)
+        // The edges of one MapPoint vertex (Optimizer.cc:623-705 / :142-190) from the point's observation list, written to
+        // edge slots e0, e0 + 1, ... of `f` (sized by the caller: at most one edge per observation) as edges of problem point
+        // `pid`.  Returns the number of edges written.
+        int emit_point(Flat &f, CamState &cs, size_t e0, MapPoint *pMP, int32_t pid, ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex,
+                       Map *pCurrentMap, bool requireSameMap)
         {
-            const Eigen::Vector3f wp = pMP->GetWorldPos();
-            const int32_t pid = (int32_t)f.mps.size();
-            int nEdges = 0;
+            size_t e = e0;
             for (; ob != ob_end; ++ob)
             {
                 KeyFrame *pKFi = ob->kf;
@@ -181,33 +192,44 @@ namespace MOV_SLAM
                 const float kp_ur = pKFi->mvuRight[leftIndex];
                 if (kp_ur >= 0)
                 {
-                    if (f.any_stereo && f.bf != (double)pKFi->mbf) f.cam_mixed = true;
-                    f.any_stereo = true;
-                    f.bf = pKFi->mbf;
+                    if (cs.any_stereo && cs.bf != (double)pKFi->mbf) cs.cam_mixed = true;
+                    cs.any_stereo = true;
+                    cs.bf = pKFi->mbf;
                 }
-                f.obs_right.push_back(kp_ur >= 0 ? (double)kp_ur : -1.0);
+                f.obs_right[e] = kp_ur >= 0 ? (double)kp_ur : -1.0;
                 // e->pCamera = pKFi->mpCamera per edge (Optimizer.cc:664): the kernels take ONE pinhole for the window, which
                 // is what every MoV-SLAM configuration has (one camera, Tracking.cc builds a single mpCamera); a window
                 // whose keyframes disagree is refused by the callers below instead of being solved with the wrong intrinsics
-                if (!f.cam_set)
+                if (!cs.cam_set)
                 {
-                    for (int k = 0; k < 4; ++k) f.cam[k] = pKFi->mpCamera->getParameter(k);
-                    f.cam_set = true;
+                    for (int k = 0; k < 4; ++k) cs.cam[k] = pKFi->mpCamera->getParameter(k);
+                    cs.cam_set = true;
                 }
                 else
                     for (int k = 0; k < 4; ++k)
-                        if (f.cam[k] != (double)pKFi->mpCamera->getParameter(k)) f.cam_mixed = true;
-                f.edge_pose.push_back(vertex);
-                f.edge_point.push_back(pid);
-                f.obs.push_back(kpUn.pt.x); f.obs.push_back(kpUn.pt.y);
-                f.inv_sigma2.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
-                f.edge_kf.push_back(pKFi);
-                f.edge_mp.push_back(pMP);
-                ++nEdges;
+                        if (cs.cam[k] != (double)pKFi->mpCamera->getParameter(k)) cs.cam_mixed = true;
+                f.edge_pose[e] = vertex;
+                f.edge_point[e] = pid;
+                f.obs[2 * e] = kpUn.pt.x; f.obs[2 * e + 1] = kpUn.pt.y;
+                f.inv_sigma2[e] = pKFi->mvInvLevelSigma2[kpUn.octave];
+                f.edge_kf[e] = pKFi;
+                f.edge_mp[e] = pMP;
+                ++e;
             }
+            return (int)(e - e0);
+        }
+
+        // One MapPoint vertex and its edges appended to `f`.  Returns the number of edges added (none: no vertex either).
+        int push_point(Flat &f, MapPoint *pMP, ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex, Map *pCurrentMap, bool requireSameMap)
+        {
+            const Eigen::Vector3f wp = pMP->GetWorldPos();
+            const size_t e0 = f.edge_pose.size();
+            f.resize_edges(e0 + (size_t)(ob_end - ob));
+            const int nEdges = emit_point(f, f, e0, pMP, (int32_t)f.mps.size(), ob, ob_end, kfIndex, pCurrentMap, requireSameMap);
+            f.resize_edges(e0 + (size_t)nEdges);
             if (nEdges > 0)
             {
-                f.point_edge0.push_back((int32_t)f.edge_pose.size() - nEdges);
+                f.point_edge0.push_back((int32_t)e0);
                 f.mps.push_back(pMP);
                 f.points.push_back(wp(0)); f.points.push_back(wp(1)); f.points.push_back(wp(2));
             }
@@ -273,6 +295,8 @@ namespace MOV_SLAM
         };
 
         thread_local Flat tls_flat;
+        thread_local std::vector<size_t> tls_point_local;
+        thread_local std::vector<int32_t> tls_nedge;
         thread_local Solved tls_solved;
 
         Solved &solve(Flat &f, int nIterations, bool bRobust, bool *pbStopFlag)
@@ -430,20 +454,24 @@ namespace MOV_SLAM
             }
         }
 
+        static const bool lapon = std::getenv("MOVBA_ADAPTER_LAPS") != nullptr;
+        double lap_t = now_ms();
+        auto lap = [&](const char *what) { if (lapon) { const double t = now_ms(); std::fprintf(stderr, "adapter lap: %-24s %.3f ms\n", what, t - lap_t); lap_t = t; } };
+        lap("selection");
         // ---- ONE copy of every local point's observation map, shared by the fixed-keyframe pass, the edge pass and the
         //      normal / depth update after the solve (the reference copies the std::map three times per point) ----
         Flat &f = tls_flat;
         f.clear();
-        f.obs_start.reserve(lLocalMapPoints.size() + 1);
-        for (MapPoint *pMP : lLocalMapPoints)
+        const size_t nLocal = lLocalMapPoints.size();
+        f.obs_start.assign(nLocal + 1, 0);
+        for (size_t lp = 0; lp < nLocal; ++lp)
         {
-            f.obs_start.push_back(f.obs_all.size());
-            const std::map<KeyFrame *, std::tuple<int, int>> observations = pMP->GetObservations();
+            const std::map<KeyFrame *, std::tuple<int, int>> observations = lLocalMapPoints[lp]->GetObservations();
             for (std::map<KeyFrame *, std::tuple<int, int>>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit)
                 f.obs_all.push_back(ObsRef{mit->first, std::get<0>(mit->second), std::get<1>(mit->second), -1});
+            f.obs_start[lp + 1] = f.obs_all.size();
         }
-        f.obs_start.push_back(f.obs_all.size());
-
+        lap("observation copies");
         // ---- fixed keyframes: other observers of the local points (Optimizer.cc:506-523) ----
         std::vector<KeyFrame *> lFixedCameras;
         for (const ObsRef &ob : f.obs_all)
@@ -460,6 +488,7 @@ namespace MOV_SLAM
         if (num_fixedKF == 0)
             return;                                             // "LBA aborted" (Optimizer.cc:525-529)
 
+        lap("fixed keyframes");
         // ---- flatten (replaces the g2o vertex / edge construction, Optimizer.cc:532-747) ----
         pCurrentMap->msOptKFs.clear();
         pCurrentMap->msFixedKFs.clear();
@@ -478,20 +507,67 @@ namespace MOV_SLAM
         KfIndex kfIndex;
         kfIndex.build(f.kfs);
 
+        lap("poses");
+        // every local point writes its vertex at its own index and its edges where its observations start (at most one
+        // edge per observation): plain indexed stores into arrays sized once.  Almost always every observation becomes an
+        // edge (all observers are local or fixed keyframes of this window) and the arrays are final as they are; otherwise
+        // the gaps are closed below.
         int nEdges = 0;
         std::vector<MapPoint *> edgeless;                        // vertices g2o would keep but never move
-        std::vector<size_t> point_local;                         // problem point k -> its index among the local map points
-        point_local.reserve(lLocalMapPoints.size());
-        for (size_t lp = 0; lp < lLocalMapPoints.size(); ++lp)
+        std::vector<size_t> &point_local = tls_point_local;      // problem point k -> its index among the local map points
+        std::vector<int32_t> &nedge = tls_nedge;
+        const size_t nObsAll = f.obs_all.size();
+        f.resize_edges(nObsAll);
+        f.mps.assign(nLocal, nullptr); f.points.resize(3 * nLocal); nedge.resize(nLocal);
+        for (size_t lp = 0; lp < nLocal; ++lp)
         {
             MapPoint *pMP = lLocalMapPoints[lp];
-            const int n = push_point(f, pMP, f.obs_all.data() + f.obs_start[lp], f.obs_all.data() + f.obs_start[lp + 1], kfIndex, pCurrentMap, true);
-            if (n == 0) edgeless.push_back(pMP);
-            else point_local.push_back(lp);
-            nEdges += n;
+            const Eigen::Vector3f wp = pMP->GetWorldPos();
+            nedge[lp] = emit_point(f, f, f.obs_start[lp], pMP, (int32_t)lp, f.obs_all.data() + f.obs_start[lp],
+                                   f.obs_all.data() + f.obs_start[lp + 1], kfIndex, pCurrentMap, true);
+            f.mps[lp] = pMP;
+            f.points[3 * lp] = wp(0); f.points[3 * lp + 1] = wp(1); f.points[3 * lp + 2] = wp(2);
         }
-        f.point_edge0.push_back((int32_t)f.edge_pose.size());
+        bool dense = true;
+        for (size_t lp = 0; lp < nLocal; ++lp)
+        {
+            nEdges += nedge[lp];
+            dense &= nedge[lp] > 0 && (size_t)nedge[lp] == f.obs_start[lp + 1] - f.obs_start[lp];
+        }
+        point_local.resize(nLocal);
+        f.point_edge0.resize(nLocal + 1);
+        if (dense)
+        {
+            for (size_t lp = 0; lp < nLocal; ++lp) { point_local[lp] = lp; f.point_edge0[lp] = (int32_t)f.obs_start[lp]; }
+            f.point_edge0[nLocal] = (int32_t)nObsAll;
+        }
+        else
+        {
+            size_t eo = 0, k = 0;
+            for (size_t lp = 0; lp < nLocal; ++lp)
+            {
+                const size_t n = (size_t)nedge[lp], src = f.obs_start[lp];
+                if (n == 0) { edgeless.push_back(lLocalMapPoints[lp]); continue; }
+                for (size_t q = 0; q < n; ++q)
+                {
+                    f.edge_pose[eo + q] = f.edge_pose[src + q]; f.edge_point[eo + q] = (int32_t)k;
+                    f.obs[2 * (eo + q)] = f.obs[2 * (src + q)]; f.obs[2 * (eo + q) + 1] = f.obs[2 * (src + q) + 1];
+                    f.inv_sigma2[eo + q] = f.inv_sigma2[src + q]; f.edge_kf[eo + q] = f.edge_kf[src + q];
+                    f.edge_mp[eo + q] = f.edge_mp[src + q]; f.obs_right[eo + q] = f.obs_right[src + q];
+                }
+                f.mps[k] = f.mps[lp];
+                for (int q = 0; q < 3; ++q) f.points[3 * k + q] = f.points[3 * lp + q];
+                f.point_edge0[k] = (int32_t)eo;
+                point_local[k] = lp;
+                eo += n; ++k;
+            }
+            f.resize_edges(eo);
+            f.mps.resize(k); f.points.resize(3 * k); point_local.resize(k);
+            f.point_edge0.resize(k + 1);
+            f.point_edge0[k] = (int32_t)eo;
+        }
         num_edges = nEdges;
+        lap("points and edges");
         if (f.cam_mixed)
         {
             report_mixed_cameras("LocalBundleAdjustment");
@@ -513,14 +589,14 @@ namespace MOV_SLAM
 
         // ---- inlier check in vpEdgesMono order (Optimizer.cc:757-775) ----
         std::vector<std::pair<KeyFrame *, MapPoint *>> vToErase;
-        vToErase.reserve(f.edge_kf.size());
         for (size_t i = 0; i < f.edge_kf.size(); i++)
         {
+            if (!s.outlier[i])
+                continue;
             MapPoint *pMP = f.edge_mp[i];
             if (pMP->isBad())
                 continue;
-            if (s.outlier[i])
-                vToErase.push_back(std::make_pair(f.edge_kf[i], pMP));
+            vToErase.push_back(std::make_pair(f.edge_kf[i], pMP));
         }
 
         // ---- write-back under the map mutex (Optimizer.cc:807-840) ----

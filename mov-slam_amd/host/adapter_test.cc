@@ -3,6 +3,7 @@
 // points, and dumps what the map received.  Needs a GPU at run time (no CPU fallback).
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -25,6 +26,7 @@ static int run_lba(const char *in, const char *out, bool global)
     if (!f) return 2;
     const std::vector<int32_t> hd = rd<int32_t>(f, 4);
     const int NP = hd[0], P = hd[1], E = hd[2];
+    const int bad_kf = hd[3] - 1;                  // (4th header word: 1 + index of a keyframe to flag bad, 0 = none)
     const std::vector<uint8_t> fixed = rd<uint8_t>(f, NP);
     const std::vector<double> poses = rd<double>(f, 7 * (size_t)NP), points = rd<double>(f, 3 * (size_t)P);
     const std::vector<int32_t> ep = rd<int32_t>(f, E), el = rd<int32_t>(f, E);
@@ -35,6 +37,11 @@ static int run_lba(const char *in, const char *out, bool global)
     if (fread(&bf, sizeof(double), 1, f) == 1) obs_right = rd<double>(f, E);
     fclose(f);
 
+    // $MOVBA_ADAPTER_REPS: the call repeated on a freshly built copy of the map; the LAST repetition is written out (its
+    // timing is the steady state of a running system: the adapter's per-thread buffers, the handle's arena and staging
+    // buffer and the crew's threads exist from the first call on)
+    const int reps = std::getenv("MOVBA_ADAPTER_REPS") ? std::max(1, std::atoi(std::getenv("MOVBA_ADAPTER_REPS"))) : 1;
+    for (int rep = 0; rep < reps; ++rep) {
     Map map;
     GeometricCamera cam({320.f, 320.f, 320.f, 240.f});
     std::vector<KeyFrame> kfs(NP);                 // contiguous: pointer order == id order == std::map order
@@ -46,6 +53,7 @@ static int run_lba(const char *in, const char *out, bool global)
                               Eigen::Vector3f((float)poses[7 * i + 4], (float)poses[7 * i + 5], (float)poses[7 * i + 6]));
         map.mvKFs.push_back(&k);
     }
+    if (bad_kf >= 0 && bad_kf < NP) kfs[bad_kf].mbBad = true;
     for (int l = 0; l < P; ++l) {
         mps[l].mnId = 5000 + l; mps[l].mpMap = &map;
         mps[l].mWorldPos = Eigen::Vector3f((float)points[3 * l], (float)points[3 * l + 1], (float)points[3 * l + 2]);
@@ -73,6 +81,12 @@ static int run_lba(const char *in, const char *out, bool global)
     if (global) Optimizer::GlobalBundleAdjustemnt(&map, 10, &stop, kfs[0].mnId, true);
     else Optimizer::LocalBundleAdjustment(pKF, &stop, &map, num_fixedKF, num_OptKF, num_MPs, num_edges);
 
+    if (std::getenv("MOVBA_ADAPTER_TIMING")) {
+        double tmr[3] = { 0, 0, 0 };
+        if (!global) movba_adapter_last_timing(tmr);
+        std::fprintf(stderr, "adapter[rep %d]: extraction %.3f ms, solve call %.3f ms, write-back %.3f ms (NP=%d P=%d E=%d)\n", rep, tmr[0], tmr[1], tmr[2], NP, P, E);
+    }
+    if (rep + 1 < reps) continue;
     std::vector<int32_t> erased;
     for (int e = 0; e < E; ++e)
         if (mps[el[e]].mObservations.find(&kfs[ep[e]]) == mps[el[e]].mObservations.end()) { erased.push_back(ep[e]); erased.push_back(el[e]); }
@@ -105,8 +119,7 @@ static int run_lba(const char *in, const char *out, bool global)
     if (!global) movba_adapter_last_timing(tm);
     fwrite(tm, sizeof(double), 3, o);
     fclose(o);
-    if (std::getenv("MOVBA_ADAPTER_TIMING"))
-        std::fprintf(stderr, "adapter: extraction %.3f ms, solve call %.3f ms, write-back %.3f ms (NP=%d P=%d E=%d)\n", tm[0], tm[1], tm[2], NP, P, E);
+    }
     return 0;
 }
 

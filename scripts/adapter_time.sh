@@ -1,0 +1,20 @@
+#!/bin/bash
+# host-side phases of Optimizer::LocalBundleAdjustment over the mock map classes (cfg3), third call on a fresh map, for
+# 1 / 2 / 4 crew threads (run through gpurun from the repo root)
+python - <<'PY'
+import sys, struct, os
+import numpy as np
+sys.path.insert(0, "mov-slam_amd")
+from movba import synth
+w = synth.cfg("cfg3")
+with open("/tmp/w3.bin", "wb") as fh:
+    fh.write(struct.pack("4i", w.n_poses, w.n_points, w.n_edges, 0))
+    for arr, dt in ((w.pose_fixed, np.uint8), (w.poses, np.float64), (w.points, np.float64), (w.edge_pose, np.int32), (w.edge_point, np.int32), (w.obs, np.float64)):
+        fh.write(np.ascontiguousarray(arr, dt).tobytes())
+PY
+make -C mov-slam_amd/host -s
+for t in 1 2 4 8; do
+  echo "threads $t"
+  MOVBA_ADAPTER_REPS=4 MOVBA_ADAPTER_THREADS=$t MOVBA_ADAPTER_LAPS=${LAPS:-} MOVBA_ADAPTER_TIMING=1 mov-slam_amd/host/adapter_test lba /tmp/w3.bin /tmp/o3_$t.bin 2>&1 | grep "adapter" | tail -${TAILN:-2}
+done
+cmp /tmp/o3_1.bin /tmp/o3_4.bin > /dev/null; echo "outputs of 1 and 4 threads differ only in the timing trailer: $(cmp -l /tmp/o3_1.bin /tmp/o3_4.bin | wc -l) bytes"

@@ -34,9 +34,10 @@ def _f32_pose(p):
     return p.astype(np.float64)
 
 
-def _write_window(path, w):
+def _write_window(path, w, bad_kf=-1):
+    """bad_kf: index of a keyframe the mock map flags bad (KeyFrame::isBad()), -1 = none"""
     with open(path, "wb") as f:
-        f.write(struct.pack("4i", w.n_poses, w.n_points, w.n_edges, 0))
+        f.write(struct.pack("4i", w.n_poses, w.n_points, w.n_edges, bad_kf + 1))
         f.write(np.ascontiguousarray(w.pose_fixed, np.uint8).tobytes())
         f.write(np.ascontiguousarray(w.poses, np.float64).tobytes())
         f.write(np.ascontiguousarray(w.points, np.float64).tobytes())
@@ -201,3 +202,36 @@ def test_pose_optimization_through_the_adapter(adapter_bin, oracle_mod, tmp_path
     assert ninl == o["n_inliers"]
     assert np.abs(pose.astype(np.float64) - _f32_pose(o["pose"])).max() < 2e-6
     assert np.array_equal(outl[:n], o["outlier"]) and (outl[n:] == 1).all()   # slots without a MapPoint stay "outlier"
+
+
+def test_local_bundle_adjustment_with_a_bad_observer(adapter_bin, oracle_mod, tmp_path):
+    """A fixed keyframe flagged bad (KeyFrame::isBad(), Optimizer.cc:515): it gets no vertex and its observations no edges,
+    so some local points have fewer edges than observations — the flattener's gap-closing path — and the result is the
+    optimum of the window without those edges; the bad keyframe itself is left alone."""
+    w = synth.cfg("small")
+    w.poses = _f32_pose(w.poses)
+    fixed_idx = np.flatnonzero(w.pose_fixed == 1)
+    b = int(fixed_idx[np.argmax(np.bincount(w.edge_pose, minlength=w.n_poses)[fixed_idx])])
+    fin, fout = str(tmp_path / "w.bin"), str(tmp_path / "o.bin")
+    _write_window(fin, w, bad_kf=b)
+    subprocess.check_call([adapter_bin, "lba", fin, fout])
+    out = _read_out(fout, w)
+    keep = w.edge_pose != b
+    assert (~keep).sum() > 0
+    w2 = synth.cfg("small"); w2.poses = w.poses
+    w2.edge_pose, w2.edge_point, w2.obs, w2.inv_sigma2 = w.edge_pose[keep], w.edge_point[keep], w.obs[keep], w.inv_sigma2[keep]
+    sub, used_pose, local_pt, keep_e = _local_subwindow(w2)
+    assert not used_pose[b]
+    o = oracle_mod.solve(sub)
+    K = w.n_free
+    assert (out["num_fixedKF"], out["num_OptKF"], out["num_edges"]) == (int(used_pose.sum()) - K, K, sub.n_edges)
+    exp_poses = w.poses.copy(); exp_poses[used_pose] = o["poses"]
+    exp_points = w.points.copy(); exp_points[local_pt] = o["points"]
+    assert quat_angle(out["poses"][:, :4].astype(np.float64), _f32_pose(exp_poses)[:, :4]).max() < 2e-6
+    np.testing.assert_allclose(out["poses"][:, 4:], exp_poses[:, 4:].astype(np.float32), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(out["points"], exp_points.astype(np.float32), rtol=2e-6, atol=2e-6)
+    ep, el = w2.edge_pose[keep_e], w2.edge_point[keep_e]
+    want = set(map(tuple, np.stack([ep, el], 1)[o["outlier"] == 1]))
+    got = set(map(tuple, out["erased"]))
+    guard = {(int(a), int(c)) for a, c, x in zip(ep, el, o["chi2"]) if abs(x - 5.0) < 1e-4}
+    assert (want ^ got) <= guard
