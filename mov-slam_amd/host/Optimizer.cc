@@ -599,6 +599,8 @@ namespace MOV_SLAM
             vToErase.push_back(std::make_pair(f.edge_kf[i], pMP));
         }
 
+        lap_t = now_ms();
+        lap("inlier check");
         // ---- write-back under the map mutex (Optimizer.cc:807-840) ----
         std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
         for (size_t i = 0; i < vToErase.size(); i++)
@@ -608,6 +610,7 @@ namespace MOV_SLAM
             pKFi->EraseMapPointMatch(pMPi);                     // before EraseObservation: it needs the index
             pMPi->EraseObservation(pKFi);
         }
+        lap("erasures");
         for (KeyFrame *pKFi : lLocalKeyFrames)                  // local keyframes only, the fixed init KF included
             pKFi->SetPose(pose_to_se3f(&s.poses[7 * kfIndex.find(pKFi)]));
 #ifdef MOVBA_MAPPOINT_HAS_SET_DISTANCES
@@ -685,6 +688,7 @@ namespace MOV_SLAM
 #endif
             pMP->UpdateNormalAndDepth();
         }
+        lap("positions, normals, depth");
         for (MapPoint *pMP : edgeless)                          // estimate unchanged; the reference still casts and updates
         {
             pMP->SetWorldPos(pMP->GetWorldPos());

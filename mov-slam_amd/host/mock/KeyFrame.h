@@ -29,8 +29,12 @@ public:
     int nCenterReads = 0;
     std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return mvCovisible; }
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    // KeyFrame.cc:298-306: the indices come from the point's own observation entry (not a search through the matches)
     void EraseMapPointMatch(MapPoint *pMP) {
-        for (auto &p : mvpMapPoints) if (p == pMP) p = nullptr;
+        const std::tuple<int, int> indexes = pMP->GetIndexInKeyFrame(this);
+        const int leftIndex = std::get<0>(indexes), rightIndex = std::get<1>(indexes);
+        if (leftIndex != -1) mvpMapPoints[leftIndex] = nullptr;
+        if (rightIndex != -1) mvpMapPoints[rightIndex] = nullptr;
     }
     bool isBad() { return mbBad; }
     Map *GetMap() { return mpMap; }

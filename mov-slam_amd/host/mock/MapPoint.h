@@ -12,6 +12,11 @@ public:
     Eigen::Vector3f GetWorldPos() { return mWorldPos; }
     std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { ++nObservationCopies(); return mObservations; }
     static long &nObservationCopies() { static long n = 0; return n; }      // test plumbing: std::map copies handed out
+    // MapPoint.cc:347-354
+    std::tuple<int, int> GetIndexInKeyFrame(KeyFrame *pKF) {
+        const auto it = mObservations.find(pKF);
+        return it != mObservations.end() ? it->second : std::tuple<int, int>(-1, -1);
+    }
     KeyFrame *GetReferenceKeyFrame() { return mpRefKF; }                     // MapPoint.h:87
     Eigen::Vector3f GetNormal() { return mNormalVector; }
     void SetNormalVector(const Eigen::Vector3f &n) { mNormalVector = n; }     // MapPoint.h:85

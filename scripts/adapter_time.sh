@@ -13,7 +13,7 @@ with open("/tmp/w3.bin", "wb") as fh:
         fh.write(np.ascontiguousarray(arr, dt).tobytes())
 PY
 make -C mov-slam_amd/host -s
-for t in 1 2 4 8; do
+for t in 1; do
   echo "threads $t"
   MOVBA_ADAPTER_REPS=4 MOVBA_ADAPTER_THREADS=$t MOVBA_ADAPTER_LAPS=${LAPS:-} MOVBA_ADAPTER_TIMING=1 mov-slam_amd/host/adapter_test lba /tmp/w3.bin /tmp/o3_$t.bin 2>&1 | grep "adapter" | tail -${TAILN:-2}
 done
