@@ -732,8 +732,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_st[b][6] = 0;  o_st[b][7] = 0;
         o_st[b][8] = c.take<double>(nb);
         o_st[b][9] = 0;
-        o_st[b][10] = c.take<double>((stereo ? 4 : 2) * (size_t)E);                                  // erecB
+        o_st[b][10] = 0;
     }
+    const size_t o_obspm = c.take<double>(2 * (size_t)s.E_free + 2), o_obsrpm = c.take<double>(stereo ? (size_t)s.E_free + 1 : 1);
     const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
     const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
     const size_t o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s.row_ent.size() * 36 + 2 : 2);
@@ -809,6 +810,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
     w.obs_r = d->obs_right ? reinterpret_cast<double *>(a + o_obsr) : nullptr; w.bf = d->bf; w.stereo = stereo ? 1 : 0;
     w.slot = reinterpret_cast<int32_t *>(a + o_slot);
+    w.obs_pm = reinterpret_cast<double *>(a + o_obspm); w.obsr_pm = reinterpret_cast<double *>(a + o_obsrpm);
     {
         const int32_t *ed = reinterpret_cast<const int32_t *>(a + o_ent);
         w.ent_i = ed; w.ent_j = ed + noff; w.ent_l = ed + 2 * noff;
@@ -832,7 +834,6 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         S.point = reinterpret_cast<double *>(a + o_st[b][2]); S.Hll = reinterpret_cast<double *>(a + o_st[b][3]);
         S.bl = reinterpret_cast<double *>(a + o_st[b][4]); S.erecA = reinterpret_cast<double *>(a + o_st[b][5]);
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
-        S.erecB = reinterpret_cast<double *>(a + o_st[b][10]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c); w.blocks_ov = reinterpret_cast<double *>(a + o_blocks_ov);

@@ -38,7 +38,6 @@ struct DevState {
     double *Fpart;   // n_pt_blocks robust-cost partials of this state
     // per-edge records of the edges of FREE keyframes, POSE-major (DevWindow::slot), written by k_point for k_schur:
     double *erecA;   // E_free x 4: camera-frame point and weight (Xc.x Xc.y Xc.z, w = rho1 * inv_sigma2): everything both Jacobians need
-    double *erecB;   // weighted residual: E_free x 2 (-w e0, -w e1), stereo windows E_free x 4 (-w e0, -w e1, -w e2, stereo flag)
 };
 
 // LM controller state, lives in HBM; every kernel reads it, k_decide/k_pcg/k_lambda_init write it.
@@ -98,6 +97,10 @@ struct DevWindow {
     const double *obs;      // E x 2 (grouped order)
     const double *isig;     // E
     const double *obs_r;    // E: right-image u of stereo observations, < 0 = monocular edge (stereo windows only)
+    double *obs_pm;         // E_free x 2: the observations of the free keyframes' edges once more, pose-major (by slot), written by the
+                            // first linearisation: the diagonal schur entries rebuild the weighted residual -w e from them and the
+                            // edge record instead of reading a second per-edge record that every trial would have to write
+    double *obsr_pm;        // E_free: right-image u by slot (stereo windows only)
     double bf;              // KeyFrame::mbf
     int32_t stereo, pad2;   // window has >= 1 stereo edge: 3-row kernels
     const int32_t *slot;    // E: pose-major slot of a grouped edge (-1: edge of a fixed pose)

@@ -238,10 +238,12 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         }
         const double wg = rho1 * om;
         const double r0 = -wg * e0, r1 = -wg * e1;
-        if (sl >= 0) {      // pose-major records for the schur pass (edges of free keyframes): (Xc, w) and the weighted residual
+        if (sl >= 0) {      // pose-major record for the schur pass (edges of free keyframes): (Xc, w)
             *reinterpret_cast<double4 *>(S1.erecA + 4 * (size_t)sl) = make_double4(x, y, z, wg);
-            if (STEREO) *reinterpret_cast<double4 *>(S1.erecB + 4 * (size_t)sl) = make_double4(r0, r1, -wg * e2, st ? 1.0 : 0.0);
-            else *reinterpret_cast<double2 *>(S1.erecB + 2 * (size_t)sl) = make_double2(r0, r1);
+            if (!BACKSUB) {     // (once per run: the observation by slot, from which the schur pass rebuilds the residual)
+                *reinterpret_cast<double2 *>(w.obs_pm + 2 * (size_t)sl) = ob;
+                if (STEREO) w.obsr_pm[sl] = ur;
+            }
         }
         F += rho0;
         const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
@@ -541,12 +543,12 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
             // slot_point; the record loads of a wave are contiguous
 #pragma unroll
             for (int u = 0; u < B; ++u) { const int kk = base + lane + 64 * u; ok[u] = kk < wend; const int k = min(kk, wend - 1); en[u] = Int4{ k, k, w.slot_point[k], 0 }; }
-            double4 rc[B], rq[B]; double2 h[B][3]; double bl[B][3];
+            double4 rc[B]; double2 ob[B]; double ur[B]; double2 h[B][3]; double bl[B][3];
 #pragma unroll
             for (int u = 0; u < B; ++u) {
                 rc[u] = *reinterpret_cast<const double4 *>(S0.erecA + 4 * (size_t)en[u].x);
-                if (NR == 3) rq[u] = *reinterpret_cast<const double4 *>(S0.erecB + 4 * (size_t)en[u].x);
-                else { const double2 t2 = *reinterpret_cast<const double2 *>(S0.erecB + 2 * (size_t)en[u].x); rq[u] = make_double4(t2.x, t2.y, 0.0, 0.0); }
+                ob[u] = *reinterpret_cast<const double2 *>(w.obs_pm + 2 * (size_t)en[u].x);
+                ur[u] = NR == 3 ? w.obsr_pm[en[u].x] : -1.0;
                 if (HPP_ONLY) { h[u][0] = h[u][1] = h[u][2] = make_double2(0.0, 0.0); bl[u][0] = bl[u][1] = bl[u][2] = 0.0; continue; }
                 const int l = en[u].z;
                 const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * l);      // 48-byte records: 16-byte aligned
@@ -556,10 +558,12 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
 #pragma unroll
             for (int u = 0; u < B; ++u) {
                 const double m = ok[u] ? 1.0 : 0.0;
-                const bool st = NR == 3 && rq[u].w != 0.0;
+                const bool st = NR == 3 && ur[u] >= 0.0;
+                // -w e, e = observation - projection of the recorded camera-frame point (include/OptimizableTypes.h: computeError)
+                const double iz = 1.0 / rc[u].z, mw = -(m * rc[u].w);
                 double rv[NR];
-                rv[0] = m * rq[u].x; rv[1] = m * rq[u].y;
-                if (NR == 3) rv[NR - 1] = (ok[u] && st) ? rq[u].z : 0.0;
+                rv[0] = mw * (ob[u].x - (w.fx * rc[u].x * iz + w.cx)); rv[1] = mw * (ob[u].y - (w.fy * rc[u].y * iz + w.cy));
+                if (NR == 3) rv[NR - 1] = st ? mw * (ur[u] - (w.fx * rc[u].x * iz + w.cx - w.bf * iz)) : 0.0;
                 schur_diag_entry<NR, HPP_ONLY>(w, rc[u], m * rc[u].w, rv, st, Ri, h[u], bl[u], lambda, sa, ha, ca, ba);
             }
         }
@@ -591,7 +595,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
                 ri[u] = *reinterpret_cast<const double4 *>(S0.erecA + 4 * (size_t)en[u].x);
                 rj[u] = *reinterpret_cast<const double4 *>(S0.erecA + 4 * (size_t)en[u].y);
                 sti[u] = false; stj[u] = false;
-                if (NR == 3) { sti[u] = S0.erecB[4 * (size_t)en[u].x + 3] != 0.0; stj[u] = S0.erecB[4 * (size_t)en[u].y + 3] != 0.0; }
+                if (NR == 3) { sti[u] = w.obsr_pm[en[u].x] >= 0.0; stj[u] = w.obsr_pm[en[u].y] >= 0.0; }
                 const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * en[u].z);
                 h[u][0] = hp[0]; h[u][1] = hp[1]; h[u][2] = hp[2];
             }
