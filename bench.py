@@ -87,11 +87,19 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the local-BA path has no CPU fallback")
+    # MOVBA_BENCH_REHEARSAL=1: the N > 1 code path on a box with ONE GPU (every rank on device 0, gloo instead of RCCL,
+    # which refuses two ranks on one device): exercises launch, sharding, timing and the JSON line, not the interconnect
+    rehearsal = os.environ.get("MOVBA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload: cfg3 on rank 0 (the configuration the metric is quoted on), cfg5 seeds on the others ----
     shape = dict(cfg2=(10, 2, 2000, 2, 6), cfg3=(50, 10, 20000, 2, 10))[args.config]
@@ -109,7 +117,9 @@ def main():
     def step():
         # host arrays in -> structure pass + H2D + whole LM loop on the device + D2H -> host arrays out
         solver.solve_prepared(pack=False)
-        return shard.gather_poses(pose_buf) if world > 1 else pose_buf
+        if world > 1:
+            return shard.gather_poses(pose_buf.cpu()) if rehearsal else shard.gather_poses(pose_buf)
+        return pose_buf
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -136,8 +146,9 @@ def main():
     res = solver.solve_prepared()                        # (untimed) the same solve once more, results unpacked
     solves_local = res["n_solves"] * args.steps         # the same window every step: bit-identical solves
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    ss = torch.tensor([float(solves_local)], dtype=torch.float64, device=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    ss = torch.tensor([float(solves_local)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(ss, op=dist.ReduceOp.SUM)
@@ -171,7 +182,7 @@ def main():
                                    f"10 LM iterations ({args.config}, seed {seed}); one window per GPU",
                        "lm_iterations_per_step": res["n_solves"], "pcg_iterations_per_step": res["pcg_iters"],
                        "window_solves_per_s": world * args.steps / dt_max,
-                       "parallelism": f"{world} independent window(s), RCCL pose all-gather" if world > 1 else "1 window"},
+                       "parallelism": (f"{world} independent window(s), " + ("gloo pose all-gather, all ranks on ONE GPU (rehearsal)" if rehearsal else "RCCL pose all-gather")) if world > 1 else "1 window"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_us": avg_s * 1e6,
