@@ -112,7 +112,8 @@ def main():
     pose_buf = torch.empty((1, w.n_poses, 7), dtype=torch.float64, device=dev)
 
     solver.set_pose_export(pose_buf.data_ptr(), pose_buf.numel() * 8)     # the solve's last kernel leaves the poses here
-    solver.prepare(w)                                    # descriptor + result buffers once, like a C++ caller's own
+    solver.prepare(w, pinned=True)                       # descriptor + result buffers once, like a C++ caller's own (the adapter's:
+                                                         # movba_host_alloc memory, which the solve's last kernel writes into directly)
 
     def step():
         # host arrays in -> structure pass + H2D + whole LM loop on the device + D2H -> host arrays out
@@ -193,7 +194,8 @@ def main():
                          "kernel_ms_per_step_all_classes": {k: v["ms"] for k, v in prof_all.items()}},
         }
         out["config"]["timed_region"] = ("movba_lba_solve: host arrays in -> structure pass, H2D, all launches, D2H -> results in "
-                                         "host memory (SURVEY 8d); identical region for cpu_baseline")
+                                         "host memory (SURVEY 8d; result arrays in movba_host_alloc memory, as the adapter's are); identical region "
+                                         "for cpu_baseline")
         out["config"]["host_phase_ms_per_step"] = {k: prof[k] / args.steps for k in ("structure_ms", "upload_ms", "download_ms")}
         extras = world == 1 and not args.no_extras
         if extras:

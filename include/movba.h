@@ -23,6 +23,7 @@
 #ifndef MOVBA_H
 #define MOVBA_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -160,6 +161,15 @@ int  movba_lba_export_poses_device(movba_handle *h, void *dst_device, int64_t ca
  * the optimised poses in it (written by the solve's last kernel; valid when movba_lba_run returns).
  * NULL unregisters.  The buffer must stay allocated while it is registered. */
 int  movba_lba_set_pose_export(movba_handle *h, void *dst_device, int64_t capacity_bytes);
+
+/* Pinned, device-visible host memory for result arrays (optional).  When `poses`, `points` or `chi2` of the
+ * movba_lba_result handed to movba_lba_solve point into a block obtained here, the solve's last kernel writes those
+ * results straight into them across the bus; otherwise they arrive in the handle's staging buffer and are copied out by
+ * the calling thread.  (g2o's own results are in place too: vertex->estimate() is read after optimize(),
+ * /root/reference/src/Optimizer.cc:822-838.)  Ordinary host memory for the CPU: read, write and keep it as long as
+ * needed; release it with movba_host_free.  Returns NULL when no device is available or the allocation fails. */
+void *movba_host_alloc(size_t bytes);
+void  movba_host_free(void *p);
 
 int  movba_get_profile(movba_handle *h, movba_profile *out);
 int  movba_reset_profile(movba_handle *h);

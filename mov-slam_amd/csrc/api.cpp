@@ -133,6 +133,10 @@ struct movba_handle {
     bool uploaded = false, ran = false;
     bool export_in_run = false;         // this run's results were written to the staging buffer behind its last kernel
     bool export_hint = false;           // set by movba_lba_solve around its run: a download follows at once
+    // movba_lba_solve: result arrays of the caller that lie in movba_host_alloc memory (poses, points, chi2): device view
+    // the export kernel writes to, and the host pointer it stands for (download skips the copy-out of exactly that array)
+    unsigned long long *user_dst[3] = {nullptr, nullptr, nullptr};
+    const void *user_host[3] = {nullptr, nullptr, nullptr};
     Structure st;
     DevWindow win{};
     size_t h2d_bytes = 0;
@@ -270,6 +274,22 @@ int ensure_stage(movba_handle *h, size_t bytes)
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&h->stage_dev), h->stage, 0));
     h->stage_cap = cap;
     return MOVBA_OK;
+}
+
+// blocks handed out by movba_host_alloc: host address range -> device view (process-wide, a handful of entries)
+struct HostBlock { char *host; size_t bytes; char *dev; };
+std::mutex g_host_blocks_mu;
+std::vector<HostBlock> g_host_blocks;
+
+// device view of [p, p + bytes) if it lies inside a movba_host_alloc block, else nullptr
+unsigned long long *host_block_view(const void *p, size_t bytes)
+{
+    if (!p) return nullptr;
+    const char *c = static_cast<const char *>(p);
+    std::lock_guard<std::mutex> lk(g_host_blocks_mu);
+    for (const HostBlock &b : g_host_blocks)
+        if (c >= b.host && c + bytes <= b.host + b.bytes) return reinterpret_cast<unsigned long long *>(b.dev + (c - b.host));
+    return nullptr;
 }
 
 // where k_export leaves a window's results in the pinned staging buffer
@@ -899,7 +919,13 @@ int lm_loop(movba_handle *h, bool parked)
         { ScopedEvents ev(h, KC_FINALIZE); HIP_TRY(launch_finalize(w, s)); }        // (also writes Ctrl to h->ctrl_host)
         // ... and the results go across the bus into the staging buffer right behind it: movba_lba_download then finds them
         // there instead of paying a launch and a stream synchronise of its own
-        if (h->export_in_run) HIP_TRY(launch_export(w, export_dst(h->stage_dev, export_layout(w), true, true, true), s));
+        if (h->export_in_run) {
+            ExportDst dst = export_dst(h->stage_dev, export_layout(w), true, true, true);
+            if (h->user_dst[0]) dst.poses = h->user_dst[0];
+            if (h->user_dst[1]) dst.points = h->user_dst[1];
+            if (h->user_dst[2]) dst.chi2 = h->user_dst[2];
+            HIP_TRY(launch_export(w, dst, s));
+        }
         final_after = t;
         return MOVBA_OK;
     };
@@ -990,6 +1016,7 @@ int movba_lba_run(movba_handle *h)
     // (the staging buffer is free once the upload's copies, queued ahead of every kernel of the run, have left it; it is as
     // large as the upload needed, which is more than the results take)
     h->export_in_run = h->export_hint && export_layout(w).end <= h->stage_cap;
+    if (!h->export_in_run) for (int k = 0; k < 3; ++k) { h->user_dst[k] = nullptr; h->user_host[k] = nullptr; }
 
     {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
         ScopedEvents ev(h, KC_SETUP);
@@ -1232,7 +1259,14 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     char *sg = h->stage;
     const ExportLayout L = export_layout(w);
     const size_t o_pose = L.o_pose, o_pt = L.o_pt, o_chi = L.o_chi, o_out = L.o_out;
+    // results a movba_lba_solve exported straight into the caller's own (movba_host_alloc) arrays are not in the staging
+    // buffer: a download into other arrays exports again
+    if (h->export_in_run) {
+        void *const arr[3] = { res->poses, res->points, res->chi2 };
+        for (int k = 0; k < 3; ++k) if (arr[k] && h->user_host[k] && h->user_host[k] != arr[k]) h->export_in_run = false;
+    }
     if (!h->export_in_run) {
+        for (int k = 0; k < 3; ++k) h->user_host[k] = nullptr;
         int rs = ensure_stage(h, L.end); if (rs) return rs;
         sg = h->stage;
         HIP_TRY(launch_export(w, export_dst(h->stage_dev, L, res->poses != nullptr, res->points != nullptr, res->chi2 != nullptr), h->stream));
@@ -1240,9 +1274,11 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     HIP_TRY(hipStreamSynchronize(h->stream));
     // out of the pinned buffer into the caller's arrays (handing half of it to the helper thread saved 20 us when the
     // thread was awake and cost 0.4 ms when it had to be woken: not worth it for a copy the caller waits on)
-    if (res->chi2) std::memcpy(res->chi2, sg + o_chi, nb_chi);
-    if (res->poses) std::memcpy(res->poses, sg + o_pose, nb_pose);
-    if (res->points) std::memcpy(res->points, sg + o_pt, nb_pt);
+    // (arrays in movba_host_alloc memory were written by the export kernel itself)
+    const bool in_place = h->export_in_run;
+    if (res->chi2 && !(in_place && h->user_host[2] == res->chi2)) std::memcpy(res->chi2, sg + o_chi, nb_chi);
+    if (res->poses && !(in_place && h->user_host[0] == res->poses)) std::memcpy(res->poses, sg + o_pose, nb_pose);
+    if (res->points && !(in_place && h->user_host[1] == res->points)) std::memcpy(res->points, sg + o_pt, nb_pt);
     if (res->outlier) std::memcpy(res->outlier, sg + o_out, (size_t)w.E);
     int n_out = 0;
     {
@@ -1274,8 +1310,15 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
     int rc = movba_lba_upload(h, desc);
     if (rc != MOVBA_OK) { res->status = rc; return rc; }
     h->export_hint = true;
+    {
+        const DevWindow &w = h->win;
+        void *const arr[3] = { res->poses, res->points, res->chi2 };
+        const size_t nb[3] = { sizeof(double) * 7 * (size_t)w.NP, sizeof(double) * 3 * (size_t)w.P, sizeof(double) * (size_t)w.E };
+        for (int k = 0; k < 3; ++k) { h->user_dst[k] = host_block_view(arr[k], nb[k]); h->user_host[k] = h->user_dst[k] ? arr[k] : nullptr; }
+    }
     rc = movba_lba_run(h);
     h->export_hint = false;
+    for (int k = 0; k < 3; ++k) h->user_dst[k] = nullptr;      // (user_host stays for the download below)
     if (rc < 0) { res->status = rc; h->stop = nullptr; return rc; }
     rc = movba_lba_download(h, res);
     h->stop = nullptr;      // keep no caller pointer after the call returns
@@ -1300,6 +1343,29 @@ int movba_lba_set_pose_export(movba_handle *h, void *dst, int64_t cap)
     h->pose_export = static_cast<double *>(dst);
     h->pose_export_cap = dst ? cap : 0;
     return MOVBA_OK;
+}
+
+void *movba_host_alloc(size_t bytes)
+{
+    if (bytes == 0) return nullptr;
+    void *p = nullptr, *d = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return nullptr; }
+    std::lock_guard<std::mutex> lk(g_host_blocks_mu);
+    g_host_blocks.push_back(HostBlock{ static_cast<char *>(p), bytes, static_cast<char *>(d) });
+    return p;
+}
+
+void movba_host_free(void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_host_blocks_mu);
+        for (size_t k = 0; k < g_host_blocks.size(); ++k)
+            if (g_host_blocks[k].host == p) { g_host_blocks.erase(g_host_blocks.begin() + (long)k); break; }
+    }
+    (void)hipDeviceSynchronize();           // a kernel still writing results into the block
+    (void)hipHostFree(p);
 }
 
 int movba_get_profile(movba_handle *h, movba_profile *out)

@@ -287,9 +287,39 @@ namespace MOV_SLAM
             std::fclose(f);
         }
 
+        // double array in movba_host_alloc memory (pinned, device-visible: the solve's last kernel writes the results into
+        // it across the bus, nothing is copied out afterwards); plain new[] when the library cannot provide it
+        struct PinnedArray
+        {
+            double *p = nullptr;
+            size_t cap = 0, n = 0;
+            bool pinned = false;
+            ~PinnedArray() { release(); }
+            void release()
+            {
+                if (p) { if (pinned) movba_host_free(p); else delete[] p; }
+                p = nullptr; cap = 0;
+            }
+            void resize(size_t count)
+            {
+                if (count > cap)
+                {
+                    release();
+                    const size_t c = count + count / 4 + 16;
+                    p = static_cast<double *>(movba_host_alloc(c * sizeof(double)));
+                    pinned = p != nullptr;
+                    if (!p) p = new double[c];
+                    cap = c;
+                }
+                n = count;
+            }
+            double *data() { return p; }
+            const double &operator[](size_t k) const { return p[k]; }
+        };
+
         struct Solved
         {
-            std::vector<double> poses, points, chi2;
+            PinnedArray poses, points, chi2;
             std::vector<uint8_t> outlier;
             int status = MOVBA_ERR_HIP;
         };

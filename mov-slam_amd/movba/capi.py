@@ -83,7 +83,8 @@ class PoseResult(C.Structure):
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
            "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
            "movba_lba_export_poses_device", "movba_lba_set_pose_export", "movba_get_profile", "movba_reset_profile",
-           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch", "movba_pose_ransac_samples"]
+           "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch", "movba_pose_ransac_samples",
+           "movba_host_alloc", "movba_host_free"]
 
 _lib = None
 
@@ -115,6 +116,10 @@ def lib():
         L.movba_pose_opt.argtypes = [C.c_void_p, C.POINTER(PoseDesc), C.POINTER(PoseResult)]
         L.movba_lba_run_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
         L.movba_pose_ransac_samples.argtypes = [C.c_int32, C.c_int32, C.c_uint32, _i]
+        L.movba_host_alloc.argtypes = [C.c_size_t]
+        L.movba_host_alloc.restype = C.c_void_p
+        L.movba_host_free.argtypes = [C.c_void_p]
+        L.movba_host_free.restype = None
         _lib = L
     return _lib
 
@@ -192,6 +197,7 @@ class Solver:
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
                  pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0):
         self._h = C.c_void_p()
+        self._pinned_blocks = []
         opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
@@ -203,6 +209,11 @@ class Solver:
         if self._h:
             lib().movba_destroy(self._h)
             self._h = C.c_void_p()
+        if getattr(self, "_pinned_blocks", None):
+            self._prep = None
+            for p in self._pinned_blocks:
+                lib().movba_host_free(p)
+            self._pinned_blocks = []
 
     def __del__(self):
         try:
@@ -211,9 +222,21 @@ class Solver:
             pass
 
     # -- results ---------------------------------------------------------------
-    def _alloc_result(self, d):
-        out = dict(poses=np.zeros((d.n_poses, 7)), points=np.zeros((d.n_points, 3)),
-                   chi2=np.zeros(d.n_edges), outlier=np.zeros(d.n_edges, np.uint8))
+    def _pinned(self, shape):
+        """float64 array in movba_host_alloc memory (released by close())"""
+        n = int(np.prod(shape))
+        p = lib().movba_host_alloc(max(8 * n, 8))
+        if not p:
+            raise MovbaError("movba_host_alloc failed")
+        self._pinned_blocks.append(p)
+        a = np.ctypeslib.as_array((C.c_double * max(n, 1)).from_address(p))[:n].reshape(shape)
+        a[...] = 0.0
+        return a
+
+    def _alloc_result(self, d, pinned=False):
+        mk = self._pinned if pinned else np.zeros
+        out = dict(poses=mk((d.n_poses, 7)), points=mk((d.n_points, 3)),
+                   chi2=mk((d.n_edges,)), outlier=np.zeros(d.n_edges, np.uint8))
         r = LbaResult()
         r.poses = _p(out["poses"], _d); r.points = _p(out["points"], _d)
         r.chi2 = _p(out["chi2"], _d); r.outlier = _p(out["outlier"], _u)
@@ -241,11 +264,11 @@ class Solver:
             out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
         return self._pack(r, out, rc)
 
-    def prepare(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
+    def prepare(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0, pinned=False):
         """Descriptor and result buffers built once for repeated solve_prepared() calls: what a C++ caller that keeps its
         flattened arrays and result buffers does (nothing is allocated or converted per call)."""
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
-        r, out = self._alloc_result(d)
+        r, out = self._alloc_result(d, pinned)      # pinned: result arrays the solve's last kernel writes into directly
         self._prep = (d, keep, r, out)
 
     def solve_prepared(self, pack=True):

@@ -626,3 +626,26 @@ def test_download_again_after_the_staging_buffer_was_reused(solver):
         for k in ("poses", "points", "chi2", "outlier"):
             np.testing.assert_array_equal(r[k], r1[k])
         assert r["n_outliers"] == r1["n_outliers"] == int(r1["outlier"].sum())
+
+
+def test_results_straight_into_pinned_caller_arrays(built_lib):
+    """movba_host_alloc: result arrays the solve's last kernel writes into across the bus (no copy-out by the calling
+    thread): same bits as through ordinary arrays; a later download into ordinary arrays exports again."""
+    w = synth.cfg("cfg3")
+    s = built_lib.Solver()
+    try:
+        ref = s.solve(w)
+        s.prepare(w, pinned=True)
+        a = s.solve_prepared()
+        b = s.solve_prepared()                             # the same pinned arrays again
+        again = s.download()                               # into ordinary arrays: not in the staging buffer, exported again
+        for r in (a, b, again):
+            for k in ("poses", "points", "chi2", "outlier"):
+                np.testing.assert_array_equal(r[k], ref[k])
+            assert r["n_outliers"] == ref["n_outliers"] and r["n_solves"] == ref["n_solves"]
+        s.upload(w); s.run()
+        c = s.download()                                   # three-phase API: ordinary arrays, staging buffer
+        for k in ("poses", "points", "chi2", "outlier"):
+            np.testing.assert_array_equal(c[k], ref[k])
+    finally:
+        s.close()
