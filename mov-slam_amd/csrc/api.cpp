@@ -113,7 +113,7 @@ struct movba_handle {
                                         // handles of a device: every extra stream of the process competes for the few hardware queues,
                                         // and two streams of a batched run that land on one queue run in turns)
     hipEvent_t copy_event = nullptr;
-    hipEvent_t count_event = nullptr;   // the pair counts of the device structure pass have reached the host
+    uint64_t count_seq = 0;             // uploads that went through the device structure pass (what the host polls for in the counts buffer)
     movba_options opt{};
     // device arena
     char *arena = nullptr;
@@ -366,7 +366,6 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     }
     if ((h->copy_stream = shared_copy_stream(device)) == nullptr ||
         hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
@@ -389,7 +388,6 @@ void movba_destroy(movba_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);        // shared: stays
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
-    if (h->count_event) (void)hipEventDestroy(h->count_event);
     harvest_events(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->arena) (void)hipFree(h->arena);
@@ -666,7 +664,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
             h->scratch_cap = cap;
         }
         char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;    // tail of the staging buffer: the pair region is packed in front of it
-        HIP_TRY(hipMemsetAsync(sa + so_err, 0, 16, h->stream));
+        HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));        // bin totals and the error word
         sd.P = s.P; sd.nfree = nf; sd.nchunks = nchunks; sd.NP = NP;
         // grouped edges, point ranges and hessian indices are read where the edge copy just put them
         sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
@@ -677,13 +675,24 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         HIP_TRY(launch_struct_count(sd, h->stream));
         // cnt and the error word are adjacent in the scratch carve: one D2H copy; the host waits for exactly that copy, the
         // stream goes on to the entry offsets of the fill kernel
-        HIP_TRY(hipMemcpyAsync(misc, sa + so_cnt, so_err + 16 - so_cnt, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipEventRecord(h->count_event, h->stream));
+        // (misc: nbins totals, the error word, the sequence number of this upload)
+        volatile int32_t *misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
+        const int32_t seq = (int32_t)(++h->count_seq & 0x7fffffff);
+        *misc_seq = seq - 1;
+        HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
+        HIP_TRY(launch_struct_scan(sd, h->stream));
         HIP_TRY(launch_struct_ptr(sd, h->stream));
         pack_b(false); slots_packed = true;
         lap("edge H2D + count launches");
-        HIP_TRY(hipEventSynchronize(h->count_event));
-        if (*reinterpret_cast<const int32_t *>(misc + (so_err - so_cnt)) != 0) return MOVBA_ERR_ARG;     // duplicate observation
+        {
+            const double t_wait = now_ms();
+            while (*misc_seq != seq) {
+                host_relax(0);
+                if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (*misc_seq != seq) return MOVBA_ERR_HIP; }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (reinterpret_cast<const int32_t *>(misc)[nbins] != 0) return MOVBA_ERR_ARG;     // duplicate observation
         lap("wait for the pair counts");
         // slots, point ids, observations and initial estimates cross the bus, then the entry lists are filled, while the
         // host lays out the pairs

@@ -12,6 +12,8 @@ hipError_t configure_kernels(int unused);
 hipError_t configure_pcg_rows();
 hipError_t configure_struct_kernels();
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
+hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s);
+hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s);
 bool struct_lds_fits(int nfree, int NP);
 hipError_t launch_struct_ptr(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);

@@ -124,7 +124,13 @@ __global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd
     if (!FILL) {
         // per-chunk counts, chunk-major: the chunk's nbins values leave as contiguous lines, and the fill pass finds its
         // chunk's row in one 10 KB stretch
-        for (int b = threadIdx.x; b < nbins; b += NT) sd.cntw[(size_t)chunk * nbins + b] = __popcll(masks[b]);
+        // ... and the bins' totals by integer atomics (order-independent): the host waits for exactly these, the scan over
+        // the chunks (needed by the fill only) runs behind their copy
+        for (int b = threadIdx.x; b < nbins; b += NT) {
+            const int pc = __popcll(masks[b]);
+            sd.cntw[(size_t)chunk * nbins + b] = pc;
+            if (pc) atomicAdd(&sd.cnt[b], pc);
+        }
     } else {
 #if !defined(MOVBA_STRUCT_SKIP) || MOVBA_STRUCT_SKIP != 2
         int k = 0;
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd
     }
 }
 
-// exclusive scan over the chunks of every bin's counts (in place) and the bin totals.  A workgroup takes 64 bins (one per
+// exclusive scan over the chunks of every bin's counts (in place).  A workgroup takes 64 bins (one per
 // lane: coalesced across bins) and cuts the chunks into 16 segments, one per wave: segment sums, a 16-step prefix through
 // LDS, then the running prefixes written back; 8 loads in flight per lane in both passes.
 __global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
@@ -173,8 +179,8 @@ __global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
     }
     seg_tot[sy][tx] = sum;
     __syncthreads();
-    int carry = 0, total = 0;
-    for (int q = 0; q < 16; ++q) { const int t = seg_tot[q][tx]; carry += q < sy ? t : 0; total += t; }
+    int carry = 0;
+    for (int q = 0; q < sy; ++q) carry += seg_tot[q][tx];
     for (int c0 = c_beg; c0 < c_end && live; c0 += 8) {
         int v[8];
 #pragma unroll
@@ -185,7 +191,6 @@ __global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
             carry += v[u];
         }
     }
-    if (live && sy == 0) sd.cnt[bin] = total;
 }
 
 // first off-diagonal entry of every pair bin: the pairs are numbered diagonal first, then the off-diagonal bins with
@@ -239,6 +244,28 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
 {
     const size_t lds = struct_lds_bytes(sd.nfree, sd.NP, false);
     hipLaunchKernelGGL(k_struct_pairs<false>, dim3(sd.nchunks), dim3(64 * kStructWaves), lds, s, sd);
+    return hipGetLastError();
+}
+
+// the bins' totals and the error word straight into the host's pinned buffer, then a sequence number the host polls:
+// a device-to-host copy plus an event wait cost ~15 us more than these stores across the bus
+__global__ __launch_bounds__(1024) void k_struct_counts_out(const int32_t *cnt, const int32_t *err, int32_t *host_cnt, int nbins, int seq)
+{
+    for (int b = threadIdx.x; b < nbins; b += 1024) host_cnt[b] = cnt[b];
+    if (threadIdx.x == 0) host_cnt[nbins] = *err;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_struct_counts_out, dim3(1), dim3(1024), 0, s, sd.cnt, sd.error, host_cnt_dev, sd.nfree * sd.nfree, seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s)
+{
     hipLaunchKernelGGL(k_struct_scan, dim3((sd.nfree * sd.nfree + 63) / 64), dim3(1024), 0, s, sd);
     return hipGetLastError();
 }
