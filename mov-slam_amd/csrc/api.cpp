@@ -113,6 +113,7 @@ struct movba_handle {
                                         // handles of a device: every extra stream of the process competes for the few hardware queues,
                                         // and two streams of a batched run that land on one queue run in turns)
     hipEvent_t copy_event = nullptr;
+    hipEvent_t edgeb_event = nullptr;   // the derived edge arrays sent early on the copy stream have arrived
     uint64_t count_seq = 0;             // uploads that went through the device structure pass (what the host polls for in the counts buffer)
     movba_options opt{};
     // device arena
@@ -366,6 +367,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     }
     if ((h->copy_stream = shared_copy_stream(device)) == nullptr ||
         hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->edgeb_event, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
@@ -388,6 +390,7 @@ void movba_destroy(movba_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);        // shared: stays
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
+    if (h->edgeb_event) (void)hipEventDestroy(h->edgeb_event);
     harvest_events(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->arena) (void)hipFree(h->arena);
@@ -587,30 +590,39 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         }
     };
     auto pack_edges = [&](bool raw_too) { pack_a(raw_too); pack_b(raw_too); };
-    bool slots_packed = false;
     if (!s.already_grouped) {
         // (rare: the helper's straight copies get permuted below, so it has to be through with them)
         const int rw = wait_helper(); if (rw) return rw;
         build_slots(h->st); rank_mode = false;
         pack_edges(false);
-        slots_packed = true;
     } else {
         while (idx_ready.load(std::memory_order_acquire) == 0) host_relax(0);
         pack_a(false);
+        pack_b(false);      // (ranks where the slots go, the keyframes' first slots, the free keyframes)
     }
     lap("pack derived arrays");
     const double t_up0 = now_ms();
     HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_a_bytes, hipMemcpyHostToDevice, h->stream));
     const uint64_t arena_gen_at_edge_copy = arena_gen_at_post;
+    // grouped edges: the rest of the derived arrays (point ids, ranks / slots, first slots) leaves at once on the copy
+    // stream, beside the structure kernels of this stream; what needs it (slot completion, fill) waits for edgeb_event
+    bool edge_b_early = false, edge_b_stale = false;
+    if (s.already_grouped && h->arena_gen == arena_gen_at_post) {
+        HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, raw_begin - edge_a_bytes, hipMemcpyHostToDevice, h->copy_stream));
+        HIP_TRY(hipEventRecord(h->edgeb_event, h->copy_stream));
+        edge_b_early = true;
+    }
     double upload_host_ms = now_ms() - t_up0;
     bool edge_b_queued = false;
     auto queue_edge_b = [&]() -> int {
-        { const int rw = wait_helper(); if (rw) return rw; }      // (its copy_event must have been recorded)
-        // the rest of the derived arrays; the caller's arrays are already on their way on the copy stream: the solve's
-        // kernels on this stream start behind them.  (Edges not grouped by point: the helper's straight copies were
-        // permuted again by pack_edges, so that part travels once more, behind the first copy.)
-        HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, raw_begin - edge_a_bytes, hipMemcpyHostToDevice, h->stream));
+        if (edge_b_early) HIP_TRY(hipStreamWaitEvent(h->stream, h->edgeb_event, 0));
+        if (!edge_b_early || edge_b_stale) {
+            // (not sent yet, or packed again since: host-built slots instead of ranks)
+            HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, raw_begin - edge_a_bytes, hipMemcpyHostToDevice, h->stream));
+        }
         if (!s.already_grouped) {
+            // the helper's straight copies were permuted again by pack_edges: that part travels once more, behind the first copy
+            { const int rw = wait_helper(); if (rw) return rw; }      // (its copy_event must have been recorded)
             HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
             HIP_TRY(hipMemcpyAsync(h->arena + raw_begin, sg + raw_begin, edge_bytes - raw_begin, hipMemcpyHostToDevice, h->stream));
         }
@@ -648,7 +660,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         rc = build_structure(*d, h->st);         // (runs build_basic again, with the slots this time)
         if (rc < 0) return rc;
         rank_mode = false;
-        if (!slots_packed) { pack_b(false); slots_packed = true; }
+        pack_b(false); edge_b_stale = true;      // (slots instead of ranks in the staging buffer now)
         noff = (size_t)(s.nentries - s.E_free);
         o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
     } else {
@@ -681,8 +693,6 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         *misc_seq = seq - 1;
         HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
         HIP_TRY(launch_struct_scan(sd, h->stream));
-        HIP_TRY(launch_struct_ptr(sd, h->stream));
-        pack_b(false); slots_packed = true;
         lap("edge H2D + count launches");
         {
             const double t_wait = now_ms();
@@ -819,6 +829,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (!(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_slotpt(); if (rq) return rq; }
     if (dev_structure && !(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_fill(); if (rq) return rq; }
     // the solve's kernels start behind the caller's arrays on the copy stream (the structure pass above did not need them)
+    { const int rw = wait_helper(); if (rw) return rw; }          // (the helper has recorded copy_event by now)
     HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
     // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were
     // copied to the staging buffer already (the next upload synchronises before it refills it)

@@ -155,7 +155,7 @@ struct StructDev {
     int32_t *cntw;              // nchunks x nfree^2: per-chunk counts, then their exclusive scan over the chunks
     int32_t *cnt;               // nfree^2: entries per pair bin
     int32_t *error;             // set when a keyframe observes a point twice
-    int32_t *ent0;              // nfree^2: first off-diagonal entry of a pair bin (i < j; k_struct_ptr -> fill)
+    int32_t *ent0;              // nfree^2: first off-diagonal entry of a pair bin (i < j; k_struct_counts_out -> fill)
     const int32_t *slot;        // E: pose-major slot of a grouped edge (fill)
     int32_t *ent_i, *ent_j, *ent_l;     // off-diagonal entry lists (fill)
     int32_t pad5, pad6;

@@ -15,7 +15,6 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s);
 bool struct_lds_fits(int nfree, int NP);
-hipError_t launch_struct_ptr(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
 hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);

@@ -193,32 +193,6 @@ __global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
     }
 }
 
-// first off-diagonal entry of every pair bin: the pairs are numbered diagonal first, then the off-diagonal bins with
-// entries in row-major order (structure.cpp, finish_pairs), and the off-diagonal entry lists follow that order, so
-// ent0[bin] is the exclusive prefix sum of cnt over the bins (i, j), i < j, taken row-major.  One workgroup: every
-// thread sums a run of consecutive bins, the run totals are scanned through LDS.
-__global__ __launch_bounds__(1024) void k_struct_ptr(StructDev sd)
-{
-    __shared__ int tot[1024];
-    const int nf = sd.nfree, nbins = nf * nf;
-    const int per = (nbins + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(nbins, b0 + per);
-    int sum = 0;
-    for (int b = b0; b < b1; ++b) sum += (b / nf < b % nf) ? sd.cnt[b] : 0;
-    tot[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele, inclusive
-        const int v = threadIdx.x >= d ? tot[threadIdx.x - d] : 0;
-        __syncthreads();
-        tot[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = tot[threadIdx.x] - sum;
-    for (int b = b0; b < b1; ++b) {
-        sd.ent0[b] = run;
-        run += (b / nf < b % nf) ? sd.cnt[b] : 0;
-    }
-}
-
 // map point of every pose-major slot (what a diagonal schur entry needs besides its slot).  With `base` the slot array
 // arrives holding each edge's rank among its keyframe's edges (structure.h, build_basic): the slots are completed here.
 __global__ __launch_bounds__(256) void k_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E)
@@ -247,20 +221,44 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
     return hipGetLastError();
 }
 
-// the bins' totals and the error word straight into the host's pinned buffer, then a sequence number the host polls:
-// a device-to-host copy plus an event wait cost ~15 us more than these stores across the bus
-__global__ __launch_bounds__(1024) void k_struct_counts_out(const int32_t *cnt, const int32_t *err, int32_t *host_cnt, int nbins, int seq)
+// One workgroup behind the count kernel:
+// (1) the bins' totals and the error word straight into the host's pinned buffer, then a sequence number the host polls (a
+//     device-to-host copy plus an event wait cost ~15 us more than these stores across the bus);
+// (2) the first off-diagonal entry of every pair bin: the pairs are numbered diagonal first, then the off-diagonal bins with
+//     entries in row-major order (structure.cpp, finish_pairs), and the off-diagonal entry lists follow that order, so
+//     ent0[bin] is the exclusive prefix sum of cnt over the bins (i, j), i < j, taken row-major: every thread sums a run of
+//     consecutive bins, the run totals are scanned through LDS.  The fill kernel therefore needs nothing from the host.
+__global__ __launch_bounds__(1024) void k_struct_counts_out(StructDev sd, int32_t *host_cnt, int seq)
 {
-    for (int b = threadIdx.x; b < nbins; b += 1024) host_cnt[b] = cnt[b];
-    if (threadIdx.x == 0) host_cnt[nbins] = *err;
+    __shared__ int tot[1024];
+    const int nf = sd.nfree, nbins = nf * nf;
+    for (int b = threadIdx.x; b < nbins; b += 1024) host_cnt[b] = sd.cnt[b];
+    if (threadIdx.x == 0) host_cnt[nbins] = *sd.error;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+
+    const int per = (nbins + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(nbins, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += (b / nf < b % nf) ? sd.cnt[b] : 0;
+    tot[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele, inclusive
+        const int v = threadIdx.x >= d ? tot[threadIdx.x - d] : 0;
+        __syncthreads();
+        tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = tot[threadIdx.x] - sum;
+    for (int b = b0; b < b1; ++b) {
+        sd.ent0[b] = run;
+        run += (b / nf < b % nf) ? sd.cnt[b] : 0;
+    }
 }
 
 hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_struct_counts_out, dim3(1), dim3(1024), 0, s, sd.cnt, sd.error, host_cnt_dev, sd.nfree * sd.nfree, seq);
+    hipLaunchKernelGGL(k_struct_counts_out, dim3(1), dim3(1024), 0, s, sd, host_cnt_dev, seq);
     return hipGetLastError();
 }
 
@@ -271,12 +269,6 @@ hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s)
 }
 
 bool struct_lds_fits(int nfree, int NP) { return struct_lds_bytes(nfree, NP, true) <= 150 * 1024; }
-
-hipError_t launch_struct_ptr(const StructDev &sd, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_struct_ptr, dim3(1), dim3(1024), 0, s, sd);
-    return hipGetLastError();
-}
 
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s)
 {
