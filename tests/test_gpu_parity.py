@@ -649,3 +649,29 @@ def test_results_straight_into_pinned_caller_arrays(built_lib):
             np.testing.assert_array_equal(c[k], ref[k])
     finally:
         s.close()
+
+
+def test_invalid_windows_are_refused_and_the_handle_keeps_working(built_lib):
+    """A keyframe observing a point twice is found by the device structure pass (reported back with the pair counts), an
+    index out of range by the host's pass over the edges: both MOVBA_ERR_ARG with nothing solved, and the handle (helper
+    thread, copy stream, arena) is as usable afterwards as before."""
+    s = built_lib.Solver()
+    try:
+        w = synth.cfg("cfg2")
+        ref = s.solve(w)
+        dup = synth.cfg("cfg2")
+        e = int(np.flatnonzero(dup.pose_fixed[dup.edge_pose] == 0)[7])
+        same_point = np.flatnonzero(dup.edge_point == dup.edge_point[e])
+        other = int(same_point[same_point != e][0])
+        dup.edge_pose = dup.edge_pose.copy(); dup.edge_pose[other] = dup.edge_pose[e]      # the point now has this keyframe twice
+        with pytest.raises(built_lib.MovbaError):
+            s.solve(dup)
+        bad = synth.cfg("cfg2")
+        bad.edge_point = bad.edge_point.copy(); bad.edge_point[-1] = bad.n_points          # out of range
+        with pytest.raises(built_lib.MovbaError):
+            s.solve(bad)
+        again = s.solve(w)
+        for k in ("poses", "points", "chi2", "outlier"):
+            np.testing.assert_array_equal(again[k], ref[k])
+    finally:
+        s.close()
