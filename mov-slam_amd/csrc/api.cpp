@@ -1327,7 +1327,10 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
 {
     if (!h || !desc || !res) return MOVBA_ERR_ARG;
     res->status = MOVBA_ERR_ARG;
+    static const bool lap_on = std::getenv("MOVBA_TIME_SOLVE") != nullptr;
+    const double t_s0 = lap_on ? now_ms() : 0.0;
     int rc = movba_lba_upload(h, desc);
+    const double t_s1 = lap_on ? now_ms() : 0.0;
     if (rc != MOVBA_OK) { res->status = rc; return rc; }
     h->export_hint = true;
     {
@@ -1340,7 +1343,9 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
     h->export_hint = false;
     for (int k = 0; k < 3; ++k) h->user_dst[k] = nullptr;      // (user_host stays for the download below)
     if (rc < 0) { res->status = rc; h->stop = nullptr; return rc; }
+    const double t_s2 = lap_on ? now_ms() : 0.0;
     rc = movba_lba_download(h, res);
+    if (lap_on) std::fprintf(stderr, "libmovba[solve]: upload %.3f  run %.3f  download %.3f ms\n", t_s1 - t_s0, t_s2 - t_s1, now_ms() - t_s2);
     h->stop = nullptr;      // keep no caller pointer after the call returns
     res->status = rc;
     return rc;
