@@ -675,3 +675,44 @@ def test_invalid_windows_are_refused_and_the_handle_keeps_working(built_lib):
             np.testing.assert_array_equal(again[k], ref[k])
     finally:
         s.close()
+
+
+def test_two_threads_two_handles_like_local_mapping_and_tracking(built_lib):
+    """System.cc:128-129: LocalMapping runs LocalBundleAdjustment on its thread while Tracking runs PoseOptimization on
+    another, each on a handle of its own (they share the device's copy stream and the pinned-block registry): both get
+    the bits of their solo runs."""
+    import threading
+    w = synth.cfg("cfg2")
+    f = synth.make_frame(n=700, seed=12)
+    a, b = built_lib.Solver(), built_lib.Solver()
+    try:
+        ref_lba = a.solve(w)
+        ref_pose = b.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0, ransac_iters=50, ransac_seed=3)
+        errs = []
+
+        def mapping():
+            try:
+                a.prepare(w, pinned=True)
+                for _ in range(25):
+                    r = a.solve_prepared()
+                    if not (np.array_equal(r["poses"], ref_lba["poses"]) and np.array_equal(r["outlier"], ref_lba["outlier"])
+                            and np.array_equal(r["chi2"], ref_lba["chi2"])):
+                        errs.append("lba result changed")
+            except Exception as exc:            # noqa: BLE001
+                errs.append(repr(exc))
+
+        def tracking():
+            try:
+                for _ in range(150):
+                    p = b.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], 5.0, 25.0, ransac_iters=50, ransac_seed=3)
+                    if not (np.array_equal(p["pose"], ref_pose["pose"]) and np.array_equal(p["outlier"], ref_pose["outlier"])):
+                        errs.append("pose result changed")
+            except Exception as exc:            # noqa: BLE001
+                errs.append(repr(exc))
+
+        ts = [threading.Thread(target=mapping), threading.Thread(target=tracking)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        assert not errs, errs[:3]
+    finally:
+        a.close(); b.close()
