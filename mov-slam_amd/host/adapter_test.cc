@@ -100,7 +100,7 @@ static int run_lba(const char *in, const char *out, bool global)
         fwrite(v, sizeof(float), 7, o);
     }
     for (int l = 0; l < P; ++l) { const Eigen::Vector3f X = mps[l].GetWorldPos(); fwrite(X.v, sizeof(float), 3, o); }
-    fwrite(erased.data(), sizeof(int32_t), erased.size(), o);
+    if (!erased.empty()) fwrite(erased.data(), sizeof(int32_t), erased.size(), o);
     int nposes = 0, nnorm = 0;
     for (int i = 0; i < NP; ++i) nposes += kfs[i].nPoseSets;
     for (int l = 0; l < P; ++l) nnorm += mps[l].nNormalUpdates;
