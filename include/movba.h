@@ -226,7 +226,7 @@ typedef struct {
     int32_t  n_inliers;         /* return value of PoseOptimization (Optimizer.cc:458)        */
     int32_t  status;
     int32_t  ransac_inliers;    /* inliers of the best hypothesis (0: stage off, or no candidate with >= 4)  */
-    int32_t  pad;
+    int32_t  lm_iters;          /* LM iterations run over the 4 rounds (g2o stops a round early when the cost stops changing) */
     double   ransac_pose[7];    /* the pose the LM started from                               */
 } movba_pose_result;
 

@@ -1439,7 +1439,7 @@ extern "C" int movba_pose_ransac_samples(int32_t n, int32_t n_hyp, uint32_t seed
 extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_pose_result *res)
 {
     if (!h || !d || !res) return MOVBA_ERR_ARG;
-    res->status = MOVBA_ERR_ARG; res->n_inliers = 0; res->ransac_inliers = 0;
+    res->status = MOVBA_ERR_ARG; res->n_inliers = 0; res->ransac_inliers = 0; res->lm_iters = 0;
     const int n = d->n;
     const int n_hyp = d->ransac_iters > 0 ? std::min(d->ransac_iters, (int32_t)MOVBA_MAX_RANSAC_ITERS) : 0;
     if (n < 0 || (n && (!d->Xw || !d->obs)) || d->rounds < 1 || d->its_per_round < 1) return MOVBA_ERR_ARG;
@@ -1451,12 +1451,18 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     const size_t o_X = c.take<double>(3 * (size_t)n), o_obs = c.take<double>(2 * (size_t)n), o_is = c.take<double>(n);
     const size_t o_samp = c.take<int32_t>(3 * (size_t)n_hyp + 1);
     const size_t h2d = c.off;
-    const size_t o_chi = c.take<double>(n), o_pose = c.take<double>(16), o_lvl = c.take<uint8_t>(n);
+    const size_t o_chi = c.take<double>(n), o_pose = c.take<double>(24), o_lvl = c.take<uint8_t>(n);
     const size_t d2h_end = c.off;
     const size_t o_cand = c.take<uint8_t>(pose_ransac_bytes(n_hyp) + 16);
     const size_t total = c.off;
-    const bool staged = pose_opt_staged_lds_bytes(n, n_hyp) <= 150 * 1024;
-    if (!staged && total > h->pose_cap) {
+    // The hypothesis stage runs as a grid of its own over the whole chip (k_pose_hyp, one workgroup per sample) on a device
+    // copy of the matches; the LM kernel then only picks the best candidate.  The LM keeps the matches in LDS when they fit
+    // (staged), reading them once from the device copy (hypothesis stage on) or straight from the pinned buffer (off), and
+    // writes its results back into the pinned buffer itself.
+    const bool grid_hyp = n_hyp > 0;
+    const bool staged = pose_opt_staged_lds_bytes(n, 0) <= 144 * 1024;
+    const bool need_arena = !staged || grid_hyp;
+    if (need_arena && total > h->pose_cap) {
         if (h->pose_arena) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->pose_arena)); h->pose_arena = nullptr; h->pose_cap = 0; }
         const size_t cap = align_up(2 * total, 1 << 16);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->pose_arena), cap));
@@ -1473,23 +1479,29 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     double *isg = reinterpret_cast<double *>(sg + o_is);
     for (int i = 0; i < n; ++i) isg[i] = d->inv_sigma2 ? d->inv_sigma2[i] : 1.0;
     if (n_hyp > 0) (void)movba_pose_ransac_samples(n, n_hyp, d->ransac_seed, reinterpret_cast<int32_t *>(sg + o_samp));
-    // staged (up to ~3 000 matches): the kernel reads the pinned buffer itself and writes its results back into it
-    if (!staged) HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
+    if (need_arena) HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
     PoseDev p{};
-    p.n = n; p.rounds = d->rounds; p.its = d->its_per_round; p.n_hyp = n_hyp;
+    p.n = n; p.rounds = d->rounds; p.its = d->its_per_round; p.n_hyp = n_hyp; p.hyp_done = 0;
     p.fx = d->fx; p.fy = d->fy; p.cx = d->cx; p.cy = d->cy; p.huber_delta = d->huber_delta; p.chi2_gate = d->chi2_gate;
     for (int k = 0; k < 7; ++k) p.pose0[k] = d->pose0[k];
-    char *a = staged ? h->stage_dev : h->pose_arena;
-    p.Xw = reinterpret_cast<double *>(a + o_X); p.obs = reinterpret_cast<double *>(a + o_obs); p.isig = reinterpret_cast<double *>(a + o_is);
-    p.chi2 = reinterpret_cast<double *>(a + o_chi); p.pose_out = reinterpret_cast<double *>(a + o_pose); p.level1 = reinterpret_cast<uint8_t *>(a + o_lvl);
-    p.samples = reinterpret_cast<const int32_t *>(a + o_samp); p.cand = reinterpret_cast<double *>(a + o_cand);
+    char *in = need_arena ? h->pose_arena : h->stage_dev;          // where the kernels read the matches
+    char *out = staged ? h->stage_dev : h->pose_arena;              // where the LM kernel leaves its results
+    p.Xw = reinterpret_cast<double *>(in + o_X); p.obs = reinterpret_cast<double *>(in + o_obs); p.isig = reinterpret_cast<double *>(in + o_is);
+    p.samples = reinterpret_cast<const int32_t *>(in + o_samp);
+    p.chi2 = reinterpret_cast<double *>(out + o_chi); p.pose_out = reinterpret_cast<double *>(out + o_pose); p.level1 = reinterpret_cast<uint8_t *>(out + o_lvl);
+    p.cand = need_arena ? reinterpret_cast<double *>(h->pose_arena + o_cand) : nullptr;
+    if (grid_hyp) {
+        HIP_TRY(launch_pose_hyp(p, h->stream));
+        p.hyp_done = 1;
+    }
     HIP_TRY(launch_pose_opt(p, staged, h->stream));
-    if (!staged) HIP_TRY(hipMemcpyAsync(sg + o_chi, a + o_chi, d2h_end - o_chi, hipMemcpyDeviceToHost, h->stream));
+    if (!staged) HIP_TRY(hipMemcpyAsync(sg + o_chi, h->pose_arena + o_chi, d2h_end - o_chi, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     const double *po = reinterpret_cast<const double *>(sg + o_pose);
     for (int k = 0; k < 7; ++k) res->pose[k] = po[k];
     res->n_inliers = (int32_t)po[7];
     res->ransac_inliers = n_hyp > 0 ? (int32_t)po[8] : 0;
+    res->lm_iters = (int32_t)po[16];
     for (int k = 0; k < 7; ++k) res->ransac_pose[k] = n_hyp > 0 ? po[9 + k] : d->pose0[k];
     if (res->outlier) std::memcpy(res->outlier, sg + o_lvl, (size_t)n);
     if (res->chi2) std::memcpy(res->chi2, sg + o_chi, sizeof(double) * (size_t)n);

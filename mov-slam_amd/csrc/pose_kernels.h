@@ -8,6 +8,7 @@ namespace movba {
 
 struct PoseDev {
     int32_t n, rounds, its, n_hyp;     // n_hyp > 0: RANSAC / P3P hypothesis stage in front of the LM (samples: n_hyp x 3 match indices)
+    int32_t hyp_done, pad;             // the candidates were solved and scored by k_pose_hyp already (tables in `cand`)
     double fx, fy, cx, cy, huber_delta, chi2_gate;
     double pose0[7];
     const double *Xw;       // n x 3
@@ -15,9 +16,9 @@ struct PoseDev {
     const double *isig;     // n
     double *chi2;           // n out
     uint8_t *level1;        // n out: outlier flags
-    double *pose_out;       // 16: pose (7) + inlier count | inliers of the best hypothesis, its pose (7)
+    double *pose_out;       // 17: pose (7) + inlier count | inliers of the best hypothesis, its pose (7) | LM iterations run
     const int32_t *samples; // n_hyp x 3
-    double *cand;           // !staged: scratch for the candidate poses and scores (pose_ransac_bytes)
+    double *cand;           // device scratch for the candidate poses and scores (pose_ransac_bytes); unused when the stage runs staged in k_pose_opt
 };
 
 // staged: inputs and outputs are device views of pinned host memory, the kernel keeps the matches in LDS
@@ -25,6 +26,7 @@ struct PoseDev {
 size_t pose_opt_staged_lds_bytes(int n, int n_hyp);
 size_t pose_ransac_bytes(int n_hyp);
 hipError_t configure_pose_kernels();
+hipError_t launch_pose_hyp(const PoseDev &p, hipStream_t s);      // the hypothesis stage as a grid of its own (inputs in device memory)
 hipError_t launch_pose_opt(const PoseDev &p, bool staged, hipStream_t s);
 
 }  // namespace movba

@@ -11,6 +11,7 @@
 #include <cfloat>
 #include <cmath>
 
+#include "device_math.h"
 #include "movba.h"
 #include "pose_kernels.h"
 
@@ -92,21 +93,31 @@ __device__ void oplus(const double u[6], const double T[7], double out[7])
     out[4] = e[4] + rx; out[5] = e[5] + ry; out[6] = e[6] + rz;
 }
 
-// fixed-order reduction of NV values per thread; result in every thread
+// fixed-order reduction of NV values per thread; result in every thread.  Inside a wave: two DPP steps sum each quad, the
+// 16 quad sums of every value cross a wave-private LDS strip and lane k adds those of value k up in order (a butterfly of
+// 64-bit shuffles per value costs ~500 cycles each: 28 of them were three quarters of an LM iteration); then the waves'
+// sums are combined in wave order.
 template <int NV>
-__device__ __forceinline__ void reduce_all(double (&v)[NV], double *lds /* kW*NV */)
+__device__ __forceinline__ void reduce_all(double (&v)[NV], double *lds /* kW * NV + kW * NV * 16 */)
 {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *strip = lds + kW * NV + wave * (NV * 16);
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double s = v[k];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-        v[k] = s;
+        double t = v[k];
+        t += dpp_mov0<0xb1>(t);
+        t += dpp_mov0<0x4e>(t);
+        if ((lane & 3) == 0) strip[k * 16 + (lane >> 2)] = t;
     }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < NV) {
+        const double2 *src = reinterpret_cast<const double2 *>(strip + lane * 16);
+        double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) lds[wave * NV + k] = v[k];
+        for (int q = 0; q < 8; ++q) { const double2 t = src[q]; s += t.x; s += t.y; }
+        lds[wave * NV + lane] = s;
     }
     __syncthreads();
 #pragma unroll
@@ -130,21 +141,25 @@ __device__ bool solve6(const double Hu[21], double lambda, const double b[6], do
             const int i = a <= c ? a : c, j = a <= c ? c : a;
             L[a * 6 + c] = Hu[i * 6 - i * (i - 1) / 2 + (j - i)] + (a == c ? lambda : 0.0);
         }
+    // (every thread runs this chain by itself with one wave per SIMD: nothing hides its latency, and an fp64 division or
+    // square root is a ~30-instruction sequence of its own.  One reciprocal square root per pivot and multiplications
+    // instead of 6 square roots and 27 divisions: the chain was a third of an LM iteration)
     bool ok = true;
+    double inv[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = L[j * 6 + j];
 #pragma unroll
         for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
         if (!(d > 0.0) || !isfinite(d)) ok = false;
-        d = sqrt(d);
-        L[j * 6 + j] = d;
+        const double r = rsqrt(d);
+        inv[j] = r;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double s = L[i * 6 + j];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = s / d;
+            L[i * 6 + j] = s * r;
         }
     }
 #pragma unroll
@@ -152,14 +167,14 @@ __device__ bool solve6(const double Hu[21], double lambda, const double b[6], do
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * x[k];
-        x[i] = s / L[i * 6 + i];
+        x[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = x[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        x[i] = s * inv[i];
     }
     return ok;
 }
@@ -179,11 +194,14 @@ __device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return Cplx{ a.re * b.re 
 __device__ __forceinline__ Cplx csub(Cplx a, Cplx b) { return Cplx{ a.re - b.re, a.im - b.im }; }
 __device__ __forceinline__ Cplx cdiv(Cplx a, Cplx b)
 {
-    const double d = b.re * b.re + b.im * b.im;
-    return Cplx{ (a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d };
+    const double id = 1.0 / (b.re * b.re + b.im * b.im);
+    return Cplx{ (a.re * b.re + a.im * b.im) * id, (a.im * b.re - a.re * b.im) * id };
 }
 
-// all four roots of z^4 + c3 z^3 + c2 z^2 + c1 z + c0 (Durand-Kerner, fixed iteration count: deterministic)
+// all four roots of z^4 + c3 z^3 + c2 z^2 + c1 z + c0 (Durand-Kerner from fixed starting points; sweeps until no root
+// moves by more than 1e-15 of the root bound, 80 at most: a sweep is a chain of ~400 dependent fp64 instructions that
+// nothing hides — one thread per hypothesis —, and 80 of them were a third of a PoseOptimization call; the usual quartic
+// is through after 10 - 20)
 __device__ void quartic_roots(double c3, double c2, double c1, double c0, Cplx z[4])
 {
     // Fujiwara bound: every root lies within 2 max(|c3|, |c2|^1/2, |c1|^1/3, |c0|^1/4)
@@ -191,7 +209,9 @@ __device__ void quartic_roots(double c3, double c2, double c1, double c0, Cplx z
     const double r0 = 0.5 * rb;
     z[0] = Cplx{ r0 * 0.9210609940028851, r0 * 0.3894183423086505 };      // radius r0, angles 0.4 + k pi / 2
     z[1] = Cplx{ -z[0].im, z[0].re }; z[2] = Cplx{ -z[0].re, -z[0].im }; z[3] = Cplx{ z[0].im, -z[0].re };
+    const double tol2 = (1e-15 * rb) * (1e-15 * rb);
     for (int it = 0; it < 80; ++it) {
+        double moved = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const Cplx x = z[k];
@@ -203,8 +223,13 @@ __device__ void quartic_roots(double c3, double c2, double c1, double c0, Cplx z
             Cplx den = Cplx{ 1.0, 0.0 };
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (j != k) den = cmul(den, csub(x, z[j]));
-            if (den.re * den.re + den.im * den.im > 0.0) z[k] = csub(x, cdiv(pv, den));
+            if (den.re * den.re + den.im * den.im > 0.0) {
+                const Cplx st = cdiv(pv, den);
+                z[k] = csub(x, st);
+                moved = fmax(moved, st.re * st.re + st.im * st.im);
+            }
         }
+        if (moved <= tol2) break;
     }
 }
 
@@ -309,13 +334,83 @@ __device__ void R2q(const double m[9], double q[4])
 
 }  // namespace
 
+// minimal sample h -> up to four candidate poses (cand[(4 h + k) * 12]: R row-major, t) and their number (nsol[h])
+__device__ void hyp_solve(const PoseDev &p, const double *Xw, const double *obs, int h, double *cand, int *nsol)
+{
+    double X[3][3], jb[3][3];
+    bool okh = true;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int i = p.samples[3 * h + m];
+        okh &= i >= 0 && i < p.n;
+        const int ii = okh ? i : 0;
+        X[m][0] = Xw[3 * ii]; X[m][1] = Xw[3 * ii + 1]; X[m][2] = Xw[3 * ii + 2];
+        const double bx = (obs[2 * ii] - p.cx) / p.fx, by = (obs[2 * ii + 1] - p.cy) / p.fy;
+        const double nn = 1.0 / sqrt(bx * bx + by * by + 1.0);
+        jb[m][0] = bx * nn; jb[m][1] = by * nn; jb[m][2] = nn;
+    }
+    double Rs[4][9], ts[4][3];
+    const int ns = okh ? p3p_grunert(X, jb, Rs, ts) : 0;
+    nsol[h] = ns;
+    for (int k = 0; k < ns; ++k) {
+        double *c = cand + ((size_t)h * 4 + k) * 12;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) c[e] = Rs[k][e];
+        c[9] = ts[k][0]; c[10] = ts[k][1]; c[11] = ts[k][2];
+    }
+}
+
+// one wave scores candidate cidx on all matches: inliers at the caller's threshold, truncated cost (score[2 cidx], [2 cidx + 1])
+__device__ void hyp_score(const PoseDev &p, const double *Xw, const double *obs, const double *isig, int cidx, const double *cand,
+                          const int *nsol, double *score, int lane)
+{
+    double cnt = 0.0, cst = 0.0;
+    if ((cidx & 3) < nsol[cidx >> 2]) {
+        const double *R = cand + (size_t)cidx * 12;
+        for (int i = lane; i < p.n; i += 64) {
+            const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
+            const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
+            const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
+            const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
+            const double om = isig[i];
+            const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
+            const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+            const bool in = (z > 0.0) && (chi2 <= p.chi2_gate);
+            cnt += in ? 1.0 : 0.0; cst += in ? chi2 : p.chi2_gate;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); cst += __shfl_xor(cst, o, 64); }
+    } else { cnt = -1.0; cst = DBL_MAX; }
+    if (lane == 0) { score[2 * cidx] = cnt; score[2 * cidx + 1] = cst; }
+}
+
+__device__ __forceinline__ void hyp_tables(const PoseDev &p, double *cand, double *&score, int *&nsol)
+{
+    score = cand + (size_t)p.n_hyp * 48;
+    nsol = reinterpret_cast<int *>(score + (size_t)p.n_hyp * 8);
+}
+
+// The hypothesis stage over the whole chip: workgroup h solves sample h (one thread: a chain of dependent fp64 work) and
+// its four waves score the four candidates.  Inside k_pose_opt's single workgroup the scoring alone — 4 n_hyp candidates x n
+// matches x ~120 fp64 instructions on one CU — took 0.18 ms of a 0.42 ms call at 50 hypotheses and 500 matches.
+__global__ __launch_bounds__(kT) void k_pose_hyp(PoseDev p)
+{
+    double *score; int *nsol;
+    hyp_tables(p, p.cand, score, nsol);
+    const int h = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) hyp_solve(p, p.Xw, p.obs, h, p.cand, nsol);
+    __syncthreads();
+    static_assert(kW == 4, "one wave per candidate of a sample");
+    hyp_score(p, p.Xw, p.obs, p.isig, 4 * h + (tid >> 6), p.cand, nsol, score, tid & 63);
+}
+
 // STAGED: the matches are read ONCE from where the host left them (its pinned staging buffer, across the bus) into LDS,
 // every pass of the 4 x 10 iterations then reads LDS, and the results are written straight back to the pinned buffer: no
 // copy engine on either side of the launch (small copies cost ~0.1 ms each, as much as the kernel itself).
 template <bool STAGED>
 __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 {
-    __shared__ double lds[kW * 28];
+    __shared__ __attribute__((aligned(16))) double lds[kW * 28 + kW * 28 * 16];      // reduce_all: the waves' sums, then a strip per wave
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int tid = threadIdx.x;
     const double *Xw = p.Xw, *obs = p.obs, *isig = p.isig;
@@ -337,53 +432,16 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     __syncthreads();
     if (p.n_hyp > 0) {
         // ---- hypothesis stage (see the header of the P3P block): thread h solves sample h, then every wave scores candidates ----
-        double *cand = STAGED ? reinterpret_cast<double *>(level1 + (((size_t)p.n + 15) & ~(size_t)15)) : p.cand;   // n_hyp x 4 x 12 poses, then x 2 scores
-        double *score = cand + (size_t)p.n_hyp * 48;
-        int *nsol = reinterpret_cast<int *>(score + (size_t)p.n_hyp * 8);
-        for (int h = tid; h < p.n_hyp; h += kT) {
-            double X[3][3], jb[3][3];
-            bool okh = true;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int i = p.samples[3 * h + m];
-                okh &= i >= 0 && i < p.n;
-                const int ii = okh ? i : 0;
-                X[m][0] = Xw[3 * ii]; X[m][1] = Xw[3 * ii + 1]; X[m][2] = Xw[3 * ii + 2];
-                const double bx = (obs[2 * ii] - p.cx) / p.fx, by = (obs[2 * ii + 1] - p.cy) / p.fy;
-                const double nn = 1.0 / sqrt(bx * bx + by * by + 1.0);
-                jb[m][0] = bx * nn; jb[m][1] = by * nn; jb[m][2] = nn;
-            }
-            double Rs[4][9], ts[4][3];
-            const int ns = okh ? p3p_grunert(X, jb, Rs, ts) : 0;
-            nsol[h] = ns;
-            for (int k = 0; k < ns; ++k) {
-                double *c = cand + ((size_t)h * 4 + k) * 12;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) c[e] = Rs[k][e];
-                c[9] = ts[k][0]; c[10] = ts[k][1]; c[11] = ts[k][2];
-            }
-        }
-        __syncthreads();
-        const int lane = tid & 63, wv = tid >> 6;
-        for (int cidx = wv; cidx < 4 * p.n_hyp; cidx += kW) {
-            double cnt = 0.0, cst = 0.0;
-            if ((cidx & 3) < nsol[cidx >> 2]) {
-                const double *R = cand + (size_t)cidx * 12;
-                for (int i = lane; i < p.n; i += 64) {
-                    const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
-                    const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
-                    const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
-                    const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-                    const double om = isig[i];
-                    const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
-                    const double chi2 = e0 * (om * e0) + e1 * (om * e1);
-                    const bool in = (z > 0.0) && (chi2 <= p.chi2_gate);
-                    cnt += in ? 1.0 : 0.0; cst += in ? chi2 : p.chi2_gate;
-                }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); cst += __shfl_xor(cst, o, 64); }
-            } else { cnt = -1.0; cst = DBL_MAX; }
-            if (lane == 0) { score[2 * cidx] = cnt; score[2 * cidx + 1] = cst; }
+        // n_hyp x 4 x 12 poses, then x 2 scores: in LDS when this workgroup runs the stage itself and the matches are staged,
+        // in device memory otherwise (hyp_done: k_pose_hyp has filled them)
+        double *cand = (STAGED && !p.hyp_done) ? reinterpret_cast<double *>(level1 + (((size_t)p.n + 15) & ~(size_t)15)) : p.cand;
+        double *score; int *nsol;
+        hyp_tables(p, cand, score, nsol);
+        if (!p.hyp_done) {
+            for (int h = tid; h < p.n_hyp; h += kT) hyp_solve(p, Xw, obs, h, cand, nsol);
+            __syncthreads();
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int cidx = wv; cidx < 4 * p.n_hyp; cidx += kW) hyp_score(p, Xw, obs, isig, cidx, cand, nsol, score, lane);
         }
         __syncthreads();
         // best candidate: most inliers, then lowest truncated cost, then lowest index; every thread scans the same table
@@ -431,7 +489,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         return F[0];
     };
 
-    int n_bad = 0;
+    int n_bad = 0, n_lm = 0;
     for (int round = 0; round < p.rounds; ++round) {
         const bool robust = round <= 2;
 #pragma unroll
@@ -442,6 +500,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         bool ok = cnt[0] > 0.0;
         double lambda = 0.0, ni = 2.0;
         for (int it = 0; it < p.its && ok; ++it) {
+            ++n_lm;
             // computeActiveErrors + buildSystem in one pass
             double R[12];
             q2R(pose, R);
@@ -502,7 +561,8 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
                 }
                 rho = (F0 - F1) / scale;
                 if (rho > 0.0 && isfinite(F1)) {
-                    double alpha = 1.0 - pow(2.0 * rho - 1.0, 3.0);
+                    const double tr = 2.0 * rho - 1.0;
+                    double alpha = 1.0 - tr * tr * tr;           // (pow(tmp, 3) in g2o)
                     alpha = fmin(alpha, 2.0 / 3.0);
                     lambda *= fmax(1.0 / 3.0, alpha); ni = 2.0; F0 = F1;
                 } else {
@@ -545,6 +605,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 #pragma unroll
         for (int k = 0; k < 7; ++k) p.pose_out[k] = pose[k];
         p.pose_out[7] = (double)(p.n - n_bad);
+        p.pose_out[16] = (double)n_lm;
     }
 }
 
@@ -553,12 +614,18 @@ size_t pose_opt_staged_lds_bytes(int n, int n_hyp) { return (size_t)n * 6 * size
 
 hipError_t configure_pose_kernels()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_pose_opt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+}
+
+hipError_t launch_pose_hyp(const PoseDev &p, hipStream_t s)
+{
+    if (p.n_hyp > 0) hipLaunchKernelGGL(k_pose_hyp, dim3(p.n_hyp), dim3(kT), 0, s, p);
+    return hipGetLastError();
 }
 
 hipError_t launch_pose_opt(const PoseDev &p, bool staged, hipStream_t s)
 {
-    if (staged) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kT), pose_opt_staged_lds_bytes(p.n, p.n_hyp), s, p);
+    if (staged) hipLaunchKernelGGL(k_pose_opt<true>, dim3(1), dim3(kT), pose_opt_staged_lds_bytes(p.n, p.hyp_done ? 0 : p.n_hyp), s, p);
     else hipLaunchKernelGGL(k_pose_opt<false>, dim3(1), dim3(kT), 0, s, p);
     return hipGetLastError();
 }

@@ -77,7 +77,7 @@ class PoseDesc(C.Structure):
 
 class PoseResult(C.Structure):
     _fields_ = [("pose", C.c_double * 7), ("outlier", _u), ("chi2", _d), ("n_inliers", C.c_int32), ("status", C.c_int32),
-                ("ransac_inliers", C.c_int32), ("pad", C.c_int32), ("ransac_pose", C.c_double * 7)]
+                ("ransac_inliers", C.c_int32), ("lm_iters", C.c_int32), ("ransac_pose", C.c_double * 7)]
 
 
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
@@ -348,4 +348,4 @@ class Solver:
         if rc < 0:
             raise MovbaError(f"movba_pose_opt: {status_string(rc)}")
         return dict(status=rc, n_inliers=r.n_inliers, pose=np.array(r.pose[:]), outlier=outl, chi2=chi2,
-                    ransac_inliers=r.ransac_inliers, ransac_pose=np.array(r.ransac_pose[:]))
+                    ransac_inliers=r.ransac_inliers, ransac_pose=np.array(r.ransac_pose[:]), lm_iters=r.lm_iters)

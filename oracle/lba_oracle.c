@@ -870,7 +870,10 @@ static void quartic_roots(double c3, double c2, double c1, double c0, cplx_t z[4
     const double r0 = 0.5 * rb;
     z[0].re = r0 * 0.9210609940028851; z[0].im = r0 * 0.3894183423086505;
     z[1].re = -z[0].im; z[1].im = z[0].re; z[2].re = -z[0].re; z[2].im = -z[0].im; z[3].re = z[0].im; z[3].im = -z[0].re;
-    for (int it = 0; it < 80; ++it)
+    /* sweeps until no root moves by more than 1e-15 of the root bound (80 at most), like the kernel */
+    const double tol2 = (1e-15 * rb) * (1e-15 * rb);
+    for (int it = 0; it < 80; ++it) {
+        double moved = 0.0;
         for (int k = 0; k < 4; ++k) {
             const cplx_t x = z[k];
             cplx_t pv = { x.re + c3, x.im };
@@ -879,8 +882,14 @@ static void quartic_roots(double c3, double c2, double c1, double c0, cplx_t z[4
             pv = c_mul(pv, x); pv.re += c0;
             cplx_t den = { 1.0, 0.0 };
             for (int j = 0; j < 4; ++j) if (j != k) den = c_mul(den, c_sub(x, z[j]));
-            if (den.re * den.re + den.im * den.im > 0.0) z[k] = c_sub(x, c_div(pv, den));
+            if (den.re * den.re + den.im * den.im > 0.0) {
+                const cplx_t st = c_div(pv, den);
+                z[k] = c_sub(x, st);
+                moved = fmax(moved, st.re * st.re + st.im * st.im);
+            }
         }
+        if (moved <= tol2) break;
+    }
 }
 
 static void cross3(const double a[3], const double b[3], double o[3])

@@ -17,8 +17,8 @@ for n in (500, 1200):
     for _ in range(50):
         t = time.perf_counter(); rr = s.pose_opt(f["Xw"], f["obs"], f["pose0"], f["cam"], hub, gate, ransac_iters=50, ransac_seed=7); tr.append(time.perf_counter() - t)
     tr.sort()
-    line = (f"n={n}: movba_pose_opt call min {ts[0]*1e3:.3f} ms median {ts[25]*1e3:.3f} ms, inliers {r['n_inliers']}"
-            f" | with the 50-hypothesis P3P stage: median {tr[25]*1e3:.3f} ms, inliers {rr['n_inliers']}")
+    line = (f"n={n}: movba_pose_opt call min {ts[0]*1e3:.3f} ms median {ts[25]*1e3:.3f} ms, inliers {r['n_inliers']} ({r['lm_iters']} LM iterations)"
+            f" | with the 50-hypothesis P3P stage: median {tr[25]*1e3:.3f} ms, inliers {rr['n_inliers']} ({rr['lm_iters']} LM iterations)")
     if "--oracle" in sys.argv:
         from oracle import oracle
         t = time.perf_counter()
