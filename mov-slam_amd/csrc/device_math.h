@@ -172,18 +172,20 @@ __device__ __forceinline__ double group_sum_dpp(double v, int G)
     return v;
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// (DPP trees: a butterfly of 64-bit __shfl_xor costs two ds_bpermute through the LDS crossbar per step)
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
 
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmax(v, dpp_mov0<0xb1>(v));
+    v = fmax(v, dpp_mov0<0x4e>(v));
+    v = fmax(v, dpp_mov0<0x141>(v));
+    v = fmax(v, dpp_mov0<0x140>(v));
+    // (the lanes the row broadcasts do not write receive 0: harmless for the maxima of magnitudes taken here, and lane 63,
+    // which is read, is written by both)
+    v = fmax(v, dpp_mov0<0x142, 0xa>(v));
+    v = fmax(v, dpp_mov0<0x143, 0xc>(v));
+    return readlane_f64(v, 63);
 }
 
 // deterministic block reduction (fixed order), result valid in every thread

@@ -193,10 +193,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             if (pg[k] < end) back_edge(pg[k], pip[k], pob[k], pom[k], pur[k]);
         for (int g = begin + sub + kPointGroup * kPre; g < end; g += kPointGroup)
             back_edge(g, w.g_pose[g], *reinterpret_cast<const double2 *>(w.obs + 2 * g), w.isig[g], STEREO ? w.obs_r[g] : -1.0);
-#pragma unroll
-        for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
-            a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
-        }
+        // (DPP moves inside the group of 8 lanes: no LDS crossbar, unlike the ds_bpermute behind __shfl_xor)
+        a0 = group_sum_dpp(a0, kPointGroup); a1 = group_sum_dpp(a1, kPointGroup); a2 = group_sum_dpp(a2, kPointGroup);
         if (valid && end > begin) {
             double H[6], D[6];
 #pragma unroll
@@ -269,12 +267,9 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         if (pg[k] < end) eval_edge(pg[k], pip[k], psl[k], pob[k], pom[k], pur[k]);
     for (int g = begin + sub + kPointGroup * kPre; g < end; g += kPointGroup)
         eval_edge(g, w.g_pose[g], w.slot[g], *reinterpret_cast<const double2 *>(w.obs + 2 * g), w.isig[g], STEREO ? w.obs_r[g] : -1.0);
-#pragma unroll
-    for (int o = kPointGroup / 2; o >= 1; o >>= 1) {
-        h0 += __shfl_xor(h0, o, 64); h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64);
-        h3 += __shfl_xor(h3, o, 64); h4 += __shfl_xor(h4, o, 64); h5 += __shfl_xor(h5, o, 64);
-        v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64);
-    }
+    h0 = group_sum_dpp(h0, kPointGroup); h1 = group_sum_dpp(h1, kPointGroup); h2 = group_sum_dpp(h2, kPointGroup);
+    h3 = group_sum_dpp(h3, kPointGroup); h4 = group_sum_dpp(h4, kPointGroup); h5 = group_sum_dpp(h5, kPointGroup);
+    v0 = group_sum_dpp(v0, kPointGroup); v1 = group_sum_dpp(v1, kPointGroup); v2 = group_sum_dpp(v2, kPointGroup);
     double hmax = 0.0;
     if (valid && sub == 0) {
         double *Hd = S1.Hll + 6 * l;
