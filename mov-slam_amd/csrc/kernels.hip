@@ -161,15 +161,18 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
             const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
             const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
-            const double e0 = ob.x - (w.fx * x / z + w.cx);
-            const double e1 = ob.y - (w.fy * y / z + w.cy);
+            // (one reciprocal per edge and multiplications: an fp64 division is a ~25-instruction sequence, and the projection
+            //  and its Jacobian would take six of them)
+            const double iz = 1.0 / z, u = w.fx * x * iz, v = w.fy * y * iz;
+            const double e0 = ob.x - (u + w.cx);
+            const double e1 = ob.y - (v + w.cy);
             double chi2 = e0 * (om * e0) + e1 * (om * e1);
-            if (STEREO && ur >= 0.0) { const double e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
+            if (STEREO && ur >= 0.0) { const double e2 = ur - (u + w.cx - w.bf * iz); chi2 += e2 * (om * e2); }
             double rho1 = 1.0;
-            if (w.huber_delta > 0.0 && !(chi2 <= dsq0)) rho1 = w.huber_delta / sqrt(chi2);
+            if (w.huber_delta > 0.0 && !(chi2 <= dsq0)) rho1 = w.huber_delta * rsqrt(chi2);
             const double wg = rho1 * om;
-            const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
-            const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
+            const double a00 = -(w.fx * iz), a02 = u * iz;
+            const double a11 = -(w.fy * iz), a12 = v * iz;
             const double *xp = pxp + 6 * h;
             // t = J_c xp  (rows of -Jpi [ -[Xc]x | I ])
             const double t0 = (a02 * y) * xp[0] + (a00 * z - a02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + a02 * xp[5];
@@ -181,7 +184,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             a2 += (a00 * R[2] + a02 * R[8]) * g0 + (a11 * R[5] + a12 * R[8]) * g1;
             if (STEREO && ur >= 0.0) {
                 // stereo row (g2o::EdgeStereoSE3ProjectXYZ): like row 0 with a02 -> a02 - bf/z^2
-                const double c02 = a02 - w.bf / (z * z);
+                const double c02 = a02 - w.bf * iz * iz;
                 const double t2 = (c02 * y) * xp[0] + (a00 * z - c02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + c02 * xp[5];
                 const double g2 = wg * t2;
                 a0 += (a00 * R[0] + c02 * R[6]) * g2; a1 += (a00 * R[1] + c02 * R[7]) * g2; a2 += (a00 * R[2] + c02 * R[8]) * g2;
@@ -219,20 +222,21 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
         const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
-        const double e0 = ob.x - (w.fx * x / z + w.cx);
-        const double e1 = ob.y - (w.fy * y / z + w.cy);
+        const double iz = 1.0 / z, u = w.fx * x * iz, v = w.fy * y * iz;      // (one reciprocal per edge: see back_edge)
+        const double e0 = ob.x - (u + w.cx);
+        const double e1 = ob.y - (v + w.cy);
         double chi2 = e0 * (om * e0) + e1 * (om * e1);
         bool st = false;
         double e2 = 0.0;
         if (STEREO) {
             st = ur >= 0.0;
-            if (st) { e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
+            if (st) { e2 = ur - (u + w.cx - w.bf * iz); chi2 += e2 * (om * e2); }
         }
         double rho0 = chi2, rho1 = 1.0;
         if (w.huber_delta > 0.0 && !(chi2 <= dsqr)) {
-            const double sq = sqrt(chi2);
+            const double rs = rsqrt(chi2), sq = chi2 * rs;
             rho0 = 2.0 * sq * w.huber_delta - dsqr;
-            rho1 = w.huber_delta / sq;
+            rho1 = w.huber_delta * rs;
         }
         const double wg = rho1 * om;
         const double r0 = -wg * e0, r1 = -wg * e1;
@@ -244,8 +248,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             }
         }
         F += rho0;
-        const double a00 = -(w.fx / z), a02 = w.fx * x / (z * z);
-        const double a11 = -(w.fy / z), a12 = w.fy * y / (z * z);
+        const double a00 = -(w.fx * iz), a02 = u * iz;
+        const double a11 = -(w.fy * iz), a12 = v * iz;
         const double p00 = a00 * R[0] + a02 * R[6], p01 = a00 * R[1] + a02 * R[7], p02 = a00 * R[2] + a02 * R[8];
         const double p10 = a11 * R[3] + a12 * R[6], p11 = a11 * R[4] + a12 * R[7], p12 = a11 * R[5] + a12 * R[8];
         h0 += wg * (p00 * p00 + p10 * p10); h1 += wg * (p00 * p01 + p10 * p11); h2 += wg * (p00 * p02 + p10 * p12);
@@ -254,7 +258,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         if (STEREO) {
             const double r2 = -wg * e2;
             if (st) {
-                const double c02 = a02 - w.bf / (z * z);
+                const double c02 = a02 - w.bf * iz * iz;
                 const double p20 = a00 * R[0] + c02 * R[6], p21 = a00 * R[1] + c02 * R[7], p22 = a00 * R[2] + c02 * R[8];
                 h0 += wg * p20 * p20; h1 += wg * p20 * p21; h2 += wg * p20 * p22;
                 h3 += wg * p21 * p21; h4 += wg * p21 * p22; h5 += wg * p22 * p22;
