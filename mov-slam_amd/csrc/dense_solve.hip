@@ -36,16 +36,7 @@ constexpr int kBackStepsFrom = 12;      // block columns beyond which the back s
 
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 
-// 1 / p by v_rcp_f64 and two Newton steps (~1 ulp): the IEEE division sequence is several hundred cycles of dependent
-// instructions, and the pivot loops below are latency chains with one of these per link
-__device__ __forceinline__ double fast_rcp(double p)
-{
-    double r = __builtin_amdgcn_rcp(p);
-    r = r * (2.0 - p * r);
-    r = r * (2.0 - p * r);
-    return r;
-}
-
+// (fast_rcp, device_math.h: the pivot loops below are latency chains with one reciprocal per link)
 __device__ __forceinline__ size_t tile_off(int I, int J) { return ((size_t)I * (I + 1) / 2 + J) * (NB * NB); }
 
 // global tile (row-major NB x NB) -> LDS image with row stride LD

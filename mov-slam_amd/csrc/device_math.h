@@ -105,12 +105,23 @@ __device__ inline void se3_oplus(const double u[6], const double T[7], double ou
 }
 
 // inverse of the symmetric 3x3 (xx xy xz yy yz zz) by cofactors
+// 1 / p by v_rcp_f64 and two Newton steps (~1 ulp; no special cases: p finite, non-zero, normal).  The IEEE division the
+// compiler emits for `1.0 / p` is a ~25-instruction dependent sequence (scale, reciprocal, four refinements, fix-up);
+// the per-edge and per-entry arithmetic of the point and schur kernels held three to six of them.
+__device__ __forceinline__ double fast_rcp(double p)
+{
+    double r = __builtin_amdgcn_rcp(p);
+    r = r * (2.0 - p * r);
+    r = r * (2.0 - p * r);
+    return r;
+}
+
 __device__ __forceinline__ void inv3sym(const double A[6], double B[6])
 {
     const double c00 = A[3] * A[5] - A[4] * A[4];
     const double c01 = A[4] * A[2] - A[1] * A[5];
     const double c02 = A[1] * A[4] - A[3] * A[2];
-    const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    const double id = fast_rcp(A[0] * c00 + A[1] * c01 + A[2] * c02);
     B[0] = c00 * id; B[1] = c01 * id; B[2] = c02 * id;
     B[3] = (A[0] * A[5] - A[2] * A[2]) * id;
     B[4] = (A[2] * A[1] - A[0] * A[4]) * id;

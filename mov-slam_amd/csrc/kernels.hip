@@ -163,7 +163,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
             // (one reciprocal per edge and multiplications: an fp64 division is a ~25-instruction sequence, and the projection
             //  and its Jacobian would take six of them)
-            const double iz = 1.0 / z, u = w.fx * x * iz, v = w.fy * y * iz;
+            const double iz = fast_rcp(z), u = w.fx * x * iz, v = w.fy * y * iz;
             const double e0 = ob.x - (u + w.cx);
             const double e1 = ob.y - (v + w.cy);
             double chi2 = e0 * (om * e0) + e1 * (om * e1);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
         const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
-        const double iz = 1.0 / z, u = w.fx * x * iz, v = w.fy * y * iz;      // (one reciprocal per edge: see back_edge)
+        const double iz = fast_rcp(z), u = w.fx * x * iz, v = w.fy * y * iz;      // (one reciprocal per edge: see back_edge)
         const double e0 = ob.x - (u + w.cx);
         const double e1 = ob.y - (v + w.cy);
         double chi2 = e0 * (om * e0) + e1 * (om * e1);
@@ -368,7 +368,7 @@ template <int NR>
 __device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y, double z, const double R[9], bool stereo,
                                           double (&P)[NR][3], double (&C)[NR][6])
 {
-    const double iz = 1.0 / z;
+    const double iz = fast_rcp(z);
     const double a00 = -w.fx * iz, a02 = w.fx * x * iz * iz, a11 = -w.fy * iz, a12 = w.fy * y * iz * iz;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { P[0][q] = a00 * R[q] + a02 * R[6 + q]; P[1][q] = a11 * R[3 + q] + a12 * R[6 + q]; }
@@ -559,7 +559,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
                 const double m = ok[u] ? 1.0 : 0.0;
                 const bool st = NR == 3 && ur[u] >= 0.0;
                 // -w e, e = observation - projection of the recorded camera-frame point (include/OptimizableTypes.h: computeError)
-                const double iz = 1.0 / rc[u].z, mw = -(m * rc[u].w);
+                const double iz = fast_rcp(rc[u].z), mw = -(m * rc[u].w);
                 double rv[NR];
                 rv[0] = mw * (ob[u].x - (w.fx * rc[u].x * iz + w.cx)); rv[1] = mw * (ob[u].y - (w.fy * rc[u].y * iz + w.cy));
                 if (NR == 3) rv[NR - 1] = st ? mw * (ur[u] - (w.fx * rc[u].x * iz + w.cx - w.bf * iz)) : 0.0;
