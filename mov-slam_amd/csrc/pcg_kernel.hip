@@ -519,8 +519,10 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             const double beta = uniform_f64(first ? 0.0 : g * inv_gamma);
             const double den = delta - beta * g * inv_alpha;          // = p.Ap of the new search direction
             if (!(den > 0.0)) { fail = true; break; }
-            inv_gamma = uniform_f64(1.0 / g);                         // independent of the alpha chain: the two divisions overlap
-            alpha = uniform_f64(g / den);
+            // (reciprocals by v_rcp_f64 + two Newton steps: the IEEE division sequence is ~25 dependent instructions, on the
+            //  critical path of every iteration; the two are independent of each other and overlap)
+            inv_gamma = uniform_f64(fast_rcp(g));
+            alpha = uniform_f64(g * fast_rcp(den));
             inv_alpha = uniform_f64(den * inv_gamma);
             first = false;
             p_r = z_r + beta * p_r;
