@@ -21,40 +21,60 @@ __device__ __forceinline__ void quat_to_R(const double q[4], double R[9])
     R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.0 - (txx + tyy);
 }
 
+// 1 / p by v_rcp_f64 and two Newton steps (~1 ulp; no special cases: p finite, non-zero, normal).  The IEEE division the
+// compiler emits for `1.0 / p` is a ~25-instruction dependent sequence (scale, reciprocal, four refinements, fix-up);
+// the per-edge and per-entry arithmetic of the point and schur kernels held three to six of them.
+__device__ __forceinline__ double fast_rcp(double p)
+{
+    double r = __builtin_amdgcn_rcp(p);
+    r = r * (2.0 - p * r);
+    r = r * (2.0 - p * r);
+    return r;
+}
+
 __device__ __forceinline__ void R_to_quat(const double m[9], double q[4])
 {
     double t = m[0] + m[4] + m[8];
     if (t > 0.0) {
-        t = sqrt(t + 1.0);
-        q[3] = 0.5 * t;
-        t = 0.5 / t;
+        const double rs = rsqrt(t + 1.0);
+        q[3] = 0.5 * ((t + 1.0) * rs);
+        t = 0.5 * rs;
         q[0] = (m[7] - m[5]) * t;
         q[1] = (m[2] - m[6]) * t;
         q[2] = (m[3] - m[1]) * t;
     } else {
         // i = argmax diagonal, written without dynamic register indexing
         if (m[0] >= m[4] && m[0] >= m[8]) {
-            t = sqrt(m[0] - m[4] - m[8] + 1.0);
-            q[0] = 0.5 * t; t = 0.5 / t;
+            const double v = m[0] - m[4] - m[8] + 1.0, rs = rsqrt(v);
+            q[0] = 0.5 * (v * rs); t = 0.5 * rs;
             q[3] = (m[7] - m[5]) * t; q[1] = (m[3] + m[1]) * t; q[2] = (m[6] + m[2]) * t;
         } else if (m[4] > m[0] && m[4] >= m[8]) {
-            t = sqrt(m[4] - m[8] - m[0] + 1.0);
-            q[1] = 0.5 * t; t = 0.5 / t;
+            const double v = m[4] - m[8] - m[0] + 1.0, rs = rsqrt(v);
+            q[1] = 0.5 * (v * rs); t = 0.5 * rs;
             q[3] = (m[2] - m[6]) * t; q[2] = (m[7] + m[5]) * t; q[0] = (m[1] + m[3]) * t;
         } else {
-            t = sqrt(m[8] - m[0] - m[4] + 1.0);
-            q[2] = 0.5 * t; t = 0.5 / t;
+            const double v = m[8] - m[0] - m[4] + 1.0, rs = rsqrt(v);
+            q[2] = 0.5 * (v * rs); t = 0.5 * rs;
             q[3] = (m[3] - m[1]) * t; q[0] = (m[2] + m[6]) * t; q[1] = (m[5] + m[7]) * t;
         }
     }
 }
 
-// SE3Quat::normalizeRotation
-__device__ __forceinline__ void quat_normalize(double q[4])
+// SE3Quat::normalizeRotation with the reference's own operations (square root, four divisions): where a pose is taken over
+// from the caller — a unit quaternion comes out bit for bit as it went in, so a keyframe nothing moves is returned unchanged
+__device__ __forceinline__ void quat_normalize_exact(double q[4])
 {
     if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
     const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+// the same inside the update chain (reciprocal square root and multiplications, ~1 ulp apart)
+__device__ __forceinline__ void quat_normalize(double q[4])
+{
+    if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double in = rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] *= in; q[1] *= in; q[2] *= in; q[3] *= in;
 }
 
 __device__ __forceinline__ void quat_rotate(const double q[4], const double v[3], double o[3])
@@ -74,7 +94,14 @@ __device__ inline void se3_oplus(const double u[6], const double T[7], double ou
     const double th = sqrt(th2);
     double a, b, c, d;
     if (th < 0.00001) { a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0; }
-    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = b; d = (th - sin(th)) / (th2 * th); }
+    else {
+        // (one sincos and one reciprocal instead of sin twice, cos and three divisions: this chain is the tail of every PCG
+        //  launch and of every pose-only LM trial)
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        const double ith = fast_rcp(th), ith2 = ith * ith;
+        a = sn * ith; b = (1.0 - cs) * ith2; c = b; d = (th - sn) * (ith2 * ith);
+    }
     // Om = [w]x ; Om2 = w w^T - th2 I
     const double Om[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
     const double Om2[9] = { wx * wx - th2, wx * wy, wx * wz, wy * wx, wy * wy - th2, wy * wz, wz * wx, wz * wy, wz * wz - th2 };
@@ -105,17 +132,6 @@ __device__ inline void se3_oplus(const double u[6], const double T[7], double ou
 }
 
 // inverse of the symmetric 3x3 (xx xy xz yy yz zz) by cofactors
-// 1 / p by v_rcp_f64 and two Newton steps (~1 ulp; no special cases: p finite, non-zero, normal).  The IEEE division the
-// compiler emits for `1.0 / p` is a ~25-instruction dependent sequence (scale, reciprocal, four refinements, fix-up);
-// the per-edge and per-entry arithmetic of the point and schur kernels held three to six of them.
-__device__ __forceinline__ double fast_rcp(double p)
-{
-    double r = __builtin_amdgcn_rcp(p);
-    r = r * (2.0 - p * r);
-    r = r * (2.0 - p * r);
-    return r;
-}
-
 __device__ __forceinline__ void inv3sym(const double A[6], double B[6])
 {
     const double c00 = A[3] * A[5] - A[4] * A[4];

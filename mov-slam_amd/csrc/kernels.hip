@@ -58,7 +58,7 @@ __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int 
     double q[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) q[k] = w.pose0[7 * i + k];
-    quat_normalize(q);
+    quat_normalize_exact(q);
     double R[9];
     quat_to_R(q, R);
 #pragma unroll

@@ -35,63 +35,9 @@ __device__ __forceinline__ void q2R(const double q[7], double R[12])
     R[9] = q[4]; R[10] = q[5]; R[11] = q[6];
 }
 
-__device__ __forceinline__ void qnorm(double q[4])
-{
-    if (q[3] < 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
-    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
-}
-
-__device__ void oplus(const double u[6], const double T[7], double out[7])
-{
-    const double wx = u[0], wy = u[1], wz = u[2];
-    const double th2 = wx * wx + wy * wy + wz * wz, th = sqrt(th2);
-    double a, b, c, d;
-    if (th < 0.00001) { a = 1.0; b = 0.5; c = 0.5; d = 1.0 / 6.0; }
-    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = b; d = (th - sin(th)) / (th2 * th); }
-    const double Om[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
-    const double Om2[9] = { wx * wx - th2, wx * wy, wx * wz, wy * wx, wy * wy - th2, wy * wz, wz * wx, wz * wy, wz * wz - th2 };
-    double m[9], V[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const double I = (i % 4 == 0) ? 1.0 : 0.0;
-        m[i] = I + a * Om[i] + b * Om2[i];
-        V[i] = I + c * Om[i] + d * Om2[i];
-    }
-    double e[7];
-    double t = m[0] + m[4] + m[8];
-    if (t > 0.0) {
-        t = sqrt(t + 1.0); e[3] = 0.5 * t; t = 0.5 / t;
-        e[0] = (m[7] - m[5]) * t; e[1] = (m[2] - m[6]) * t; e[2] = (m[3] - m[1]) * t;
-    } else if (m[0] >= m[4] && m[0] >= m[8]) {
-        t = sqrt(m[0] - m[4] - m[8] + 1.0); e[0] = 0.5 * t; t = 0.5 / t;
-        e[3] = (m[7] - m[5]) * t; e[1] = (m[3] + m[1]) * t; e[2] = (m[6] + m[2]) * t;
-    } else if (m[4] > m[0] && m[4] >= m[8]) {
-        t = sqrt(m[4] - m[8] - m[0] + 1.0); e[1] = 0.5 * t; t = 0.5 / t;
-        e[3] = (m[2] - m[6]) * t; e[2] = (m[7] + m[5]) * t; e[0] = (m[1] + m[3]) * t;
-    } else {
-        t = sqrt(m[8] - m[0] - m[4] + 1.0); e[2] = 0.5 * t; t = 0.5 / t;
-        e[3] = (m[3] - m[1]) * t; e[0] = (m[2] + m[6]) * t; e[1] = (m[5] + m[7]) * t;
-    }
-    e[4] = V[0] * u[3] + V[1] * u[4] + V[2] * u[5];
-    e[5] = V[3] * u[3] + V[4] * u[4] + V[5] * u[5];
-    e[6] = V[6] * u[3] + V[7] * u[4] + V[8] * u[5];
-    qnorm(e);
-    double r[4];
-    r[3] = e[3] * T[3] - e[0] * T[0] - e[1] * T[1] - e[2] * T[2];
-    r[0] = e[3] * T[0] + e[0] * T[3] + e[1] * T[2] - e[2] * T[1];
-    r[1] = e[3] * T[1] + e[1] * T[3] + e[2] * T[0] - e[0] * T[2];
-    r[2] = e[3] * T[2] + e[2] * T[3] + e[0] * T[1] - e[1] * T[0];
-    const double *v = T + 4;
-    double ux = e[1] * v[2] - e[2] * v[1], uy = e[2] * v[0] - e[0] * v[2], uz = e[0] * v[1] - e[1] * v[0];
-    ux += ux; uy += uy; uz += uz;
-    const double rx = v[0] + e[3] * ux + (e[1] * uz - e[2] * uy);
-    const double ry = v[1] + e[3] * uy + (e[2] * ux - e[0] * uz);
-    const double rz = v[2] + e[3] * uz + (e[0] * uy - e[1] * ux);
-    qnorm(r);
-    out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
-    out[4] = e[4] + rx; out[5] = e[5] + ry; out[6] = e[6] + rz;
-}
+// (SE3 update and quaternion helpers: device_math.h, shared with the local-BA kernels)
+__device__ __forceinline__ void qnorm(double q[4]) { quat_normalize(q); }
+__device__ __forceinline__ void oplus(const double u[6], const double T[7], double out[7]) { se3_oplus(u, T, out); }
 
 // fixed-order reduction of NV values per thread; result in every thread.  Inside a wave: two DPP steps sum each quad, the
 // 16 quad sums of every value cross a wave-private LDS strip and lane k adds those of value k up in order (a butterfly of
@@ -427,7 +373,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     double pose0[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) pose0[k] = p.pose0[k];
-    qnorm(pose0);
+    quat_normalize_exact(pose0);
     for (int i = tid; i < p.n; i += kT) level1[i] = 0;
     __syncthreads();
     if (p.n_hyp > 0) {
@@ -481,7 +427,8 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
             const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
             const double om = isig[i];
-            const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
+            const double iz = fast_rcp(z);
+            const double e0 = obs[2 * i] - (p.fx * x * iz + p.cx), e1 = obs[2 * i + 1] - (p.fy * y * iz + p.cy);
             const double chi2 = e0 * (om * e0) + e1 * (om * e1);
             F[0] += (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) ? 2.0 * sqrt(chi2) * p.huber_delta - dsqr : chi2;
         }
@@ -514,15 +461,17 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
                 const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
                 const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
                 const double om = isig[i];
-                const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
+                // (one reciprocal per match and pass instead of six divisions)
+                const double iz = fast_rcp(z), uu = p.fx * x * iz, vv = p.fy * y * iz;
+                const double e0 = obs[2 * i] - (uu + p.cx), e1 = obs[2 * i + 1] - (vv + p.cy);
                 const double chi2 = e0 * (om * e0) + e1 * (om * e1);
                 double rho0 = chi2, rho1 = 1.0;
                 if (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) {
-                    const double sq = sqrt(chi2);
-                    rho0 = 2.0 * sq * p.huber_delta - dsqr; rho1 = p.huber_delta / sq;
+                    const double rs = rsqrt(chi2), sq = chi2 * rs;
+                    rho0 = 2.0 * sq * p.huber_delta - dsqr; rho1 = p.huber_delta * rs;
                 }
                 const double wg = rho1 * om, r0 = -wg * e0, r1 = -wg * e1;
-                const double a00 = -(p.fx / z), a02 = p.fx * x / (z * z), a11 = -(p.fy / z), a12 = p.fy * y / (z * z);
+                const double a00 = -(p.fx * iz), a02 = uu * iz, a11 = -(p.fy * iz), a12 = vv * iz;
                 const double C0[6] = { a02 * y, a00 * z - a02 * x, -a00 * y, a00, 0.0, a02 };
                 const double C1[6] = { -a11 * z + a12 * y, -a12 * x, a11 * x, 0.0, a11, a12 };
                 int u = 0;
