@@ -231,7 +231,7 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     // <= 1).  The pivot loop is unrolled by 6 so that the tile row / column holding pivot k + 1 are compile-time indices.
     static_assert(kNC == 96 && kT == 512, "tile layout written for 96 x 96 on 512 threads");
     double *dsc = gj + 4 * kNC + 2;                         // kNC: 1 / sqrt(diagonal)
-    if (tid < kNC) { const double d = Ac[tid * kNC + tid]; dsc[tid] = (d > 0.0 && isfinite(d)) ? 1.0 / sqrt(d) : 0.0; if (!(d > 0.0) || !isfinite(d)) s_bad = 1; }
+    if (tid < kNC) { const double d = Ac[tid * kNC + tid]; dsc[tid] = (d > 0.0 && isfinite(d)) ? rsqrt(d) : 0.0; if (!(d > 0.0) || !isfinite(d)) s_bad = 1; }
     __syncthreads();
     const int rg = tid >> 4, cg = tid & 15;
     double t[3][6];

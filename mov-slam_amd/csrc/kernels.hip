@@ -738,7 +738,8 @@ __device__ __forceinline__ void decide_body(const DevWindow &w)
     bool lambda_ok = true;
     int accepted = 0;
     if (rho > 0.0 && isfinite(F1)) {
-        double alpha = 1.0 - pow(2.0 * rho - 1.0, 3.0);
+        const double tr = 2.0 * rho - 1.0;
+        double alpha = 1.0 - tr * tr * tr;             // (pow(tmp, 3) in g2o: a library call of ~100 instructions here)
         alpha = fmin(alpha, 2.0 / 3.0);
         c->lambda *= fmax(1.0 / 3.0, alpha);
         c->nu = 2.0;
