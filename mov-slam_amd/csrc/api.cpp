@@ -494,7 +494,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
     HIP_TRY(hipStreamSynchronize(h->copy_stream));
     char *sg = h->stage;
+    // (a window is a stereo window when any observation carries a right-image coordinate; looked up on this thread — the first
+    //  stereo observation ends the scan — so that nothing the layout below depends on is produced by the helper thread)
     bool stereo = false;
+    if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
     // helper: straight copies of the caller's arrays (valid as they are when the edges come grouped by map point, the
     // reference's own order; an ungrouped window has them permuted again below) and the scan for stereo observations
     char *const arena_at_post = h->arena;
@@ -503,7 +506,12 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::atomic<int> idx_ready{0};
     // (every way out of this function waits for the helper first: it reads the caller's arrays and writes to this frame)
     struct HelperGuard { Worker &w; ~HelperGuard() { w.wait(); } } helper_guard{h->packer};
-    h->packer.post([=, &stereo, &raw_copy_err, &idx_ready]() {
+    // (MOVBA_HELPER_DELAY_US: the helper starts that much later — for tests: whatever this thread takes from the helper
+    //  without waiting for it shows up as a wrong result instead of hiding behind the usual timing)
+    const char *delay_env = std::getenv("MOVBA_HELPER_DELAY_US");
+    const int helper_delay_us = delay_env ? std::atoi(delay_env) : 0;
+    h->packer.post([=, &raw_copy_err, &idx_ready]() {
+        if (helper_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(helper_delay_us));
         // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_edges otherwise)
         std::memcpy(sg + o_gpose, d->edge_pose, sizeof(int32_t) * (size_t)E);
         std::memcpy(sg + o_gpoint, d->edge_point, sizeof(int32_t) * (size_t)E);
@@ -519,12 +527,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)E);
         send(o_obs, o_isig);
         std::memcpy(sg + o_isig, d->inv_sigma2, sizeof(double) * (size_t)E);
-        if (d->obs_right) {
-            std::memcpy(sg + o_obsr, d->obs_right, sizeof(double) * (size_t)E);
-            bool st = false;
-            for (int e = 0; e < E && !st; ++e) st = d->obs_right[e] >= 0.0;
-            stereo = st;
-        }
+        if (d->obs_right) std::memcpy(sg + o_obsr, d->obs_right, sizeof(double) * (size_t)E);
         std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
         std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
         send(o_isig, edge_bytes_grouped);
@@ -787,6 +790,9 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
     const size_t total = c.off;
 
+    // (a reallocation of the arena or of the staging buffer below must find the helper thread through with both: it reads
+    //  the caller's arrays into the staging buffer and sends them to the arena it was given at the start)
+    if (total > h->arena_cap || h2d - hole + misc_bytes > h->stage_cap) { const int rw = wait_helper(); if (rw) return rw; }
     rc2 = ensure_arena(h, total); if (rc2) return rc2;
     if (h->arena_gen != arena_gen_at_edge_copy) {
         // the arena was reallocated (told by its generation: the new allocation may sit at the old address): queue the

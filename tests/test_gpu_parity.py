@@ -716,3 +716,31 @@ def test_two_threads_two_handles_like_local_mapping_and_tracking(built_lib):
         assert not errs, errs[:3]
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("case", ["stereo", "mono", "regrow", "ungrouped"])
+def test_a_late_helper_thread_changes_nothing(built_lib, case, monkeypatch):
+    """The upload's helper thread (staging copies of the caller's arrays and their transfer) started 3 ms late: everything the
+    calling thread takes from it must be behind a wait — a stereo window (layout depends on the stereo flag), an upload
+    that reallocates the arena, edges that are permuted after the helper's straight copies."""
+    s = built_lib.Solver()
+    try:
+        if case == "stereo":
+            w = synth.make_window(12, 3, 1500, seed=262210, run_lo=4, run_hi=9, stereo_frac=0.5)
+        elif case == "ungrouped":
+            w = synth.cfg("cfg2")
+            pm = np.random.default_rng(3).permutation(w.n_edges)
+            w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[pm], w.edge_point[pm], w.obs[pm], w.inv_sigma2[pm]
+        else:
+            w = synth.cfg("cfg2")
+        if case == "regrow":
+            s.solve(synth.cfg("small"))                    # a small arena first
+        ref_solver = built_lib.Solver()
+        ref = ref_solver.solve(w)
+        ref_solver.close()
+        monkeypatch.setenv("MOVBA_HELPER_DELAY_US", "3000")
+        r = s.solve(w)
+        for k in ("poses", "points", "chi2", "outlier"):
+            np.testing.assert_array_equal(r[k], ref[k])
+    finally:
+        s.close()
