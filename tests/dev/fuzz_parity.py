@@ -55,7 +55,9 @@ for it in range(n):
     outl = int(((ro['outlier'] != rg['outlier']) & ~guard).sum())
     # decisions taken on rounding noise (|F0 - F1| <= 1e-9 F0: the solve has converged to machine precision) are a guard band
     f0, f1 = ro['trace']['f0'], ro['trace']['f1']
-    nz = np.flatnonzero(np.abs(f0 - f1) <= 1e-9 * np.abs(f0))
+    # ... and so are decisions at a cost 18 orders of magnitude under the initial one (a noise-free window solved to the last
+    # bit: residuals of 1e-13 px, whose squares are rounding noise in absolute terms)
+    nz = np.flatnonzero((np.abs(f0 - f1) <= 1e-9 * np.abs(f0)) | (f0 <= 1e-18 * f0[0]))
     k0 = int(nz[0]) if len(nz) else len(f0)
     same = np.array_equal(ro['trace']['accept'][:k0], rg['trace']['accept'][:k0]) and (k0 < len(f0) or ro['n_solves'] == rg['n_solves'])
     ok = dq < tol_q and dt < tol_t and pt < tol_p and outl == 0 and same

@@ -23,7 +23,7 @@ def noise_floor_trial(o):
     is a sum over all edges; a solve that has converged to machine precision keeps running, g2o has no convergence test, and
     the sign of F0 - F1 is then arbitrary).  Decisions from there on are a guard band, like |chi2 - 5| <= 1e-6 for the flags."""
     f0, f1 = o["trace"]["f0"], o["trace"]["f1"]
-    k = np.flatnonzero(np.abs(f0 - f1) <= 1e-9 * np.abs(f0))
+    k = np.flatnonzero((np.abs(f0 - f1) <= 1e-9 * np.abs(f0)) | (f0 <= 1e-18 * f0[0]))     # (or a cost at the absolute rounding floor)
     return int(k[0]) if len(k) else len(f0)
 
 
