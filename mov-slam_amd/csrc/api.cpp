@@ -138,6 +138,7 @@ struct movba_handle {
     // the export kernel writes to, and the host pointer it stands for (download skips the copy-out of exactly that array)
     unsigned long long *user_dst[3] = {nullptr, nullptr, nullptr};
     const void *user_host[3] = {nullptr, nullptr, nullptr};
+    bool exported[3] = {true, true, true};      // which of poses / points / chi2 the run's export wrote (the caller asked for)
     Structure st;
     DevWindow win{};
     size_t h2d_bytes = 0;
@@ -946,7 +947,7 @@ int lm_loop(movba_handle *h, bool parked)
         // ... and the results go across the bus into the staging buffer right behind it: movba_lba_download then finds them
         // there instead of paying a launch and a stream synchronise of its own
         if (h->export_in_run) {
-            ExportDst dst = export_dst(h->stage_dev, export_layout(w), true, true, true);
+            ExportDst dst = export_dst(h->stage_dev, export_layout(w), h->exported[0], h->exported[1], h->exported[2]);
             if (h->user_dst[0]) dst.poses = h->user_dst[0];
             if (h->user_dst[1]) dst.points = h->user_dst[1];
             if (h->user_dst[2]) dst.chi2 = h->user_dst[2];
@@ -1289,7 +1290,7 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     // buffer: a download into other arrays exports again
     if (h->export_in_run) {
         void *const arr[3] = { res->poses, res->points, res->chi2 };
-        for (int k = 0; k < 3; ++k) if (arr[k] && h->user_host[k] && h->user_host[k] != arr[k]) h->export_in_run = false;
+        for (int k = 0; k < 3; ++k) if (arr[k] && (!h->exported[k] || (h->user_host[k] && h->user_host[k] != arr[k]))) h->export_in_run = false;
     }
     if (!h->export_in_run) {
         for (int k = 0; k < 3; ++k) h->user_host[k] = nullptr;
@@ -1343,7 +1344,10 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
         const DevWindow &w = h->win;
         void *const arr[3] = { res->poses, res->points, res->chi2 };
         const size_t nb[3] = { sizeof(double) * 7 * (size_t)w.NP, sizeof(double) * 3 * (size_t)w.P, sizeof(double) * (size_t)w.E };
-        for (int k = 0; k < 3; ++k) { h->user_dst[k] = host_block_view(arr[k], nb[k]); h->user_host[k] = h->user_dst[k] ? arr[k] : nullptr; }
+        for (int k = 0; k < 3; ++k) {
+            h->user_dst[k] = host_block_view(arr[k], nb[k]); h->user_host[k] = h->user_dst[k] ? arr[k] : nullptr;
+            h->exported[k] = arr[k] != nullptr;          // (an array the caller does not ask for does not cross the bus)
+        }
     }
     rc = movba_lba_run(h);
     h->export_hint = false;

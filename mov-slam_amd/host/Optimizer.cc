@@ -319,7 +319,7 @@ namespace MOV_SLAM
 
         struct Solved
         {
-            PinnedArray poses, points, chi2;
+            PinnedArray poses, points;
             std::vector<uint8_t> outlier;
             int status = MOVBA_ERR_HIP;
         };
@@ -351,9 +351,10 @@ namespace MOV_SLAM
             d.flags = MOVBA_FLAG_STALE_ERROR_QUIRK;
             d.stop = reinterpret_cast<const volatile uint8_t *>(pbStopFlag);
             s.poses.resize(f.poses.size()); s.points.resize(f.points.size());
-            s.chi2.resize(f.edge_pose.size()); s.outlier.resize(f.edge_pose.size());
+            s.outlier.resize(f.edge_pose.size());
             movba_lba_result r{};
-            r.poses = s.poses.data(); r.points = s.points.data(); r.chi2 = s.chi2.data(); r.outlier = s.outlier.data();
+            r.poses = s.poses.data(); r.points = s.points.data(); r.outlier = s.outlier.data();
+            r.chi2 = nullptr;                                    // (the gate's verdict is all Optimizer.cc:757-775 uses: not asked for, not transferred)
             dump_window(d);
             s.status = movba_lba_solve(h, &d, &r);
             return s;

@@ -233,13 +233,15 @@ class Solver:
         a[...] = 0.0
         return a
 
-    def _alloc_result(self, d, pinned=False):
+    def _alloc_result(self, d, pinned=False, chi2=True):
         mk = self._pinned if pinned else np.zeros
         out = dict(poses=mk((d.n_poses, 7)), points=mk((d.n_points, 3)),
-                   chi2=mk((d.n_edges,)), outlier=np.zeros(d.n_edges, np.uint8))
+                   chi2=mk((d.n_edges,)) if chi2 else np.zeros(0), outlier=np.zeros(d.n_edges, np.uint8))
         r = LbaResult()
         r.poses = _p(out["poses"], _d); r.points = _p(out["points"], _d)
-        r.chi2 = _p(out["chi2"], _d); r.outlier = _p(out["outlier"], _u)
+        if chi2:
+            r.chi2 = _p(out["chi2"], _d)                  # (left NULL: the per-edge chi2 is neither exported nor copied out)
+        r.outlier = _p(out["outlier"], _u)
         return r, out
 
     @staticmethod
@@ -264,11 +266,12 @@ class Solver:
             out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
         return self._pack(r, out, rc)
 
-    def prepare(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0, pinned=False):
+    def prepare(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0, pinned=False, chi2=True):
         """Descriptor and result buffers built once for repeated solve_prepared() calls: what a C++ caller that keeps its
         flattened arrays and result buffers does (nothing is allocated or converted per call)."""
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
-        r, out = self._alloc_result(d, pinned)      # pinned: result arrays the solve's last kernel writes into directly
+        r, out = self._alloc_result(d, pinned, chi2)      # pinned: result arrays the solve's last kernel writes into directly
+        self._keep = (d, keep)
         self._prep = (d, keep, r, out)
 
     def solve_prepared(self, pack=True):

@@ -744,3 +744,23 @@ def test_a_late_helper_thread_changes_nothing(built_lib, case, monkeypatch):
             np.testing.assert_array_equal(r[k], ref[k])
     finally:
         s.close()
+
+
+def test_results_the_caller_does_not_ask_for_are_not_transferred(built_lib):
+    """movba_lba_result::chi2 == NULL (the adapter's case: only the gate's verdict is used, Optimizer.cc:757-775): the other
+    results are the same, and a later download that does ask for chi2 exports it from the resident window."""
+    w = synth.cfg("cfg2")
+    s = built_lib.Solver()
+    try:
+        ref = s.solve(w)
+        for pinned in (False, True):
+            s.prepare(w, pinned=pinned, chi2=False)
+            r = s.solve_prepared()
+            for k in ("poses", "points", "outlier"):
+                np.testing.assert_array_equal(r[k], ref[k])
+            assert r["n_outliers"] == ref["n_outliers"] and r["chi2"].size == 0
+            full = s.download()
+            for k in ("poses", "points", "chi2", "outlier"):
+                np.testing.assert_array_equal(full[k], ref[k])
+    finally:
+        s.close()
