@@ -643,11 +643,15 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
     // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
     size_t noff = 0, o_ent = 0, o_slotpt = 0;
+    // 8-byte packed entries when slots and point ids fit (any realistic window; MOVBA_ENTRIES_UNPACKED=1 keeps the 12-byte form, for tests)
+    const bool ent_packed = s.E_free < kEntPackSlots && P < kEntPackPoints && !std::getenv("MOVBA_ENTRIES_UNPACKED");
+    auto ent_words = [&]() { return (ent_packed ? 2 : 3) * noff + 4; };       // int32 words of the entry region
     bool filled_early = false;
     uint64_t fill_gen = 0;
     auto launch_fill = [&]() -> int {
         int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
         sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff;
+        sd.ent64 = ent_packed ? reinterpret_cast<unsigned long long *>(h->arena + o_ent) : nullptr;
         sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
         sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
         sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
@@ -718,7 +722,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
             if (n > (int64_t)0x7fffffff / 4) return MOVBA_ERR_ARG;
             noff = (size_t)n;
         }
-        o_ent = c.take<int32_t>(3 * noff + 4);
+        o_ent = c.take<int32_t>(ent_words());
         o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
         if (c.off <= h->arena_cap && h->arena_gen == arena_gen_at_post) {
             int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
@@ -764,7 +768,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
     const size_t o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
-    if (!dev_structure) o_ent = c.take<int32_t>(3 * noff + 4);       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
+    if (!dev_structure) o_ent = c.take<int32_t>(ent_words());       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
     const size_t h2d = c.off;
     // ---- device-only region ----
     size_t o_st[2][11];
@@ -811,8 +815,13 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     // ---- pack the pair region ----
     if (!dev_structure && noff) {
         int32_t *eh = reinterpret_cast<int32_t *>(sp(o_ent));
-        std::memcpy(eh, s.ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s.ent_j.data(), sizeof(int32_t) * noff);
-        std::memcpy(eh + 2 * noff, s.ent_l.data(), sizeof(int32_t) * noff);
+        if (ent_packed) {
+            unsigned long long *e64 = reinterpret_cast<unsigned long long *>(eh);
+            for (size_t k = 0; k < noff; ++k) e64[k] = ent_pack(s.ent_i[k], s.ent_j[k], s.ent_l[k]);
+        } else {
+            std::memcpy(eh, s.ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s.ent_j.data(), sizeof(int32_t) * noff);
+            std::memcpy(eh + 2 * noff, s.ent_l.data(), sizeof(int32_t) * noff);
+        }
     }
     std::memcpy(sp(o_items), s.items.data(), sizeof(Item) * (size_t)s.nitems);
     std::memcpy(sp(o_sched), s.sched.data(), sizeof(SchedItem) * s.sched.size());
@@ -861,6 +870,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     {
         const int32_t *ed = reinterpret_cast<const int32_t *>(a + o_ent);
         w.ent_i = ed; w.ent_j = ed + noff; w.ent_l = ed + 2 * noff;
+        w.ent64 = ent_packed ? reinterpret_cast<const unsigned long long *>(a + o_ent) : nullptr;
         w.slot_point = reinterpret_cast<const int32_t *>(a + o_slotpt); w.n_diag = s.E_free;
     }
     w.items = reinterpret_cast<Item *>(a + o_items);

@@ -21,6 +21,10 @@ constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-ite
 //                 [36,42) sum of B_i Dinv b_l           (diagonal pairs only)
 //                 [42,63) upper triangle of Hpp_ii      (diagonal pairs only)
 //                 [63,69) b_p,i                          (diagonal pairs only)
+// packed off-diagonal schur entries: 22 + 22 bits of pose-major slots, 20 bits of map point (8 bytes instead of 12 per entry)
+constexpr int kEntPackSlots = 1 << 22, kEntPackPoints = 1 << 20;
+__host__ __device__ inline unsigned long long ent_pack(int si, int sj, int l) { return (unsigned long long)(unsigned)si | ((unsigned long long)(unsigned)sj << 22) | ((unsigned long long)(unsigned)l << 44); }
+
 constexpr int kPointGroup = 8;      // lanes cooperating on one map point
 #ifndef MOVBA_POINT_BLOCK
 #define MOVBA_POINT_BLOCK 256
@@ -108,6 +112,8 @@ struct DevWindow {
     // and list every edge of the pose in slot order), only the map point of a slot is stored.  Off-diagonal pairs: entry k
     // of the global numbering at k - n_diag in three arrays (slot of the edge of pose i, of pose j, map point): 12 bytes.
     const int32_t *ent_i, *ent_j, *ent_l, *slot_point;
+    const unsigned long long *ent64;    // the off-diagonal entries packed (slot of i: bits 0-21, slot of j: 22-43, point: 44-63) when the window
+                                        // allows (kEntPackSlots / kEntPackPoints), else null and the three arrays above hold them
     int32_t n_diag, pad5;   // entries of the diagonal pairs = edges of free poses
     const Item *items;
     const SchedItem *sched; // k_schur launch schedule: 8 x sched_per_xcd slots (structure.h)
@@ -157,7 +163,8 @@ struct StructDev {
     int32_t *error;             // set when a keyframe observes a point twice
     int32_t *ent0;              // nfree^2: first off-diagonal entry of a pair bin (i < j; k_struct_counts_out -> fill)
     const int32_t *slot;        // E: pose-major slot of a grouped edge (fill)
-    int32_t *ent_i, *ent_j, *ent_l;     // off-diagonal entry lists (fill)
+    int32_t *ent_i, *ent_j, *ent_l;     // off-diagonal entry lists (fill), or ...
+    unsigned long long *ent64;          // ... the packed form (non-null: used instead)
     int32_t pad5, pad6;
 };
 

@@ -585,7 +585,8 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
             for (int u = 0; u < B; ++u) {
                 const int kk = base + lane + 64 * u; ok[u] = kk < wend;
                 const int k = min(kk, wend - 1) - w.n_diag;
-                en[u] = Int4{ w.ent_i[k], w.ent_j[k], w.ent_l[k], 0 };
+                if (w.ent64) { const unsigned long long e = w.ent64[k]; en[u] = Int4{ (int)(e & 0x3fffffu), (int)((e >> 22) & 0x3fffffu), (int)(e >> 44), 0 }; }
+                else en[u] = Int4{ w.ent_i[k], w.ent_j[k], w.ent_l[k], 0 };
             }
             // edges of keyframe i (and of j) shared with the other one, in map-point order: ascending pose-major records
             double4 ri[B], rj[B]; double2 h[B][3]; bool sti[B], stj[B];

@@ -93,9 +93,9 @@ __global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd
         const int bin = lo * nf + hi;
         const int pos = ent0_row[bin] + cnt_row[bin] + __popcll(masks[bin] & lower);
         // pose-major slots of the two edges, the one of the lower hessian index first
-        sd.ent_i[pos] = (ha <= hb) ? sa : sb;
-        sd.ent_j[pos] = (ha <= hb) ? sb : sa;
-        sd.ent_l[pos] = l;
+        const int si = (ha <= hb) ? sa : sb, sj = (ha <= hb) ? sb : sa;
+        if (sd.ent64) sd.ent64[pos] = ent_pack(si, sj, l);            // one 8-byte store instead of three scattered 4-byte ones
+        else { sd.ent_i[pos] = si; sd.ent_j[pos] = sj; sd.ent_l[pos] = l; }
     };
 #if !defined(MOVBA_STRUCT_SKIP) || MOVBA_STRUCT_SKIP != 1
     {

@@ -764,3 +764,22 @@ def test_results_the_caller_does_not_ask_for_are_not_transferred(built_lib):
                 np.testing.assert_array_equal(full[k], ref[k])
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("host_structure", [False, True])
+def test_packed_and_unpacked_schur_entries_give_the_same_bits(built_lib, monkeypatch, host_structure):
+    """Off-diagonal schur entries travel as one 64-bit word (22 + 22 bits of slots, 20 of map point) when the window allows,
+    else as three int32 arrays: same results either way, from the device's structure pass and from the host's."""
+    w = synth.cfg("cfg2")
+    if host_structure:
+        monkeypatch.setenv("MOVBA_HOST_STRUCTURE", "1")
+    s = built_lib.Solver()
+    try:
+        a = s.solve(w)
+        monkeypatch.setenv("MOVBA_ENTRIES_UNPACKED", "1")
+        b = s.solve(w)
+        for k in ("poses", "points", "chi2", "outlier"):
+            np.testing.assert_array_equal(a[k], b[k])
+        np.testing.assert_array_equal(a["trace"]["f1"], b["trace"]["f1"])
+    finally:
+        s.close()
