@@ -54,6 +54,7 @@ struct Worker {
     int state = 0;              // 0 idle, 1 job posted, 2 job done
     bool quit = false;
     std::atomic<int> posted{0}; // set with state = 1: what the thread polls while it stays awake between jobs
+    int spin_ms = 4;            // how long it stays awake after a job (0 with movba_options::host_wait = 1: it sleeps at once)
     void post(std::function<void()> j)
     {
         if (!th.joinable())
@@ -66,7 +67,7 @@ struct Worker {
                         lk.unlock();
                         const auto t_spin = std::chrono::steady_clock::now();
                         while (posted.load(std::memory_order_acquire) == 0 &&
-                               std::chrono::steady_clock::now() - t_spin < std::chrono::milliseconds(4)) {
+                               std::chrono::steady_clock::now() - t_spin < std::chrono::milliseconds(spin_ms)) {
 #if defined(__x86_64__)
                             __builtin_ia32_pause();
 #endif
@@ -359,6 +360,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         if (opt->pcg_coarse < 0) h->opt.pcg_coarse = 0;
         h->opt.host_wait = opt->host_wait == 1 ? 1 : 0;
     }
+    if (h->opt.host_wait == 1) h->packer.spin_ms = 0;      // (a caller that asks for yielding waits does not want a spinning helper either)
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
     if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
     if (stream) { h->stream = static_cast<hipStream_t>(stream); }
