@@ -497,9 +497,15 @@ namespace MOV_SLAM
         f.obs_start.assign(nLocal + 1, 0);
         for (size_t lp = 0; lp < nLocal; ++lp)
         {
+#ifdef MOVBA_MAPPOINT_HAS_FOR_EACH_OBSERVATION
+            // (the optional accessor of INTEGRATION.md 1.3: the same entries in the same order, read under the point's lock
+            //  without the std::map copy and its node allocations — 1.8 of the 2.9 ms of this phase at 20 000 points)
+            lLocalMapPoints[lp]->ForEachObservation([&](KeyFrame *pKFo, int left, int right) { f.obs_all.push_back(ObsRef{pKFo, left, right, -1}); });
+#else
             const std::map<KeyFrame *, std::tuple<int, int>> observations = lLocalMapPoints[lp]->GetObservations();
             for (std::map<KeyFrame *, std::tuple<int, int>>::const_iterator mit = observations.begin(); mit != observations.end(); ++mit)
                 f.obs_all.push_back(ObsRef{mit->first, std::get<0>(mit->second), std::get<1>(mit->second), -1});
+#endif
             f.obs_start[lp + 1] = f.obs_all.size();
         }
         lap("observation copies");

@@ -12,6 +12,15 @@ public:
     Eigen::Vector3f GetWorldPos() { return mWorldPos; }
     std::map<KeyFrame *, std::tuple<int, int>> GetObservations() { ++nObservationCopies(); return mObservations; }
     static long &nObservationCopies() { static long n = 0; return n; }      // test plumbing: std::map copies handed out
+#ifdef MOVBA_MAPPOINT_HAS_FOR_EACH_OBSERVATION
+    // the second accessor INTEGRATION.md offers MoV-SLAM's MapPoint.h: the observations visited in map order under the
+    // point's lock, without the std::map copy (and its node allocations) GetObservations() hands out
+    template <class F> void ForEachObservation(F &&f) {
+        ++nObservationVisits();
+        for (const auto &o : mObservations) f(o.first, std::get<0>(o.second), std::get<1>(o.second));
+    }
+#endif
+    static long &nObservationVisits() { static long n = 0; return n; }       // test plumbing
     // MapPoint.cc:347-354
     std::tuple<int, int> GetIndexInKeyFrame(KeyFrame *pKF) {
         const auto it = mObservations.find(pKF);

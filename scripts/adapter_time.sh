@@ -14,3 +14,5 @@ with open("/tmp/w3.bin", "wb") as fh:
 PY
 make -C mov-slam_amd/host -s
 MOVBA_ADAPTER_REPS=4 MOVBA_ADAPTER_LAPS=${LAPS:-} MOVBA_ADAPTER_TIMING=1 mov-slam_amd/host/adapter_test lba /tmp/w3.bin /tmp/o3.bin 2>&1 | grep "adapter" | tail -${TAILN:-2}
+echo "with MapPoint::ForEachObservation (-DMOVBA_MAPPOINT_HAS_FOR_EACH_OBSERVATION):"
+MOVBA_ADAPTER_REPS=4 MOVBA_ADAPTER_LAPS=${LAPS:-} MOVBA_ADAPTER_TIMING=1 mov-slam_amd/host/adapter_test_foreach lba /tmp/w3.bin /tmp/o3f.bin 2>&1 | grep "adapter" | tail -${TAILN:-2}

@@ -235,3 +235,24 @@ def test_local_bundle_adjustment_with_a_bad_observer(adapter_bin, oracle_mod, tm
     got = set(map(tuple, out["erased"]))
     guard = {(int(a), int(c)) for a, c, x in zip(ep, el, o["chi2"]) if abs(x - 5.0) < 1e-4}
     assert (want ^ got) <= guard
+
+
+@pytest.mark.parametrize("name", ["small", "cfg2", "stereo"])
+def test_adapter_with_the_for_each_observation_accessor(adapter_bin, tmp_path, name):
+    """-DMOVBA_MAPPOINT_HAS_FOR_EACH_OBSERVATION (the second optional accessor INTEGRATION.md offers MapPoint.h): the
+    observations are visited under the point's lock instead of being copied as a std::map: no copy at all, same map."""
+    exe = os.path.join(HOST, "adapter_test_foreach")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", HOST, "-s"])
+    w = synth.make_window(6, 2, 150, seed=43, run_lo=2, run_hi=5, stereo_frac=0.7) if name == "stereo" else synth.cfg(name)
+    w.poses = _f32_pose(w.poses)
+    fin, fa, fb = str(tmp_path / "w.bin"), str(tmp_path / "a.bin"), str(tmp_path / "b.bin")
+    _write_window(fin, w)
+    subprocess.check_call([adapter_bin, "lba", fin, fa])
+    subprocess.check_call([exe, "lba", fin, fb])
+    a, b = _read_out(fa, w), _read_out(fb, w)
+    assert a["n_observation_copies"] > 0 and b["n_observation_copies"] == 0
+    for k in ("poses", "points", "erased", "normals", "dist"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("num_fixedKF", "num_OptKF", "num_edges", "n_erased", "change_idx", "n_pose_sets", "n_normal_updates", "n_center_reads"):
+        assert a[k] == b[k], k
