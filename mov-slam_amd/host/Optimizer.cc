@@ -67,10 +67,16 @@ namespace MOV_SLAM
         {
             std::vector<KeyFrame *> key;
             std::vector<int32_t> val;
+            std::vector<uint8_t> usable;        // per vertex: !isBad() && same map (see build)
             size_t mask = 0;
             static size_t hash(const KeyFrame *p) { return (size_t)((reinterpret_cast<uintptr_t>(p) >> 4) * 0x9E3779B97F4A7C15ull >> 20); }
-            void build(const std::vector<KeyFrame *> &kfs)
+            // `pCurrentMap` non-null: a keyframe of another map yields no edges (Optimizer.cc:646).  The edge loop asks
+            // KeyFrame::isBad() and GetMap() — a mutex each in MoV-SLAM's classes — once per window keyframe here instead
+            // of once per observation (the reference asks per observation, :646, :155: 2 x 110 000 locks at cfg3)
+            void build(const std::vector<KeyFrame *> &kfs, Map *pCurrentMap)
             {
+                usable.resize(kfs.size());
+                for (size_t i = 0; i < kfs.size(); ++i) usable[i] = (!kfs[i]->isBad() && (!pCurrentMap || kfs[i]->GetMap() == pCurrentMap)) ? 1 : 0;
                 size_t cap = 16;
                 while (cap < 2 * kfs.size() + 2) cap <<= 1;
                 key.assign(cap, nullptr); val.assign(cap, -1); mask = cap - 1;
@@ -174,16 +180,17 @@ namespace MOV_SLAM
         int emit_point(Flat &f, CamState &cs, size_t e0, MapPoint *pMP, int32_t pid, ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex,
                        Map *pCurrentMap, bool requireSameMap)
         {
+            (void)pCurrentMap; (void)requireSameMap;             // (folded into kfIndex.usable by its build)
             size_t e = e0;
             for (; ob != ob_end; ++ob)
             {
                 KeyFrame *pKFi = ob->kf;
                 const int32_t vertex = kfIndex.find(pKFi);
                 ob->vertex = vertex;
-                if (pKFi->isBad() || (requireSameMap && pKFi->GetMap() != pCurrentMap))
-                    continue;
                 if (vertex < 0)
                     continue;                                   // observer without a vertex
+                if (!kfIndex.usable[vertex])
+                    continue;                                   // pKFi->isBad() || pKFi->GetMap() != pCurrentMap, asked once per keyframe
                 const int leftIndex = ob->left;
                 if (leftIndex == -1)
                     continue;
@@ -394,7 +401,7 @@ namespace MOV_SLAM
         }
         sort_poses(f);
         KfIndex kfIndex;
-        kfIndex.build(f.kfs);
+        kfIndex.build(f.kfs, nullptr);                  // (BundleAdjustment takes keyframes of any map: requireSameMap = false)
 
         // MapPoints without any edge are left out of the problem (vbNotIncludedMP, Optimizer.cc:273-281)
         std::vector<bool> vbNotIncludedMP(vpMP.size(), true);
@@ -542,7 +549,7 @@ namespace MOV_SLAM
         }
         sort_poses(f);
         KfIndex kfIndex;
-        kfIndex.build(f.kfs);
+        kfIndex.build(f.kfs, pCurrentMap);
 
         lap("poses");
         // every local point writes its vertex at its own index and its edges where its observations start (at most one
