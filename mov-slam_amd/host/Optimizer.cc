@@ -484,7 +484,9 @@ namespace MOV_SLAM
             const std::vector<MapPoint *> vpMPs = pKFi->GetMapPointMatches();
             for (MapPoint *pMP : vpMPs)
             {
-                if (pMP && !pMP->isBad() && pMP->GetMap() == pCurrentMap && pMP->mnBALocalForKF != pKF->mnId)
+                // (the reference's conjunction, Optimizer.cc:489-499, with the plain member test first: a point seen by five
+                //  local keyframes is met five times, and MapPoint::isBad() / GetMap() take three mutexes between them)
+                if (pMP && pMP->mnBALocalForKF != pKF->mnId && !pMP->isBad() && pMP->GetMap() == pCurrentMap)
                 {
                     lLocalMapPoints.push_back(pMP);
                     pMP->mnBALocalForKF = pKF->mnId;

@@ -1,5 +1,6 @@
 // Mock of include/KeyFrame.h (:154, :172, :198, :201, :218, :233, :254, :270-271, :293, :298, :323-324, :340, :441; mbf :312).
 #pragma once
+#include <mutex>
 #include <vector>
 #include "mock_math.h"
 #include "GeometricCamera.h"
@@ -8,10 +9,12 @@
 namespace MOV_SLAM {
 class KeyFrame {
 public:
-    Sophus::SE3f GetPose() { return mTcw; }
-    void SetPose(const Sophus::SE3f &T) { mTcw = T; ++nPoseSets; }
+    // (locks as in KeyFrame.cc)
+    Sophus::SE3f GetPose() { std::unique_lock<std::mutex> lock(mMutexPose); return mTcw; }
+    void SetPose(const Sophus::SE3f &T) { std::unique_lock<std::mutex> lock(mMutexPose); mTcw = T; ++nPoseSets; }
     // KeyFrame.h:155: mOw = Twc.translation() = -Rcw^T tcw, in float like Sophus::SE3f::inverse()
     Eigen::Vector3f GetCameraCenter() {
+        std::unique_lock<std::mutex> lock(mMutexPose);
         ++nCenterReads;
         const float x = mTcw.q.qx, y = mTcw.q.qy, z = mTcw.q.qz, w = mTcw.q.qw;
         const float R[9] = { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
@@ -27,8 +30,8 @@ public:
     const std::vector<float> mvScaleFactors = std::vector<float>{1.f, 1.2f, 1.44f, 1.728f, 2.0736f, 2.48832f, 2.985984f, 3.5831808f};
     std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
     int nCenterReads = 0;
-    std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { return mvCovisible; }
-    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { std::unique_lock<std::mutex> lock(mMutexConnections); return mvCovisible; }
+    std::vector<MapPoint *> GetMapPointMatches() { std::unique_lock<std::mutex> lock(mMutexFeatures); return mvpMapPoints; }
     // KeyFrame.cc:298-306: the indices come from the point's own observation entry (not a search through the matches)
     void EraseMapPointMatch(MapPoint *pMP) {
         const std::tuple<int, int> indexes = pMP->GetIndexInKeyFrame(this);
@@ -36,8 +39,8 @@ public:
         if (leftIndex != -1) mvpMapPoints[leftIndex] = nullptr;
         if (rightIndex != -1) mvpMapPoints[rightIndex] = nullptr;
     }
-    bool isBad() { return mbBad; }
-    Map *GetMap() { return mpMap; }
+    bool isBad() { std::unique_lock<std::mutex> lock(mMutexConnections); return mbBad; }
+    Map *GetMap() { std::unique_lock<std::mutex> lock(mMutexMap); return mpMap; }
     long unsigned int mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul, mnBAGlobalForKF = 0;
     Sophus::SE3f mTcwGBA;
     std::vector<cv::KeyPoint> mvKeysUn;
@@ -45,6 +48,7 @@ public:
     float mbf = 0.f;
     std::vector<float> mvInvLevelSigma2 = std::vector<float>(8, 1.0f);
     GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
+    std::mutex mMutexPose, mMutexConnections, mMutexFeatures, mMutexMap;
     // test plumbing
     Sophus::SE3f mTcw; std::vector<KeyFrame *> mvCovisible; std::vector<MapPoint *> mvpMapPoints;
     bool mbBad = false; Map *mpMap = nullptr; int nPoseSets = 0;
@@ -54,10 +58,17 @@ public:
 inline void MapPoint::UpdateNormalAndDepth()
 {
     ++nNormalUpdates;
-    if (mbBad) return;
-    const std::map<KeyFrame *, std::tuple<int, int>> observations = mObservations;
-    KeyFrame *pRefKF = mpRefKF;
-    const Eigen::Vector3f Pos = mWorldPos;
+    std::map<KeyFrame *, std::tuple<int, int>> observations;
+    KeyFrame *pRefKF;
+    Eigen::Vector3f Pos;
+    {
+        std::unique_lock<std::mutex> lock1(mMutexFeatures);       // MapPoint.cc:367-375
+        std::unique_lock<std::mutex> lock2(mMutexPos);
+        if (mbBad) return;
+        observations = mObservations;
+        pRefKF = mpRefKF;
+        Pos = mWorldPos;
+    }
     if (observations.empty()) return;
     Eigen::Vector3f normal; normal.setZero();
     int n = 0;
@@ -74,6 +85,7 @@ inline void MapPoint::UpdateNormalAndDepth()
     const int level = pRefKF->mvKeysUn[leftIndex].octave;                    // NLeft == -1
     const float levelScaleFactor = pRefKF->mvScaleFactors[level];
     const int nLevels = pRefKF->mnScaleLevels;
+    std::unique_lock<std::mutex> lock3(mMutexPos);                  // :429-434
     mfMaxDistance = dist * levelScaleFactor;
     mfMinDistance = mfMaxDistance / pRefKF->mvScaleFactors[nLevels - 1];
     mNormalVector = normal / n;
