@@ -277,7 +277,7 @@ def main():
                     raw = open(fout, "rb").read()
                     tm = struct.unpack_from("3d", raw, len(raw) - 24)
                 out["config"]["adapter_host_ms"] = {"extraction": tm[0], "solve_call": tm[1], "write_back": tm[2],
-                                                    "note": "Optimizer::LocalBundleAdjustment over mock KeyFrame/MapPoint classes, fourth call of the process "
+                                                    "note": "Optimizer::LocalBundleAdjustment over mock KeyFrame/MapPoint classes (taking the reference's locks), fourth call of the process "
                                                             "on a fresh copy of the map (buffers, arena and handle warm, as in a running system): one "
                                                             "GetObservations() copy per point, normal/depth stored from the GPU result"}
             except Exception as exc:                        # context only
