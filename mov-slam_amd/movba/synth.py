@@ -215,3 +215,143 @@ def make_frame(n: int = 500, seed: int = 1001, outlier_frac: float = 0.10, pix_s
     pose0 = _f32(pose0); pose0[:4] /= np.linalg.norm(pose0[:4])
     return dict(Xw=_f32(Xw), obs=_f32(obs), pose0=pose0, truth=truth, is_outlier=is_out,
                 cam=(FX, FY, CX, CY))
+
+
+# ---------------------------------------------------------------------------------------------
+# Covisibility patterns beyond the contiguous-run generator above (round 3).
+#
+# make_window() gives every map point a contiguous run of observing keyframes, and keyframe ids follow the
+# trajectory: the reduced system is banded.  The reference's local window is "every keyframe sharing >= 15 points
+# with pKF" (/root/reference/src/KeyFrame.cc:227-231, 408-427; selection src/Optimizer.cc:464-477): all of them
+# covisible through pKF and mostly with each other, ids in order of creation, not of position.  The patterns below
+# produce such windows with consistent geometry (every observation is the projection of its map point):
+#   hub      keyframes clustered around one place, all looking at the same scene: every pair shares points,
+#   revisit  the trajectory comes back over itself: keyframe k and k + 25 see the same points,
+#   shuffle_ids()  any window with its keyframe ids permuted (same graph, id order != spatial order).
+# ---------------------------------------------------------------------------------------------
+def _poses_from(centres, yaw):
+    NP = len(yaw)
+    Rcw = np.zeros((NP, 3, 3)); tcw = np.zeros((NP, 3))
+    for i in range(NP):
+        c, s = np.cos(yaw[i]), np.sin(yaw[i])
+        Rwc = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+        Rcw[i] = Rwc.T
+        tcw[i] = -Rcw[i] @ centres[i]
+    return Rcw, tcw
+
+
+def make_pattern_window(pattern: str, n_free: int, n_fixed: int, n_points: int, seed: int,
+                        run_lo: int = 2, run_hi: int = 10, outlier_frac: float = 0.05, pix_sigma: float = 0.5,
+                        rot_sigma_deg: float = 0.5, trans_sigma: float = 0.02, point_sigma: float = 0.05,
+                        min_obs: int = 2, revisit_gap: int = 25) -> Window:
+    """Window with the covisibility pattern `pattern` ("hub" | "revisit"); noise model, camera, float32 rounding, edge order
+    and the choice of fixed keyframes (the n_fixed lowest ids) as make_window()."""
+    rng = np.random.default_rng(seed)
+    NP = n_free + n_fixed
+    k = np.arange(NP, dtype=np.float64)
+    if pattern == "hub":
+        centres = np.stack([rng.uniform(-1.5, 1.5, NP), rng.uniform(-0.3, 0.3, NP), rng.uniform(-1.0, 1.0, NP)], axis=1)
+        yaw = rng.uniform(-0.15, 0.15, NP)
+        order_key = None
+    elif pattern == "revisit":
+        # second pass over the same stretch of path, half a keyframe spacing out of step and 0.2 m to the side
+        first = NP - revisit_gap if NP > revisit_gap else NP
+        s = np.where(k < first, k, k - revisit_gap + 0.5)
+        side = np.where(k < first, 0.0, 0.2)
+        centres = np.stack([0.30 * s, 0.05 * np.sin(0.3 * s) + side, 0.02 * s], axis=1)
+        yaw = 0.01 * s
+        order_key = s
+    else:
+        raise KeyError(pattern)
+    Rcw, tcw = _poses_from(centres, yaw)
+    by_path = np.argsort(order_key, kind="stable") if order_key is not None else None
+    path_rank = np.argsort(by_path) if by_path is not None else None
+
+    pts, e_pose, e_point, e_uv = [], [], [], []
+    n_kept = 0
+    while n_kept < n_points:
+        m = max(256, (n_points - n_kept) * 2)
+        anchor = rng.integers(0, NP, size=m)
+        depth = rng.uniform(6.0 if pattern == "hub" else 4.0, 30.0, size=m)
+        u = rng.uniform(0.0, WIDTH, size=m); v = rng.uniform(0.0, HEIGHT, size=m)
+        run = rng.integers(run_lo, run_hi + 1, size=m)
+        off = rng.integers(0, run_hi + 1, size=m)
+        Xc = np.stack([(u - CX) / FX * depth, (v - CY) / FY * depth, depth], axis=1)
+        Xw = np.einsum('mji,mj->mi', Rcw[anchor], Xc - tcw[anchor])        # Rcw^T (Xc - t)
+        Y = np.einsum('kij,mj->mki', Rcw, Xw) + tcw[None, :, :]             # (m, NP, 3): the candidates in every camera
+        z = Y[:, :, 2]
+        zs = np.where(z > 0.1, z, 1.0)
+        uu = FX * Y[:, :, 0] / zs + CX; vv = FY * Y[:, :, 1] / zs + CY
+        vis = (z > 0.1) & (uu >= 0) & (uu < WIDTH) & (vv >= 0) & (vv < HEIGHT)
+        for j in range(m):
+            if n_kept >= n_points:
+                break
+            if pattern == "hub":
+                cand = np.flatnonzero(vis[j])
+                if len(cand) < min_obs:
+                    continue
+                ks = np.sort(rng.choice(cand, size=min(int(run[j]), len(cand)), replace=False))
+            else:
+                a = int(path_rank[anchor[j]])
+                first_r = a - int(off[j]) % int(run[j])
+                ranks = [r for r in range(first_r, first_r + int(run[j])) if 0 <= r < NP]
+                ks = np.sort([int(by_path[r]) for r in ranks if vis[j, by_path[r]]])
+            if len(ks) < min_obs:
+                continue
+            pts.append(Xw[j])
+            for kk in ks:
+                e_pose.append(int(kk)); e_point.append(n_kept); e_uv.append((uu[j, kk], vv[j, kk]))
+            n_kept += 1
+
+    truth_points = np.array(pts)
+    edge_pose = np.array(e_pose, dtype=np.int32); edge_point = np.array(e_point, dtype=np.int32)
+    obs = np.array(e_uv, dtype=np.float64)
+    E = len(edge_pose)
+    obs = obs + rng.normal(0.0, pix_sigma, size=(E, 2))
+    is_out = rng.random(E) < outlier_frac
+    mag = rng.uniform(5.0, 30.0, size=E); ang = rng.uniform(0.0, 2 * np.pi, size=E)
+    obs[is_out] += np.stack([mag * np.cos(ang), mag * np.sin(ang)], axis=1)[is_out]
+
+    truth_poses = np.zeros((NP, 7)); poses = np.zeros((NP, 7))
+    fixed = np.zeros(NP, dtype=np.uint8); fixed[:n_fixed] = 1
+    for i in range(NP):
+        truth_poses[i, :4] = quat_from_R(Rcw[i]); truth_poses[i, 4:] = tcw[i]
+        if fixed[i]:
+            poses[i] = truth_poses[i]
+        else:
+            dR = _rodrigues(np.deg2rad(rot_sigma_deg) * rng.normal(size=3))
+            poses[i, :4] = quat_from_R(dR @ Rcw[i]); poses[i, 4:] = tcw[i] + trans_sigma * rng.normal(size=3)
+    points = truth_points + point_sigma * rng.normal(size=truth_points.shape)
+    poses = _f32(poses)
+    poses[:, :4] /= np.linalg.norm(poses[:, :4], axis=1, keepdims=True)
+    return Window(poses=poses, pose_fixed=fixed, points=_f32(points), edge_pose=edge_pose, edge_point=edge_point,
+                  obs=_f32(obs), inv_sigma2=np.ones(E), truth_poses=truth_poses, truth_points=truth_points,
+                  meta=dict(seed=seed, K=n_free, F=n_fixed, P=n_points, E=E, outliers=int(is_out.sum()), pattern=pattern))
+
+
+def shuffle_ids(w: Window, seed: int) -> Window:
+    """The same graph with the keyframe ids permuted (fixed flags, estimates and observations follow their keyframe); edges
+    re-sorted into the reference's order (point ascending, then keyframe id ascending)."""
+    rng = np.random.default_rng(seed)
+    NP = w.n_poses
+    new_of_old = rng.permutation(NP)                    # keyframe `old` becomes id new_of_old[old]
+    old_of_new = np.argsort(new_of_old)
+    ep = new_of_old[w.edge_pose].astype(np.int32)
+    order = np.lexsort((ep, w.edge_point))
+    meta = dict(w.meta); meta["pattern"] = (meta.get("pattern", "run") + "+shuffled"); meta["id_perm"] = new_of_old
+    return Window(poses=w.poses[old_of_new], pose_fixed=w.pose_fixed[old_of_new], points=w.points,
+                  edge_pose=ep[order], edge_point=w.edge_point[order], obs=w.obs[order], inv_sigma2=w.inv_sigma2[order],
+                  cam=w.cam, huber_delta=w.huber_delta, chi2_gate=w.chi2_gate, max_iters=w.max_iters,
+                  truth_poses=None if w.truth_poses is None else w.truth_poses[old_of_new], truth_points=w.truth_points,
+                  meta=meta, obs_right=None if w.obs_right is None else w.obs_right[order], bf=w.bf)
+
+
+def pattern_cfg(name: str, seed: int | None = None) -> Window:
+    """cfg3-sized windows (50 + 10 keyframes x 20 000 map points) of the other covisibility patterns."""
+    if name == "hub":
+        return make_pattern_window("hub", 50, 10, 20000, 3001 if seed is None else seed)
+    if name == "revisit":
+        return make_pattern_window("revisit", 50, 10, 20000, 3002 if seed is None else seed, run_lo=2, run_hi=10)
+    if name == "shuffled":
+        return shuffle_ids(cfg("cfg3"), 3003 if seed is None else seed)
+    raise KeyError(name)

@@ -1,0 +1,39 @@
+"""Window solves of the covisibility patterns (hub / revisit / shuffled ids) beside cfg3: which reduced solver ran, CG
+iterations, time per resident solve and per movba_lba_solve call, parity against the oracle (run on a GPU box)."""
+import os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
+import numpy as np
+from movba import capi, synth
+from oracle import oracle
+
+names = sys.argv[1:] or ["cfg3", "shuffled", "revisit", "hub"]
+out = {}
+s = capi.Solver(profile=True)
+for name in names:
+    w = synth.cfg("cfg3") if name == "cfg3" else synth.pattern_cfg(name)
+    plan = capi.structure_probe(w)
+    o = oracle.solve(w)
+    s.prepare(w, pinned=True)
+    for _ in range(3):
+        s.solve_prepared(pack=False)
+    n = 10
+    t = time.perf_counter()
+    for _ in range(n):
+        s.solve_prepared(pack=False)
+    t_call = 1e3 * (time.perf_counter() - t) / n
+    r = s.solve_prepared()
+    s.upload(w); s.run()
+    t = time.perf_counter()
+    for _ in range(n):
+        s.run()
+    s.download()
+    t_res = 1e3 * (time.perf_counter() - t) / n
+    s.reset_profile(); s.solve_prepared(pack=False); kp = s.profile()["kernels"]
+    out[name] = dict(E=w.n_edges, pairs=plan["n_pairs"], overflow=plan["pcg_overflow"], wave_entries=plan["pcg_max_wave_entries"],
+                     n_solves=r["n_solves"], n_direct=r["n_direct"], giveups=r["n_pcg_giveups"], cg_iters=r["pcg_iters"],
+                     ms_call=t_call, ms_resident=t_res, solve_kernels_ms=kp["k_pcg"]["ms"], schur_ms=kp["k_schur"]["ms"],
+                     dpose=float(np.abs(r["poses"] - o["poses"]).max()), accept_equal=bool(np.array_equal(r["trace"]["accept"], o["trace"]["accept"])),
+                     outlier_mismatch=int((r["outlier"] != o["outlier"]).sum()))
+    print(name, json.dumps(out[name]), flush=True)
+s.close()

@@ -165,6 +165,25 @@ def test_direct_solver_from_the_first_trial_on_ordinary_windows(built_lib, oracl
         assert np.array_equal(r[k], r2[k]), k          # bit-reproducible, also through the park / resume
 
 
+@pytest.mark.parametrize("name", ["hub", "revisit", "shuffled"])
+def test_covisibility_patterns_the_reference_produces(solver, oracle_mod, built_lib, name):
+    """cfg3-sized windows (50 + 10 keyframes x 20 000 map points) whose covisibility is not a contiguous run of keyframe ids:
+    hub = every keyframe pair shares points (what GetVectorCovisibleKeyFrames() returns, KeyFrame.cc:227-231, 408-427, taken
+    by Optimizer.cc:464-477), revisit = the trajectory comes back (keyframe k and k + 25 see the same points), shuffled =
+    cfg3's graph with ids in another order than positions.  Parity with the oracle, and WHICH reduced solver ran."""
+    w = synth.pattern_cfg(name)
+    plan = built_lib.structure_probe(w)
+    r, o = solver.solve(w), oracle_mod.solve(w)
+    check_against(r, o, w)
+    if name == "hub":
+        assert plan["n_pairs"] == 50 * 51 // 2                    # the reduced system is dense
+    else:
+        assert plan["n_pairs"] == built_lib.structure_probe(synth.cfg("cfg3"))["n_pairs"] or name == "revisit"
+    # the solver that ran is reported: either every trial on the direct solver, or a PCG that converged every time
+    assert r["n_direct"] == r["n_solves"] or (r["n_direct"] == 0 and r["pcg_iters"] > 0)
+    assert r["n_chol_fail"] == 0
+
+
 WEAK_TOL = dict(rot=1e-6, trans=1e-6, point=1e-4)      # see test_weakly_constrained_windows
 
 
