@@ -197,6 +197,13 @@ typedef struct {
 int  movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info,
                            int32_t *edge_perm /* E or NULL */, int32_t *free_index /* n_poses or NULL */);
 
+/* Host only (no device needed): the static schedule of the one-launch direct solver that stands in for the reference's
+ * LinearSolverCSparse factorisation (Optimizer.cc:535) for a reduced system of n_block_cols 48-wide block columns — for
+ * tests, which replay it against its own flags.  info[0..3] = supported, workgroups, tile slots per workgroup, tasks;
+ * task_ptr (workgroups + 1) and tasks (8 int32 each: op, slot, I, K, k, 0, 0, 0) are filled up to their capacities. */
+int  movba_dense_plan_probe(int32_t n_block_cols, int32_t max_groups, int32_t max_slots, int32_t info[4],
+                            int32_t *task_ptr, int32_t task_ptr_cap, int32_t *tasks, int32_t tasks_cap);
+
 /* Pose-only optimisation behind Optimizer::PoseOptimization (Optimizer.cc:397-459), over the
  * reference's EdgeSE3ProjectXYZOnlyPose (include/OptimizableTypes.h:30-58). */
 typedef struct {

@@ -148,6 +148,10 @@ struct movba_handle {
     int run_status = MOVBA_OK;          // decided per run (MOVBA_STOPPED when the flag was up before the solve)
     PcgParams pp{};
     bool rows_kernel = false;
+    DensePlan dplan;                    // static schedule of the one-launch direct solver (kept across uploads of the same size)
+    int dplan_nt = -1;
+    bool dense_flags_clean = false;     // the window's hand-off flags have been zeroed since its upload (done before the first direct launch)
+    unsigned dense_epoch = 0;           // direct launches on this window so far: the value a flag of the current launch carries
     char *scratch = nullptr;            // structure-pass temporaries (struct_kernels.hip)
     size_t scratch_cap = 0;
     // movba_lba_run_batch (kept by the first handle of a batch): device views, PCG plans and block prefixes of the windows
@@ -376,7 +380,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->ctrl_host_dev), h->ctrl_host, 0) != hipSuccess ||
         configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess ||
-        configure_dense_kernels() != hipSuccess ||
+        configure_dense_kernels() != hipSuccess || configure_dense_persist() != hipSuccess ||
         configure_pose_kernels() != hipSuccess) {
         movba_destroy(h);
         return MOVBA_ERR_HIP;
@@ -454,6 +458,18 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
     }
     if (free_index) std::memcpy(free_index, s.hidx.data(), sizeof(int32_t) * s.hidx.size());
     return rc;
+}
+
+int movba_dense_plan_probe(int32_t n_block_cols, int32_t max_groups, int32_t max_slots, int32_t info[4], int32_t *task_ptr, int32_t task_ptr_cap,
+                           int32_t *tasks, int32_t tasks_cap)
+{
+    if (!info || n_block_cols < 1) return MOVBA_ERR_ARG;
+    DensePlan p;
+    build_dense_plan(n_block_cols, p, max_groups > 0 ? max_groups : kDenseMaxGroups, max_slots > 0 ? max_slots : kDenseMaxSlots);
+    info[0] = p.ok ? 1 : 0; info[1] = p.G; info[2] = p.slots; info[3] = (int32_t)p.tasks.size();
+    if (p.ok && task_ptr) for (int g = 0; g <= p.G && g < task_ptr_cap; ++g) task_ptr[g] = p.task_ptr[g];
+    if (p.ok && tasks) std::memcpy(tasks, p.tasks.data(), sizeof(DenseTask) * std::min<size_t>(p.tasks.size(), (size_t)std::max(tasks_cap, 0)));
+    return MOVBA_OK;
 }
 
 int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
@@ -770,6 +786,12 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
     const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
     const size_t o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
+    // one-launch direct solver: the static schedule depends on the number of block columns only (rebuilt when that changes)
+    const int ntile = dense_ntile(nf);
+    static const bool dense_multi = std::getenv("MOVBA_DENSE_MULTILAUNCH") != nullptr;
+    if (h->dplan_nt != ntile) { build_dense_plan(ntile, h->dplan); h->dplan_nt = ntile; }
+    const bool dense_one = !dense_multi && dense_persist_supported(h->dplan);
+    const size_t o_dtp = c.take<int32_t>(dense_one ? h->dplan.task_ptr.size() : 1), o_dtk = c.take<DenseTask>(dense_one ? h->dplan.tasks.size() : 1);
     if (!dev_structure) o_ent = c.take<int32_t>(ent_words());       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
     const size_t h2d = c.off;
     // ---- device-only region ----
@@ -792,9 +814,12 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
     const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
-    const int ntile = dense_ntile(nf);
     const size_t o_dtiles = c.take<double>(dense_tiles_doubles(nf)), o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1), o_dfail = c.take<int32_t>(4);
     const size_t o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
+    const size_t o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_count(ntile) + 8 : 8);
+    const size_t o_dcontrib = c.take<double>(dense_one ? (size_t)ntile * ntile * kDenseNB : 1);
+    static const bool dense_stamps = std::getenv("MOVBA_DENSE_STAMPS") != nullptr;
+    const size_t o_dstamps = c.take<unsigned long long>(dense_one && dense_stamps ? 3 * h->dplan.tasks.size() : 1);
     const size_t total = c.off;
 
     // (a reallocation of the arena or of the staging buffer below must find the helper thread through with both: it reads
@@ -840,6 +865,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     std::memcpy(sp(o_cij), s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
     std::memcpy(sp(o_multi), s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
     std::memcpy(sp(o_pid), s.pid.data(), sizeof(int32_t) * (size_t)nf * nf);
+    if (dense_one) {
+        std::memcpy(sp(o_dtp), h->dplan.task_ptr.data(), sizeof(int32_t) * h->dplan.task_ptr.size());
+        std::memcpy(sp(o_dtk), h->dplan.tasks.data(), sizeof(DenseTask) * h->dplan.tasks.size());
+    }
     lap("carve + pack pair region");
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
@@ -904,6 +933,12 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
     w.dense.pid = reinterpret_cast<const int32_t *>(a + o_pid); w.dense.fail = reinterpret_cast<int32_t *>(a + o_dfail);
     w.dense.ntile = ntile; w.dense.n = 6 * nf; w.dense.xsol = reinterpret_cast<double *>(a + o_dx);
+    w.dense.task_ptr = reinterpret_cast<const int32_t *>(a + o_dtp); w.dense.tasks = reinterpret_cast<const DenseTask *>(a + o_dtk);
+    w.dense.flags = reinterpret_cast<unsigned *>(a + o_dflags); w.dense.failw = w.dense.flags + dense_flag_count(ntile);
+    w.dense.contrib = reinterpret_cast<double *>(a + o_dcontrib);
+    w.dense.stamps = dense_one && dense_stamps ? reinterpret_cast<unsigned long long *>(a + o_dstamps) : nullptr;
+    w.dense.G = dense_one ? h->dplan.G : 0; w.dense.slots = dense_one ? h->dplan.slots : 0;
+    h->dense_flags_clean = false; h->dense_epoch = 0;
     w.direct_only = h->rows_kernel ? 0 : 1;
     w.lds_poses = point_lds_need(NP, nf) <= kPointLdsLimit ? 1 : 0;
     h->uploaded = true;
@@ -935,6 +970,38 @@ PcgParams run_pcg_params(const movba_handle *h)
     for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) one_row_per_wave &= pp.wave_row0[wv + 1] - pp.wave_row0[wv] <= 1;
     pp.use_coarse = (h->opt.pcg_coarse && h->rows_kernel) ? (one_row_per_wave ? 2 : 1) : 0;
     return pp;
+}
+
+// the direct solve of the current trial: one launch when the window's schedule fits (dense_persist.hip), else the launch per
+// block column of dense_solve.hip.  The hand-off flags are zeroed once per uploaded window; every launch has its own epoch.
+hipError_t queue_direct(movba_handle *h)
+{
+    const DevWindow &w = h->win;
+    if (w.dense.G <= 0) return launch_dense_solve(w, h->stream);
+    if (!h->dense_flags_clean) {
+        const hipError_t e = hipMemsetAsync(w.dense.flags, 0, sizeof(uint32_t) * ((size_t)dense_flag_count(w.dense.ntile) + 8), h->stream);
+        if (e != hipSuccess) return e;
+        h->dense_flags_clean = true; h->dense_epoch = 0;
+    }
+    const hipError_t el = launch_dense_persist(w, ++h->dense_epoch, h->stream);
+    if (w.dense.stamps && el == hipSuccess && h->dense_epoch == 3) {
+        // diagnostic (MOVBA_DENSE_STAMPS=1): the third direct launch of a window, task by task, in 10 ns ticks from the first start
+        const size_t nt_ = h->dplan.tasks.size();
+        std::vector<unsigned long long> st(3 * nt_);
+        if (hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(st.data(), w.dense.stamps, sizeof(unsigned long long) * 3 * nt_, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            for (size_t k = 0; k < nt_; ++k) if (st[3 * k] && st[3 * k] < t0) t0 = st[3 * k];
+            static const char *names[] = { "ASM", "UPD", "DIAG", "OFF", "RHS", "BSX", "BSC", "EPI" };
+            for (int g = 0; g < h->dplan.G; ++g)
+                for (int t = h->dplan.task_ptr[g]; t < h->dplan.task_ptr[g + 1]; ++t) {
+                    const DenseTask &tk = h->dplan.tasks[t];
+                    std::fprintf(stderr, "libmovba[dense]: wg %3d %-4s (%2d,%2d) k=%2d  start %7.2f us  wait %6.2f  work %6.2f\n", g, names[tk.op], tk.I, tk.K, tk.k,
+                                 0.01 * (double)(st[3 * t] - t0), st[3 * t + 1] ? 0.01 * (double)(st[3 * t + 1] - st[3 * t]) : 0.0,
+                                 0.01 * (double)(st[3 * t + 2] - (st[3 * t + 1] ? st[3 * t + 1] : st[3 * t])));
+                }
+        }
+    }
+    return el;
 }
 
 // The LM trial loop of the handle's window on its own stream, from the state the device is in: a fresh window (after the
@@ -970,7 +1037,7 @@ int lm_loop(movba_handle *h, bool parked)
     };
     auto queue_solve = [&]() -> int {
         ScopedEvents ev(h, KC_PCG);
-        if (direct) HIP_TRY(launch_dense_solve(w, s));
+        if (direct) HIP_TRY(queue_direct(h));
         else HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, s));
         return MOVBA_OK;
     };

@@ -1,0 +1,669 @@
+// k_dense_persist: the direct solve of the reduced camera system in ONE launch.
+//
+// The reference's step is an exact sparse Cholesky (LinearSolverCSparse, /root/reference/src/Optimizer.cc:535; a failed
+// factorisation rejects the LM trial).  dense_solve.hip does the same arithmetic with one launch per 48-wide block column
+// (28 us each, whatever the size); here the whole solve — assembly of S from the schur partials, blocked Cholesky,
+// forward and back substitution, pose update — is one launch of up to 248 workgroups that hand finished tiles to each
+// other through L2:
+//   * every 48 x 48 tile of the lower block triangle has an OWNER workgroup (dense_plan.h) that keeps it in LDS from
+//     assembly to the end: tile (I, K) -= L(I, k) L(K, k)^T for every block column k < K as soon as that column's tiles
+//     are published (fp64 matrix cores), then L(I, K) = tile L(K, K)^-T by a panel sweep against the published diagonal
+//     tile D_K (every owner of column K factors D_K for itself: nobody waits for a factor), then L(I, K) is published;
+//   * workgroup K owns the diagonal tile (K, K) and the one to its left, so the dependent chain
+//     D_(K-1) -> L(K, K-1) -> D_K crosses workgroups once per block column;
+//   * the right-hand side rides along as row 48 of the diagonal owner's own factorisation of D_K (forward substitution by
+//     augmentation), the back substitution L^T x = y runs from the last block row up with one 48-vector per tile in flight;
+//   * hand-offs follow cdna_hip_programming.md Guideline 16 in its write-through form: payload by sc1 stores, every storing
+//     wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the flag (= the launch's epoch, so flags are
+//     never reset between launches); the consumer's wave 0 polls the flag with sc1 loads, the workgroup barrier behind the
+//     match releases the other waves, and EVERY load of handed-off bytes is an sc1 load (no acquire fence needed: one
+//     workgroup per CU, hipMalloc memory, 8-byte accesses — the first row of MI355X_MICROARCH.md's hand-off table);
+//   * every wait is bounded by the 100 MHz clock: a workgroup that waits 20 ms gives up, marks the solve failed (the LM
+//     trial is rejected and the host reports MOVBA_ERR_HIP through Ctrl::n_sync_timeouts) and leaves; so do the others.
+// Fixed summation order everywhere (each tile has one owner, updates in column order): bit-reproducible run to run.
+#include <hip/hip_runtime.h>
+
+#include "dense_plan.h"
+#include "dense_tile.h"
+#include "device_math.h"
+#include "device_types.h"
+#include "kernels.h"
+
+namespace movba {
+
+using namespace dense;
+
+namespace {
+
+constexpr int kPT = 256;                        // threads: 4 waves, one per SIMD
+constexpr int kTileLds = NB * LD;               // doubles of one LDS tile image
+constexpr unsigned long long kWaitTicks = 2000000ull;      // 20 ms of the 100 MHz clock
+__host__ __device__ constexpr int kBadOff(int nslots) { return (2 + nslots) * kTileLds + 660; }     // LDS word of sweep_tiles' bad-pivot flag (in the carve's spare doubles)
+
+// every word that travels between workgroups is a GLOBAL agent-scope access (global_load / global_store ... sc1, never flat_)
+typedef __attribute__((address_space(1))) long long g_i64;
+typedef __attribute__((address_space(1))) unsigned g_u32;
+__device__ __forceinline__ double ld_sc1(const double *p)
+{
+    return __longlong_as_double(__hip_atomic_load((const g_i64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(double *p, double v)
+{
+    __hip_atomic_store((g_i64 *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ld_flag(const unsigned *p) { return __hip_atomic_load((const g_u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(unsigned *p, unsigned v) { __hip_atomic_store((g_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct Lds {
+    double *A, *B;          // two scratch tiles (MFMA operands; the sweeps' column table spans both)
+    double *slots;          // the workgroup's own tiles
+    double *rrow, *yv, *xv, *xs, *ps, *pivb, *rinvb, *red;
+    lds_vint *prog;         // pivots published by the factorising wave
+    int *abort;
+};
+
+__device__ __forceinline__ Lds carve(double *sm, int nslots)
+{
+    Lds l;
+    l.A = sm; l.B = sm + kTileLds; l.slots = sm + 2 * kTileLds;
+    double *p = l.slots + (size_t)nslots * kTileLds;
+    l.rrow = p; l.yv = p + 64; l.xv = p + 128; l.xs = p + 192; l.ps = p + 256; l.pivb = p + 512; l.rinvb = p + 576; l.red = p + 640;
+    l.prog = (lds_vint *)(p + 656);
+    l.abort = reinterpret_cast<int *>(p + 657);
+    return l;
+}
+
+// global tile (row-major NB x NB) <-> LDS image (row stride LD): 16-byte sc1 (write-through / L1-bypassing) accesses through a
+// buffer descriptor of the tile, all of a thread's accesses in flight (a tile is 1 152 x 16 bytes: 4.5 per thread)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kTileBytes = NB * NB * 8, kTileVec = kTileBytes / 16;
+#ifdef MOVBA_DENSE_NO_B128
+__device__ __forceinline__ void fetch_tile(const double *g, double *lds, int tid)
+{
+    double v[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) v[q] = ld_sc1(g + tid + kPT * q);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const int e = tid + kPT * q, r = e / NB, c = e - r * NB; lds[r * LD + c] = v[q]; }
+}
+__device__ __forceinline__ void publish_tile(double *g, const double *lds, int tid)
+{
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const int e = tid + kPT * q, r = e / NB, c = e - r * NB; st_sc1(g + e, lds[r * LD + c]); }
+}
+#else
+__device__ __forceinline__ void fetch_tile(const double *g, double *lds, int tid)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g), 0, kTileBytes, 0x00020000);
+    u32x4 v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { const int e = tid + kPT * q; v[q] = __builtin_amdgcn_raw_buffer_load_b128(r, (e < kTileVec ? e : 0) * 16, 0, 16); }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = tid + kPT * q;
+        if (e < kTileVec) {
+            const int row = (2 * e) / NB, c = 2 * e - row * NB;
+            lds[row * LD + c] = __hiloint2double((int)v[q].y, (int)v[q].x); lds[row * LD + c + 1] = __hiloint2double((int)v[q].w, (int)v[q].z);
+        }
+    }
+}
+
+__device__ __forceinline__ void publish_tile(double *g, const double *lds, int tid)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(g, 0, kTileBytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int e = tid + kPT * q;
+        if (e < kTileVec) {
+            const int row = (2 * e) / NB, c = 2 * e - row * NB;
+            const double a = lds[row * LD + c], b = lds[row * LD + c + 1];
+            const u32x4 v = { (unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b) };
+            __builtin_amdgcn_raw_buffer_store_b128(v, r, e * 16, 0, 16);
+        }
+    }
+}
+#endif
+
+// every storing wave drains its stores, the workgroup meets, ONE lane stores the flag
+__device__ __forceinline__ void set_flag(unsigned *flags, int idx, unsigned epoch, int tid)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) st_flag(flags + idx, epoch);
+}
+
+// wave 0 polls n flags (lane i the i-th, 64 per pass) until all carry the epoch; the barrier behind releases the others.
+// false: gave up after kWaitTicks (the workgroup then leaves the solve)
+template <typename IdxFn>
+__device__ __forceinline__ bool wg_wait(const unsigned *flags, unsigned epoch, int n, IdxFn idx, const Lds &l, int tid)
+{
+    if (tid < 64) {
+        bool good = true;
+        for (int base = 0; base < n && good; base += 64) {
+            const int i = base + tid;
+            const bool mine = i < n;
+            const unsigned *f = flags + idx(mine ? i : base);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const bool ok = ld_flag(f) == epoch;
+                if (__all(ok || !mine)) break;
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) { good = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (!good && tid == 0) *l.abort = 1;
+    }
+    __syncthreads();
+    return *l.abort == 0;
+}
+
+// slot -= A B^T, the nine 16 x 16 MFMA tiles dealt round-robin to the four waves
+__device__ __forceinline__ void tile_update(double *C, const double *As, const double *Bs, int wv, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int q = wv + 4 * u;
+        if (q < 9) {
+            const int mt = q / 3, ntc = q - mt * 3;
+            double *cp = C + (mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
+            dbl4 acc = dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
+            acc = tile_mfma(As, Bs, mt, ntc, lane, acc);
+            cp[0] = acc.x; cp[4 * LD] = acc.y; cp[8 * LD] = acc.z; cp[12 * LD] = acc.w;
+        }
+    }
+}
+
+// S (damped) of tile (I, K) from the schur work-item partials into an LDS image: the element map and the item order of
+// k_dense_assemble (dense_solve.hip), so both direct solvers and the PCG see the same matrix to the last bit
+__device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int I, int K, double lambda, int dst_off, int tid)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];     // (LDS addressed from its own symbol: ds_ instructions, not flat_)
+    double *dst = sm + dst_off;
+    const DenseSys &ds = w.dense;
+    const int nf = w.nfree, n = ds.n;
+    // (global pointers said to be global: plain global_load instead of flat_load)
+    typedef const __attribute__((address_space(1))) double *gdp;
+    typedef const __attribute__((address_space(1))) int32_t *gip;
+    const gdp part = (gdp)w.part;
+    const gip pid = (gip)ds.pid, pis = (gip)w.pair_item_start;
+    constexpr int kPer = NB * NB / kPT;
+    int pr[kPer], kk[kPer], uu[kPer], i0[kPer], i1[kPer];
+    double pad[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int e = tid + kPT * q, r = e / NB, cc = e - r * NB;
+        const int gr = I * NB + r, gc = K * NB + cc;
+        pr[q] = -1; kk[q] = 0; uu[q] = -1; pad[q] = 0.0;
+        if (gr >= n || gc >= n) pad[q] = (gr == gc) ? 1.0 : 0.0;
+        else {
+            const int bi = gr / 6, a = gr - bi * 6, bj = gc / 6, b = gc - bj * 6;
+            const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
+            pr[q] = pid[(size_t)lo * nf + hi];
+            kk[q] = bi <= bj ? a * 6 + b : b * 6 + a;
+            if (bi == bj) { uu[q] = 42 + (a <= b ? ut6(a, b) : ut6(b, a)); pad[q] = a == b ? lambda : 0.0; }
+        }
+    }
+    int maxlen = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        i0[q] = pr[q] >= 0 ? pis[pr[q]] : 0; i1[q] = pr[q] >= 0 ? pis[pr[q] + 1] : 0;
+        maxlen = max(maxlen, i1[q] - i0[q]);
+    }
+    // sums in item order, the loads of four items of every element in flight together (a diagonal pair of cfg3 is cut into
+    // five work items: one item after the other the tile took five dependent memory round trips more)
+    double sacc[kPer], hpp[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) { sacc[q] = 0.0; hpp[q] = 0.0; }
+#ifndef MOVBA_DENSE_ASM_ROUNDS
+    (void)maxlen;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q)
+        for (int itx = i0[q]; itx < i1[q]; ++itx) {
+            sacc[q] += part[(size_t)itx * kPartStride + kk[q]];
+            if (uu[q] >= 0) hpp[q] += part[(size_t)itx * kPartStride + uu[q]];
+        }
+#else
+    // (variant under test) four items of every element in flight: unconditional loads from clamped, always valid addresses,
+    // masked adds in item order
+    for (int base = 0; base < maxlen; base += 4) {
+        double sv[kPer][4], hv[kPer][4];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int itx = i0[q] + base + u;
+                const int itc = itx < i1[q] ? itx : (i1[q] > i0[q] ? i1[q] - 1 : 0);
+                sv[q][u] = part[(size_t)itc * kPartStride + kk[q]];
+                hv[q][u] = part[(size_t)itc * kPartStride + (uu[q] >= 0 ? uu[q] : 0)];
+            }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = i0[q] + base + u < i1[q];
+                sacc[q] += in ? sv[q][u] : 0.0;
+                hpp[q] += (in && uu[q] >= 0) ? hv[q][u] : 0.0;
+            }
+    }
+#endif
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        double v = pad[q];
+        if (pr[q] >= 0) v = uu[q] >= 0 ? (hpp[q] + pad[q]) - sacc[q] : -sacc[q];
+        const int e = tid + kPT * q, r = e / NB, cc = e - r * NB;
+        dst[r * LD + cc] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The stacked sweep  [D; U] -> [L(K, K); U L(K, K)^-T]  of a diagonal tile D (48 x 48, LDS image at d_off) and up to 48 more
+// rows U (the workgroup's own tile, or the right-hand side row), in three panels of 16 columns:
+//   chain   the panel's 16 pivots with one ROW PER LANE and the panel's 16 entries of the row in registers; pivot row k is
+//           lane k, broadcast entry by entry with v_readlane (no LDS round trip, no barrier inside the chain):
+//           p_rc -= (p_rk / p_kk) p_kc for c > k.  Wave 0 holds the rows of D from the panel's diagonal block down; wave 1
+//           holds that diagonal block ONCE MORE on its lanes 0..15 (the same arithmetic, bit for bit) and the rows of U on
+//           lanes 16..63, so neither wave needs anything from the other inside a panel;
+//   trail   [D22; U2] -= [L21; U1] L21^T on the fp64 matrix cores, 16 x 16 blocks dealt to the four waves.
+// 48 dependent pivots of ~100 cycles each instead of 48 LDS round trips of ~900 (the single-wave sweeps of dense_tile.h
+// took 18 us of a 25 us block column).  The upper triangle of a diagonal block is carried as its symmetric image.
+// Returns true (to every thread) when a pivot was not positive: the caller marks the factorisation failed.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int K>
+struct PanelStep {
+    static __device__ __forceinline__ void run(double (&p)[16], double (&pk)[16], bool &bad)
+    {
+        double piv = readlane_f64(p[K], K);
+        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
+        pk[K] = piv;
+        const double td = p[K] * fast_rcp(piv);
+        // the pivot row's entries first, each into scalar registers of its own, then the updates: read one by one in front of
+        // its update every v_readlane pair was followed by the wait states of the scalar-to-vector hazard
+        double s[16];
+#pragma unroll
+        for (int c = K + 1; c < 16; ++c) s[c] = readlane_f64(p[c], K);
+#pragma unroll
+        for (int c = K + 1; c < 16; ++c) p[c] -= td * s[c];
+        PanelStep<K + 1>::run(p, pk, bad);
+    }
+};
+template <>
+struct PanelStep<16> {
+    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], bool &) {}
+};
+
+__device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int n_urows, int flag_off)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];     // (LDS addressed from its own symbol: ds_ instructions, not flat_)
+    double *D = sm + d_off, *U = sm + u_off;
+    int *s_bad = reinterpret_cast<int *>(sm + flag_off);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_ublk = (n_urows + 15) >> 4;
+    if (tid == 0) *s_bad = 0;
+#pragma unroll 1
+    for (int pn = 0; pn < 3; ++pn) {
+        const int c0 = 16 * pn;
+        double pr[16], pk[16];
+        double *rowp = D;
+        bool writes = false, chain = false;
+        int diag_i = 16;                                // lanes of wave 0 below 16 hold a row of the diagonal block: entries right of the diagonal are not stored
+        if (wv == 0) {
+            const int nr = NB - c0, i = lane < nr ? lane : nr - 1;      // (lanes past the last row shadow it; nothing of theirs is stored)
+            rowp = D + (c0 + i) * LD + c0; writes = lane < nr; chain = true; diag_i = lane;
+        } else if (wv == 1 && n_urows > 0) {
+            const int r = lane - 16 < n_urows ? lane - 16 : n_urows - 1;
+            rowp = lane < 16 ? D + (c0 + lane) * LD + c0 : U + r * LD + c0;
+            writes = lane >= 16 && lane - 16 < n_urows; chain = true;
+        }
+        bool bad = false;
+        if (chain) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pr[c] = rowp[c];
+            PanelStep<0>::run(pr, pk, bad);
+        }
+        __syncthreads();                                // wave 1 has read the diagonal block before wave 0 stores its factor over it
+        if (chain) {
+            if (bad && lane == 0) *s_bad = 1;
+            if (writes) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    // 1 / sqrt(pivot) by v_rsq_f64 and two Newton steps
+                    double rs = __builtin_amdgcn_rsq(pk[c]);
+                    rs = rs * (1.5 - 0.5 * pk[c] * rs * rs);
+                    rs = rs * (1.5 - 0.5 * pk[c] * rs * rs);
+                    rowp[c] = c <= diag_i ? pr[c] * rs : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (pn == 2) break;
+        // ---- trailing blocks of this panel: D blocks (rb, cb), rb >= cb > pn, then U blocks (ub, cb) ----
+        const int ncb = 2 - pn;                         // column blocks right of the panel
+        const int nD = ncb * (ncb + 1) / 2, nblk = nD + n_ublk * ncb;
+        for (int q = wv; q < nblk; q += 4) {
+            int rb, cb;
+            const double *Arow;
+            double *Cbase;
+            if (q < nD) {
+                // (pn == 0: blocks (1,1), (2,1), (2,2); pn == 1: block (2,2))
+                if (pn == 0) { cb = q < 2 ? 1 : 2; rb = q == 0 ? 1 : 2; } else { cb = 2; rb = 2; }
+                Arow = D + (16 * rb) * LD; Cbase = D + (16 * rb) * LD + 16 * cb;
+            } else {
+                const int qq = q - nD;
+                rb = qq / ncb; cb = pn + 1 + (qq - rb * ncb);
+                Arow = U + (16 * rb) * LD; Cbase = U + (16 * rb) * LD + 16 * cb;
+            }
+            const double *ap = Arow + (lane & 15) * LD + c0 + (lane >> 4);
+            const double *bp = D + (16 * cb + (lane & 15)) * LD + c0 + (lane >> 4);
+            double *cp = Cbase + (lane >> 4) * LD + (lane & 15);
+            dbl4 acc = dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
+#pragma unroll
+            for (int k4 = 0; k4 < 16; k4 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ap[k4], bp[k4], acc, 0, 0, 0);
+            cp[0] = acc.x; cp[4 * LD] = acc.y; cp[8 * LD] = acc.z; cp[12 * LD] = acc.w;
+        }
+        __syncthreads();
+    }
+    return *s_bad != 0;
+}
+
+
+// L^T x = s for one 48 x 48 factor (LDS image at l_off) by ONE wave, unknown t on lane t, from the last unknown up: x_k is
+// broadcast from lane k (v_readlane), every lane above the diagonal subtracts its L[k][t] x_k.  Fully unrolled with the
+// factor's column t in registers (static indices): the chain per unknown is readlane -> multiply -> fused update; as a loop
+// over k with a select per step it took 4.5 us per block row, most of the back substitution's chain.
+template <int K>
+struct BackStep {
+    static __device__ __forceinline__ void run(double &sv, const double (&lk)[NB], const double (&rd)[NB])
+    {
+        const double xk = readlane_f64(sv, K) * rd[K];
+        sv -= lk[K] * xk;
+        BackStep<K - 1>::run(sv, lk, rd);
+    }
+};
+template <>
+struct BackStep<-1> {
+    static __device__ __forceinline__ void run(double &, const double (&)[NB], const double (&)[NB]) {}
+};
+
+__device__ __attribute__((noinline)) double back_solve48(int l_off, double sv, int lane)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const double *L = sm + l_off;
+    const int t = lane < NB ? lane : NB - 1;
+    double lk[NB], rd[NB];
+    const double rdl = fast_rcp(L[t * LD + t]);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) { const double v = L[k * LD + t]; lk[k] = (k > lane) ? v : 0.0; }      // only the rows below the diagonal act on unknown t
+#pragma unroll
+    for (int k = 0; k < NB; ++k) rd[k] = readlane_f64(rdl, k);
+    BackStep<NB - 1>::run(sv, lk, rd);
+    return sv * rdl;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epoch)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    Ctrl *c = w.ctrl;
+    if (c->done == 1) return;
+    const DenseSys &ds = w.dense;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = ds.ntile, n = ds.n;
+    const Lds l = carve(sm, ds.slots);
+    unsigned *flags = ds.flags;
+    const double lambda = c->lambda;
+    if (tid == 0) { *l.abort = 0; *l.prog = 0; }
+    __syncthreads();
+    bool aborted = false;
+
+    const int t0 = ds.task_ptr[blockIdx.x], t1 = ds.task_ptr[blockIdx.x + 1];
+    for (int t = t0; t < t1 && !aborted; ++t) {
+        const DenseTask tk = ds.tasks[t];
+        const int I = tk.I, K = tk.K, k = tk.k;
+        if (ds.stamps && tid == 0) { ds.stamps[3 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); ds.stamps[3 * (size_t)t + 1] = 0; }
+        const int slot_off = (2 + tk.slot) * kTileLds;
+        double *slot = sm + slot_off;
+        switch (tk.op) {
+        case DT_ASM: {
+            assemble_tile(w, I, K, lambda, slot_off, tid);
+            if (I == K && tid < NB) {
+                // right-hand side b_S = b_p - sum B Dinv b_l of this block column; b_p is kept for computeScale
+                const int gc = K * NB + tid;
+                double v = 0.0;
+                if (gc < n) {
+                    const int bj = gc / 6, a = gc - bj * 6;
+                    double bb = 0.0, cb = 0.0;
+                    const int j0 = w.pair_item_start[bj], j1 = w.pair_item_start[bj + 1];
+                    for (int base = j0; base < j1; base += 8) {             // (eight items in flight, summed in item order)
+                        double bv[8], cv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const bool in = base + u < j1;
+                            bv[u] = in ? w.part[(size_t)(base + u) * kPartStride + 63 + a] : 0.0;
+                            cv[u] = in ? w.part[(size_t)(base + u) * kPartStride + 36 + a] : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { bb += bv[u]; cb += cv[u]; }
+                    }
+                    st_sc1(w.bp + gc, bb);
+                    v = bb - cb;
+                }
+                l.rrow[tid] = v;
+            }
+            __syncthreads();
+            break;
+        }
+        case DT_UPD: {
+            // operands this workgroup produced itself are read where they lie (its own LDS slots: pad[0] / pad[1] of the task);
+            // the others are waited for and fetched
+#ifdef MOVBA_DENSE_NO_OWN
+            const int sa = -1, sb = -1;
+#else
+            const int sa = tk.pad[0], sb = I == K ? tk.pad[0] : tk.pad[1];
+#endif
+            const int fa = sa < 0 ? dense_flag_F(nt, I, k) : -1, fb = (I != K && sb < 0) ? dense_flag_F(nt, K, k) : -1;
+            const int nw = (fa >= 0) + (fb >= 0);
+            if (nw > 0 && !wg_wait(flags, epoch, nw, [&](int i) { return (i == 0 && fa >= 0) ? fa : fb; }, l, tid)) { aborted = true; break; }
+            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (sa < 0) fetch_tile(ds.tiles + tile_off(I, k), l.A, tid);
+            if (I != K && sb < 0) fetch_tile(ds.tiles + tile_off(K, k), l.B, tid);
+            if (sa < 0 || (I != K && sb < 0)) __syncthreads();
+            const double *Ap = sa < 0 ? l.A : sm + (2 + sa) * kTileLds;
+            const double *Bp = I == K ? Ap : (sb < 0 ? l.B : sm + (2 + sb) * kTileLds);
+            tile_update(slot, Ap, Bp, wv, lane);
+            __syncthreads();
+            break;
+        }
+        case DT_DIAG: {
+            publish_tile(ds.tiles + tile_off(K, K), slot, tid);
+            set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
+            break;
+        }
+        case DT_OFF: {
+            if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_PD(nt, K); }, l, tid)) { aborted = true; break; }
+            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            fetch_tile(ds.tiles + tile_off(K, K), l.B, tid);      // D_K, factored in place in the scratch tile
+            __syncthreads();
+            if (sweep_tiles(kTileLds, slot_off, NB, kBadOff(ds.slots)) && tid == 0) st_flag(ds.failw, epoch);
+            publish_tile(ds.tiles + tile_off(I, K), slot, tid);
+            set_flag(flags, dense_flag_F(nt, I, K), epoch, tid);
+            break;
+        }
+        case DT_RHS: {
+            // r_K -= L(K, k) y_k for every block column to the left, then the workgroup's own factorisation of D_K with the
+            // right-hand side as row 48: L(K, K) stays in the slot for the back substitution, y_K is published
+            for (int kk = 0; kk < K && !aborted; ++kk) {
+                if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_F(nt, nt, kk); }, l, tid)) { aborted = true; break; }
+            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                fetch_tile(ds.tiles + tile_off(K, kk), l.A, tid);
+                if (tid < NB) l.xs[tid] = ld_sc1(ds.tiles + tile_off(nt, kk) + tid);
+                __syncthreads();
+                const int g = tid / NB, cc = tid - g * NB;
+                if (g < 5) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 10; ++q) { const int col = g + 5 * q; if (col < NB) s += l.A[cc * LD + col] * l.xs[col]; }
+                    l.ps[g * NB + cc] = s;
+                }
+                __syncthreads();
+                if (tid < NB) l.rrow[tid] -= (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid];
+                __syncthreads();
+            }
+            if (aborted) break;
+            // the right-hand side as the one row of a 16-row block of U (scratch tile A: free now)
+            if (tid < NB) l.A[tid] = l.rrow[tid];
+            __syncthreads();
+            if (sweep_tiles(slot_off, 0, 1, kBadOff(ds.slots)) && tid == 0) st_flag(ds.failw, epoch);
+            if (tid < NB) l.yv[tid] = l.A[tid];
+            __syncthreads();
+            if (tid < NB) st_sc1(ds.tiles + tile_off(nt, K) + tid, l.yv[tid]);
+            set_flag(flags, dense_flag_F(nt, nt, K), epoch, tid);
+            break;
+        }
+        case DT_BSX: {
+            const int J = K, nc = nt - 1 - J;
+            if (nc > 0 && !wg_wait(flags, epoch, nc, [&](int i) { return dense_flag_FC(nt, J + 1 + i, J); }, l, tid)) { aborted = true; break; }
+            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (tid < 64) {
+                double sv = 0.0;
+                if (tid < NB) {
+                    double acc = 0.0;
+                    for (int i0 = J + 1; i0 < nt; i0 += 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = i0 + u < nt ? ld_sc1(ds.contrib + ((size_t)(i0 + u) * nt + J) * NB + tid) : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc += v[u];
+                    }
+                    sv = l.yv[tid] - acc;
+                }
+#ifdef MOVBA_DENSE_OLD_BSX
+                if (tid < NB) l.rinvb[tid] = fast_rcp(slot[tid * LD + tid]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                {
+                    double lk = tid < NB ? slot[(NB - 1) * LD + tid] : 0.0, rk = l.rinvb[NB - 1];
+                    for (int kk = NB - 1; kk >= 0; --kk) {
+                        const double lcur = lk, rcur = rk;
+                        if (kk > 0) { lk = tid < NB ? slot[(kk - 1) * LD + tid] : 0.0; rk = l.rinvb[kk - 1]; }
+                        const double xk = readlane_f64(sv, kk) * rcur;
+                        if (tid == kk) sv = xk;
+                        else if (tid < kk) sv -= lcur * xk;
+                    }
+                }
+#else
+                sv = back_solve48(slot_off, sv, tid);
+#endif
+                if (tid < NB) { l.xv[tid] = sv; st_sc1(ds.xsol + J * NB + tid, sv); }
+            }
+            set_flag(flags, dense_flag_FX(nt, J), epoch, tid);
+            break;
+        }
+        case DT_BSC: {
+            // c(I, J) = L(I, J)^T x_I with J = K: column sums over the tile's rows in five row groups, combined in fixed order
+            // (x_I of the workgroup's own diagonal tile is still in LDS: pad[0] of the task)
+            if (tk.pad[0] != 1) {
+                if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_FX(nt, I); }, l, tid)) { aborted = true; break; }
+                if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                if (tid < NB) l.xs[tid] = ld_sc1(ds.xsol + I * NB + tid);
+            } else if (tid < NB) l.xs[tid] = l.xv[tid];
+            __syncthreads();
+            const int g = tid / NB, cc = tid - g * NB;
+            if (g < 5) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) { const int r = g + 5 * q; if (r < NB) s += slot[r * LD + cc] * l.xs[r]; }
+                l.ps[g * NB + cc] = s;
+            }
+            __syncthreads();
+            if (tid < NB) st_sc1(ds.contrib + ((size_t)I * nt + K) * NB + tid, (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid]);
+            set_flag(flags, dense_flag_FC(nt, I, K), epoch, tid);
+            break;
+        }
+        case DT_EPI: {
+            if (!wg_wait(flags, epoch, nt, [&](int i) { return dense_flag_FX(nt, i); }, l, tid)) { aborted = true; break; }
+            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            break;      // (the outputs follow the loop)
+        }
+        default: break;
+        }
+        if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (blockIdx.x != 0) {
+        if (aborted && tid == 0) st_flag(ds.failw + 1, epoch);
+        return;
+    }
+
+    // ---- workgroup 0: increment, pose part of computeScale(), trial poses (VertexSE3Expmap::oplusImpl); releases a parked
+    // solve (Ctrl::done 2 -> 0).  A solve that gave up on a wait is reported as a failed factorisation AND counted. ----
+    __syncthreads();
+    const bool fail = aborted || ld_flag(ds.failw) == epoch ||
+                      ld_flag(ds.failw + 1) == epoch;
+    double *x = l.A;                                // n <= 2 tiles of scratch (dense_persist_supported)
+    double sc = 0.0;
+    for (int idx = tid; idx < n; idx += kPT) {
+        const double xv = fail ? 0.0 : ld_sc1(ds.xsol + idx);
+        const double bpv = fail ? 0.0 : ld_sc1(w.bp + idx);
+        w.xp[idx] = xv;
+        sc += xv * (lambda * xv + bpv);
+        x[idx] = xv;
+    }
+    const double scs = block_reduce<kPT / 64, false>(sc, l.red);
+    const int cur = c->cur;
+    const DevState &S0 = w.st[cur];
+    const DevState &S1 = w.st[cur ^ 1];
+    for (int i = tid; i < w.NP; i += kPT) {
+        double T[7], Tn[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) T[q] = S0.pose[7 * i + q];
+        const int h = w.hidx[i];
+        if (h >= 0) {
+            double u[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) u[q] = x[6 * h + q];
+            se3_oplus(u, T, Tn);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) Tn[q] = T[q];
+        }
+        double R[9];
+        quat_to_R(Tn, R);
+#pragma unroll
+        for (int q = 0; q < 7; ++q) S1.pose[7 * i + q] = Tn[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) S1.Rt[12 * i + q] = R[q];
+        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
+    }
+    if (tid == 0) {
+        w.scale_part[w.n_pt_blocks] = scs;
+        c->pcg_fail = fail ? 1 : 0;
+        c->pcg_last_iters = -1;                     // trace marker: this trial was solved directly
+        c->n_direct += 1;
+        if (fail) c->n_chol_fail += 1;
+        if (aborted || ld_flag(ds.failw + 1) == epoch) c->n_sync_timeouts += 1;
+        if (c->done == 2) c->done = 0;              // the solve was parked for this: the kernels behind run again
+    }
+}
+
+size_t dense_persist_lds_bytes(int slots) { return ((size_t)(2 + slots) * kTileLds + 672) * sizeof(double); }
+
+bool dense_persist_supported(const DensePlan &p)
+{
+    return p.ok && p.nt * NB <= 2 * kTileLds && dense_persist_lds_bytes(p.slots) <= 160 * 1024 - 1024;
+}
+
+hipError_t launch_dense_persist(const DevWindow &w, unsigned epoch, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dense_persist, dim3(w.dense.G), dim3(kPT), dense_persist_lds_bytes(w.dense.slots), s, w, epoch);
+    return hipGetLastError();
+}
+
+hipError_t configure_dense_persist()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dense_persist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
+}  // namespace movba

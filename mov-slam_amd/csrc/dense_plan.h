@@ -1,0 +1,52 @@
+// Static schedule of the one-launch direct solver (dense_persist.hip): who owns which 48 x 48 tile of the reduced
+// camera system, and in which order every workgroup runs its tasks.
+//
+// The reference factors S with a sparse direct solver whatever its pattern (LinearSolverCSparse,
+// /root/reference/src/Optimizer.cc:535).  Here S is factored as a dense blocked Cholesky in ONE launch: every tile of the
+// lower block triangle has an owner workgroup that keeps it in LDS for the whole factorisation and applies the updates
+// of the block columns to its left as those columns are published (right-looking, owner computes); the finished tiles
+// L(I, K) are the only data that travel between workgroups (write-through stores + one flag each).  The order of a
+// workgroup's tasks is a host-built list sorted by a key under which every task depends only on tasks of smaller keys:
+// the globally smallest unfinished task can always run, so the schedule cannot deadlock while its workgroups are
+// resident (and every device-side wait is bounded by a clock, dense_persist.hip).
+// Pure C++ (no HIP): checked on the CPU by simulating the flags (tests/test_dense_plan_cpu.py).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace movba {
+
+enum DenseOp : int32_t {
+    DT_ASM = 0,     // tile (I, K) <- S (and, for a diagonal tile, the right-hand side row) from the schur partials
+    DT_UPD = 1,     // tile (I, K) -= L(I, k) L(K, k)^T                      waits F(I, k), F(K, k)
+    DT_DIAG = 2,    // publish the updated diagonal tile D_K                  sets PD(K)
+    DT_OFF = 3,     // L(I, K) = tile (I, K) L(K, K)^-T (sweep against D_K)   waits PD(K), sets F(I, K)
+    DT_RHS = 4,     // diagonal owner: y_K (forward substitution) and L(K, K) waits FY(k), k < K, sets FY(K)
+    DT_BSX = 5,     // diagonal owner: x_J = L(J, J)^-T (y_J - sum_I c(I, J))   waits FC(I, J), I > J, sets FX(J)
+    DT_BSC = 6,     // owner of (I, J): c(I, J) = L(I, J)^T x_I               waits FX(I), sets FC(I, J)
+    DT_EPI = 7,     // increments, computeScale's pose part, trial poses      waits FX(*)
+};
+
+struct DenseTask { int32_t op, slot, I, K, k, pad[3]; };       // 32 bytes: one scalar load; DT_UPD: pad[0] / pad[1] = own LDS slot of L(I, k) / L(K, k), -1 = fetch
+
+constexpr int kDenseMaxSlots = 6;       // tiles a workgroup keeps in LDS (2 scratch tiles beside them: 150 KB)
+constexpr int kDenseMaxGroups = 248;    // workgroups of the launch (one per CU, a few CUs to spare)
+
+struct DensePlan {
+    int nt = 0, G = 0, slots = 0;       // block columns, workgroups, tile slots per workgroup
+    bool ok = false;                    // false: the system does not fit the one-launch solver (multi-launch path instead)
+    std::vector<int32_t> task_ptr;      // G + 1
+    std::vector<DenseTask> tasks;
+    std::vector<int32_t> owner, slot;   // nt (nt + 1) / 2: tile (I, K) at I (I + 1) / 2 + K
+};
+
+// flags of the launch (one 32-bit word each, compared with the launch's epoch)
+constexpr inline int dense_flag_F(int nt, int I, int K) { return I * nt + K; }                  // I in [0, nt]: row nt = FY
+constexpr inline int dense_flag_PD(int nt, int K) { return (nt + 1) * nt + K; }
+constexpr inline int dense_flag_FX(int nt, int J) { return (nt + 2) * nt + J; }
+constexpr inline int dense_flag_FC(int nt, int I, int J) { return (nt + 3) * nt + I * nt + J; }
+constexpr inline int dense_flag_count(int nt) { return (2 * nt + 3) * nt + 8; }
+
+void build_dense_plan(int nt, DensePlan &p, int max_groups = kDenseMaxGroups, int max_slots = kDenseMaxSlots);
+
+}  // namespace movba

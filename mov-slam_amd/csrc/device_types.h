@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 
+#include "dense_plan.h"
 #include "structure.h"
 
 namespace movba {
@@ -56,7 +57,9 @@ struct Ctrl {
     // the first trial whose PCG broke down or ran into its iteration cap.  done == 2 parks the solve until the host has
     // queued the direct kernels for that trial (HostStatus::pause_seq).
     int32_t solver_mode, n_pause, n_direct, n_chol_fail;
-    int32_t direct_from, pad_c[3];      // n_solves at the switch to the direct solver (-1: never)
+    int32_t direct_from;                // n_solves at the switch to the direct solver (-1: never)
+    int32_t n_sync_timeouts;            // one-launch direct solver: solves in which a workgroup gave up waiting for another (dense_persist.hip)
+    int32_t pad_c[2];
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
     unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8], dbg_wseg[8][8];
 };
@@ -89,6 +92,14 @@ struct DenseSys {
     const int32_t *pid;         // nfree x nfree: pair id of block (i <= j) or -1
     int32_t *fail;              // != 0: a pivot was not positive (the trial is rejected like a failed CSparse factorisation)
     int32_t ntile, n;           // column tiles; unknowns (6 nfree)
+    // one-launch form (dense_persist.hip): the static schedule (dense_plan.h), the hand-off flags (compared with the launch's
+    // epoch), the two failure words (bad pivot, wait given up), the back substitution's per-tile contributions
+    const int32_t *task_ptr;
+    const DenseTask *tasks;
+    unsigned *flags, *failw;
+    double *contrib;            // ntile x ntile x NB
+    unsigned long long *stamps; // diagnostic (MOVBA_DENSE_STAMPS=1): per task 3 readings of the 100 MHz clock (start, wait over, end), else null
+    int32_t G, slots;           // workgroups of the launch, LDS tile slots per workgroup (G == 0: multi-launch path only)
 };
 
 struct DevWindow {

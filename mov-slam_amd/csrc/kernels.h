@@ -46,6 +46,10 @@ size_t pcg_rows_lds_bytes(int nfree, int nrowent);
 // direct solver (dense_solve.hip): assemble + one launch per block column + back substitution / pose update
 hipError_t configure_dense_kernels();
 hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s);
+// ... and in one launch (dense_persist.hip) when the static schedule fits (dense_plan.h)
+hipError_t configure_dense_persist();
+bool dense_persist_supported(const DensePlan &p);
+hipError_t launch_dense_persist(const DevWindow &w, unsigned epoch, hipStream_t s);
 size_t dense_tiles_doubles(int nfree);
 int dense_ntile(int nfree);
 // the point kernels stage every keyframe's rotation in LDS up to this many bytes; larger windows read them through L2

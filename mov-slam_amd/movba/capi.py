@@ -84,7 +84,7 @@ EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destro
            "movba_lba_upload", "movba_lba_reset", "movba_lba_run", "movba_lba_download",
            "movba_lba_export_poses_device", "movba_lba_set_pose_export", "movba_get_profile", "movba_reset_profile",
            "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch", "movba_pose_ransac_samples",
-           "movba_host_alloc", "movba_host_free"]
+           "movba_host_alloc", "movba_host_free", "movba_dense_plan_probe"]
 
 _lib = None
 
@@ -118,6 +118,7 @@ def lib():
         L.movba_pose_ransac_samples.argtypes = [C.c_int32, C.c_int32, C.c_uint32, _i]
         L.movba_host_alloc.argtypes = [C.c_size_t]
         L.movba_host_alloc.restype = C.c_void_p
+        L.movba_dense_plan_probe.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, C.c_int32]
         L.movba_host_free.argtypes = [C.c_void_p]
         L.movba_host_free.restype = None
         _lib = L
@@ -171,6 +172,18 @@ def structure_probe(w):
                 pcg_overflow=bool(info.pcg_overflow), pcg_max_wave_entries=info.pcg_max_wave_entries,
                 n_row_entries=info.n_row_entries, n_sched_slots=info.n_sched_slots, sched_items=info.sched_items,
                 sched_max_permille=info.sched_max_permille, slots_ok=bool(info.slots_ok), perm=perm, free_index=fidx)
+
+
+def dense_plan(nt: int, max_groups: int = 0, max_slots: int = 0):
+    """Static schedule of the one-launch direct solver for nt block columns (host only): dict(ok, G, slots, task_ptr, tasks)
+    with tasks as rows (op, slot, I, K, k)."""
+    info = np.zeros(4, np.int32)
+    lib().movba_dense_plan_probe(nt, max_groups, max_slots, _p(info, _i), None, 0, None, 0)
+    if not info[0]:
+        return dict(ok=False, G=0, slots=0, task_ptr=np.zeros(1, np.int32), tasks=np.zeros((0, 5), np.int32))
+    tp = np.zeros(info[1] + 1, np.int32); tk = np.zeros((info[3], 8), np.int32)
+    lib().movba_dense_plan_probe(nt, max_groups, max_slots, _p(info, _i), _p(tp, _i), len(tp), _p(tk, _i), info[3])
+    return dict(ok=True, G=int(info[1]), slots=int(info[2]), task_ptr=tp, tasks=tk[:, :5])
 
 
 def ransac_samples(n: int, n_hyp: int, seed: int) -> np.ndarray:

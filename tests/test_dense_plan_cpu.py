@@ -1,0 +1,87 @@
+"""Static schedule of the one-launch direct solver (mov-slam_amd/csrc/dense_plan.{h,cpp}; the kernel is dense_persist.hip):
+replayed on the CPU against its own flags.  The solver stands in for the reference's LinearSolverCSparse factorisation
+(/root/reference/src/Optimizer.cc:535); on the device every workgroup runs its task list in order and waits for flags other
+workgroups set, so the list must (1) cover the blocked Cholesky exactly, (2) never wait for a flag nobody sets, (3) always
+leave some workgroup able to run — whatever the speeds of the workgroups."""
+import numpy as np
+import pytest
+
+ASM, UPD, DIAG, OFF, RHS, BSX, BSC, EPI = range(8)
+
+
+def waits_and_sets(op, I, K, k, nt):
+    """(flags a task waits for, flag it sets)"""
+    if op == ASM: return [], None
+    if op == UPD: return [("F", I, k)] + ([("F", K, k)] if I != K else []), None
+    if op == DIAG: return [], ("PD", K)
+    if op == OFF: return [("PD", K)], ("F", I, K)
+    if op == RHS: return [("FY", q) for q in range(K)], ("FY", K)
+    if op == BSX: return [("FY", K)] + [("FC", i, K) for i in range(K + 1, nt)], ("FX", K)
+    if op == BSC: return [("FX", I)], ("FC", I, K)
+    if op == EPI: return [("FX", j) for j in range(nt)], None
+    raise AssertionError(op)
+
+
+def replay(plan, nt, order_rng):
+    """run the workgroups' lists in a random interleaving; returns the number of tasks executed"""
+    tp, tk = plan["task_ptr"], plan["tasks"]
+    pc = tp[:-1].copy()
+    flags, done = set(), 0
+    upd_seen = {}                         # tile -> columns applied so far (must be 0, 1, 2, ... in order)
+    state = {}                            # tile -> "asm" / "final"
+    slots = {}                            # (workgroup, slot) -> tile
+    while True:
+        runnable = [g for g in range(plan["G"]) if pc[g] < tp[g + 1] and all(f in flags for f in waits_and_sets(*tk[pc[g], [0, 2, 3, 4]], nt)[0])]
+        if not runnable:
+            break
+        g = int(order_rng.choice(runnable))
+        op, slot, I, K, k = (int(v) for v in tk[pc[g]])
+        tile = (I, K)
+        if op == ASM:
+            assert tile not in state and slots.setdefault((g, slot), tile) == tile
+            state[tile] = "asm"; upd_seen[tile] = 0
+        elif op == UPD:
+            assert state[tile] == "asm" and upd_seen[tile] == k and slots[(g, slot)] == tile
+            upd_seen[tile] += 1
+        elif op in (DIAG, OFF):
+            assert state[tile] == "asm" and upd_seen[tile] == K and slots[(g, slot)] == tile    # every column to the left applied
+            state[tile] = "final"
+        elif op in (RHS, BSX):
+            assert state[(K, K)] == "final" and slots[(g, slot)] == (K, K)
+        elif op == BSC:
+            assert state[tile] == "final" and slots[(g, slot)] == tile
+        s = waits_and_sets(op, I, K, k, nt)[1]
+        if s is not None:
+            assert s not in flags
+            flags.add(s)
+        pc[g] += 1; done += 1
+    assert (pc == tp[1:]).all(), "schedule stalls: some workgroup waits for a flag that is never set"
+    return done, state
+
+
+@pytest.mark.parametrize("nt", [1, 2, 3, 7, 10, 19, 24, 50])
+def test_schedule_covers_the_factorisation_and_never_stalls(built_lib, nt):
+    plan = built_lib.dense_plan(nt)
+    assert plan["ok"] and plan["G"] <= 248 and plan["slots"] <= 6
+    for seed in range(3 if nt <= 24 else 1):
+        done, state = replay(plan, nt, np.random.default_rng(seed))
+        assert done == len(plan["tasks"])
+        assert set(state) == {(I, K) for K in range(nt) for I in range(K, nt)} and set(state.values()) == {"final"}
+    # the chain D_(K-1) -> L(K, K-1) -> D_K stays inside one workgroup: the diagonal tile's owner owns the tile to its left
+    tk, tp = plan["tasks"], plan["task_ptr"]
+    owner = {}
+    for g in range(plan["G"]):
+        for op, slot, I, K, k in tk[tp[g]:tp[g + 1]]:
+            if op == ASM:
+                owner[(int(I), int(K))] = g
+    for K in range(1, nt):
+        assert owner[(K, K)] == owner[(K, K - 1)] == K
+    assert int((tk[:, 0] == EPI).sum()) == 1 and owner[(0, 0)] == 0
+
+
+def test_systems_beyond_the_slots_of_one_launch_are_refused(built_lib):
+    assert not built_lib.dense_plan(60)["ok"]                   # 1 830 tiles > 248 workgroups x 6 slots
+    assert not built_lib.dense_plan(8, max_groups=4)["ok"]      # more block columns than workgroups
+    small = built_lib.dense_plan(8, max_groups=12, max_slots=4)
+    assert small["ok"] and small["G"] == 12 and small["slots"] <= 4
+    replay(small, 8, np.random.default_rng(1))
