@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOVBA_VERSION 2
+#define MOVBA_VERSION 3
 
 /* status codes */
 #define MOVBA_OK              0
@@ -40,6 +40,9 @@ extern "C" {
 #define MOVBA_ERR_ARG        -1
 #define MOVBA_ERR_HIP        -2   /* HIP runtime failure (no device, OOM, launch error)       */
 #define MOVBA_ERR_STATE      -3   /* call order violated (run before upload, ...)             */
+#define MOVBA_ERR_DEVICE_WAIT -4  /* one-launch direct solver: a workgroup gave up waiting for another (20 ms); the results
+                                     of the solve are not trustworthy and are not returned as MOVBA_OK               */
+#define MOVBA_ERR_TOO_LARGE  -5   /* the window's reduced system exceeds what the direct solver can hold             */
 
 /* flags */
 #define MOVBA_FLAG_STALE_ERROR_QUIRK 1u  /* chi2 of a rejected last trial, as g2o leaves it */
@@ -95,11 +98,14 @@ typedef struct {
     int32_t tr_accept[MOVBA_MAX_TRACE];
     int32_t tr_pcg_iters[MOVBA_MAX_TRACE];   /* PCG iterations of the trial; -1: solved by the direct solver */
     /* Reduced solve (LinearSolverCSparse in the reference, Optimizer.cc:535): on-chip PCG for windows of up to 80 free
-     * keyframes, dense Cholesky otherwise and from the first trial whose PCG gave up (breakdown or iteration cap). */
+     * keyframes whose reduced matrix fits the PCG workgroup's registers, dense Cholesky otherwise (more keyframes, or
+     * denser covisibility) and from the first trial whose PCG gave up (breakdown or iteration cap). */
     int32_t n_direct;           /* trials solved by the direct solver                                          */
     int32_t direct_from;        /* n_solves at the switch to the direct solver (0: whole solve), -1: never     */
     int32_t n_chol_fail;        /* trials whose factorisation met a non-positive pivot: rejected, as g2o does  */
     int32_t n_pcg_giveups;      /* 0 or 1: the PCG gave up once, the solve went on with the direct solver      */
+    int32_t n_sync_timeouts;    /* direct solves in which a workgroup gave up waiting (status is then MOVBA_ERR_DEVICE_WAIT) */
+    int32_t pad_r;
 } movba_lba_result;
 
 /* Solver options (all have defaults; pass NULL to movba_create for defaults). */
@@ -115,6 +121,10 @@ typedef struct {
                                  * 0 = spin on the progress word (default, lowest latency), 1 = sched_yield() between
                                  * looks (for a LocalMapping thread that shares its core with Tracking; the upload's helper
                                  * thread then sleeps between uploads instead of staying awake for 4 ms after each)    */
+    int32_t pcg_spill;          /* 1 = keep the PCG for windows whose reduced matrix does not fit the PCG workgroup's registers
+                                 * (list tails read from an L2 copy every iteration); 0 = default: such windows take the
+                                 * one-launch direct solver from the first trial                                        */
+    int32_t solver;             /* 0 = default (PCG where it fits, direct solver elsewhere), 1 = direct solver for every window */
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */

@@ -338,6 +338,8 @@ const char *movba_status_string(int s)
     case MOVBA_ERR_ARG: return "invalid argument";
     case MOVBA_ERR_HIP: return "HIP runtime error";
     case MOVBA_ERR_STATE: return "invalid call order";
+    case MOVBA_ERR_DEVICE_WAIT: return "direct solver: a workgroup gave up waiting for another";
+    case MOVBA_ERR_TOO_LARGE: return "reduced system too large for the direct solver";
     default: return "unknown";
     }
 }
@@ -355,7 +357,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     movba_handle *h = new (std::nothrow) movba_handle();
     if (!h) return MOVBA_ERR_HIP;
     h->device = device;
-    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0;
     if (opt) {
         if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
         if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
@@ -363,6 +365,8 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         h->opt.profile = opt->profile;
         if (opt->pcg_coarse < 0) h->opt.pcg_coarse = 0;
         h->opt.host_wait = opt->host_wait == 1 ? 1 : 0;
+        h->opt.pcg_spill = opt->pcg_spill == 1 ? 1 : 0;
+        h->opt.solver = opt->solver == 1 ? 1 : 0;
     }
     if (h->opt.host_wait == 1) h->packer.spin_ms = 0;      // (a caller that asks for yielding waits does not want a spinning helper either)
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
@@ -756,6 +760,17 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (!edge_b_queued) { const int rq = queue_edge_b(); if (rq) return rq; }
     h->pp = PcgParams{};
     h->rows_kernel = pcg_rows_supported(s.nfree, s.row_ptr.data(), &h->pp);
+    // A reduced matrix far beyond the PCG workgroup's registers (dense covisibility: every keyframe pair shares points, as in
+    // the reference's own windows, KeyFrame.cc:227-231) is not iterated over from L2: the one-launch direct solver takes the
+    // window from the first trial, whatever its pattern.  Measured (profiles/r03*_patterns.json): hub 50 keyframes, 2 550 gather
+    // entries against the 1 024 the registers hold: PCG 283 us per trial, direct 195; 80 keyframes with cfg3's band, 1 580
+    // entries: PCG 220, direct 274 — so the switch sits at twice the register capacity.
+    // (movba_options::pcg_spill = 1 keeps the spilling PCG whatever the size; ::solver = 1 takes every window direct.)
+    {
+        const int cap = 2 * 64 * (kPcgRowsThreads / 64);        // gather entries the PCG workgroup keeps in VGPRs
+        const bool far_over = h->rows_kernel && h->pp.overflow && (int)s.row_ent.size() > 2 * cap;
+        if (h->rows_kernel && ((far_over && !h->opt.pcg_spill) || h->opt.solver == 1)) h->rows_kernel = false;
+    }
     if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     lap("pcg plan + coarse lists");
 
@@ -819,7 +834,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_count(ntile) + 8 : 8);
     const size_t o_dcontrib = c.take<double>(dense_one ? (size_t)ntile * ntile * kDenseNB : 1);
     static const bool dense_stamps = std::getenv("MOVBA_DENSE_STAMPS") != nullptr;
-    const size_t o_dstamps = c.take<unsigned long long>(dense_one && dense_stamps ? 3 * h->dplan.tasks.size() : 1);
+    const size_t o_dstamps = c.take<unsigned long long>(dense_one && dense_stamps ? 6 * h->dplan.tasks.size() : 1);
     const size_t total = c.off;
 
     // (a reallocation of the arena or of the staging buffer below must find the helper thread through with both: it reads
@@ -987,17 +1002,19 @@ hipError_t queue_direct(movba_handle *h)
     if (w.dense.stamps && el == hipSuccess && h->dense_epoch == 3) {
         // diagnostic (MOVBA_DENSE_STAMPS=1): the third direct launch of a window, task by task, in 10 ns ticks from the first start
         const size_t nt_ = h->dplan.tasks.size();
-        std::vector<unsigned long long> st(3 * nt_);
-        if (hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(st.data(), w.dense.stamps, sizeof(unsigned long long) * 3 * nt_, hipMemcpyDeviceToHost) == hipSuccess) {
+        std::vector<unsigned long long> st(6 * nt_);
+        if (hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(st.data(), w.dense.stamps, sizeof(unsigned long long) * 6 * nt_, hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long t0 = ~0ull;
-            for (size_t k = 0; k < nt_; ++k) if (st[3 * k] && st[3 * k] < t0) t0 = st[3 * k];
+            for (size_t k = 0; k < nt_; ++k) if (st[6 * k] && st[6 * k] < t0) t0 = st[6 * k];
             static const char *names[] = { "ASM", "UPD", "DIAG", "OFF", "RHS", "BSX", "BSC", "EPI" };
             for (int g = 0; g < h->dplan.G; ++g)
                 for (int t = h->dplan.task_ptr[g]; t < h->dplan.task_ptr[g + 1]; ++t) {
                     const DenseTask &tk = h->dplan.tasks[t];
-                    std::fprintf(stderr, "libmovba[dense]: wg %3d %-4s (%2d,%2d) k=%2d  start %7.2f us  wait %6.2f  work %6.2f\n", g, names[tk.op], tk.I, tk.K, tk.k,
-                                 0.01 * (double)(st[3 * t] - t0), st[3 * t + 1] ? 0.01 * (double)(st[3 * t + 1] - st[3 * t]) : 0.0,
-                                 0.01 * (double)(st[3 * t + 2] - (st[3 * t + 1] ? st[3 * t + 1] : st[3 * t])));
+                    const unsigned long long *q = &st[6 * (size_t)t];
+                    std::fprintf(stderr, "libmovba[dense]: wg %3d %-4s (%2d,%2d) k=%2d  start %7.2f us  wait %6.2f  work %6.2f", g, names[tk.op], tk.I, tk.K, tk.k,
+                                 0.01 * (double)(q[0] - t0), q[1] ? 0.01 * (double)(q[1] - q[0]) : 0.0, 0.01 * (double)(q[5] - (q[1] ? q[1] : q[0])));
+                    if (q[2] && q[3]) std::fprintf(stderr, "   [fetch %5.2f  sweep %5.2f  publish %5.2f]", 0.01 * (double)(q[2] - q[1]), 0.01 * (double)(q[3] - q[2]), 0.01 * (double)(q[5] - q[3]));
+                    std::fprintf(stderr, "\n");
                 }
         }
     }
@@ -1356,7 +1373,7 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     res->status = pre;
     res->iters_done = 0; res->n_solves = 0; res->n_outliers = 0; res->pcg_iters = 0; res->last_rejected = 0;
     res->lambda = 0; res->cost0 = 0; res->cost = 0; res->n_trace = 0;
-    res->n_direct = 0; res->direct_from = -1; res->n_chol_fail = 0; res->n_pcg_giveups = 0;
+    res->n_direct = 0; res->direct_from = -1; res->n_chol_fail = 0; res->n_pcg_giveups = 0; res->n_sync_timeouts = 0; res->pad_r = 0;
     if (pre != MOVBA_OK) return pre;
     const double t0 = now_ms();
     const DevWindow &w = h->win;
@@ -1405,7 +1422,15 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
         res->tr_lambda[k] = c.tr_lambda[k]; res->tr_f0[k] = c.tr_f0[k]; res->tr_f1[k] = c.tr_f1[k];
         res->tr_rho[k] = c.tr_rho[k]; res->tr_accept[k] = c.tr_accept[k]; res->tr_pcg_iters[k] = c.tr_pcg[k];
     }
+    res->n_sync_timeouts = c.n_sync_timeouts;
     h->prof.download_ms += now_ms() - t0;
+    if (c.n_sync_timeouts > 0) {
+        // (the trials concerned were rejected like failed factorisations, so the state is a valid LM state — but not the one the
+        //  reference's exact solver would have reached: never handed out as a success)
+        std::fprintf(stderr, "libmovba: the one-launch direct solver gave up waiting between workgroups in %d solve(s): results discarded\n", c.n_sync_timeouts);
+        res->status = MOVBA_ERR_DEVICE_WAIT;
+        return MOVBA_ERR_DEVICE_WAIT;
+    }
     return MOVBA_OK;
 }
 

@@ -77,21 +77,6 @@ __device__ __forceinline__ Lds carve(double *sm, int nslots)
 // buffer descriptor of the tile, all of a thread's accesses in flight (a tile is 1 152 x 16 bytes: 4.5 per thread)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileBytes = NB * NB * 8, kTileVec = kTileBytes / 16;
-#ifdef MOVBA_DENSE_NO_B128
-__device__ __forceinline__ void fetch_tile(const double *g, double *lds, int tid)
-{
-    double v[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) v[q] = ld_sc1(g + tid + kPT * q);
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { const int e = tid + kPT * q, r = e / NB, c = e - r * NB; lds[r * LD + c] = v[q]; }
-}
-__device__ __forceinline__ void publish_tile(double *g, const double *lds, int tid)
-{
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { const int e = tid + kPT * q, r = e / NB, c = e - r * NB; st_sc1(g + e, lds[r * LD + c]); }
-}
-#else
 __device__ __forceinline__ void fetch_tile(const double *g, double *lds, int tid)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g), 0, kTileBytes, 0x00020000);
@@ -122,7 +107,6 @@ __device__ __forceinline__ void publish_tile(double *g, const double *lds, int t
         }
     }
 }
-#endif
 
 // every storing wave drains its stores, the workgroup meets, ONE lane stores the flag
 __device__ __forceinline__ void set_flag(unsigned *flags, int idx, unsigned epoch, int tid)
@@ -175,7 +159,7 @@ __device__ __forceinline__ void tile_update(double *C, const double *As, const d
 
 // S (damped) of tile (I, K) from the schur work-item partials into an LDS image: the element map and the item order of
 // k_dense_assemble (dense_solve.hip), so both direct solvers and the PCG see the same matrix to the last bit
-__device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int I, int K, double lambda, int dst_off, int tid)
+__device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int I, int K, double lambda, int dst_off, int rrow_off, int tid)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];     // (LDS addressed from its own symbol: ds_ instructions, not flat_)
     double *dst = sm + dst_off;
@@ -186,6 +170,19 @@ __device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int 
     typedef const __attribute__((address_space(1))) int32_t *gip;
     const gdp part = (gdp)w.part;
     const gip pid = (gip)ds.pid, pis = (gip)w.pair_item_start;
+    // A diagonal tile holds eight diagonal pairs, each cut into several work items (five at cfg3) whose records are summed
+    // for 57 of the tile's elements and for the right-hand side: their records (contiguous: the diagonal pairs come first, in
+    // order) are staged in the two scratch tiles by one coalesced pass and summed from LDS — element by element from
+    // memory the tile took five dependent round trips more (12 us at the head of the solve's chain).
+    int item0 = 0, nstage = 0;
+    if (I == K) {
+        const int b0 = K * (NB / 6), b1 = min(b0 + NB / 6, nf);
+        item0 = pis[b0];
+        nstage = pis[b1] - item0;
+        if (nstage * kPartStride > 2 * kTileLds) nstage = 0;       // (a keyframe with tens of thousands of edges: summed from memory)
+        for (int e = tid; e < nstage * kPartStride; e += kPT) sm[e] = part[(size_t)item0 * kPartStride + e];
+        __syncthreads();
+    }
     constexpr int kPer = NB * NB / kPT;
     int pr[kPer], kk[kPer], uu[kPer], i0[kPer], i1[kPer];
     double pad[kPer];
@@ -203,55 +200,53 @@ __device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int 
             if (bi == bj) { uu[q] = 42 + (a <= b ? ut6(a, b) : ut6(b, a)); pad[q] = a == b ? lambda : 0.0; }
         }
     }
-    int maxlen = 0;
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         i0[q] = pr[q] >= 0 ? pis[pr[q]] : 0; i1[q] = pr[q] >= 0 ? pis[pr[q] + 1] : 0;
-        maxlen = max(maxlen, i1[q] - i0[q]);
     }
     // sums in item order, the loads of four items of every element in flight together (a diagonal pair of cfg3 is cut into
     // five work items: one item after the other the tile took five dependent memory round trips more)
     double sacc[kPer], hpp[kPer];
 #pragma unroll
     for (int q = 0; q < kPer; ++q) { sacc[q] = 0.0; hpp[q] = 0.0; }
-#ifndef MOVBA_DENSE_ASM_ROUNDS
-    (void)maxlen;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q)
-        for (int itx = i0[q]; itx < i1[q]; ++itx) {
-            sacc[q] += part[(size_t)itx * kPartStride + kk[q]];
-            if (uu[q] >= 0) hpp[q] += part[(size_t)itx * kPartStride + uu[q]];
+    for (int q = 0; q < kPer; ++q) {
+        if (uu[q] >= 0 && nstage > 0) {
+            for (int itx = i0[q]; itx < i1[q]; ++itx) {
+                sacc[q] += sm[(itx - item0) * kPartStride + kk[q]];
+                hpp[q] += sm[(itx - item0) * kPartStride + uu[q]];
+            }
+        } else {
+            for (int itx = i0[q]; itx < i1[q]; ++itx) {
+                sacc[q] += part[(size_t)itx * kPartStride + kk[q]];
+                if (uu[q] >= 0) hpp[q] += part[(size_t)itx * kPartStride + uu[q]];
+            }
         }
-#else
-    // (variant under test) four items of every element in flight: unconditional loads from clamped, always valid addresses,
-    // masked adds in item order
-    for (int base = 0; base < maxlen; base += 4) {
-        double sv[kPer][4], hv[kPer][4];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int itx = i0[q] + base + u;
-                const int itc = itx < i1[q] ? itx : (i1[q] > i0[q] ? i1[q] - 1 : 0);
-                sv[q][u] = part[(size_t)itc * kPartStride + kk[q]];
-                hv[q][u] = part[(size_t)itc * kPartStride + (uu[q] >= 0 ? uu[q] : 0)];
-            }
-#pragma unroll
-        for (int q = 0; q < kPer; ++q)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = i0[q] + base + u < i1[q];
-                sacc[q] += in ? sv[q][u] : 0.0;
-                hpp[q] += (in && uu[q] >= 0) ? hv[q][u] : 0.0;
-            }
     }
-#endif
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         double v = pad[q];
         if (pr[q] >= 0) v = uu[q] >= 0 ? (hpp[q] + pad[q]) - sacc[q] : -sacc[q];
         const int e = tid + kPT * q, r = e / NB, cc = e - r * NB;
         dst[r * LD + cc] = v;
+    }
+    if (I == K && tid < NB) {
+        // right-hand side b_S = b_p - sum B Dinv b_l of this block column; b_p is kept for computeScale
+        const int gc = K * NB + tid;
+        double v = 0.0;
+        if (gc < n) {
+            const int bj = gc / 6, a = gc - bj * 6;
+            double bb = 0.0, cb = 0.0;
+            const int j0 = pis[bj], j1 = pis[bj + 1];
+            if (nstage > 0) {
+                for (int itx = j0; itx < j1; ++itx) { bb += sm[(itx - item0) * kPartStride + 63 + a]; cb += sm[(itx - item0) * kPartStride + 36 + a]; }
+            } else {
+                for (int itx = j0; itx < j1; ++itx) { bb += part[(size_t)itx * kPartStride + 63 + a]; cb += part[(size_t)itx * kPartStride + 36 + a]; }
+            }
+            st_sc1(w.bp + gc, bb);
+            v = bb - cb;
+        }
+        sm[rrow_off + tid] = v;
     }
 }
 
@@ -422,51 +417,23 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
     for (int t = t0; t < t1 && !aborted; ++t) {
         const DenseTask tk = ds.tasks[t];
         const int I = tk.I, K = tk.K, k = tk.k;
-        if (ds.stamps && tid == 0) { ds.stamps[3 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); ds.stamps[3 * (size_t)t + 1] = 0; }
+        if (ds.stamps && tid == 0) { ds.stamps[6 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); for (int q = 1; q < 5; ++q) ds.stamps[6 * (size_t)t + q] = 0; }
         const int slot_off = (2 + tk.slot) * kTileLds;
         double *slot = sm + slot_off;
         switch (tk.op) {
         case DT_ASM: {
-            assemble_tile(w, I, K, lambda, slot_off, tid);
-            if (I == K && tid < NB) {
-                // right-hand side b_S = b_p - sum B Dinv b_l of this block column; b_p is kept for computeScale
-                const int gc = K * NB + tid;
-                double v = 0.0;
-                if (gc < n) {
-                    const int bj = gc / 6, a = gc - bj * 6;
-                    double bb = 0.0, cb = 0.0;
-                    const int j0 = w.pair_item_start[bj], j1 = w.pair_item_start[bj + 1];
-                    for (int base = j0; base < j1; base += 8) {             // (eight items in flight, summed in item order)
-                        double bv[8], cv[8];
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const bool in = base + u < j1;
-                            bv[u] = in ? w.part[(size_t)(base + u) * kPartStride + 63 + a] : 0.0;
-                            cv[u] = in ? w.part[(size_t)(base + u) * kPartStride + 36 + a] : 0.0;
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) { bb += bv[u]; cb += cv[u]; }
-                    }
-                    st_sc1(w.bp + gc, bb);
-                    v = bb - cb;
-                }
-                l.rrow[tid] = v;
-            }
+            assemble_tile(w, I, K, lambda, slot_off, (2 + ds.slots) * kTileLds, tid);      // (the right-hand side row into Lds::rrow)
             __syncthreads();
             break;
         }
         case DT_UPD: {
             // operands this workgroup produced itself are read where they lie (its own LDS slots: pad[0] / pad[1] of the task);
             // the others are waited for and fetched
-#ifdef MOVBA_DENSE_NO_OWN
-            const int sa = -1, sb = -1;
-#else
             const int sa = tk.pad[0], sb = I == K ? tk.pad[0] : tk.pad[1];
-#endif
             const int fa = sa < 0 ? dense_flag_F(nt, I, k) : -1, fb = (I != K && sb < 0) ? dense_flag_F(nt, K, k) : -1;
             const int nw = (fa >= 0) + (fb >= 0);
             if (nw > 0 && !wg_wait(flags, epoch, nw, [&](int i) { return (i == 0 && fa >= 0) ? fa : fb; }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
             if (sa < 0) fetch_tile(ds.tiles + tile_off(I, k), l.A, tid);
             if (I != K && sb < 0) fetch_tile(ds.tiles + tile_off(K, k), l.B, tid);
             if (sa < 0 || (I != K && sb < 0)) __syncthreads();
@@ -483,10 +450,14 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
         }
         case DT_OFF: {
             if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_PD(nt, K); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
             fetch_tile(ds.tiles + tile_off(K, K), l.B, tid);      // D_K, factored in place in the scratch tile
             __syncthreads();
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
             if (sweep_tiles(kTileLds, slot_off, NB, kBadOff(ds.slots)) && tid == 0) st_flag(ds.failw, epoch);
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+            // (published BEFORE this workgroup goes on to its diagonal tile: the next block column's owner needs L(I, K) for
+            //  the update of its own sub-diagonal tile as much as it needs D_I; deferring it behind D_I was measured slower)
             publish_tile(ds.tiles + tile_off(I, K), slot, tid);
             set_flag(flags, dense_flag_F(nt, I, K), epoch, tid);
             break;
@@ -496,7 +467,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             // right-hand side as row 48: L(K, K) stays in the slot for the back substitution, y_K is published
             for (int kk = 0; kk < K && !aborted; ++kk) {
                 if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_F(nt, nt, kk); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
                 fetch_tile(ds.tiles + tile_off(K, kk), l.A, tid);
                 if (tid < NB) l.xs[tid] = ld_sc1(ds.tiles + tile_off(nt, kk) + tid);
                 __syncthreads();
@@ -525,7 +496,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
         case DT_BSX: {
             const int J = K, nc = nt - 1 - J;
             if (nc > 0 && !wg_wait(flags, epoch, nc, [&](int i) { return dense_flag_FC(nt, J + 1 + i, J); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
             if (tid < 64) {
                 double sv = 0.0;
                 if (tid < NB) {
@@ -539,24 +510,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
                     }
                     sv = l.yv[tid] - acc;
                 }
-#ifdef MOVBA_DENSE_OLD_BSX
-                if (tid < NB) l.rinvb[tid] = fast_rcp(slot[tid * LD + tid]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                {
-                    double lk = tid < NB ? slot[(NB - 1) * LD + tid] : 0.0, rk = l.rinvb[NB - 1];
-                    for (int kk = NB - 1; kk >= 0; --kk) {
-                        const double lcur = lk, rcur = rk;
-                        if (kk > 0) { lk = tid < NB ? slot[(kk - 1) * LD + tid] : 0.0; rk = l.rinvb[kk - 1]; }
-                        const double xk = readlane_f64(sv, kk) * rcur;
-                        if (tid == kk) sv = xk;
-                        else if (tid < kk) sv -= lcur * xk;
-                    }
-                }
-#else
                 sv = back_solve48(slot_off, sv, tid);
-#endif
                 if (tid < NB) { l.xv[tid] = sv; st_sc1(ds.xsol + J * NB + tid, sv); }
             }
             set_flag(flags, dense_flag_FX(nt, J), epoch, tid);
@@ -567,7 +521,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             // (x_I of the workgroup's own diagonal tile is still in LDS: pad[0] of the task)
             if (tk.pad[0] != 1) {
                 if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_FX(nt, I); }, l, tid)) { aborted = true; break; }
-                if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
                 if (tid < NB) l.xs[tid] = ld_sc1(ds.xsol + I * NB + tid);
             } else if (tid < NB) l.xs[tid] = l.xv[tid];
             __syncthreads();
@@ -585,12 +539,12 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
         }
         case DT_EPI: {
             if (!wg_wait(flags, epoch, nt, [&](int i) { return dense_flag_FX(nt, i); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
             break;      // (the outputs follow the loop)
         }
         default: break;
         }
-        if (ds.stamps && tid == 0) ds.stamps[3 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
+        if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 5] = __builtin_amdgcn_s_memrealtime();
     }
     if (blockIdx.x != 0) {
         if (aborted && tid == 0) st_flag(ds.failw + 1, epoch);

@@ -27,7 +27,8 @@ enum DenseOp : int32_t {
     DT_EPI = 7,     // increments, computeScale's pose part, trial poses      waits FX(*)
 };
 
-struct DenseTask { int32_t op, slot, I, K, k, pad[3]; };       // 32 bytes: one scalar load; DT_UPD: pad[0] / pad[1] = own LDS slot of L(I, k) / L(K, k), -1 = fetch
+struct DenseTask { int32_t op, slot, I, K, k, pad[3]; };       // 32 bytes: one scalar load; DT_UPD: pad[0] / pad[1] = own LDS slot of L(I, k) / L(K, k), -1 = fetch;
+                                                                // DT_BSC: pad[0] = 1: x_I is in this workgroup's LDS
 
 constexpr int kDenseMaxSlots = 6;       // tiles a workgroup keeps in LDS (2 scratch tiles beside them: 150 KB)
 constexpr int kDenseMaxGroups = 248;    // workgroups of the launch (one per CU, a few CUs to spare)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MOVBA_LIB") or os.path.join(os.path.dirname(_HERE), "
 
 MAX_TRACE = 128
 NKERNELS = 6
-OK, STOPPED, NO_FIXED, EMPTY, ERR_ARG, ERR_HIP, ERR_STATE = 0, 1, 2, 3, -1, -2, -3
+OK, STOPPED, NO_FIXED, EMPTY, ERR_ARG, ERR_HIP, ERR_STATE, ERR_DEVICE_WAIT, ERR_TOO_LARGE = 0, 1, 2, 3, -1, -2, -3, -4, -5
 FLAG_STALE_ERROR_QUIRK = 1
 
 _d = C.POINTER(C.c_double)
@@ -48,12 +48,13 @@ class LbaResult(C.Structure):
                 ("tr_lambda", C.c_double * MAX_TRACE), ("tr_f0", C.c_double * MAX_TRACE),
                 ("tr_f1", C.c_double * MAX_TRACE), ("tr_rho", C.c_double * MAX_TRACE),
                 ("tr_accept", C.c_int32 * MAX_TRACE), ("tr_pcg_iters", C.c_int32 * MAX_TRACE),
-                ("n_direct", C.c_int32), ("direct_from", C.c_int32), ("n_chol_fail", C.c_int32), ("n_pcg_giveups", C.c_int32)]
+                ("n_direct", C.c_int32), ("direct_from", C.c_int32), ("n_chol_fail", C.c_int32), ("n_pcg_giveups", C.c_int32),
+                ("n_sync_timeouts", C.c_int32), ("pad_r", C.c_int32)]
 
 
 class Options(C.Structure):
     _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
-                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32)]
+                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -176,14 +177,14 @@ def structure_probe(w):
 
 def dense_plan(nt: int, max_groups: int = 0, max_slots: int = 0):
     """Static schedule of the one-launch direct solver for nt block columns (host only): dict(ok, G, slots, task_ptr, tasks)
-    with tasks as rows (op, slot, I, K, k)."""
+    with tasks as rows (op, slot, I, K, k, pad0, pad1)."""
     info = np.zeros(4, np.int32)
     lib().movba_dense_plan_probe(nt, max_groups, max_slots, _p(info, _i), None, 0, None, 0)
     if not info[0]:
-        return dict(ok=False, G=0, slots=0, task_ptr=np.zeros(1, np.int32), tasks=np.zeros((0, 5), np.int32))
+        return dict(ok=False, G=0, slots=0, task_ptr=np.zeros(1, np.int32), tasks=np.zeros((0, 7), np.int32))
     tp = np.zeros(info[1] + 1, np.int32); tk = np.zeros((info[3], 8), np.int32)
     lib().movba_dense_plan_probe(nt, max_groups, max_slots, _p(info, _i), _p(tp, _i), len(tp), _p(tk, _i), info[3])
-    return dict(ok=True, G=int(info[1]), slots=int(info[2]), task_ptr=tp, tasks=tk[:, :5])
+    return dict(ok=True, G=int(info[1]), slots=int(info[2]), task_ptr=tp, tasks=tk[:, :7])
 
 
 def ransac_samples(n: int, n_hyp: int, seed: int) -> np.ndarray:
@@ -208,10 +209,11 @@ class Solver:
     """One handle = one device + one stream (movba_create / movba_destroy)."""
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
-                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0):
+                 pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0,
+                 pcg_spill: bool = False, direct: bool = False):
         self._h = C.c_void_p()
         self._pinned_blocks = []
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait)
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, 1 if direct else 0)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()
@@ -263,6 +265,7 @@ class Solver:
         out.update(status=rc, iters_done=r.iters_done, n_solves=r.n_solves, n_outliers=r.n_outliers,
                    pcg_iters=r.pcg_iters, last_rejected=r.last_rejected, lam=r.lambda_, cost0=r.cost0, cost=r.cost,
                    n_direct=r.n_direct, direct_from=r.direct_from, n_chol_fail=r.n_chol_fail, n_pcg_giveups=r.n_pcg_giveups,
+                   n_sync_timeouts=r.n_sync_timeouts,
                    trace=dict(lam=np.array(r.tr_lambda[:n]), f0=np.array(r.tr_f0[:n]), f1=np.array(r.tr_f1[:n]),
                               rho=np.array(r.tr_rho[:n]), accept=np.array(r.tr_accept[:n]),
                               pcg=np.array(r.tr_pcg_iters[:n])))

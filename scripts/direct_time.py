@@ -19,7 +19,7 @@ cases = [("cfg3", synth.cfg("cfg3"), {}), ("80kf", synth.make_window(80, 10, 400
          ("150kf", synth.make_window(150, 6, 6000, 9, run_lo=2, run_hi=10), {}),
          ("150kf-60k", synth.make_window(150, 10, 60000, 9, run_lo=2, run_hi=10), {}),
          ("400kf", synth.make_window(400, 8, 12000, 9, run_lo=2, run_hi=12), dict(max_iters=3))]
-pcg = capi.Solver(profile=True); direct = capi.Solver(pcg_max_iters=1, profile=True)
+pcg = capi.Solver(profile=True); direct = capi.Solver(direct=True, profile=True)
 for name, w, kw in cases:
     t0 = time.perf_counter(); o = oracle.solve(w, **kw); to = 1e3 * (time.perf_counter() - t0)
     pcg.reset_profile(); direct.reset_profile()

@@ -7,9 +7,9 @@ import numpy as np
 from movba import capi, synth
 from oracle import oracle
 
-names = sys.argv[1:] or ["cfg3", "shuffled", "revisit", "hub"]
+names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg3", "shuffled", "revisit", "hub"]
 out = {}
-s = capi.Solver(profile=True)
+s = capi.Solver(profile=True, direct="--direct" in sys.argv, pcg_spill="--spill" in sys.argv)
 for name in names:
     w = synth.cfg("cfg3") if name == "cfg3" else synth.pattern_cfg(name)
     plan = capi.structure_probe(w)

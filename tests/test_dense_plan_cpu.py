@@ -9,16 +9,17 @@ import pytest
 ASM, UPD, DIAG, OFF, RHS, BSX, BSC, EPI = range(8)
 
 
-def waits_and_sets(op, I, K, k, nt):
+def waits_and_sets(op, I, K, k, p0, p1, nt):
     """(flags a task waits for, flag it sets)"""
-    if op == ASM: return [], None
-    if op == UPD: return [("F", I, k)] + ([("F", K, k)] if I != K else []), None
-    if op == DIAG: return [], ("PD", K)
-    if op == OFF: return [("PD", K)], ("F", I, K)
-    if op == RHS: return [("FY", q) for q in range(K)], ("FY", K)
-    if op == BSX: return [("FY", K)] + [("FC", i, K) for i in range(K + 1, nt)], ("FX", K)
-    if op == BSC: return [("FX", I)], ("FC", I, K)
-    if op == EPI: return [("FX", j) for j in range(nt)], None
+    if op == ASM: return [], []
+    if op == UPD:       # operands the workgroup owns itself (p0 / p1 = their LDS slots) are not waited for: program order
+        return ([("F", I, k)] if p0 < 0 else []) + ([("F", K, k)] if I != K and p1 < 0 else []), []
+    if op == DIAG: return [], [("PD", K)]
+    if op == OFF: return [("PD", K)], [("F", I, K)]
+    if op == RHS: return [("FY", q) for q in range(K)], [("FY", K)]
+    if op == BSX: return [("FY", K)] + [("FC", i, K) for i in range(K + 1, nt)], [("FX", K)]
+    if op == BSC: return ([] if p0 == 1 else [("FX", I)]), [("FC", I, K)]
+    if op == EPI: return [("FX", j) for j in range(nt)], []
     raise AssertionError(op)
 
 
@@ -31,11 +32,11 @@ def replay(plan, nt, order_rng):
     state = {}                            # tile -> "asm" / "final"
     slots = {}                            # (workgroup, slot) -> tile
     while True:
-        runnable = [g for g in range(plan["G"]) if pc[g] < tp[g + 1] and all(f in flags for f in waits_and_sets(*tk[pc[g], [0, 2, 3, 4]], nt)[0])]
+        runnable = [g for g in range(plan["G"]) if pc[g] < tp[g + 1] and all(f in flags for f in waits_and_sets(*tk[pc[g], [0, 2, 3, 4, 5, 6]], nt)[0])]
         if not runnable:
             break
         g = int(order_rng.choice(runnable))
-        op, slot, I, K, k = (int(v) for v in tk[pc[g]])
+        op, slot, I, K, k, p0, p1 = (int(v) for v in tk[pc[g]])
         tile = (I, K)
         if op == ASM:
             assert tile not in state and slots.setdefault((g, slot), tile) == tile
@@ -50,8 +51,7 @@ def replay(plan, nt, order_rng):
             assert state[(K, K)] == "final" and slots[(g, slot)] == (K, K)
         elif op == BSC:
             assert state[tile] == "final" and slots[(g, slot)] == tile
-        s = waits_and_sets(op, I, K, k, nt)[1]
-        if s is not None:
+        for s in waits_and_sets(op, I, K, k, p0, p1, nt)[1]:
             assert s not in flags
             flags.add(s)
         pc[g] += 1; done += 1
@@ -71,7 +71,7 @@ def test_schedule_covers_the_factorisation_and_never_stalls(built_lib, nt):
     tk, tp = plan["tasks"], plan["task_ptr"]
     owner = {}
     for g in range(plan["G"]):
-        for op, slot, I, K, k in tk[tp[g]:tp[g + 1]]:
+        for op, slot, I, K, k, p0, p1 in tk[tp[g]:tp[g + 1]]:
             if op == ASM:
                 owner[(int(I), int(K))] = g
     for K in range(1, nt):

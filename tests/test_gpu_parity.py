@@ -81,12 +81,25 @@ def test_baseline_configs_full_size(solver, oracle_mod, name):
 
 
 def test_dense_covisibility_window_spills_list_tails_to_l2(solver, oracle_mod, built_lib):
-    """Long tracks (10-30 keyframes per point): the reduced matrix is nearly dense, the gather lists
-    exceed what one wave keeps in VGPRs and their tails are read from the L2 copy of S."""
+    """Long tracks (10-30 keyframes per point): the reduced matrix is nearly dense and exceeds what the PCG workgroup keeps
+    in VGPRs.  Up to twice the register capacity the PCG still runs, reading its list tails from the L2 copy of S; beyond
+    (the 50-keyframe hub window of test_covisibility_patterns_...) the one-launch direct solver takes the window.  Both
+    solvers on this window, each against the oracle."""
     w = synth.make_window(40, 4, 3000, seed=5, run_lo=10, run_hi=30)
     plan = built_lib.structure_probe(w)
     assert plan["pcg_on_chip"] and plan["pcg_overflow"] and plan["max_degree"] >= 25
-    check_against(solver.solve(w), oracle_mod.solve(w), w)
+    o = oracle_mod.solve(w)
+    r = solver.solve(w)
+    check_against(r, o, w)
+    assert (r["n_direct"] == r["n_solves"]) == (plan["n_row_entries"] > 2048) and r["n_sync_timeouts"] == 0
+    for kw in (dict(pcg_spill=True), dict(direct=True)):
+        s = built_lib.Solver(**kw)
+        try:
+            r2 = s.solve(w)
+        finally:
+            s.close()
+        check_against(r2, o, w)
+        assert (r2["n_direct"] == r2["n_solves"]) == ("direct" in kw) and (r2["pcg_iters"] > 0) == ("pcg_spill" in kw)
 
 
 def test_pairs_sharing_thousands_of_points_are_cut_into_several_work_items(solver, oracle_mod, built_lib):
@@ -179,9 +192,31 @@ def test_covisibility_patterns_the_reference_produces(solver, oracle_mod, built_
         assert plan["n_pairs"] == 50 * 51 // 2                    # the reduced system is dense
     else:
         assert plan["n_pairs"] == built_lib.structure_probe(synth.cfg("cfg3"))["n_pairs"] or name == "revisit"
-    # the solver that ran is reported: either every trial on the direct solver, or a PCG that converged every time
-    assert r["n_direct"] == r["n_solves"] or (r["n_direct"] == 0 and r["pcg_iters"] > 0)
-    assert r["n_chol_fail"] == 0
+    # the solver that ran is reported: the dense window on the one-launch direct solver from the first trial, the others on a
+    # PCG that converged every time
+    if name == "hub":
+        assert r["n_direct"] == r["n_solves"] and r["direct_from"] == 0 and r["pcg_iters"] == 0
+    else:
+        assert r["n_direct"] == 0 and r["pcg_iters"] > 0
+    assert r["n_chol_fail"] == 0 and r["n_sync_timeouts"] == 0
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "hub", "revisit"])
+def test_every_window_on_the_one_launch_direct_solver(built_lib, oracle_mod, name):
+    """movba_options::solver = 1: the exact factorisation (the reference's LinearSolverCSparse, Optimizer.cc:535) for every
+    trial of every window, in one launch per trial (dense_persist.hip).  Same LM path as the oracle's exact solve, no
+    workgroup ever gives up a wait, bit-reproducible."""
+    w = synth.cfg(name) if name.startswith("cfg") else synth.pattern_cfg(name)
+    s = built_lib.Solver(direct=True)
+    try:
+        r, r2 = s.solve(w), s.solve(w)
+    finally:
+        s.close()
+    check_against(r, oracle_mod.solve(w), w)
+    assert r["n_direct"] == r["n_solves"] and r["direct_from"] == 0 and r["n_pcg_giveups"] == 0 and r["pcg_iters"] == 0
+    assert r["n_chol_fail"] == 0 and r["n_sync_timeouts"] == 0
+    for k in ("poses", "points", "chi2", "outlier"):
+        assert np.array_equal(r[k], r2[k]), k
 
 
 WEAK_TOL = dict(rot=1e-6, trans=1e-6, point=1e-4)      # see test_weakly_constrained_windows
