@@ -125,6 +125,10 @@ typedef struct {
                                  * (list tails read from an L2 copy every iteration); 0 = default: such windows take the
                                  * one-launch direct solver from the first trial                                        */
     int32_t solver;             /* 0 = default (PCG where it fits, direct solver elsewhere), 1 = direct solver for every window */
+    int32_t reorder;            /* 0 = default: free keyframes are renumbered by covisibility (reverse Cuthill-McKee on the pair
+                                 * graph) when that shrinks the reduced matrix's envelope by a fifth or more; -1 = keep the
+                                 * caller's order (KeyFrame::mnId order, as the reference numbers its vertices)             */
+    int32_t pad_o;
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */
@@ -203,6 +207,8 @@ typedef struct {
     int32_t sched_items;        /* work items found in the schedule (must equal n_items)      */
     int32_t sched_max_permille; /* heaviest XCD segment / mean segment weight, x1000          */
     int32_t slots_ok;           /* pose-major edge slots are a bijection onto 0..E_free-1     */
+    int32_t reordered;          /* 1: the free keyframes were renumbered by covisibility (free_index is the new numbering) */
+    int32_t pad_s;
 } movba_structure_info;
 int  movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info,
                            int32_t *edge_perm /* E or NULL */, int32_t *free_index /* n_poses or NULL */);

@@ -357,7 +357,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     movba_handle *h = new (std::nothrow) movba_handle();
     if (!h) return MOVBA_ERR_HIP;
     h->device = device;
-    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0; h->opt.reorder = 0; h->opt.pad_o = 0;
     if (opt) {
         if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
         if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
@@ -367,6 +367,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         h->opt.host_wait = opt->host_wait == 1 ? 1 : 0;
         h->opt.pcg_spill = opt->pcg_spill == 1 ? 1 : 0;
         h->opt.solver = opt->solver == 1 ? 1 : 0;
+        h->opt.reorder = opt->reorder == -1 ? -1 : 0;
     }
     if (h->opt.host_wait == 1) h->packer.spin_ms = 0;      // (a caller that asks for yielding waits does not want a spinning helper either)
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
@@ -426,7 +427,7 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
     const int rc = build_structure(*desc, s);
     if (rc < 0) return rc;
     info->n_free = s.nfree; info->n_pairs = s.npairs; info->n_entries = s.nentries; info->n_items = s.nitems;
-    info->max_degree = s.max_degree; info->already_grouped = s.already_grouped ? 1 : 0;
+    info->max_degree = s.max_degree; info->already_grouped = s.already_grouped ? 1 : 0; info->reordered = s.reordered ? 1 : 0; info->pad_s = 0;
     info->pcg_on_chip = 0; info->pcg_overflow = 0; info->pcg_max_wave_entries = 0; info->n_row_entries = (int32_t)s.row_ent.size();
     if (rc == MOVBA_OK && s.nfree > 0) {
         PcgParams pp{};
@@ -558,6 +559,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     });
     // (the pose-major slots are left to the device when the edges come grouped by point: the pass leaves each edge's rank
     // among its keyframe's edges where the slots go)
+    h->st.no_reorder = h->opt.reorder == -1;
     int rc = build_basic(*d, h->st, reinterpret_cast<int32_t *>(sg + o_slot));
     bool rank_mode = true;              // the staging buffer's slot array holds ranks; pose_slot0 the keyframes' first slots
     lap("build_basic");
@@ -734,6 +736,26 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         }
         if (reinterpret_cast<const int32_t *>(misc)[nbins] != 0) return MOVBA_ERR_ARG;     // duplicate observation
         lap("wait for the pair counts");
+        // covisibility ordering (structure.h): a window whose keyframe ids do not follow its covisibility graph is renumbered
+        // here, from the counts: hessian indices, free-pose list and first slots are sent again (a few hundred bytes) and the
+        // count / scan kernels run once more in the new numbering (the host permutes its copy of the counts itself)
+        if (!h->st.no_reorder) {
+            std::vector<int32_t> new_of_old;
+            if (covisibility_order(nf, reinterpret_cast<const int32_t *>(misc), new_of_old)) {
+                apply_pose_order(h->st, new_of_old, reinterpret_cast<int32_t *>(misc));
+                h->st.reordered = true;
+                std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
+                std::memcpy(sg + o_base, s.pose_slot0.data(), sizeof(int32_t) * NP);
+                std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
+                HIP_TRY(hipMemcpyAsync(h->arena + o_hidx, sg + o_hidx, sizeof(int32_t) * NP, hipMemcpyHostToDevice, h->stream));
+                edge_b_stale = true;
+                HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));
+                HIP_TRY(launch_struct_count(sd, h->stream));
+                HIP_TRY(launch_struct_counts_out(sd, nullptr, 0, h->stream));
+                HIP_TRY(launch_struct_scan(sd, h->stream));
+                lap("covisibility reorder + recount");
+            }
+        }
         // slots, point ids, observations and initial estimates cross the bus, then the entry lists are filled, while the
         // host lays out the pairs
         { const int rq = queue_edge_b(); if (rq) return rq; }

@@ -232,11 +232,13 @@ __global__ __launch_bounds__(1024) void k_struct_counts_out(StructDev sd, int32_
 {
     __shared__ int tot[1024];
     const int nf = sd.nfree, nbins = nf * nf;
-    for (int b = threadIdx.x; b < nbins; b += 1024) host_cnt[b] = sd.cnt[b];
-    if (threadIdx.x == 0) host_cnt[nbins] = *sd.error;
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (host_cnt) {         // (null on the second pass of a renumbered window: the host has permuted its copy itself)
+        for (int b = threadIdx.x; b < nbins; b += 1024) host_cnt[b] = sd.cnt[b];
+        if (threadIdx.x == 0) host_cnt[nbins] = *sd.error;
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 
     const int per = (nbins + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(nbins, b0 + per);
     int sum = 0;

@@ -14,7 +14,7 @@ int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out)
     if (E && (!d.edge_pose || !d.edge_point || !d.obs || !d.inv_sigma2)) return MOVBA_ERR_ARG;
     // keep the vectors' capacity across calls (a handle solves window after window: fresh multi-MB allocations
     // would be paid in page faults every time)
-    s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0;
+    s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0; s.reordered = false;
     s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.sched.clear(); s.sched_per_xcd = 0; s.row_ent.clear();
     s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.ent_i.clear(); s.ent_j.clear(); s.ent_l.clear(); s.E_free = 0;
     s.NP = NP; s.P = P; s.E = E;
@@ -235,6 +235,86 @@ int finish_pairs(Structure& s, const int32_t* cnt)
     return MOVBA_OK;
 }
 
+bool covisibility_order(int nf, const int32_t* cnt, std::vector<int32_t>& new_of_old)
+{
+    new_of_old.resize(nf);
+    for (int i = 0; i < nf; ++i) new_of_old[i] = i;
+    if (nf < 3) return false;
+    auto linked = [&](int a, int b) { return a == b ? false : (a < b ? cnt[(size_t)a * nf + b] : cnt[(size_t)b * nf + a]) > 0; };
+    std::vector<int32_t> deg(nf, 0);
+    for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) if (cnt[(size_t)i * nf + j] > 0) { deg[i]++; deg[j]++; }
+    // envelope of an order: sum over rows of (row - first linked column)
+    auto envelope = [&](const std::vector<int32_t>& old_of_new) {
+        int64_t env = 0;
+        for (int r = 0; r < nf; ++r) {
+            int first = r;
+            for (int c = 0; c < r; ++c) if (linked(old_of_new[r], old_of_new[c])) { first = c; break; }
+            env += r - first;
+        }
+        return env;
+    };
+    // Cuthill-McKee from a pseudo-peripheral keyframe of every component (smallest degree, then two sweeps to the farthest
+    // level's smallest-degree keyframe), neighbours by ascending (degree, index); reversed at the end
+    std::vector<int32_t> order, level(nf), queue;
+    std::vector<uint8_t> placed(nf, 0);
+    auto bfs = [&](int root, std::vector<int32_t>& out) {           // over unplaced keyframes only
+        out.clear(); out.push_back(root);
+        std::fill(level.begin(), level.end(), -1); level[root] = 0;
+        for (size_t h = 0; h < out.size(); ++h) {
+            const int v = out[h];
+            const size_t first = out.size();
+            for (int u = 0; u < nf; ++u) if (!placed[u] && level[u] < 0 && linked(v, u)) { level[u] = level[v] + 1; out.push_back(u); }
+            std::sort(out.begin() + first, out.end(), [&](int a, int b) { return deg[a] != deg[b] ? deg[a] < deg[b] : a < b; });
+        }
+        return level[out.back()];
+    };
+    order.reserve(nf);
+    for (;;) {
+        int root = -1;
+        for (int i = 0; i < nf; ++i) if (!placed[i] && (root < 0 || deg[i] < deg[root])) root = i;
+        if (root < 0) break;
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            const int depth = bfs(root, queue);
+            int far = -1;
+            for (int v : queue) if (level[v] == depth && (far < 0 || deg[v] < deg[far])) far = v;
+            if (far == root) break;
+            root = far;
+        }
+        bfs(root, queue);
+        for (int v : queue) { placed[v] = 1; order.push_back(v); }
+    }
+    std::reverse(order.begin(), order.end());
+    std::vector<int32_t> natural(nf);
+    for (int i = 0; i < nf; ++i) natural[i] = i;
+    const int64_t env_nat = envelope(natural), env_rcm = envelope(order);
+    // taken only when clearly better: a window already numbered along its path keeps its numbering (and its device-side
+    // structure pass as it ran)
+    if (!(env_rcm * 5 < env_nat * 4)) return false;
+    for (int k = 0; k < nf; ++k) new_of_old[order[k]] = k;
+    return true;
+}
+
+void apply_pose_order(Structure& s, const std::vector<int32_t>& new_of_old, int32_t* cnt)
+{
+    const int nf = s.nfree;
+    std::vector<int32_t> fp(nf);
+    for (int h = 0; h < nf; ++h) fp[new_of_old[h]] = s.free_pose[h];
+    s.free_pose = fp;
+    for (int h = 0; h < nf; ++h) s.hidx[s.free_pose[h]] = h;
+    // pose-major slots follow the hessian order: the diagonal pair of keyframe h lists its edges at its first slot
+    int run = 0;
+    for (int h = 0; h < nf; ++h) { s.pose_slot0[s.free_pose[h]] = run; run += s.pose_edges[s.free_pose[h]]; }
+    if (cnt) {
+        std::vector<int32_t> c2((size_t)nf * nf, 0);
+        for (int i = 0; i < nf; ++i)
+            for (int j = i; j < nf; ++j) {
+                const int a = new_of_old[i], b = new_of_old[j];
+                c2[(size_t)std::min(a, b) * nf + std::max(a, b)] = cnt[(size_t)i * nf + j];
+            }
+        std::memcpy(cnt, c2.data(), sizeof(int32_t) * c2.size());
+    }
+}
+
 int build_structure(const movba_lba_desc& d, Structure& s)
 {
     const int rc = build_basic(d, s);
@@ -251,6 +331,23 @@ int build_structure(const movba_lba_desc& d, Structure& s)
             int32_t *row = &cnt[(size_t)fe_h[a] * nf];
             for (int b = a; b < fe_start[l + 1]; ++b) row[fe_h[b]]++;
         }
+    if (nf <= 80 && !s.no_reorder) {
+        std::vector<int32_t> new_of_old;
+        if (covisibility_order(nf, cnt.data(), new_of_old)) {
+            // renumber, then slots, observer lists and counts once more in the new numbering
+            apply_pose_order(s, new_of_old, nullptr);
+            build_slots(s);
+            const int rf2 = free_lists(s, fe_start, fe_h, fe_g);
+            if (rf2 != MOVBA_OK) return rf2;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int l = 0; l < P; ++l)
+                for (int a = fe_start[l]; a < fe_start[l + 1]; ++a) {
+                    int32_t *row = &cnt[(size_t)fe_h[a] * nf];
+                    for (int b = a; b < fe_start[l + 1]; ++b) row[fe_h[b]]++;
+                }
+            s.reordered = true;
+        }
+    }
     const int rp = finish_pairs(s, cnt.data());
     if (rp != MOVBA_OK) return rp;
     // off-diagonal entries only: diagonal entry k is slot k (structure.h)

@@ -28,6 +28,8 @@ struct Structure {
     int npairs = 0, nitems = 0, max_degree = 0;
     int64_t nentries = 0;
     bool already_grouped = true;
+    bool reordered = false;             // the free keyframes were renumbered by covisibility (covisibility_order)
+    bool no_reorder = false;            // caller's wish: keep the given numbering (tests, comparisons)
     int n_fixed = 0;
     std::vector<int32_t> hidx;          // NP: hessian index or -1
     std::vector<int32_t> free_pose;     // nfree: pose index
@@ -90,5 +92,16 @@ int build_structure(const movba_lba_desc& d, Structure& s);
 int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out = nullptr);
 void build_slots(Structure& s);                               // (s.gp must still be valid: the caller's arrays, or s.g_pose)
 int finish_pairs(Structure& s, const int32_t* cnt);           // cnt[i*nfree+j] (i <= j) -> pairs, items, gather lists
+
+// Covisibility ordering of the free keyframes.  The reference numbers its pose vertices by KeyFrame::mnId
+// (/root/reference/src/Optimizer.cc:557-566), i.e. by time of creation; g2o's CSparse solver then reorders the reduced
+// system itself (block AMD).  The PCG's aggregates (runs of consecutive block rows), its coarse modes (linear in the row
+// index) and the schur launch schedule (by block row) want keyframes that share points to be neighbours in the numbering,
+// which creation order gives only while the camera never comes back and ids are handed out along the path.  From the pair
+// counts cnt[i*nf+j] (i <= j) this computes a reverse Cuthill-McKee order of the covisibility graph and says whether it is
+// worth taking (its envelope is clearly smaller than the given order's); apply_pose_order then renumbers hessian indices,
+// free-pose list, first slots and the counts.  Results do not depend on the numbering beyond rounding.
+bool covisibility_order(int nf, const int32_t* cnt, std::vector<int32_t>& new_of_old);
+void apply_pose_order(Structure& s, const std::vector<int32_t>& new_of_old, int32_t* cnt /* nf x nf, permuted in place; may be null */);
 
 }  // namespace movba

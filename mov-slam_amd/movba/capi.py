@@ -54,7 +54,7 @@ class LbaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
-                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32)]
+                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32), ("reorder", C.c_int32), ("pad_o", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -66,7 +66,8 @@ class StructureInfo(C.Structure):
     _fields_ = [("n_free", C.c_int32), ("n_pairs", C.c_int32), ("n_entries", C.c_int64), ("n_items", C.c_int32),
                 ("max_degree", C.c_int32), ("already_grouped", C.c_int32), ("pcg_on_chip", C.c_int32),
                 ("pcg_overflow", C.c_int32), ("pcg_max_wave_entries", C.c_int32), ("n_row_entries", C.c_int32),
-                ("n_sched_slots", C.c_int32), ("sched_items", C.c_int32), ("sched_max_permille", C.c_int32), ("slots_ok", C.c_int32)]
+                ("n_sched_slots", C.c_int32), ("sched_items", C.c_int32), ("sched_max_permille", C.c_int32), ("slots_ok", C.c_int32),
+                ("reordered", C.c_int32), ("pad_s", C.c_int32)]
 
 
 class PoseDesc(C.Structure):
@@ -172,7 +173,7 @@ def structure_probe(w):
                 max_degree=info.max_degree, already_grouped=bool(info.already_grouped), pcg_on_chip=bool(info.pcg_on_chip),
                 pcg_overflow=bool(info.pcg_overflow), pcg_max_wave_entries=info.pcg_max_wave_entries,
                 n_row_entries=info.n_row_entries, n_sched_slots=info.n_sched_slots, sched_items=info.sched_items,
-                sched_max_permille=info.sched_max_permille, slots_ok=bool(info.slots_ok), perm=perm, free_index=fidx)
+                sched_max_permille=info.sched_max_permille, slots_ok=bool(info.slots_ok), reordered=bool(info.reordered), perm=perm, free_index=fidx)
 
 
 def dense_plan(nt: int, max_groups: int = 0, max_slots: int = 0):
@@ -210,10 +211,10 @@ class Solver:
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
                  pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0,
-                 pcg_spill: bool = False, direct: bool = False):
+                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True):
         self._h = C.c_void_p()
         self._pinned_blocks = []
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, 1 if direct else 0)
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, 1 if direct else 0, 0 if reorder else -1, 0)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()

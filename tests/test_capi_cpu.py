@@ -25,8 +25,8 @@ def test_library_exports_every_symbol_declared_in_header(built_lib):
 def test_ctypes_struct_sizes_match_header_layout(built_lib):
     # int32 x3 (+pad) | 7 pointers | 6 doubles | 2 int32 + u32 (+pad) | pointer
     assert ctypes.sizeof(built_lib.LbaDesc) == 16 + 7 * 8 + 6 * 8 + 16 + 8 + 16
-    assert ctypes.sizeof(built_lib.Options) == 40
-    assert ctypes.sizeof(built_lib.StructureInfo) == 64
+    assert ctypes.sizeof(built_lib.Options) == 48
+    assert ctypes.sizeof(built_lib.StructureInfo) == 72
 
 
 def _np_structure(w):
@@ -71,6 +71,38 @@ def test_schur_launch_schedule_and_pose_major_slots(built_lib, shape):
         assert s["sched_max_permille"] <= 1250, s["sched_max_permille"]
     # diagonal pairs are cut finer than off-diagonal ones, never below one item per pair
     assert s["n_items"] >= s["n_pairs"]
+
+
+def _envelope(w, hidx):
+    """sum over block rows of (row - first linked column) of the reduced matrix's pattern in the numbering hidx"""
+    nf = int(hidx.max()) + 1
+    A = np.zeros((nf, nf), bool)
+    order = np.argsort(w.edge_point, kind="stable")
+    ep, el = hidx[w.edge_pose[order]], w.edge_point[order]
+    start = np.searchsorted(el, np.arange(w.n_points + 1))
+    for l in range(w.n_points):
+        hs = ep[start[l]:start[l + 1]]; hs = hs[hs >= 0]
+        A[np.ix_(hs, hs)] = True
+    return int(sum(r - int(np.argmax(A[r, :r + 1])) for r in range(nf)))
+
+
+def test_keyframes_are_renumbered_by_covisibility_when_their_ids_do_not_follow_the_graph(built_lib):
+    """The reference numbers pose vertices by KeyFrame::mnId (Optimizer.cc:557-566).  A window numbered along its path keeps
+    that numbering; the same graph with shuffled ids, or a path that comes back over itself, is renumbered (reverse
+    Cuthill-McKee on the pair graph) so that covisible keyframes are neighbours again."""
+    w = synth.make_window(24, 4, 1500, seed=3, run_lo=2, run_hi=6)
+    s0 = built_lib.structure_probe(w)
+    assert not s0["reordered"]
+    env0 = _envelope(w, s0["free_index"])
+    for ws in (synth.shuffle_ids(w, 5), synth.make_pattern_window("revisit", 24, 4, 1500, seed=3, run_lo=2, run_hi=6, revisit_gap=12)):
+        s1 = built_lib.structure_probe(ws)
+        f = s1["free_index"]
+        assert s1["reordered"] and sorted(f[f >= 0]) == list(range(s1["n_free"])) and (f[ws.pose_fixed == 1] == -1).all()
+        natural = -np.ones(ws.n_poses, int); idx = np.flatnonzero(ws.pose_fixed == 0); natural[idx] = np.arange(len(idx))
+        assert _envelope(ws, f) <= 1.5 * env0 and _envelope(ws, f) < 0.6 * _envelope(ws, natural)
+        assert s1["slots_ok"] and s1["sched_items"] == s1["n_items"]
+    hub = synth.make_pattern_window("hub", 12, 2, 400, seed=4)
+    assert not built_lib.structure_probe(hub)["reordered"]          # every pair linked: nothing to gain
 
 
 def test_structure_probe_groups_shuffled_edges_stably(built_lib):
