@@ -36,7 +36,7 @@ def measured_traffic(kernel_class):
     """HBM-side bytes per launch of a kernel class from the newest committed rocprofv3 PMC summary
     (profiles/*_pmc_traffic.json, made by scripts/profile_gpu.sh + scripts/summarise_profiles.py on the
     same bench command: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, launches with work only).
-    Raw counter sum; FETCH_SIZE under-reports wide coalesced streams by up to 2x on gfx950."""
+    FETCH_SIZE under-reports 16-byte-per-lane loads by 2x on gfx950: the summary's corrected figure is used when present."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
@@ -44,7 +44,9 @@ def measured_traffic(kernel_class):
     d = json.load(open(files[-1]))
     for name, v in d["kernels"].items():
         if ROCPROF_NAME.get(kernel_class, "?") in name:
-            return v["hbm_bytes_per_launch_raw"], os.path.basename(files[-1])
+            # corrected as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE counts half the bytes of 16-byte-per-lane
+            # loads; the share of such loads per kernel is read off the ISA (scripts/isa_load_widths.py), the summary keeps both
+            return v.get("hbm_bytes_per_launch_corrected", v["hbm_bytes_per_launch_raw"]), os.path.basename(files[-1])
     return None, None
 
 KERNEL_CLASSES = ["k_schur", "k_pcg", "k_point<backsub>", "k_decide", "setup(init+linearize+lambda)", "k_finalize"]
@@ -200,6 +202,7 @@ def main():
                          "per_kernel": per_kernel, "per_kernel_note": "HIP events around every launch of one untimed solve",
                          "kernel_ms_per_step_all_classes": {k: v["ms"] for k, v in prof_all.items()}},
         }
+        out["per_kernel"] = per_kernel
         out["config"]["timed_region"] = ("movba_lba_solve: host arrays in -> structure pass, H2D, all launches, D2H -> results in "
                                          "host memory (SURVEY 8d; result arrays in movba_host_alloc memory, as the adapter's are); identical region "
                                          "for cpu_baseline")
@@ -256,6 +259,41 @@ def main():
                     bs_.close()
             except Exception as exc:                        # context only
                 out["config"]["batched_windows"] = {"error": str(exc)}
+        if extras and args.config == "cfg3":
+            # for information only (never `value`): the same solve on cfg3-sized windows of the covisibility patterns the
+            # reference produces (movba/synth.py: shuffled ids, a path that comes back, a hub where every pair shares points)
+            # and cfg3 itself on the one-launch direct solver
+            try:
+                pats = {}
+                def time_window(sv, ww):
+                    sv.prepare(ww, pinned=True)
+                    for _ in range(2):
+                        sv.solve_prepared(pack=False)
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        sv.solve_prepared(pack=False)
+                    tc = (time.perf_counter() - t1) / 5
+                    rr = sv.solve_prepared()
+                    sv.upload(ww); sv.run(); torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        sv.run()
+                    torch.cuda.synchronize(dev)
+                    trs = (time.perf_counter() - t1) / 5
+                    return {"ms_per_window_solve": 1e3 * tc, "ms_resident": 1e3 * trs, "lm_iterations_per_step": rr["n_solves"],
+                            "pcg_iterations_per_step": rr["pcg_iters"], "direct_trials": rr["n_direct"], "E": ww.n_edges}
+                ps = capi.Solver(device=local_rank, stream=stream.cuda_stream)
+                for pname in ("shuffled", "revisit", "hub"):
+                    pats[pname] = time_window(ps, synth.pattern_cfg(pname))
+                ps.close()
+                pd = capi.Solver(device=local_rank, stream=stream.cuda_stream, direct=True)
+                pats["cfg3_on_the_direct_solver"] = time_window(pd, w)
+                pd.close()
+                pats["note"] = ("cfg3-sized windows, same timed regions as `value` (ms_per_window_solve) and config.resident_window (ms_resident); "
+                                "direct_trials > 0: the one-launch dense Cholesky solved those trials (dense covisibility)")
+                out["config"]["covisibility_patterns"] = pats
+            except Exception as exc:                        # context only
+                out["config"]["covisibility_patterns"] = {"error": str(exc)}
         if extras:
             # for information only: host-side cost of the Optimizer.h adapter around the solve on this window (mock map classes,
             # mov-slam_amd/host/adapter_test): window selection + flattening, and the write-back under the map mutex

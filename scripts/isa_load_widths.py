@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Global loads of every kernel by width, read off the gfx950 ISA (hipcc -save-temps of the product sources): what decides how
+rocprofv3's FETCH_SIZE has to be corrected.  MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts exactly half of the bytes of
+16-byte-per-lane loads (global_load_dwordx4 / buffer_load_dwordx4, with or without `lds`); narrower loads are taken at face
+value.  With s = share of a kernel's load BYTES that 16-byte loads account for (static count: instructions x width),
+    true_fetch = FETCH_SIZE / (1 - s / 2).
+Writes profiles/<tag>_isa_load_widths.json; scripts/summarise_profiles.py applies it.
+
+    python scripts/isa_load_widths.py r03
+"""
+import json, os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, "mov-slam_amd", "csrc")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+W = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16, "ubyte": 1, "sbyte": 1, "ushort": 2, "sshort": 2, "short_d16": 2, "short_d16_hi": 2, "ubyte_d16": 1, "ubyte_d16_hi": 1}
+pat = re.compile(r"^\s*(global_load|buffer_load|flat_load)_(\w+?)\s")
+out = {}
+with tempfile.TemporaryDirectory() as tmp:
+    for f in ("kernels.hip", "pcg_kernel.hip", "dense_solve.hip", "dense_persist.hip", "struct_kernels.hip", "pose_kernels.hip"):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include", f"-I{CS}", "--offload-arch=gfx950", "-munsafe-fp-atomics",
+                               "-ffp-contract=on", "-Wno-unused-function", "-save-temps", "-c", os.path.join(CS, f), "-o", os.path.join(tmp, "x.o")], cwd=tmp,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        asm = [p for p in os.listdir(tmp) if p.endswith("gfx950.s") and p.startswith(f.split(".")[0])][0]
+        cur = None
+        for line in open(os.path.join(tmp, asm)):
+            m = re.match(r"^(_ZN5movba\w+):", line)
+            if m:
+                cur = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+                out.setdefault(cur, {})
+                continue
+            m = pat.match(line)
+            if m and cur:
+                w = W.get(m.group(2))
+                if w:
+                    out[cur][w] = out[cur].get(w, 0) + 1
+res = {}
+for k, v in out.items():
+    tot = sum(w * n for w, n in v.items())
+    if tot:
+        res[k] = {"loads_by_bytes_per_lane": {str(w): n for w, n in sorted(v.items())}, "share_of_load_bytes_16B": (16 * v.get(16, 0)) / tot}
+json.dump({"tag": tag, "note": "static instruction counts per kernel symbol (device functions called by a kernel are listed on their own)", "kernels": res},
+          open(os.path.join(ROOT, "profiles", f"{tag}_isa_load_widths.json"), "w"), indent=1)
+for k, v in sorted(res.items()):
+    print(f"{v['share_of_load_bytes_16B']:.2f}  {k[:110]}")

@@ -1,0 +1,18 @@
+#!/bin/bash
+# rocprofv3 kernel trace + stats of one window solve loop per covisibility pattern and of cfg3 on the one-launch direct solver
+# (run through gpurun from the repo root):  gpurun_out/prof_<tag>_<name>/stats -> profiles/<tag>_<name>_kernel_stats.csv
+TAG=${1:-r03}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+for name in cfg3 shuffled revisit hub; do
+  OUT=$ROOT/gpurun_out/prof_${TAG}_$name; mkdir -p $OUT
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/pattern_time.py $name > $OUT/stats.log 2>&1 || exit 1
+  cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $ROOT/gpurun_out/${TAG}_${name}_kernel_stats.csv || exit 1
+done
+OUT=$ROOT/gpurun_out/prof_${TAG}_cfg3_direct; mkdir -p $OUT
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/pattern_time.py cfg3 --direct > $OUT/stats.log 2>&1 || exit 1
+cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $ROOT/gpurun_out/${TAG}_cfg3_direct_kernel_stats.csv || exit 1
+OUT=$ROOT/gpurun_out/prof_${TAG}_big_direct; mkdir -p $OUT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/direct_time.py > $OUT/stats.log 2>&1 || exit 1
+cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $ROOT/gpurun_out/${TAG}_direct_time_kernel_stats.csv || exit 1
+tail -6 $OUT/stats.log

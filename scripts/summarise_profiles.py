@@ -7,7 +7,8 @@ Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats) and profiles/
 per kernel, launches with real work only (no-op run-ahead launches fetch ~nothing and would dilute the
 average), mean FETCH_SIZE / WRITE_SIZE per launch in bytes.  FETCH_SIZE is reported in KiB of 64-B
 requests; MI355X_MICROARCH.md (HBM section) says it counts exactly half of the bytes of a wide coalesced
-stream on gfx950 — both the raw and the doubled figure are kept, bench.py quotes the raw sum and names it.
+stream on gfx950 — the raw and the doubled figure are kept, and the CORRECTED one: fetch / (1 - s/2) with s the share of the
+kernel's load bytes moved by 16-byte-per-lane loads (ISA count, scripts/isa_load_widths.py); bench.py quotes the corrected one.
 """
 import csv
 import glob
@@ -35,6 +36,12 @@ def per_kernel(path, counter):
 
 
 fetch, write = per_kernel("pmc_fetch", "FETCH_SIZE"), per_kernel("pmc_write", "WRITE_SIZE")
+# share of each kernel's load bytes that 16-byte-per-lane loads account for (scripts/isa_load_widths.py): FETCH_SIZE counts
+# those at half their bytes (MI355X_MICROARCH.md, HBM section), narrower loads at face value
+widths = {}
+wf = sorted(glob.glob(os.path.join(root, "profiles", "*_isa_load_widths.json")))
+if wf:
+    widths = {k: v["share_of_load_bytes_16B"] for k, v in json.load(open(wf[-1]))["kernels"].items()}
 out = {}
 for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, []), write.get(k, [])
@@ -46,6 +53,10 @@ for k in sorted(set(fetch) | set(write)):
               "fetch_kib_mean": sum(fw) / len(fw), "write_kib_mean": sum(ww) / len(ww),
               "hbm_bytes_per_launch_raw": 1024 * (sum(fw) / len(fw) + sum(ww) / len(ww)),
               "hbm_bytes_per_launch_fetch_doubled": 1024 * (2 * sum(fw) / len(fw) + sum(ww) / len(ww))}
+    share = next((v for n, v in widths.items() if n == k or n.split("(")[0] == k.split("(")[0]), None)
+    if share is not None:
+        out[k]["share_of_load_bytes_16B"] = share
+        out[k]["hbm_bytes_per_launch_corrected"] = 1024 * ((sum(fw) / len(fw)) / (1.0 - 0.5 * share) + sum(ww) / len(ww))
 json.dump({"tag": tag, "units": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch (rocprofv3 --pmc, separate passes)", "kernels": out},
           open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 for k, v in out.items():
