@@ -268,6 +268,20 @@ namespace MOV_SLAM
         // host-side phases of the last LocalBundleAdjustment call of this thread: extraction (selection + flattening), solve
         // call, write-back (ms); read through movba_adapter_last_timing()
         thread_local double tls_timing[3] = {0, 0, 0};
+        // what became of this thread's last optimisation call: MOVBA_OK, one of the reference's own silent returns (> 0:
+        // stopped, nothing to optimise, no fixed keyframe), or a library error (< 0: the map was left untouched although the
+        // reference would have optimised it); library errors are also counted process-wide (movba_adapter_error_count())
+        thread_local int tls_last_status = 0;
+        std::atomic<long> g_library_errors{0};
+        void note_status(const char *who, int status)
+        {
+            tls_last_status = status;
+            if (status < 0)
+            {
+                g_library_errors.fetch_add(1, std::memory_order_relaxed);
+                std::fprintf(stderr, "MOV_SLAM::Optimizer::%s: libmovba returned %d (%s): optimisation SKIPPED, map left as it was\n", who, status, movba_status_string(status));
+            }
+        }
 
         // $MOVBA_DUMP_DIR/lba_<n>.mbw: the flattened window, for replay on a GPU box without the reference's
         // stack (layout in mov-slam_amd/movba/capture.py)
@@ -376,6 +390,8 @@ namespace MOV_SLAM
     } // namespace
 
     double adapter_timing(int k) { return tls_timing[k]; }
+    int adapter_last_status() { return tls_last_status; }
+    long adapter_error_count() { return g_library_errors.load(std::memory_order_relaxed); }
 
     void Optimizer::GlobalBundleAdjustemnt(Map *pMap, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust)
     {
@@ -417,10 +433,12 @@ namespace MOV_SLAM
         if (f.cam_mixed)
         {
             report_mixed_cameras("BundleAdjustment");
+            note_status("BundleAdjustment", MOVBA_ERR_ARG);
             return;
         }
 
         const Solved &s = solve(f, nIterations, bRobust, pbStopFlag);
+        note_status("BundleAdjustment", s.status);
         if (s.status != MOVBA_OK)
             return;
 
@@ -617,6 +635,7 @@ namespace MOV_SLAM
         if (f.cam_mixed)
         {
             report_mixed_cameras("LocalBundleAdjustment");
+            note_status("LocalBundleAdjustment", MOVBA_ERR_ARG);
             return;
         }
 
@@ -630,20 +649,24 @@ namespace MOV_SLAM
         const Solved &s = solve(f, 10, true, pbStopFlag);
         const double t_solve1 = now_ms();
         tls_timing[1] = t_solve1 - t_solve0;
+        note_status("LocalBundleAdjustment", s.status);
         if (s.status != MOVBA_OK)
-            return;                                             // stopped / nothing to do / no device: map untouched
+            return;                                             // stopped / nothing to do / library error: map untouched
 
-        // ---- inlier check in vpEdgesMono order (Optimizer.cc:757-775) ----
+        // ---- inlier check (Optimizer.cc:757-803): the monocular edges in their order, THEN the stereo edges in theirs — the
+        // reference keeps them in separate vectors (vpEdgesMono / vpEdgesStereo), so in a mixed window every monocular outlier
+        // is erased before the first stereo one ----
         std::vector<std::pair<KeyFrame *, MapPoint *>> vToErase;
-        for (size_t i = 0; i < f.edge_kf.size(); i++)
-        {
-            if (!s.outlier[i])
-                continue;
-            MapPoint *pMP = f.edge_mp[i];
-            if (pMP->isBad())
-                continue;
-            vToErase.push_back(std::make_pair(f.edge_kf[i], pMP));
-        }
+        for (int pass = 0; pass < (f.any_stereo ? 2 : 1); ++pass)
+            for (size_t i = 0; i < f.edge_kf.size(); i++)
+            {
+                if (!s.outlier[i] || (f.any_stereo && (f.obs_right[i] >= 0.0) != (pass == 1)))
+                    continue;
+                MapPoint *pMP = f.edge_mp[i];
+                if (pMP->isBad())
+                    continue;
+                vToErase.push_back(std::make_pair(f.edge_kf[i], pMP));
+            }
 
         lap_t = now_ms();
         lap("inlier check");
@@ -691,7 +714,7 @@ namespace MOV_SLAM
                 KeyFrame *pRefKF = pMP->GetReferenceKeyFrame();  // after the erasures (EraseObservation may move it)
                 Eigen::Vector3f normal;
                 normal.setZero();
-                int n = 0, refLeft = -1, refIdx = -1;
+                int n = 0, refLeft = -1, refIdx = -1, nobs_expected = 0;
                 bool fallback = false, any = false;
                 for (; ob != ob_end && !fallback; ++ob)
                 {
@@ -705,6 +728,8 @@ namespace MOV_SLAM
                     if (erased)
                         continue;                               // EraseObservation removed it before the update
                     any = true;
+                    // (what MapPoint::AddObservation counted for this observation, MapPoint.cc:162-165: stereo twice)
+                    nobs_expected += (ob->left != -1 && ob->kf->mvuRight[ob->left] >= 0) ? 2 : 1;
                     if (ob->vertex < 0 || ob->right != -1) { fallback = true; break; }
                     if (ob->left != -1)
                     {
@@ -716,6 +741,11 @@ namespace MOV_SLAM
                 }
                 if (!fallback && !any)
                     continue;                                   // observations.empty(): nothing is updated
+                // the observation list was copied BEFORE the solve: if another thread has added or erased an observation of
+                // this point since (Tracking / LoopClosing hold no map mutex for that), MapPoint::Observations() no longer
+                // matches the snapshot minus this call's erasures, and the reference's own update re-reads the point
+                if (!fallback && pMP->Observations() != nobs_expected)
+                    fallback = true;
                 if (fallback || refIdx < 0 || refLeft < 0 || pRefKF->NLeft != -1 || n == 0)
                 {
                     pMP->UpdateNormalAndDepth();
@@ -820,3 +850,9 @@ extern "C" void movba_adapter_last_timing(double out[3])
 {
     for (int k = 0; k < 3; ++k) out[k] = MOV_SLAM::adapter_timing(k);
 }
+
+// What became of the calling thread's last BundleAdjustment / LocalBundleAdjustment call: 0 = optimised, > 0 = one of the
+// reference's own silent returns (MOVBA_STOPPED, MOVBA_NO_FIXED, MOVBA_EMPTY), < 0 = libmovba error: optimisation skipped
+// where the reference would have run it.  movba_adapter_error_count(): such skips in this process so far.
+extern "C" int movba_adapter_last_status(void) { return MOV_SLAM::adapter_last_status(); }
+extern "C" long movba_adapter_error_count(void) { return MOV_SLAM::adapter_error_count(); }

@@ -12,6 +12,8 @@
 using namespace MOV_SLAM;
 
 extern "C" void movba_adapter_last_timing(double out[3]);
+extern "C" int movba_adapter_last_status(void);
+extern "C" long movba_adapter_error_count(void);
 
 template <typename T> static std::vector<T> rd(FILE *f, size_t n)
 {
@@ -64,7 +66,7 @@ static int run_lba(const char *in, const char *out, bool global)
         cv::KeyPoint kp; kp.pt.x = (float)obs[2 * e]; kp.pt.y = (float)obs[2 * e + 1]; kp.octave = 0;
         const int idx = (int)k.mvKeysUn.size();
         k.mvKeysUn.push_back(kp); k.mvuRight.push_back(obs_right.empty() ? -1.f : (float)obs_right[e]); k.mvpMapPoints.push_back(&mps[el[e]]);
-        mps[el[e]].mObservations[&k] = std::make_tuple(idx, -1);
+        mps[el[e]].AddObservation(&k, idx);               // (nObs as MapPoint.cc:139-169 counts it: a stereo observation twice)
         if (!mps[el[e]].mpRefKF) mps[el[e]].mpRefKF = &k;           // the keyframe that created the point
     }
     // the newest free keyframe is the one LocalMapping passes in; every other free keyframe is covisible
@@ -87,9 +89,11 @@ static int run_lba(const char *in, const char *out, bool global)
         std::fprintf(stderr, "adapter[rep %d]: extraction %.3f ms, solve call %.3f ms, write-back %.3f ms (NP=%d P=%d E=%d)\n", rep, tmr[0], tmr[1], tmr[2], NP, P, E);
     }
     if (rep + 1 < reps) continue;
+    // the (keyframe, map point) pairs EraseObservation removed, per point in call order (a point that went bad on the way —
+    // nObs <= 2, SetBadFlag — has lost its remaining observations without further calls)
     std::vector<int32_t> erased;
-    for (int e = 0; e < E; ++e)
-        if (mps[el[e]].mObservations.find(&kfs[ep[e]]) == mps[el[e]].mObservations.end()) { erased.push_back(ep[e]); erased.push_back(el[e]); }
+    for (int l = 0; l < P; ++l)
+        for (KeyFrame *k : mps[l].vErasedBy) { erased.push_back((int32_t)(k - kfs.data())); erased.push_back(l); }
     FILE *o = fopen(out, "wb");
     const int32_t oh[5] = { num_fixedKF, num_OptKF, num_edges, (int32_t)(erased.size() / 2), map.mnChangeIdx };
     fwrite(oh, sizeof(int32_t), 5, o);
@@ -118,6 +122,19 @@ static int run_lba(const char *in, const char *out, bool global)
     double tm[3] = { 0, 0, 0 };
     if (!global) movba_adapter_last_timing(tm);
     fwrite(tm, sizeof(double), 3, o);
+    // per point: bad flag, nObs, observations left, index of the reference keyframe; per keyframe: matches still set; then the
+    // adapter's status plumbing
+    for (int l = 0; l < P; ++l) {
+        const int32_t v[4] = { mps[l].mbBad ? 1 : 0, mps[l].nObs, (int32_t)mps[l].mObservations.size(), mps[l].mpRefKF ? (int32_t)(mps[l].mpRefKF - kfs.data()) : -1 };
+        fwrite(v, sizeof(int32_t), 4, o);
+    }
+    for (int i = 0; i < NP; ++i) {
+        int32_t live = 0;
+        for (MapPoint *m : kfs[i].mvpMapPoints) live += m != nullptr;
+        fwrite(&live, sizeof(int32_t), 1, o);
+    }
+    const int32_t st[3] = { movba_adapter_last_status(), (int32_t)movba_adapter_error_count(), (int32_t)map.mspErased.size() };
+    fwrite(st, sizeof(int32_t), 3, o);
     fclose(o);
     }
     return 0;

@@ -39,6 +39,7 @@ public:
         if (leftIndex != -1) mvpMapPoints[leftIndex] = nullptr;
         if (rightIndex != -1) mvpMapPoints[rightIndex] = nullptr;
     }
+    void EraseMapPointMatch(const int &idx) { std::unique_lock<std::mutex> lock(mMutexFeatures); mvpMapPoints[idx] = nullptr; }   // KeyFrame.cc:292-296
     bool isBad() { std::unique_lock<std::mutex> lock(mMutexConnections); return mbBad; }
     Map *GetMap() { std::unique_lock<std::mutex> lock(mMutexMap); return mpMap; }
     long unsigned int mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul, mnBAGlobalForKF = 0;
@@ -53,6 +54,49 @@ public:
     Sophus::SE3f mTcw; std::vector<KeyFrame *> mvCovisible; std::vector<MapPoint *> mvpMapPoints;
     bool mbBad = false; Map *mpMap = nullptr; int nPoseSets = 0;
 };
+inline void MapPoint::AddObservation(KeyFrame *pKF, int idx)
+{
+    std::unique_lock<std::mutex> lock(mMutexFeatures);
+    std::tuple<int, int> indexes = mObservations.count(pKF) ? mObservations[pKF] : std::tuple<int, int>(-1, -1);
+    if (pKF->NLeft != -1 && idx >= pKF->NLeft) std::get<1>(indexes) = idx; else std::get<0>(indexes) = idx;
+    mObservations[pKF] = indexes;
+    if (!pKF->mpCamera2 && pKF->mvuRight[idx] >= 0) nObs += 2; else nObs++;
+}
+inline void MapPoint::EraseObservation(KeyFrame *pKF)
+{
+    bool bBad = false;
+    {
+        std::unique_lock<std::mutex> lock(mMutexFeatures);
+        if (mObservations.count(pKF)) {
+            const std::tuple<int, int> indexes = mObservations[pKF];
+            const int leftIndex = std::get<0>(indexes), rightIndex = std::get<1>(indexes);
+            if (leftIndex != -1) { if (!pKF->mpCamera2 && pKF->mvuRight[leftIndex] >= 0) nObs -= 2; else nObs--; }
+            if (rightIndex != -1) nObs--;
+            mObservations.erase(pKF); ++nErased; vErasedBy.push_back(pKF);
+            if (mpRefKF == pKF && !mObservations.empty()) mpRefKF = mObservations.begin()->first;   // (the reference dereferences begin() of an empty map here)
+            if (nObs <= 2) bBad = true;
+        }
+    }
+    if (bBad) SetBadFlag();
+}
+inline void MapPoint::SetBadFlag()
+{
+    std::map<KeyFrame *, std::tuple<int, int>> obs;
+    {
+        std::unique_lock<std::mutex> lock1(mMutexFeatures);
+        std::unique_lock<std::mutex> lock2(mMutexPos);
+        mbBad = true;
+        obs = mObservations;
+        mObservations.clear();
+    }
+    for (auto mit = obs.begin(); mit != obs.end(); ++mit) {
+        KeyFrame *pKF = mit->first;
+        const int leftIndex = std::get<0>(mit->second), rightIndex = std::get<1>(mit->second);
+        if (leftIndex != -1) pKF->EraseMapPointMatch(leftIndex);
+        if (rightIndex != -1) pKF->EraseMapPointMatch(rightIndex);
+    }
+    mpMap->EraseMapPoint(this);
+}
 // MapPoint::UpdateNormalAndDepth as the reference computes it (MapPoint.cc:362-435): the mean of the unit viewing rays of
 // all observers, and the scale-invariance distances from the reference keyframe.  Defined here because it needs KeyFrame.
 inline void MapPoint::UpdateNormalAndDepth()

@@ -13,6 +13,8 @@ public:
     long unsigned int GetInitKFid() { return mnInitKFid; }
     KeyFrame *GetOriginKF() { return mpOriginKF; }
     void IncreaseChangeIndex() { ++mnChangeIdx; }
+    void EraseMapPoint(MapPoint *pMP) { std::unique_lock<std::mutex> lock(mMutexMap); mspErased.insert(pMP); }      // Map.cc: the point leaves mspMapPoints
+    std::mutex mMutexMap; std::set<MapPoint *> mspErased;
     std::mutex mMutexMapUpdate;
     std::set<long unsigned int> msOptKFs, msFixedKFs;
     // test plumbing

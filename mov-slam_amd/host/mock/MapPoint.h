@@ -3,6 +3,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 #include "mock_math.h"
 #include "Map.h"
 namespace MOV_SLAM {
@@ -38,14 +39,13 @@ public:
     void SetMinMaxDistance(float mn, float mx) { std::unique_lock<std::mutex> lock(mMutexPos); mfMinDistance = mn; mfMaxDistance = mx; }
 #endif
     void UpdateNormalAndDepth();                                             // MapPoint.cc:362-435, restated on the mock types below
-    // MapPoint.cc:171-209: the reference keyframe moves on when its observation goes; <= 2 observations left: bad point
-    void EraseObservation(KeyFrame *pKF) {
-        std::unique_lock<std::mutex> lock(mMutexFeatures);
-        if (!mObservations.count(pKF)) return;
-        mObservations.erase(pKF); ++nErased;
-        if (mpRefKF == pKF && !mObservations.empty()) mpRefKF = mObservations.begin()->first;
-        if (mObservations.size() <= 2) mbBad = true;
-    }
+    // MapPoint.cc:139-169: nObs counts a stereo observation (mvuRight >= 0, no second camera) twice
+    void AddObservation(KeyFrame *pKF, int idx);
+    int Observations() { std::unique_lock<std::mutex> lock(mMutexFeatures); return nObs; }                                     // MapPoint.cc:224-228
+    // MapPoint.cc:171-209: the reference keyframe moves on when its observation goes; nObs <= 2 afterwards: SetBadFlag()
+    void EraseObservation(KeyFrame *pKF);
+    // MapPoint.cc:230-258: the point leaves the map: observations cleared, its slot nulled in every observer
+    void SetBadFlag();
     bool isBad() { std::unique_lock<std::mutex> lock1(mMutexFeatures, std::defer_lock); std::unique_lock<std::mutex> lock2(mMutexPos, std::defer_lock); std::lock(lock1, lock2); return mbBad; }   // :314-320
     Map *GetMap() { std::unique_lock<std::mutex> lock(mMutexMap); return mpMap; }
     long unsigned int mnId = 0, mnBALocalForKF = ~0ul, mnBAGlobalForKF = 0;
@@ -54,7 +54,8 @@ public:
     static std::mutex &mGlobalMutex() { static std::mutex m; return m; }
     // test plumbing
     Eigen::Vector3f mWorldPos; std::map<KeyFrame *, std::tuple<int, int>> mObservations;
-    bool mbBad = false; Map *mpMap = nullptr; int nErased = 0, nNormalUpdates = 0;
+    bool mbBad = false; Map *mpMap = nullptr; int nErased = 0, nNormalUpdates = 0, nObs = 0;
+    std::vector<KeyFrame *> vErasedBy;      // EraseObservation calls that found their observation, in call order
     KeyFrame *mpRefKF = nullptr; Eigen::Vector3f mNormalVector; float mfMinDistance = 0.f, mfMaxDistance = 0.f;
 };
 }  // namespace MOV_SLAM
