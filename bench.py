@@ -162,6 +162,9 @@ def main():
         dist.all_reduce(ss, op=dist.ReduceOp.SUM)
     dt_max, solves_total = float(tt.item()), float(ss.item())
 
+    if rank == 0 and os.environ.get("MOVBA_BENCH_DUMP_POSES"):
+        # (tests: the gathered poses of the last timed step, one block per rank)
+        np.save(os.environ["MOVBA_BENCH_DUMP_POSES"], gathered.detach().cpu().numpy())
     if rank == 0:
         ab = algorithmic_bytes(K, F, P, E)
         dk = prof["kernels"][dominant]

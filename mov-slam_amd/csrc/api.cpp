@@ -204,6 +204,20 @@ inline void host_relax(int mode)
 #endif
 }
 
+// Words the device writes into pinned host memory while the host polls them (k_decide's progress word, the PCG's park
+// counter, the structure pass's sequence number): read with acquire loads — what is published before them (the counts, the
+// controller's copy) is read after them — and written from the host with release stores.
+inline uint64_t rd_progress(const HostStatus *hs) { return __atomic_load_n(&hs->progress, __ATOMIC_ACQUIRE); }
+inline int32_t rd_pause(const HostStatus *hs) { return __atomic_load_n(&hs->pause_seq, __ATOMIC_ACQUIRE); }
+inline void wr_stop(HostStatus *hs, int32_t v) { __atomic_store_n(&hs->stop, v, __ATOMIC_RELEASE); }
+inline bool caller_stop(const volatile uint8_t *p) { return p && __atomic_load_n(p, __ATOMIC_RELAXED) != 0; }
+// how long the device may go without ANY progress (a changed progress word, or new work queued) before the host gives up
+inline double watchdog_ms()
+{
+    static const double v = [] { const char *e = std::getenv("MOVBA_WATCHDOG_MS"); const double x = e ? std::atof(e) : 0.0; return x > 0.0 ? x : 60000.0; }();
+    return v;
+}
+
 struct Carver {
     size_t off = 0;
     template <typename T> size_t take(size_t count)
@@ -621,6 +635,10 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (!s.already_grouped) {
         // (rare: the helper's straight copies get permuted below, so it has to be through with them)
         const int rw = wait_helper(); if (rw) return rw;
+        // ... and so do its transfers out of the staging buffer (found by ThreadSanitizer over the fake device, tests/hipstub: the
+        // copy engine was still reading the caller-order observations while they were being permuted; harmless for the result —
+        // the permuted region is sent again behind that copy — but a torn first copy is nothing to rely on)
+        HIP_TRY(hipEventSynchronize(h->copy_event));
         build_slots(h->st); rank_mode = false;
         pack_edges(false);
     } else {
@@ -722,17 +740,16 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         // (misc: nbins totals, the error word, the sequence number of this upload)
         volatile int32_t *misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
         const int32_t seq = (int32_t)(++h->count_seq & 0x7fffffff);
-        *misc_seq = seq - 1;
+        __atomic_store_n(misc_seq, seq - 1, __ATOMIC_RELAXED);
         HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
         HIP_TRY(launch_struct_scan(sd, h->stream));
         lap("edge H2D + count launches");
         {
             const double t_wait = now_ms();
-            while (*misc_seq != seq) {
+            while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
                 host_relax(0);
-                if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (*misc_seq != seq) return MOVBA_ERR_HIP; }
+                if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) return MOVBA_ERR_HIP; }
             }
-            std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (reinterpret_cast<const int32_t *>(misc)[nbins] != 0) return MOVBA_ERR_ARG;     // duplicate observation
         lap("wait for the pair counts");
@@ -1054,9 +1071,10 @@ int lm_loop(movba_handle *h, bool parked)
     // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
     bool direct = !h->rows_kernel;
     int pauses_seen = 0;
-    if (!parked) h->hstat->pause_seq = 0;
+    if (!parked) __atomic_store_n(&h->hstat->pause_seq, 0, __ATOMIC_RELAXED);
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
-    const double t_start = now_ms();
+    double t_progress = now_ms();                   // last time the device's progress word changed or work was queued
+    uint64_t last_pg = ~0ull;
     // k_finalize + the Ctrl read-back are queued speculatively behind a trial that is likely the last one, so that the
     // end of the solve does not wait for a host round trip; a later trial simply queues them again
     int t = 0, final_after = -1;
@@ -1088,9 +1106,9 @@ int lm_loop(movba_handle *h, bool parked)
     // The device parked the solve (k_pcg_rows gave up on trial `td`): every trial set queued behind has turned into no-ops.
     // Queue the direct solver for that trial (its schur partials are still in place) and carry on in direct mode.
     auto answer_pause = [&]() -> int {
-        pauses_seen = h->hstat->pause_seq;
+        pauses_seen = rd_pause(h->hstat);
         direct = true;
-        t = (int)(h->hstat->progress & 0xffffff);
+        t = (int)(rd_progress(h->hstat) & 0xffffff);
         int rq = queue_solve(); if (rq != MOVBA_OK) return rq;
         rq = queue_tail(); if (rq != MOVBA_OK) return rq;
         ++t;
@@ -1105,27 +1123,30 @@ int lm_loop(movba_handle *h, bool parked)
             // (k_decide publishes trials_done, it and done as one word)
             bool finished = false, paused = false;
             for (;;) {
-                const uint64_t pg = h->hstat->progress;
+                const uint64_t pg = rd_progress(h->hstat);
+                if (pg != last_pg) { last_pg = pg; t_progress = now_ms(); }
                 const int td = (int)(pg & 0xffffff), it_done = (int)((pg >> 24) & 0xffffff);
                 if ((pg >> 48) & 1) { finished = true; break; }
-                if (h->hstat->pause_seq != pauses_seen) { paused = true; break; }
+                if (rd_pause(h->hstat) != pauses_seen) { paused = true; break; }
                 const int left = w.max_iters - it_done;
                 const int limit = left < h->opt.run_ahead ? (left > 1 ? left : 1) : h->opt.run_ahead;
                 if (t - td < limit) break;
                 if (final_after != t && t - td < h->opt.run_ahead) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
-                if (h->stop && *h->stop) h->hstat->stop = 1;
-                if (now_ms() - t_start > 60000.0) {
+                if (caller_stop(h->stop)) wr_stop(h->hstat, 1);
+                if (now_ms() - t_progress > watchdog_ms()) {
                     // raise the device-side stop flag on the way out: whatever is still queued on the stream turns into
                     // no-op launches as soon as a k_decide sees it, and the window has to be uploaded again
-                    std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
-                    h->hstat->stop = 1; h->uploaded = false;
+                    std::fprintf(stderr, "libmovba: device made no progress for %.0f ms, giving up\n", watchdog_ms());
+                    wr_stop(h->hstat, 1); h->uploaded = false;
+                    (void)hipStreamSynchronize(s);          // nothing of this solve is left queued when the caller gets the error
                     return MOVBA_ERR_HIP;
                 }
                 host_relax(h->opt.host_wait);
             }
             if (finished) break;
             if (paused) { const int rq = answer_pause(); if (rq != MOVBA_OK) return rq; --t; continue; }
-            if (h->stop && *h->stop) h->hstat->stop = 1;
+            if (caller_stop(h->stop)) wr_stop(h->hstat, 1);
+            t_progress = now_ms();                          // (new work queued counts as progress)
             if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
             { const int rq = queue_solve(); if (rq != MOVBA_OK) return rq; }
             { const int rq = queue_tail(); if (rq != MOVBA_OK) return rq; }
@@ -1133,7 +1154,7 @@ int lm_loop(movba_handle *h, bool parked)
         if (final_after != t) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
         HIP_TRY(hipStreamSynchronize(s));
         // a park that happened behind the last queued set is only seen now
-        if (h->hstat->pause_seq == pauses_seen) break;
+        if (rd_pause(h->hstat) == pauses_seen) break;
         const int rq = answer_pause(); if (rq != MOVBA_OK) return rq;
     }
     harvest_events(h);
@@ -1152,12 +1173,12 @@ int movba_lba_run(movba_handle *h)
     h->ran = false; h->run_status = MOVBA_OK;
     if (h->early_status != MOVBA_OK) { h->ran = true; return h->early_status; }
     // early return before the solve (src/Optimizer.cc:749-751); not sticky: the next run looks at the flag again
-    if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
+    if (caller_stop(h->stop)) { h->run_status = MOVBA_STOPPED; h->ran = true; return MOVBA_STOPPED; }
     // (a registered export buffer too small for this window is ignored rather than overrun)
     h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
     const DevWindow &w = h->win;
     hipStream_t s = h->stream;
-    h->hstat->progress = 0; h->hstat->stop = 0;
+    __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0);
     // (the staging buffer is free once the upload's copies, queued ahead of every kernel of the run, have left it; it is as
     // large as the upload needed, which is more than the results take)
     h->export_in_run = h->export_hint && export_layout(w).end <= h->stage_cap;
@@ -1215,7 +1236,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
         movba_handle *h = hs[i];
         h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false;
         if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
-        if (h->stop && *h->stop) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
+        if (caller_stop(h->stop)) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
         if (!h->rows_kernel) { solo.push_back(h); continue; }
         act.push_back(h);
     }
@@ -1287,7 +1308,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             for (int i = 0; i < m; ++i) {
                 movba_handle *h = G.hs[i];
                 h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
-                h->hstat->progress = 0; h->hstat->stop = 0; h->hstat->pause_seq = 0;
+                __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0); __atomic_store_n(&h->hstat->pause_seq, 0, __ATOMIC_RELAXED);
                 wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
                 pps[i] = run_pcg_params(h);
                 const DevWindow &w = h->win;
@@ -1322,19 +1343,22 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             HIP_TRY(launch_lambda_init_batch(G.b, G.s));
         }
         // ---- trial sets: each group a bounded number of sets ahead of its slowest window still running ----
-        const double t_start = now_ms();
+        double t_progress = now_ms();               // last time some window's progress word changed or work was queued
+        uint64_t last_sum = ~0ull;
         for (;;) {
             bool all_finished = true;
+            uint64_t pg_sum = 0;
             for (int g = 0; g < ngroups; ++g) {
                 Group &G = grp[g];
                 if (G.finished) continue;
                 int td_min = 1 << 30, it_min = 1 << 30, running = 0;
                 for (movba_handle *h : G.hs) {
-                    const uint64_t pg = h->hstat->progress;
-                    if (((pg >> 48) & 1) || h->hstat->pause_seq != 0) continue;      // done, or parked for the direct solver
+                    const uint64_t pg = rd_progress(h->hstat);
+                    pg_sum += pg;
+                    if (((pg >> 48) & 1) || rd_pause(h->hstat) != 0) continue;      // done, or parked for the direct solver
                     ++running;
                     td_min = std::min(td_min, (int)(pg & 0xffffff)); it_min = std::min(it_min, (int)((pg >> 24) & 0xffffff));
-                    if (h->stop && *h->stop) h->hstat->stop = 1;
+                    if (caller_stop(h->stop)) wr_stop(h->hstat, 1);
                 }
                 if (running == 0 || G.t >= G.max_trials) {
                     if (G.final_after != G.t) { HIP_TRY(launch_finalize_batch(G.b, G.nb_final, G.s)); G.final_after = G.t; }
@@ -1359,11 +1383,14 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 HIP_TRY(launch_point_batch(G.b, G.nb_point, true, stereo, ldsp, G.lds_back, G.s));
                 HIP_TRY(launch_decide_batch(G.b, G.s));
                 G.t += 1;
+                t_progress = now_ms();
             }
             if (all_finished) break;
-            if (now_ms() - t_start > 60000.0) {
-                std::fprintf(stderr, "libmovba: device made no progress for 60 s, giving up\n");
-                for (movba_handle *h : act) { h->hstat->stop = 1; h->uploaded = false; }
+            if (pg_sum != last_sum) { last_sum = pg_sum; t_progress = now_ms(); }
+            if (now_ms() - t_progress > watchdog_ms()) {
+                std::fprintf(stderr, "libmovba: device made no progress for %.0f ms, giving up\n", watchdog_ms());
+                for (movba_handle *h : act) { wr_stop(h->hstat, 1); h->uploaded = false; }
+                for (int g = 0; g < ngroups; ++g) (void)hipStreamSynchronize(grp[g].s);
                 return MOVBA_ERR_HIP;
             }
             host_relax(h0->opt.host_wait);
@@ -1375,7 +1402,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
         HIP_TRY(hipStreamSynchronize(s));           // (every group was finalised behind its last trial set, in stream order)
         // windows whose PCG gave up parked themselves: each finishes on the direct solver from where it stands
         for (movba_handle *h : act) {
-            if (h->hstat->pause_seq != 0 && !((h->hstat->progress >> 48) & 1)) {
+            if (rd_pause(h->hstat) != 0 && !((rd_progress(h->hstat) >> 48) & 1)) {
                 const int rl = lm_loop(h, true);
                 if (rl != MOVBA_OK) return rl;
             }

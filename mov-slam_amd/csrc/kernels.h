@@ -7,6 +7,7 @@
 namespace movba {
 
 constexpr int kPcgRowsThreads = 512;    // 8 waves: 2 per SIMD, 256 VGPRs per lane
+constexpr int kPcgPlanWaves = kPcgRowsThreads / 64, kPcgPlanOwnBatch = 10;     // (pcg_plan.cpp / pcg_kernel.hip)
 
 hipError_t configure_kernels(int unused);
 hipError_t configure_pcg_rows();

@@ -617,52 +617,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows_b(BatchDev b, int trial)
     pcg_rows_body<OVERFLOW>(b.wins[wi], pp, trial, role);
 }
 
-size_t pcg_rows_lds_bytes(int nfree, int nrowent)
-{
-    const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    const size_t solve = (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC / 2 + kNC + 32 * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
-    const size_t coarse = ((size_t)kNC * kNC + 5 * kNC + 8) * sizeof(double) + 2 * sizeof(int32_t) * ((size_t)nrowent + 2);   // the second workgroup (coarse_level.h)
-    return solve > coarse ? solve : coarse;
-}
-
-// Deals block rows to the waves so that every wave gets about the same number of gather-list
-// entries (the mat-vec work) and at most 10 block rows (60 owner lanes).  A wave holds 64 entry
-// pairs in VGPRs; anything beyond that is flagged as overflow (read from an L2 copy of S).
-bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
-{
-    if (nfree <= 0 || nfree > 10 * kNW) return false;
-    const int nrowent = row_ptr[nfree];
-    if (pcg_rows_lds_bytes(nfree, nrowent) > 159 * 1024) return false;
-    // smallest per-wave entry budget for which a greedy fill (<= 10 rows per wave) needs <= kNW waves
-    auto fill = [&](int cap, int32_t *out) {
-        int b = 0, wv = 0;
-        for (; wv < kNW && b < nfree; ++wv) {
-            int e = b + 1;                                      // a wave always takes at least one row
-            while (e < nfree && e - b < 10 && row_ptr[e + 1] - row_ptr[b] <= cap) ++e;
-            if (out) out[wv + 1] = e;
-            b = e;
-        }
-        if (out) for (; wv < kNW; ++wv) out[wv + 1] = nfree;
-        return b == nfree;
-    };
-    if (nfree <= kNW) {
-        // one keyframe per wave: the aggregates are single keyframes and the coarse level is the exact inverse (fresh mode)
-        for (int wv = 0; wv <= kNW; ++wv) pp->wave_row0[wv] = wv < nfree ? wv : nfree;
-        pp->overflow = 0;
-        return true;
-    }
-    int lo = 1, hi = nrowent > 1 ? nrowent : 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) / 2;
-        if (fill(mid, nullptr)) hi = mid; else lo = mid + 1;
-    }
-    pp->wave_row0[0] = 0;
-    if (!fill(lo, pp->wave_row0)) return false;
-    pp->overflow = 0;
-    for (int wv = 0; wv < kNW; ++wv)
-        if (row_ptr[pp->wave_row0[wv + 1]] - row_ptr[pp->wave_row0[wv]] > 128) pp->overflow = 1;
-    return true;
-}
+static_assert(kNW == kPcgPlanWaves && kNC == kCoarseDim && kOwnBatch == kPcgPlanOwnBatch, "pcg_plan.cpp sizes the LDS carve of this kernel");
 
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
 {

@@ -1,0 +1,211 @@
+// The "device" of the CPU-only concurrency tests: every launch_* wrapper of mov-slam_amd/csrc/kernels.h as a closure on the
+// fake stream (fake_hip.cpp).  The closures READ what the real kernels read and WRITE what they write (checksums and
+// stand-in values, no bundle adjustment), follow the LM controller's protocol with the host (Ctrl::done, the progress word,
+// the park counter, the stop flag) and can be told to misbehave (fake_set_mode): park the solve for the direct solver at a
+// given trial, or stop making progress (a hung device) — so that ThreadSanitizer and the tests see the host's state machine
+// under every hand-off it has.  Test infrastructure only.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstring>
+#include <vector>
+
+#include "device_types.h"
+#include "kernels.h"
+#include "pose_kernels.h"
+
+namespace {
+std::atomic<int> g_park_trial{-1}, g_stall_after{-1};
+std::atomic<long> g_sink{0};
+
+long sum_bytes(const void *p, size_t n)
+{
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    long s = 0;
+    for (size_t k = 0; k < n; k += 64) s += c[k];
+    if (n) s += c[n - 1];
+    return s;
+}
+}  // namespace
+
+extern "C" void fake_set_mode(int park_trial, int stall_after)
+{
+    g_park_trial.store(park_trial); g_stall_after.store(stall_after);
+}
+
+namespace movba {
+
+hipError_t configure_kernels(int) { return hipSuccess; }
+hipError_t configure_pcg_rows() { return hipSuccess; }
+hipError_t configure_struct_kernels() { return hipSuccess; }
+hipError_t configure_dense_kernels() { return hipSuccess; }
+hipError_t configure_dense_persist() { return hipSuccess; }
+hipError_t configure_pose_kernels() { return hipSuccess; }
+bool struct_lds_fits(int, int) { return true; }
+size_t point_lds_need(int NP, int) { return (size_t)NP * 96; }
+size_t point_lds_bytes_for(const DevWindow &w, bool, bool) { return (size_t)w.NP * 96; }
+int schur_blocks(const DevWindow &w) { return 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI)); }
+size_t dense_tiles_doubles(int nfree) { const size_t nt = ((size_t)6 * nfree + kDenseNB - 1) / kDenseNB; return (nt + 1) * (nt + 2) / 2 * (size_t)(kDenseNB * kDenseNB); }
+int dense_ntile(int nfree) { return (6 * nfree + kDenseNB - 1) / kDenseNB; }
+bool dense_persist_supported(const DensePlan &p) { return p.ok; }
+size_t pose_ransac_bytes(int n_hyp) { return (size_t)n_hyp * 64; }
+size_t pose_opt_staged_lds_bytes(int n, int) { return (size_t)n * 48; }
+
+// ---- structure pass: the pair counts for real (the host lays the window out from them), the rest reads its inputs ----
+hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
+{
+    fake_enqueue(s, [sd] {
+        const int nf = sd.nfree;
+        std::vector<int> hs;
+        for (int l = 0; l < sd.P; ++l) {
+            hs.clear();
+            for (int e = sd.pt_start[l]; e < sd.pt_start[l + 1]; ++e) { const int h = sd.hidx[sd.g_pose[e]]; if (h >= 0) hs.push_back(h); }
+            for (size_t a = 0; a < hs.size(); ++a)
+                for (size_t b = a; b < hs.size(); ++b) {
+                    if (a != b && hs[a] == hs[b]) { *sd.error = 1; continue; }
+                    const int lo = hs[a] < hs[b] ? hs[a] : hs[b], hi = hs[a] < hs[b] ? hs[b] : hs[a];
+                    sd.cnt[lo * nf + hi] += 1;
+                }
+        }
+    });
+    return hipSuccess;
+}
+hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt, int seq, hipStream_t s)
+{
+    fake_enqueue(s, [sd, host_cnt, seq] {
+        const int nbins = sd.nfree * sd.nfree;
+        if (host_cnt) {
+            for (int b = 0; b < nbins; ++b) host_cnt[b] = sd.cnt[b];
+            host_cnt[nbins] = *sd.error;
+            __atomic_store_n(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE);
+        }
+        int run = 0;
+        for (int b = 0; b < nbins; ++b) { sd.ent0[b] = run; if (b / sd.nfree < b % sd.nfree) run += sd.cnt[b]; }
+    });
+    return hipSuccess;
+}
+hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s)
+{
+    fake_enqueue(s, [sd] { g_sink += sum_bytes(sd.cnt, sizeof(int32_t) * sd.nfree * sd.nfree); sd.cntw[0] = 0; });
+    return hipSuccess;
+}
+hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s)
+{
+    fake_enqueue(s, [sd] {
+        const int E = sd.pt_start[sd.P];
+        g_sink += sum_bytes(sd.slot, sizeof(int32_t) * E) + sum_bytes(sd.g_pose, sizeof(int32_t) * E) + sum_bytes(sd.hidx, sizeof(int32_t) * sd.NP) + sum_bytes(sd.ent0, 4);
+        if (sd.ent64) sd.ent64[0] = 1; else sd.ent_i[0] = 1;
+    });
+    return hipSuccess;
+}
+hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s)
+{
+    fake_enqueue(s, [=] {
+        for (int g = 0; g < E; ++g) {
+            int sl = slot[g];
+            if (base) { const int b = base[g_pose[g]]; sl = b >= 0 ? b + sl : -1; slot[g] = sl; }
+            if (sl >= 0) slot_point[sl] = g_point[g];
+        }
+    });
+    return hipSuccess;
+}
+
+// ---- the LM controller's protocol ----
+namespace {
+void fake_init(const DevWindow &w)
+{
+    // reads everything the upload sent (the caller's arrays crossed on the copy stream: the solve waits for their event)
+    g_sink += sum_bytes(w.pose0, 56 * (size_t)w.NP) + sum_bytes(w.point0, 24 * (size_t)w.P) + sum_bytes(w.obs, 16 * (size_t)w.E) + sum_bytes(w.isig, 8 * (size_t)w.E) +
+              sum_bytes(w.g_pose, 4 * (size_t)w.E) + sum_bytes(w.g_point, 4 * (size_t)w.E) + sum_bytes(w.slot, 4 * (size_t)w.E) + sum_bytes(w.items, sizeof(Item) * (size_t)w.nitems) +
+              sum_bytes(w.sched, 32) + sum_bytes(w.row_ptr, 4 * ((size_t)w.nfree + 1)) + sum_bytes(w.hidx, 4 * (size_t)w.NP);
+    if (w.obs_r) g_sink += sum_bytes(w.obs_r, 8 * (size_t)w.E);
+    if (w.dense.G > 0) g_sink += sum_bytes(w.dense.tasks, 32) + sum_bytes(w.dense.task_ptr, 4 * ((size_t)w.dense.G + 1));
+    std::memcpy(w.st[0].pose, w.pose0, 56 * (size_t)w.NP);
+    std::memcpy(w.st[0].point, w.point0, 24 * (size_t)w.P);
+    Ctrl *c = w.ctrl;
+    std::memset(c, 0, sizeof(Ctrl));
+    c->nu = 2.0; c->done = (w.max_iters <= 0) ? 1 : 0; c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
+}
+void fake_decide(const DevWindow &w)
+{
+    Ctrl *c = w.ctrl;
+    if (c->done) return;
+    const int stall = g_stall_after.load();
+    if (stall >= 0 && c->n_solves >= stall) return;              // a hung device: no progress, no completion
+    c->n_solves += 1; c->it += 1; c->iters_done = c->it;
+    if (c->n_trace < kMaxTrace) { c->tr_accept[c->n_trace] = 1; c->tr_pcg[c->n_trace] = c->pcg_last_iters; c->n_trace += 1; }
+    if (c->it >= w.max_iters || __atomic_load_n(&w.hstat->stop, __ATOMIC_ACQUIRE)) c->done = 1;
+    __atomic_store_n(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, c->done == 1), __ATOMIC_RELEASE);
+}
+void fake_pcg(const DevWindow &w)
+{
+    Ctrl *c = w.ctrl;
+    if (c->done) return;
+    if (g_park_trial.load() >= 0 && c->n_solves >= g_park_trial.load() && c->solver_mode == 0) {
+        c->solver_mode = 1; c->direct_from = c->n_solves; c->n_pause += 1; c->done = 2;
+        __atomic_store_n(&w.hstat->pause_seq, c->n_pause, __ATOMIC_RELEASE);
+        return;
+    }
+    c->pcg_last_iters = 7; c->pcg_total_iters += 7;
+}
+void fake_direct(const DevWindow &w)
+{
+    Ctrl *c = w.ctrl;
+    if (c->done == 1) return;
+    if (w.dense.G > 0) g_sink += sum_bytes(w.dense.flags, 16);
+    c->pcg_last_iters = -1; c->n_direct += 1;
+    if (c->done == 2) c->done = 0;
+}
+void fake_finalize(const DevWindow &w)
+{
+    for (int e = 0; e < w.E; ++e) { w.out_chi2[e] = 1.0; w.out_outlier[e] = 0; }
+    if (w.pose_export) std::memcpy(w.pose_export, w.st[0].pose, 56 * (size_t)w.NP);
+    std::memcpy(w.ctrl_out, w.ctrl, sizeof(Ctrl));
+    if (w.ctrl->done == 1) __atomic_store_n(&w.hstat->progress, HostStatus::pack(w.ctrl->n_solves, w.ctrl->it, 1), __ATOMIC_RELEASE);
+}
+}  // namespace
+
+hipError_t launch_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_init(w); }); return hipSuccess; }
+hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done; }); return hipSuccess; }
+hipError_t launch_schur(const DevWindow &w, int, int, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + (w.ent64 ? (long)w.ent64[0] : (long)w.ent_i[0]) + w.slot_point[0]; }); return hipSuccess; }
+hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->lambda = 1e-3; }); return hipSuccess; }
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done; }); return hipSuccess; }
+hipError_t launch_decide(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_decide(w); }); return hipSuccess; }
+hipError_t launch_finalize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_finalize(w); }); return hipSuccess; }
+hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
+{
+    fake_enqueue(s, [w, d] {
+        if (d.poses) std::memcpy(d.poses, w.st[0].pose, 56 * (size_t)w.NP);
+        if (d.points) std::memcpy(d.points, w.st[0].point, 24 * (size_t)w.P);
+        if (d.chi2) std::memcpy(d.chi2, w.out_chi2, 8 * (size_t)w.E);
+        std::memcpy(d.outlier, w.out_outlier, (size_t)w.E);
+    });
+    return hipSuccess;
+}
+hipError_t launch_pcg_rows(const DevWindow &w, int, const PcgParams &, int, hipStream_t s) { fake_enqueue(s, [w] { fake_pcg(w); }); return hipSuccess; }
+hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_direct(w); }); return hipSuccess; }
+hipError_t launch_dense_persist(const DevWindow &w, unsigned, hipStream_t s) { fake_enqueue(s, [w] { fake_direct(w); }); return hipSuccess; }
+
+// ---- batched launches: the same closures over the windows of the batch (the device arrays are read where the host put them) ----
+hipError_t launch_init_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_init(b.wins[i]); }); return hipSuccess; }
+hipError_t launch_point_batch(const BatchDev &b, int, bool, bool, bool, size_t, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) g_sink += b.wins[i].ctrl->done + b.blk_point[i]; }); return hipSuccess; }
+hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) g_sink += b.wins[i].ctrl->done + b.blk_schur[i]; }); return hipSuccess; }
+hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) b.wins[i].ctrl->lambda = 1e-3; }); return hipSuccess; }
+hipError_t launch_decide_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_decide(b.wins[i]); }); return hipSuccess; }
+hipError_t launch_finalize_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_finalize(b.wins[i]); }); return hipSuccess; }
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i]); } }); return hipSuccess; }
+
+// ---- pose-only optimisation: echoes the start pose, every match an inlier ----
+hipError_t launch_pose_hyp(const PoseDev &p, hipStream_t s) { fake_enqueue(s, [p] { g_sink += sum_bytes(p.Xw, 24 * (size_t)p.n) + sum_bytes(p.samples, 12 * (size_t)p.n_hyp); }); return hipSuccess; }
+hipError_t launch_pose_opt(const PoseDev &p, bool, hipStream_t s)
+{
+    fake_enqueue(s, [p] {
+        g_sink += sum_bytes(p.obs, 16 * (size_t)p.n) + sum_bytes(p.isig, 8 * (size_t)p.n);
+        for (int k = 0; k < 7; ++k) { p.pose_out[k] = p.pose0[k]; p.pose_out[9 + k] = p.pose0[k]; }
+        p.pose_out[7] = p.n; p.pose_out[8] = p.n; p.pose_out[16] = 1;
+        for (int i = 0; i < p.n; ++i) { p.chi2[i] = 0.5; p.level1[i] = 0; }
+    });
+    return hipSuccess;
+}
+
+}  // namespace movba

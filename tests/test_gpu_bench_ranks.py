@@ -1,0 +1,45 @@
+"""bench.py's N > 1 path on the GPU box (one GPU there: MOVBA_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo for
+the pose all-gather, RCCL refuses two ranks on one device): launch, one window per rank (BASELINE cfg5: weak scaling, no
+data-path collective), barrier + max-over-ranks timing, the gathered poses and the ONE JSON line of rank 0.  The 8-GPU curve
+itself is the driver's to measure."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from movba import shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_with_two_ranks_gathers_the_poses_of_both_windows(built_lib, tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dump = str(tmp_path / "poses.npy")
+    env = dict(os.environ, MOVBA_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", MOVBA_BENCH_DUMP_POSES=dump)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)     # a fresh child process, not an exec of this one
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["unit"] == "LM iterations/s" and "roofline" in out and "rehearsal" in out["config"]["parallelism"]
+    # both ranks solved 10 LM iterations per step: whole-job value = all ranks' solves / max-over-ranks time
+    assert abs(out["value"] - 2 * 10 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    g = np.load(dump)
+    assert g.shape[0] == 2 and g.shape[-1] == 7
+    # rank 0 solved cfg3 (seed 1003), rank 1 the cfg5 window of seed 2001: each block equals the solo solve of its window
+    sv = built_lib.Solver()
+    try:
+        for rank, seed in ((0, 1003), (1, shard.window_seed(1))):
+            w = synth.make_window(50, 10, 20000, seed, run_lo=2, run_hi=10)
+            r = sv.solve(w)
+            assert np.array_equal(g[rank].reshape(-1, 7), r["poses"]), rank
+    finally:
+        sv.close()

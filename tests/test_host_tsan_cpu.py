@@ -1,0 +1,21 @@
+"""libmovba's HOST side under ThreadSanitizer on the CPU: api.cpp (upload with its helper thread and the shared copy stream, the
+LM loop polling the device's progress, park / resume for the direct solver, batched runs, the stop flag, the watchdog),
+structure.cpp, dense_plan.cpp and pcg_plan.cpp compiled against a stand-in HIP runtime whose streams are threads
+(tests/hipstub/: test infrastructure, nothing of it ships), driven from several threads.  The fake device follows the LM
+controller's protocol and can park a solve or stop making progress; it computes no bundle adjustment."""
+import os
+import subprocess
+
+from conftest import ROOT
+
+STUB = os.path.join(ROOT, "tests", "hipstub")
+
+
+def test_host_state_machine_is_race_free_and_the_watchdog_fires_on_a_stalled_device():
+    subprocess.check_call(["make", "-C", STUB, "-s"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66")
+    p = subprocess.run([os.path.join(STUB, "host_tsan_driver")], env=env, capture_output=True, text=True, timeout=600)
+    assert "WARNING: ThreadSanitizer" not in p.stderr, p.stderr[:4000]
+    assert p.returncode == 0 and p.stdout.strip().endswith("HOST-TSAN OK"), p.stderr[-2000:]
+    # scenario 5 of the driver: a device that stops making progress gives the call back through the watchdog
+    assert "device made no progress for 200 ms" in p.stderr
