@@ -30,16 +30,18 @@ def test_bench_with_two_ranks_gathers_the_poses_of_both_windows(built_lib, tmp_p
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["unit"] == "LM iterations/s" and "roofline" in out and "rehearsal" in out["config"]["parallelism"]
-    # both ranks solved 10 LM iterations per step: whole-job value = all ranks' solves / max-over-ranks time
-    assert abs(out["value"] - 2 * 10 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     g = np.load(dump)
     assert g.shape[0] == 2 and g.shape[-1] == 7
     # rank 0 solved cfg3 (seed 1003), rank 1 the cfg5 window of seed 2001: each block equals the solo solve of its window
     sv = built_lib.Solver()
+    solves = 0
     try:
         for rank, seed in ((0, 1003), (1, shard.window_seed(1))):
             w = synth.make_window(50, 10, 20000, seed, run_lo=2, run_hi=10)
             r = sv.solve(w)
             assert np.array_equal(g[rank].reshape(-1, 7), r["poses"]), rank
+            solves += r["n_solves"]
     finally:
         sv.close()
+    # whole-job value = the LM iterations of ALL ranks' steps / the max-over-ranks time of the timed region
+    assert abs(out["value"] - solves * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
