@@ -239,6 +239,15 @@ typedef struct {
      * all matches at chi2_gate and the best one starts the LM when it has at least 4 inliers.  0: LM from pose0. */
     int32_t ransac_iters;       /* <= MOVBA_MAX_RANSAC_ITERS                                  */
     uint32_t ransac_seed;
+    /* `confidence` of cv::solvePnPRansac (Optimizer.cc:437; 0.95 in TartanAir.yaml): the standard stopping rule
+     * N = log(1 - confidence) / log(1 - w^3), w = inlier ratio of the best hypothesis so far.  The device scores all
+     * ransac_iters samples at once; the rule decides which of them a sequential RANSAC over the same samples would have
+     * drawn: only those are eligible (ransac_samples_used in the result).  <= 0 or >= 1: all samples are eligible.
+     * lo_iters > 0: one local-optimisation step on the winner (USAC's LO): LM refit on its inliers (no robust kernel,
+     * lo_iters iterations), kept when the refit pose scores more inliers (ties: lower truncated cost). */
+    double  confidence;
+    int32_t lo_iters;
+    int32_t pad_p;
 } movba_pose_desc;
 
 #define MOVBA_MAX_RANSAC_ITERS 256
@@ -252,6 +261,10 @@ typedef struct {
     int32_t  ransac_inliers;    /* inliers of the best hypothesis (0: stage off, or no candidate with >= 4)  */
     int32_t  lm_iters;          /* LM iterations run over the 4 rounds (g2o stops a round early when the cost stops changing) */
     double   ransac_pose[7];    /* the pose the LM started from                               */
+    int32_t  ransac_samples_used;   /* minimal samples the stopping rule admitted (<= ransac_iters)                  */
+    int32_t  lo_accepted;       /* 1: the local-optimisation refit replaced the winning hypothesis                   */
+    int32_t  lo_inliers;        /* inliers of the pose the LM started from, at chi2_gate (after the LO step)          */
+    int32_t  pad_q;
 } movba_pose_result;
 
 int  movba_pose_opt(movba_handle *h, const movba_pose_desc *desc, movba_pose_result *res);

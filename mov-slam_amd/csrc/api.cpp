@@ -1603,6 +1603,7 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
 {
     if (!h || !d || !res) return MOVBA_ERR_ARG;
     res->status = MOVBA_ERR_ARG; res->n_inliers = 0; res->ransac_inliers = 0; res->lm_iters = 0;
+    res->ransac_samples_used = 0; res->lo_accepted = 0; res->lo_inliers = 0; res->pad_q = 0;
     const int n = d->n;
     const int n_hyp = d->ransac_iters > 0 ? std::min(d->ransac_iters, (int32_t)MOVBA_MAX_RANSAC_ITERS) : 0;
     if (n < 0 || (n && (!d->Xw || !d->obs)) || d->rounds < 1 || d->its_per_round < 1) return MOVBA_ERR_ARG;
@@ -1645,6 +1646,7 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     if (need_arena) HIP_TRY(hipMemcpyAsync(h->pose_arena, sg, h2d, hipMemcpyHostToDevice, h->stream));
     PoseDev p{};
     p.n = n; p.rounds = d->rounds; p.its = d->its_per_round; p.n_hyp = n_hyp; p.hyp_done = 0;
+    p.confidence = d->confidence; p.lo_its = n_hyp > 0 && d->lo_iters > 0 ? d->lo_iters : 0;
     p.fx = d->fx; p.fy = d->fy; p.cx = d->cx; p.cy = d->cy; p.huber_delta = d->huber_delta; p.chi2_gate = d->chi2_gate;
     for (int k = 0; k < 7; ++k) p.pose0[k] = d->pose0[k];
     char *in = need_arena ? h->pose_arena : h->stage_dev;          // where the kernels read the matches
@@ -1665,6 +1667,7 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     res->n_inliers = (int32_t)po[7];
     res->ransac_inliers = n_hyp > 0 ? (int32_t)po[8] : 0;
     res->lm_iters = (int32_t)po[16];
+    res->ransac_samples_used = n_hyp > 0 ? (int32_t)po[17] : 0; res->lo_accepted = n_hyp > 0 ? (int32_t)po[18] : 0; res->lo_inliers = n_hyp > 0 ? (int32_t)po[19] : 0;
     for (int k = 0; k < 7; ++k) res->ransac_pose[k] = n_hyp > 0 ? po[9 + k] : d->pose0[k];
     if (res->outlier) std::memcpy(res->outlier, sg + o_lvl, (size_t)n);
     if (res->chi2) std::memcpy(res->chi2, sg + o_chi, sizeof(double) * (size_t)n);

@@ -376,6 +376,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     quat_normalize_exact(pose0);
     for (int i = tid; i < p.n; i += kT) level1[i] = 0;
     __syncthreads();
+    bool have_hyp = false;
     if (p.n_hyp > 0) {
         // ---- hypothesis stage (see the header of the P3P block): thread h solves sample h, then every wave scores candidates ----
         // n_hyp x 4 x 12 poses, then x 2 scores: in LDS when this workgroup runs the stage itself and the matches are staged,
@@ -390,11 +391,24 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             for (int cidx = wv; cidx < 4 * p.n_hyp; cidx += kW) hyp_score(p, Xw, obs, isig, cidx, cand, nsol, score, lane);
         }
         __syncthreads();
-        // best candidate: most inliers, then lowest truncated cost, then lowest index; every thread scans the same table
-        int best = -1; double bc = 3.5, bs = DBL_MAX;                   // a pose needs at least 4 inliers to replace the caller's
-        for (int cidx = 0; cidx < 4 * p.n_hyp; ++cidx) {
-            const double cnt = score[2 * cidx], cst = score[2 * cidx + 1];
-            if (cnt > bc || (cnt == bc && best >= 0 && cst < bs)) { best = cidx; bc = cnt; bs = cst; }
+        // best candidate: most inliers, then lowest truncated cost, then lowest index; every thread scans the same table.
+        // The samples are walked in the order a sequential RANSAC would draw them, with its stopping rule (cv::solvePnPRansac's
+        // `confidence`, Optimizer.cc:437): after sample h, N = log(1 - confidence) / log(1 - w^3) with w the inlier ratio of the best
+        // pose so far; the walk ends once h + 1 >= N — hypotheses behind that point were scored (all at once, on the grid) but are
+        // not eligible, as they would never have been drawn.
+        int best = -1, used = p.n_hyp; double bc = 3.5, bs = DBL_MAX;   // a pose needs at least 4 inliers to replace the caller's
+        const bool stop_rule = p.confidence > 0.0 && p.confidence < 1.0;
+        const double lconf = stop_rule ? log(1.0 - p.confidence) : 0.0;
+        for (int h = 0; h < p.n_hyp; ++h) {
+            for (int cidx = 4 * h; cidx < 4 * h + 4; ++cidx) {
+                const double cnt = score[2 * cidx], cst = score[2 * cidx + 1];
+                if (cnt > bc || (cnt == bc && best >= 0 && cst < bs)) { best = cidx; bc = cnt; bs = cst; }
+            }
+            if (stop_rule && best >= 0) {
+                const double wr = bc / (double)p.n, w3 = wr * wr * wr;
+                const double need = w3 >= 1.0 ? 0.0 : lconf / log(1.0 - w3);
+                if ((double)(h + 1) >= need) { used = h + 1; break; }
+            }
         }
         if (best >= 0) {
             const double *R = cand + (size_t)best * 12;
@@ -404,11 +418,12 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             R2q(Rm, pose0);
             pose0[4] = R[9]; pose0[5] = R[10]; pose0[6] = R[11];
         }
+        have_hyp = best >= 0;
         if (tid == 0) {
-            p.pose_out[8] = best >= 0 ? bc : 0.0;
 #pragma unroll
             for (int k = 0; k < 7; ++k) p.pose_out[9 + k] = pose0[k];
         }
+        if (tid == 0) { p.pose_out[8] = best >= 0 ? bc : 0.0; p.pose_out[17] = (double)used; p.pose_out[18] = 0.0; p.pose_out[19] = best >= 0 ? bc : 0.0; }
         __syncthreads();
     }
     double pose[7];
@@ -437,16 +452,14 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     };
 
     int n_bad = 0, n_lm = 0;
-    for (int round = 0; round < p.rounds; ++round) {
-        const bool robust = round <= 2;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) pose[k] = pose0[k];
+    // the LM iterations of one round over the active matches (level1 == 0), from and into `pose`
+    auto lm_round = [&](bool robust, int its) {
         double cnt[1] = { 0.0 };
         for (int i = tid; i < p.n; i += kT) cnt[0] += level1[i] ? 0.0 : 1.0;
         reduce_all<1>(cnt, lds);
         bool ok = cnt[0] > 0.0;
         double lambda = 0.0, ni = 2.0;
-        for (int it = 0; it < p.its && ok; ++it) {
+        for (int it = 0; it < its && ok; ++it) {
             ++n_lm;
             // computeActiveErrors + buildSystem in one pass
             double R[12];
@@ -524,6 +537,56 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             } while (rho < 0.0 && qmax < 10);
             if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = false;
         }
+    };
+    // inliers of a pose at the hypothesis threshold: count and truncated cost (the scores of the hypothesis stage)
+    auto score_pose = [&](const double T[7], double &cnt_o, double &cst_o, bool mark) {
+        double R[12];
+        q2R(T, R);
+        double sc[2] = { 0.0, 0.0 };
+        for (int i = tid; i < p.n; i += kT) {
+            const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
+            const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
+            const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
+            const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
+            const double om = isig[i];
+            const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
+            const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+            const bool in = (z > 0.0) && (chi2 <= p.chi2_gate);
+            sc[0] += in ? 1.0 : 0.0; sc[1] += in ? chi2 : p.chi2_gate;
+            if (mark) level1[i] = in ? 0 : 1;
+        }
+        reduce_all<2>(sc, lds);
+        cnt_o = sc[0]; cst_o = sc[1];
+    };
+    // ---- local optimisation of the winning hypothesis (USAC's LO step; cv::solvePnPRansac refits on the inliers too): LM on its
+    // inliers without robust kernel, kept when the refit pose has more inliers at the same threshold (ties: lower truncated
+    // cost).  The four rounds below then start from that pose, over all matches. ----
+    if (have_hyp && p.lo_its > 0) {
+        double c0, s0, c1, s1;
+        __syncthreads();
+        score_pose(pose0, c0, s0, true);
+        __syncthreads();
+        lm_round(false, p.lo_its);
+        score_pose(pose, c1, s1, false);
+        const bool keep = c1 > c0 || (c1 == c0 && s1 < s0);
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) pose0[k] = pose[k];
+        }
+        __syncthreads();
+        for (int i = tid; i < p.n; i += kT) level1[i] = 0;
+        if (tid == 0) {
+            p.pose_out[18] = keep ? 1.0 : 0.0; p.pose_out[19] = keep ? c1 : c0;
+#pragma unroll
+            for (int k = 0; k < 7; ++k) p.pose_out[9 + k] = pose0[k];
+        }
+        __syncthreads();
+    }
+    for (int round = 0; round < p.rounds; ++round) {
+        const bool robust = round <= 2;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pose[k] = pose0[k];
+        lm_round(robust, p.its);
         // classify every match at the round's final pose (mvbOutlier, Optimizer.cc:452-456)
         double R[12];
         q2R(pose, R);

@@ -777,10 +777,12 @@ namespace MOV_SLAM
     int Optimizer::PoseOptimization(Frame *pFrame, const bool isLost, const int iterationCount, const double reprojectionError,
                                     const double reprojectErrorLost, const double confidence, const int algorithm)
     {
-        // `confidence` (early termination of the sampling) and `algorithm` (which OpenCV sampler / scorer: 38 = USAC_MAGSAC)
-        // steer cv::solvePnPRansac's internals; the hypothesis stage here always draws iterationCount minimal samples and
-        // scores them by inlier count at the reprojection threshold
-        (void)confidence; (void)algorithm;
+        // `confidence` is cv::solvePnPRansac's stopping rule: the hypothesis stage scores all iterationCount minimal samples at
+        // once, and only those a sequential RANSAC over the same samples would have drawn before stopping are eligible.
+        // `algorithm` picks OpenCV's sampler / scorer (38 = USAC_MAGSAC, sigma-consensus scoring): the stage here scores by inlier
+        // count at the reprojection threshold (ties by truncated cost), followed — like the USAC pipeline — by one local
+        // optimisation of the winner on its inliers and the final refit (the four LM rounds); the flag itself is not interpreted.
+        (void)algorithm;
         // ---- gather 3D-2D matches (Optimizer.cc:404-413) ----
         std::vector<double> Xw, obs;
         std::vector<int> indx;
@@ -821,6 +823,8 @@ namespace MOV_SLAM
         // scored on the GPU, the best one starts the LM
         d.ransac_iters = std::max(0, iterationCount);
         d.ransac_seed = kPoseRansacSeed;
+        d.confidence = confidence;
+        d.lo_iters = 10;
         std::vector<uint8_t> outl(indx.size(), 1);
         movba_pose_result r{};
         r.outlier = outl.data(); r.chi2 = nullptr;

@@ -74,12 +74,14 @@ class PoseDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("Xw", _d), ("obs", _d), ("inv_sigma2", _d),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("pose0", C.c_double * 7), ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
-                ("rounds", C.c_int32), ("its_per_round", C.c_int32), ("ransac_iters", C.c_int32), ("ransac_seed", C.c_uint32)]
+                ("rounds", C.c_int32), ("its_per_round", C.c_int32), ("ransac_iters", C.c_int32), ("ransac_seed", C.c_uint32),
+                ("confidence", C.c_double), ("lo_iters", C.c_int32), ("pad_p", C.c_int32)]
 
 
 class PoseResult(C.Structure):
     _fields_ = [("pose", C.c_double * 7), ("outlier", _u), ("chi2", _d), ("n_inliers", C.c_int32), ("status", C.c_int32),
-                ("ransac_inliers", C.c_int32), ("lm_iters", C.c_int32), ("ransac_pose", C.c_double * 7)]
+                ("ransac_inliers", C.c_int32), ("lm_iters", C.c_int32), ("ransac_pose", C.c_double * 7),
+                ("ransac_samples_used", C.c_int32), ("lo_accepted", C.c_int32), ("lo_inliers", C.c_int32), ("pad_q", C.c_int32)]
 
 
 EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destroy", "movba_lba_solve",
@@ -350,7 +352,8 @@ class Solver:
     def set_profile_mask(self, mask: int):
         lib().movba_set_profile_mask(self._h, mask)
 
-    def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None, ransac_iters=0, ransac_seed=1) -> dict:
+    def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None, ransac_iters=0, ransac_seed=1,
+                 confidence=0.0, lo_iters=0) -> dict:
         Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
         n = len(Xw)
         d = PoseDesc()
@@ -362,10 +365,12 @@ class Solver:
         d.pose0 = (C.c_double * 7)(*pose0)
         d.huber_delta, d.chi2_gate, d.rounds, d.its_per_round = huber_delta, chi2_gate, rounds, its
         d.ransac_iters, d.ransac_seed = ransac_iters, ransac_seed
+        d.confidence, d.lo_iters = confidence, lo_iters
         outl = np.zeros(n, np.uint8); chi2 = np.zeros(n)
         r = PoseResult(); r.outlier = _p(outl, _u); r.chi2 = _p(chi2, _d)
         rc = lib().movba_pose_opt(self._h, C.byref(d), C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_pose_opt: {status_string(rc)}")
         return dict(status=rc, n_inliers=r.n_inliers, pose=np.array(r.pose[:]), outlier=outl, chi2=chi2,
-                    ransac_inliers=r.ransac_inliers, ransac_pose=np.array(r.ransac_pose[:]), lm_iters=r.lm_iters)
+                    ransac_inliers=r.ransac_inliers, ransac_pose=np.array(r.ransac_pose[:]), lm_iters=r.lm_iters,
+                    ransac_samples_used=r.ransac_samples_used, lo_accepted=r.lo_accepted, lo_inliers=r.lo_inliers)

@@ -742,12 +742,87 @@ static double pose_errors(const lba_oracle_pose_problem *pb, const double pose[7
     return F;
 }
 
+/* The LM iterations of one round of the pose-only optimisation over the active matches (level1[i] == 0), from and into `pose`
+ * (g2o's OptimizationAlgorithmLevenberg on one VertexSE3Expmap with EdgeSE3ProjectXYZOnlyPose edges: SURVEY App. A.4). */
+static void pose_lm_round(const lba_oracle_pose_problem *pb, double pose[7], const uint8_t *level1, int robust, int its, double *err)
+{
+    const int n = pb->n;
+    const double cam[4] = { pb->fx, pb->fy, pb->cx, pb->cy };
+    const double I9[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+        int n_act = 0;
+    for (int i = 0; i < n; ++i) n_act += !level1[i];
+    double lambda = 0.0, ni = 2.0;
+    int ok = n_act > 0;
+    for (int it = 0; it < its && ok; ++it) {
+        double F0 = pose_errors(pb, pose, level1, robust, err);
+        double H[36] = { 0 }, b[6] = { 0 };
+        for (int i = 0; i < n; ++i) {
+            if (level1[i]) continue;
+            double Xc[3], Jp[6], Jc[12];
+            lba_oracle_se3_map(pose, pb->Xw + 3 * i, Xc);
+            edge_jacobians(I9, Xc, cam, Jp, Jc);
+            const double om = pb->inv_sigma2[i];
+            double wgt = 1.0;
+            if (robust && pb->huber_delta > 0.0) {
+                double rho[3];
+                lba_oracle_huber(om * (err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]), pb->huber_delta, rho);
+                wgt = rho[1];
+            }
+            const double wo = wgt * om, r0 = -om * err[2 * i] * wgt, r1 = -om * err[2 * i + 1] * wgt;
+            for (int a = 0; a < 6; ++a) {
+                b[a] += Jc[a] * r0 + Jc[6 + a] * r1;
+                for (int c = 0; c < 6; ++c) H[a * 6 + c] += wo * (Jc[a] * Jc[c] + Jc[6 + a] * Jc[6 + c]);
+            }
+        }
+        if (it == 0) {
+            double md = 0.0;
+            for (int a = 0; a < 6; ++a) md = fmax(fabs(H[a * 7]), md);
+            lambda = 1e-5 * md;
+            ni = 2.0;
+        }
+        double rho = 0.0;
+        int qmax = 0;
+        do {
+            double bk[7], Hd[36], x[6];
+            memcpy(bk, pose, sizeof bk);
+            memcpy(Hd, H, sizeof Hd);
+            for (int a = 0; a < 6; ++a) Hd[a * 7] += lambda;
+            const int ok2 = chol_solve(Hd, 6, b, x);
+            if (ok2) {
+                double ex[7];
+                lba_oracle_se3_exp(x, ex);
+                lba_oracle_se3_mul(ex, pose, pose);
+            }
+            double F1 = pose_errors(pb, pose, level1, robust, err);
+            if (!ok2) F1 = DBL_MAX;
+            double scale = 0.0;
+            if (ok2) for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+            scale += 1e-3;
+            rho = (F0 - F1) / scale;
+            if (rho > 0.0 && isfinite(F1)) {
+                double alpha = 1.0 - pow(2.0 * rho - 1.0, 3);
+                alpha = fmin(alpha, 2.0 / 3.0);
+                lambda *= fmax(1.0 / 3.0, alpha);
+                ni = 2.0;
+                F0 = F1;
+            } else {
+                lambda *= ni;
+                ni *= 2.0;
+                memcpy(pose, bk, sizeof bk);
+                if (!isfinite(lambda)) { qmax++; break; }
+            }
+            qmax++;
+        } while (rho < 0.0 && qmax < 10);
+        if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = 0;
+    }
+}
+
 int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
                         uint8_t *outlier, double *chi2_out)
 {
     const int n = pb->n;
     const double cam[4] = { pb->fx, pb->fy, pb->cx, pb->cy };
-    const double I9[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    
     double *err = (double *)calloc(2 * (size_t)n + 2, sizeof(double));
     uint8_t *level1 = (uint8_t *)calloc((size_t)n + 1, 1);
     double pose[7], pose0[7];
@@ -759,72 +834,7 @@ int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
     for (int round = 0; round < pb->rounds; ++round) {
         const int robust = (round <= 2) ? 1 : 0;           /* kernel dropped after round 2 */
         memcpy(pose, pose0, sizeof pose);                  /* restart from the initial estimate */
-        int n_act = 0;
-        for (int i = 0; i < n; ++i) n_act += !level1[i];
-        double lambda = 0.0, ni = 2.0;
-        int ok = n_act > 0;
-        for (int it = 0; it < pb->its_per_round && ok; ++it) {
-            double F0 = pose_errors(pb, pose, level1, robust, err);
-            double H[36] = { 0 }, b[6] = { 0 };
-            for (int i = 0; i < n; ++i) {
-                if (level1[i]) continue;
-                double Xc[3], Jp[6], Jc[12];
-                lba_oracle_se3_map(pose, pb->Xw + 3 * i, Xc);
-                edge_jacobians(I9, Xc, cam, Jp, Jc);
-                const double om = pb->inv_sigma2[i];
-                double wgt = 1.0;
-                if (robust && pb->huber_delta > 0.0) {
-                    double rho[3];
-                    lba_oracle_huber(om * (err[2 * i] * err[2 * i] + err[2 * i + 1] * err[2 * i + 1]), pb->huber_delta, rho);
-                    wgt = rho[1];
-                }
-                const double wo = wgt * om, r0 = -om * err[2 * i] * wgt, r1 = -om * err[2 * i + 1] * wgt;
-                for (int a = 0; a < 6; ++a) {
-                    b[a] += Jc[a] * r0 + Jc[6 + a] * r1;
-                    for (int c = 0; c < 6; ++c) H[a * 6 + c] += wo * (Jc[a] * Jc[c] + Jc[6 + a] * Jc[6 + c]);
-                }
-            }
-            if (it == 0) {
-                double md = 0.0;
-                for (int a = 0; a < 6; ++a) md = fmax(fabs(H[a * 7]), md);
-                lambda = 1e-5 * md;
-                ni = 2.0;
-            }
-            double rho = 0.0;
-            int qmax = 0;
-            do {
-                double bk[7], Hd[36], x[6];
-                memcpy(bk, pose, sizeof bk);
-                memcpy(Hd, H, sizeof Hd);
-                for (int a = 0; a < 6; ++a) Hd[a * 7] += lambda;
-                const int ok2 = chol_solve(Hd, 6, b, x);
-                if (ok2) {
-                    double ex[7];
-                    lba_oracle_se3_exp(x, ex);
-                    lba_oracle_se3_mul(ex, pose, pose);
-                }
-                double F1 = pose_errors(pb, pose, level1, robust, err);
-                if (!ok2) F1 = DBL_MAX;
-                double scale = 0.0;
-                if (ok2) for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
-                scale += 1e-3;
-                rho = (F0 - F1) / scale;
-                if (rho > 0.0 && isfinite(F1)) {
-                    double alpha = 1.0 - pow(2.0 * rho - 1.0, 3);
-                    alpha = fmin(alpha, 2.0 / 3.0);
-                    lambda *= fmax(1.0 / 3.0, alpha);
-                    ni = 2.0;
-                    F0 = F1;
-                } else {
-                    lambda *= ni;
-                    ni *= 2.0;
-                    memcpy(pose, bk, sizeof bk);
-                    if (!isfinite(lambda)) { qmax++; break; }
-                }
-                qmax++;
-            } while (rho < 0.0 && qmax < 10);
-            if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = 0;
-        }
+        pose_lm_round(pb, pose, level1, robust, pb->its_per_round, err);
         /* re-classify every correspondence at the round's final pose */
         n_bad = 0;
         for (int i = 0; i < n; ++i) {
@@ -970,11 +980,35 @@ static int p3p_grunert(double X[3][3], double j[3][3], double Rs[4][9], double t
 
 /* Best pose over n_hyp minimal samples (n_hyp x 3 match indices).  pose_out = pb->pose0 (normalised) when no candidate
  * reaches 4 inliers.  Returns the inlier count of the pose returned (0 in that case). */
-int lba_oracle_pose_ransac(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double pose_out[7])
+static void pose_score(const lba_oracle_pose_problem *pb, const double pose[7], double *cnt_o, double *cst_o, uint8_t *mark)
+{
+    const double cam[4] = { pb->fx, pb->fy, pb->cx, pb->cy };
+    double cnt = 0.0, cst = 0.0;
+    for (int i = 0; i < pb->n; ++i) {
+        double Xc[3], e[2];
+        lba_oracle_se3_map(pose, pb->Xw + 3 * i, Xc);
+        edge_error(Xc, pb->obs + 2 * i, cam, e);
+        const double om = pb->inv_sigma2 ? pb->inv_sigma2[i] : 1.0;
+        const double chi2 = om * (e[0] * e[0] + e[1] * e[1]);
+        const int in = (Xc[2] > 0.0) && (chi2 <= pb->chi2_gate);
+        cnt += in ? 1.0 : 0.0; cst += in ? chi2 : pb->chi2_gate;
+        if (mark) mark[i] = in ? 0 : 1;
+    }
+    *cnt_o = cnt; *cst_o = cst;
+}
+
+/* The same with cv::solvePnPRansac's stopping rule and one local-optimisation step (Optimizer.cc:437: confidence 0.95,
+ * flag 38 = USAC_MAGSAC, whose pipeline refits the best model on its inliers):
+ *   confidence in (0, 1): the samples are walked in order; after sample h, N = log(1 - confidence) / log(1 - w^3) with w the
+ *     inlier ratio of the best pose so far, and the walk ends once h + 1 >= N (info[0] = samples admitted);
+ *   lo_its > 0: LM refit of the winner on its inliers at chi2_gate, no robust kernel, lo_its iterations; kept when it has
+ *     more inliers, or as many at a lower truncated cost (info[1] = kept, info[2] = inliers of the pose returned). */
+int lba_oracle_pose_ransac_lo(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double confidence, int lo_its,
+                              double pose_out[7], int32_t info[3])
 {
     const int n = pb->n;
     double best_cnt = 3.5, best_cost = DBL_MAX, bestR[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, bestt[3] = { 0, 0, 0 };
-    int have = 0;
+    int have = 0, used = n_hyp;
     for (int h = 0; h < n_hyp; ++h) {
         double X[3][3], jb[3][3];
         int okh = 1;
@@ -1007,14 +1041,38 @@ int lba_oracle_pose_ransac(const lba_oracle_pose_problem *pb, int n_hyp, const i
                 memcpy(bestR, R, sizeof bestR); memcpy(bestt, t, sizeof bestt);
             }
         }
+        if (confidence > 0.0 && confidence < 1.0 && have) {
+            const double wr = best_cnt / (double)n, w3 = wr * wr * wr;
+            const double need = w3 >= 1.0 ? 0.0 : log(1.0 - confidence) / log(1.0 - w3);
+            if ((double)(h + 1) >= need) { used = h + 1; break; }
+        }
     }
+    if (info) { info[0] = used; info[1] = 0; info[2] = have ? (int32_t)best_cnt : 0; }
     memcpy(pose_out, pb->pose0, 7 * sizeof(double));
     lba_oracle_se3_normalize(pose_out);
     if (!have) return 0;
     R_to_quat(bestR, pose_out);
     pose_out[4] = bestt[0]; pose_out[5] = bestt[1]; pose_out[6] = bestt[2];
     lba_oracle_se3_normalize(pose_out);
+    if (lo_its > 0) {
+        uint8_t *mark = (uint8_t *)calloc((size_t)n + 1, 1);
+        double *err = (double *)calloc(2 * (size_t)n + 2, sizeof(double));
+        double c0, s0, c1, s1, refit[7];
+        pose_score(pb, pose_out, &c0, &s0, mark);
+        memcpy(refit, pose_out, sizeof refit);
+        pose_lm_round(pb, refit, mark, 0, lo_its, err);
+        pose_score(pb, refit, &c1, &s1, NULL);
+        const int keep = c1 > c0 || (c1 == c0 && s1 < s0);
+        if (keep) memcpy(pose_out, refit, sizeof refit);
+        if (info) { info[1] = keep; info[2] = (int32_t)(keep ? c1 : c0); }
+        free(mark); free(err);
+    }
     return (int)best_cnt;
+}
+
+int lba_oracle_pose_ransac(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double pose_out[7])
+{
+    return lba_oracle_pose_ransac_lo(pb, n_hyp, samples, 0.0, 0, pose_out, NULL);
 }
 
 

@@ -127,6 +127,9 @@ int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
  * (n_hyp x 3 match indices), scored at pb->chi2_gate; pose_out = normalised pb->pose0 and 0 when no candidate has
  * >= 4 inliers.  Returns the inlier count of the returned pose. */
 int lba_oracle_pose_ransac(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double pose_out[7]);
+/* ... with the stopping rule of `confidence` and one local-optimisation step (lba_oracle.c); info: samples admitted, refit kept, inliers */
+int lba_oracle_pose_ransac_lo(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double confidence, int lo_its,
+                              double pose_out[7], int32_t info[3]);
 
 /* threads of the OpenMP timing variant (liblba_oracle_omp.so); the serial library always answers 1 */
 int lba_oracle_set_threads(int n);

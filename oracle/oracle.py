@@ -172,8 +172,9 @@ def pose_opt(Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_
     return dict(n_inliers=ninl, pose=pose, outlier=outl, chi2=chi2)
 
 
-def pose_ransac(Xw, obs, pose0, cam, chi2_gate, samples, inv_sigma2=None) -> dict:
-    """Hypothesis stage of PoseOptimization: best P3P pose over the given minimal samples ((H, 3) match indices)."""
+def pose_ransac(Xw, obs, pose0, cam, chi2_gate, samples, inv_sigma2=None, confidence=0.0, lo_its=0) -> dict:
+    """Hypothesis stage of PoseOptimization: best P3P pose over the given minimal samples ((H, 3) match indices); with
+    cv::solvePnPRansac's stopping rule (confidence) and one local-optimisation step (lo_its LM iterations on the inliers)."""
     n = len(Xw)
     Xw = np.ascontiguousarray(Xw, np.float64); obs = np.ascontiguousarray(obs, np.float64)
     isg = np.ones(n) if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float64)
@@ -183,10 +184,11 @@ def pose_ransac(Xw, obs, pose0, cam, chi2_gate, samples, inv_sigma2=None) -> dic
     pb.fx, pb.fy, pb.cx, pb.cy = cam
     pb.pose0 = (C.c_double * 7)(*pose0)
     pb.huber_delta, pb.chi2_gate, pb.rounds, pb.its_per_round = 0.0, chi2_gate, 0, 0
-    pose = np.zeros(7)
-    L = lib(); L.lba_oracle_pose_ransac.restype = C.c_int
-    cnt = L.lba_oracle_pose_ransac(C.byref(pb), C.c_int(len(samples)), _p(samples, _i), _p(pose, _d))
-    return dict(n_inliers=cnt, pose=pose)
+    pose = np.zeros(7); info = np.zeros(3, np.int32)
+    L = lib(); L.lba_oracle_pose_ransac_lo.restype = C.c_int
+    cnt = L.lba_oracle_pose_ransac_lo(C.byref(pb), C.c_int(len(samples)), _p(samples, _i), C.c_double(confidence), C.c_int(lo_its),
+                                      _p(pose, _d), _p(info, _i))
+    return dict(n_inliers=cnt, pose=pose, samples_used=int(info[0]), lo_accepted=int(info[1]), lo_inliers=int(info[2]))
 
 
 def se3_exp(u):

@@ -627,6 +627,35 @@ def test_pose_optimization_hypothesis_stage_does_not_depend_on_the_start_pose(so
     assert r3["n_inliers"] < 0.5 * r["n_inliers"] or np.abs(r3["pose"][4:] - f["truth"][4:]).max() > 0.5
 
 
+@pytest.mark.parametrize("outlier_frac,hub,conf", [(0.10, 5.0, 0.95), (0.55, 5.0, 0.95), (0.70, 8.0, 0.95), (0.70, 8.0, 0.999)])
+def test_pose_optimization_stopping_rule_and_local_optimisation(solver, oracle_mod, built_lib, outlier_frac, hub, conf):
+    """cv::solvePnPRansac's `confidence` (Optimizer.cc:437, 0.95) as the stopping rule N = log(1 - c) / log(1 - w^3) over the
+    samples in drawing order — the device scores all 50 at once, only those a sequential RANSAC would have drawn are eligible —
+    and one local-optimisation step (LM refit of the winner on its inliers, kept when it scores better), as the USAC pipeline
+    behind flag 38 has.  Against the oracle's restatement on the same samples; and, independently, with 70 % outliers at the
+    lost-frame threshold (reprojectErrorLost = 8 px) the generating inliers are still recovered from a far-off start pose."""
+    f = synth.make_frame(n=500, seed=1001, outlier_frac=outlier_frac)
+    n = len(f["Xw"]); gate = hub * hub
+    bad0 = _far_off_pose(f["truth"], 150.0, np.array([2.0, -1.5, 1.7]))
+    samples = built_lib.ransac_samples(n, 50, 7)
+    o_r = oracle_mod.pose_ransac(f["Xw"], f["obs"], bad0, f["cam"], gate, samples, confidence=conf, lo_its=10)
+    o = oracle_mod.pose_opt(f["Xw"], f["obs"], o_r["pose"], f["cam"], hub, gate)
+    r = solver.pose_opt(f["Xw"], f["obs"], bad0, f["cam"], hub, gate, ransac_iters=50, ransac_seed=7, confidence=conf, lo_iters=10)
+    assert r["status"] == 0 and r["ransac_samples_used"] == o_r["samples_used"] and r["ransac_inliers"] == o_r["n_inliers"]
+    assert r["lo_accepted"] == o_r["lo_accepted"] and r["lo_inliers"] == o_r["lo_inliers"] >= r["ransac_inliers"]
+    assert np.abs(r["ransac_pose"] - o_r["pose"]).max() < 1e-7
+    assert r["n_inliers"] == o["n_inliers"] and np.abs(r["pose"] - o["pose"]).max() < 1e-8
+    # the rule's arithmetic, from the inlier ratios alone: few outliers end the sampling early, many take every sample
+    w_in = 1.0 - outlier_frac
+    assert (r["ransac_samples_used"] < 50) == (np.log(1 - conf) / np.log(1 - (0.9 * w_in) ** 3) < 50)
+    # the generating inliers are recovered, the pose is the true one
+    assert ((r["outlier"] == 1) == f["is_outlier"]).mean() > 0.985
+    assert np.abs(r["pose"][4:] - f["truth"][4:]).max() < 0.05 and quat_angle(r["pose"][None, :4], f["truth"][None, :4]).max() < 4e-3
+    # the sampling stops where a sequential RANSAC would: eligible samples only — all 50 without a confidence
+    r_all = solver.pose_opt(f["Xw"], f["obs"], bad0, f["cam"], hub, gate, ransac_iters=50, ransac_seed=7, lo_iters=10)
+    assert r_all["ransac_samples_used"] == 50 and r_all["ransac_inliers"] >= r["ransac_inliers"]
+
+
 def test_pose_optimization_hypothesis_stage_beyond_the_lds_staging_limit(solver, oracle_mod, built_lib):
     f = synth.make_frame(n=4000, seed=77, outlier_frac=0.4)
     bad0 = _far_off_pose(f["truth"], 150.0, np.array([2.0, -1.5, 1.7]))
