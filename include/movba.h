@@ -43,6 +43,10 @@ extern "C" {
 #define MOVBA_ERR_DEVICE_WAIT -4  /* one-launch direct solver: a workgroup gave up waiting for another (20 ms); the results
                                      of the solve are not trustworthy and are not returned as MOVBA_OK               */
 #define MOVBA_ERR_TOO_LARGE  -5   /* the window's reduced system exceeds what the direct solver can hold             */
+/* Free keyframes per window: <= 80 the on-chip PCG (where the reduced matrix fits its registers), <= 432 the one-launch
+ * direct solver, beyond that one launch per block column; the solution vector of the latter's back substitution lives in
+ * LDS (48 doubles per 8 keyframes beside 28 KB of work space: 159 KB at 2 700 keyframes). */
+#define MOVBA_MAX_FREE_KEYFRAMES 2700
 
 /* flags */
 #define MOVBA_FLAG_STALE_ERROR_QUIRK 1u  /* chi2 of a rejected last trial, as g2o leaves it */

@@ -440,6 +440,7 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
     Structure s;
     const int rc = build_structure(*desc, s);
     if (rc < 0) return rc;
+    if (s.nfree > MOVBA_MAX_FREE_KEYFRAMES) return MOVBA_ERR_TOO_LARGE;
     info->n_free = s.nfree; info->n_pairs = s.npairs; info->n_entries = s.nentries; info->n_items = s.nitems;
     info->max_degree = s.max_degree; info->already_grouped = s.already_grouped ? 1 : 0; info->reordered = s.reordered ? 1 : 0; info->pad_s = 0;
     info->pcg_on_chip = 0; info->pcg_overflow = 0; info->pcg_max_wave_entries = 0; info->n_row_entries = (int32_t)s.row_ent.size();
@@ -595,6 +596,13 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK;
     }
     const int nf = s.nfree;
+    // beyond the one-launch direct solver (dense_plan.h) the multi-launch one holds the solution vector in LDS and the lower
+    // block triangle in HBM: refused by name past that, instead of failing in a launch
+    if (nf > MOVBA_MAX_FREE_KEYFRAMES) {
+        (void)wait_helper();
+        std::fprintf(stderr, "libmovba: %d free keyframes: the reduced system exceeds the direct solver's capacity (%d)\n", nf, MOVBA_MAX_FREE_KEYFRAMES);
+        return MOVBA_ERR_TOO_LARGE;
+    }
     const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
     const size_t edge_bytes = s.already_grouped ? edge_bytes_grouped : edge_bytes_max;
     const int nbins = nf * nf;
@@ -642,7 +650,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         build_slots(h->st); rank_mode = false;
         pack_edges(false);
     } else {
-        while (idx_ready.load(std::memory_order_acquire) == 0) host_relax(0);
+        while (idx_ready.load(std::memory_order_acquire) == 0) host_relax(h->opt.host_wait);
         pack_a(false);
         pack_b(false);      // (ranks where the slots go, the keyframes' first slots, the free keyframes)
     }
@@ -747,7 +755,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         {
             const double t_wait = now_ms();
             while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
-                host_relax(0);
+                host_relax(h->opt.host_wait);
                 if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) return MOVBA_ERR_HIP; }
             }
         }

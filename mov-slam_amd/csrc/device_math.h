@@ -32,6 +32,17 @@ __device__ __forceinline__ double fast_rcp(double p)
     return r;
 }
 
+// ... and where a zero can come in (the depth of a map point lying exactly on a keyframe's z = 0 plane): 1 / 0 = inf like the
+// IEEE division of Pinhole::project (src/CameraModels/Pinhole.cpp:36-43), so that the edge's chi2 — and with it the robust
+// cost the LM decides on — is inf as in the reference, not NaN (the Newton step alone makes inf * (2 - 0 * inf) = NaN)
+__device__ __forceinline__ double fast_rcp_zero_safe(double p)
+{
+    const double r0 = __builtin_amdgcn_rcp(p);
+    double r = r0 * (2.0 - p * r0);
+    r = r * (2.0 - p * r);
+    return p == 0.0 ? r0 : r;
+}
+
 __device__ __forceinline__ void R_to_quat(const double m[9], double q[4])
 {
     double t = m[0] + m[4] + m[8];

@@ -163,7 +163,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
             // (one reciprocal per edge and multiplications: an fp64 division is a ~25-instruction sequence, and the projection
             //  and its Jacobian would take six of them)
-            const double iz = fast_rcp(z), u = w.fx * x * iz, v = w.fy * y * iz;
+            const double iz = fast_rcp_zero_safe(z), u = w.fx * x * iz, v = w.fy * y * iz;
             const double e0 = ob.x - (u + w.cx);
             const double e1 = ob.y - (v + w.cy);
             double chi2 = e0 * (om * e0) + e1 * (om * e1);
@@ -222,7 +222,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
         const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
-        const double iz = fast_rcp(z), u = w.fx * x * iz, v = w.fy * y * iz;      // (one reciprocal per edge: see back_edge)
+        const double iz = fast_rcp_zero_safe(z), u = w.fx * x * iz, v = w.fy * y * iz;      // (one reciprocal per edge: see back_edge)
         const double e0 = ob.x - (u + w.cx);
         const double e1 = ob.y - (v + w.cy);
         double chi2 = e0 * (om * e0) + e1 * (om * e1);

@@ -93,6 +93,24 @@ EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destro
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must hold ONE copy of the HIP runtime.  libmovba.so needs `libamdhip64.so.7` (found in /opt/rocm); torch's
+    libtorch_hip.so needs `libamdhip64.so` (found in torch/lib by its rpath: another FILE with the same soname, 7).  Loaded
+    first, torch's copy satisfies libmovba's soname; loaded second, it is mapped beside ROCm's copy, and the second runtime
+    finds no device ("no ROCm-capable device is detected": profiles/r03p_hip_runtime_copies.log).  So when torch is installed
+    its copy is mapped (RTLD_GLOBAL) before libmovba.so — without importing torch — and both bind to that one whichever is
+    imported first; without torch (the C++ adapter inside MoV-SLAM) ROCm's own copy is the only one there is."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libmovba.so; raise loudly when the HIP extension has not been built."""
     global _lib
@@ -100,6 +118,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MovbaError(f"{LIB_PATH} not found: build it with `make -C mov-slam_amd/csrc` "
                              "(or __graft_entry__.build()); there is no CPU fallback")
+        _one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.movba_status_string.restype = C.c_char_p
         L.movba_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(Options)]

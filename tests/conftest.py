@@ -51,15 +51,6 @@ def built_lib():
 
 @pytest.fixture(scope="session")
 def solver(built_lib):
-    # torch brings its own copy of the HIP runtime: when a test creates a torch stream for the first time AFTER libmovba
-    # has been working the device for a while, torch's runtime has been seen to report "No HIP GPUs are available";
-    # initialising it first keeps every ordering of the tests working (bench.py does the same by construction)
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except ImportError:
-        pass
     s = built_lib.Solver()          # raises loudly if the HIP library or the device is missing
     yield s
     s.close()

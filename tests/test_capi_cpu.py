@@ -140,6 +140,23 @@ def test_structure_probe_rejects_bad_indices_and_duplicates(built_lib):
     assert built_lib.structure_probe(empty)["status"] == built_lib.EMPTY
 
 
+def test_windows_beyond_the_direct_solvers_capacity_are_refused_by_name(built_lib):
+    """MOVBA_MAX_FREE_KEYFRAMES (2 700): past it the multi-launch direct solver's back substitution no longer fits its LDS;
+    the window is refused with MOVBA_ERR_TOO_LARGE at the structure pass instead of failing in a launch."""
+    K = 2701
+    poses = np.zeros((K + 1, 7)); poses[:, 3] = 1.0
+    fixed = np.zeros(K + 1, np.uint8); fixed[0] = 1
+    ep = np.stack([np.zeros(K, np.int32), np.arange(1, K + 1, dtype=np.int32)], 1).reshape(-1)      # every point: the fixed keyframe + one free
+    el = np.repeat(np.arange(K, dtype=np.int32), 2)
+    w = synth.Window(poses=poses, pose_fixed=fixed, points=np.ones((K, 3)), edge_pose=ep, edge_point=el, obs=np.zeros((2 * K, 2)), inv_sigma2=np.ones(2 * K))
+    with pytest.raises(built_lib.MovbaError, match="too large"):
+        built_lib.structure_probe(w)
+    assert built_lib.ERR_TOO_LARGE == -5 and "too large" in built_lib.status_string(-5)
+    w2 = synth.Window(poses=poses[:K], pose_fixed=fixed[:K], points=np.ones((K - 1, 3)), edge_pose=ep[:2 * (K - 1)], edge_point=el[:2 * (K - 1)],
+                      obs=np.zeros((2 * (K - 1), 2)), inv_sigma2=np.ones(2 * (K - 1)))
+    assert built_lib.structure_probe(w2)["n_free"] == 2700
+
+
 def test_create_fails_loudly_without_a_gpu(built_lib):
     import torch
     if torch.cuda.is_available():

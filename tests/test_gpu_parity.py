@@ -238,6 +238,29 @@ def test_weakly_constrained_windows(solver, oracle_mod, K, F, P, lo, hi, seed):
     assert r["n_direct"] > 0 or r["pcg_iters"] < 200 * r["n_solves"]
 
 
+def test_point_on_the_z0_plane_of_an_observing_keyframe(solver, oracle_mod):
+    """A map point whose camera-frame depth is exactly 0 in one of its observers (Xc.z == 0: Pinhole::project divides by zero,
+    Pinhole.cpp:36-43).  The reference's gate (Optimizer.cc:769) has two tests, chi2 > 5.0 and !isDepthPositive(): the edge comes
+    out flagged through the depth test whatever its chi2 is (inf, like the IEEE division gives: the product's Newton-refined
+    reciprocal is made zero-safe where depths are inverted).  The robust cost is inf from the start, the normal equations hold
+    NaN, every factorisation fails (F1 = DBL_MAX) and no trial moves the state: the estimates come back as they went in, in
+    the oracle and on the GPU alike.  (Whether g2o counts such a trial as accepted — DBL_MAX against inf over a scale term that
+    holds NaN — and what it leaves in the edges' errors is pinned by nothing the reference holds: not compared.)"""
+    w = synth.cfg("small")
+    assert np.array_equal(w.poses[0], [0, 0, 0, 1, 0, 0, 0]) and w.pose_fixed[0] == 1         # keyframe 0: identity pose, Xc == Xw
+    e0 = int(np.flatnonzero(w.edge_pose == 0)[0]); l0 = int(w.edge_point[e0])
+    w.points = w.points.copy(); w.points[l0, 2] = 0.0
+    for iters in (10, 3):
+        r, o = solver.solve(w, max_iters=iters), oracle_mod.solve(w, max_iters=iters)
+        assert r["status"] == o["status"] == 0 and r["n_sync_timeouts"] == 0
+        assert r["outlier"][e0] == 1 and o["outlier"][e0] == 1 and not np.isfinite(o["chi2"][e0]) and not np.isfinite(r["chi2"][e0])
+        assert np.array_equal(r["points"], w.points) and np.array_equal(o["points"], w.points)
+        assert np.isfinite(r["poses"]).all() and np.abs(r["poses"] - o["poses"]).max() < 1e-15
+    # and the window is solved as usual once the point is off the plane again
+    w.points[l0, 2] = 1e-3
+    assert solver.solve(w)["status"] == 0
+
+
 def test_converged_window_keeps_deciding_on_rounding_noise(solver, oracle_mod):
     """130 keyframes over 30 points (fuzz seed 894021): the cost reaches its floor in trial 6, the remaining trials decide
     on |F0 - F1| ~ 1e-11: the accept trace is compared up to there, the final state in full."""
@@ -547,6 +570,47 @@ def test_batched_run_is_bit_identical_to_solo_runs(built_lib, oracle_mod):
         for s, i in zip(sub, (4, 0, 6)):
             assert np.array_equal(s.download()["poses"], solo[i]["poses"])
     finally:
+        for s in solvers:
+            s.close()
+
+
+def test_batched_run_beside_uploads_and_solves_on_another_handle(built_lib):
+    """The second group of a batched run shares the device's copy stream with every handle's upload helper (api.cpp: each extra
+    stream competes for the hardware queues).  Handles stay correct under that coupling: while one thread runs batches, another
+    uploads and solves on a handle of its own; every result equals its solo run bit for bit.  (What the coupling costs is the
+    out-of-phase schedule of the batch while the other handle uploads: include/movba.h, movba_lba_run_batch.)"""
+    import threading
+    ws = [synth.make_window(12 + 4 * i, 2, 1500, seed=4300 + i, run_lo=2, run_hi=6) for i in range(4)]
+    other_w = synth.make_window(20, 3, 3000, seed=4400, run_lo=2, run_hi=7)
+    st, solvers = _shared_stream_solvers(built_lib, len(ws))
+    other = built_lib.Solver()
+    errs = []
+    try:
+        solo = [s.solve(w) for s, w in zip(solvers, ws)]
+        other_solo = other.solve(other_w)
+        for s, w in zip(solvers, ws):
+            s.upload(w)
+
+        def side():
+            try:
+                for _ in range(12):
+                    r = other.solve(other_w)
+                    if not (np.array_equal(r["poses"], other_solo["poses"]) and np.array_equal(r["outlier"], other_solo["outlier"])):
+                        errs.append("other handle differs")
+            except Exception as exc:          # noqa: BLE001
+                errs.append(repr(exc))
+
+        th = threading.Thread(target=side)
+        th.start()
+        for _ in range(6):
+            assert built_lib.run_batch(solvers) == 0
+            for s, a in zip(solvers, solo):
+                b = s.download()
+                assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"]) and np.array_equal(a["outlier"], b["outlier"])
+        th.join()
+        assert not errs, errs
+    finally:
+        other.close()
         for s in solvers:
             s.close()
 
