@@ -314,13 +314,23 @@ def main():
                         for arr, dt in ((wf.pose_fixed, np.uint8), (wf.poses, np.float64), (wf.points, np.float64), (wf.edge_pose, np.int32),
                                         (wf.edge_point, np.int32), (wf.obs, np.float64)):
                             fh.write(np.ascontiguousarray(arr, dt).tobytes())
-                    subprocess.check_call([exe, "lba", fin, fout], env=dict(os.environ, MOVBA_ADAPTER_REPS="4"))
-                    raw = open(fout, "rb").read()
-                    tm = struct.unpack_from("3d", raw, len(raw) - 24)
+                    def adapter_times(extra_env):
+                        subprocess.check_call([exe, "lba", fin, fout], env=dict(os.environ, MOVBA_ADAPTER_REPS="4", **extra_env))
+                        raw = open(fout, "rb").read()
+                        # (timing triple in front of the per-point / per-keyframe / status trailer of adapter_test)
+                        off = 20 + 28 * wf.n_poses + 12 * wf.n_points
+                        n_er = struct.unpack_from("5i", raw, 0)[3]
+                        off += 8 * n_er + 8 + 8 + 20 * wf.n_points
+                        return struct.unpack_from("3d", raw, off)
+                    tm = adapter_times({})
+                    tm_ref = adapter_times({"MOVBA_ADAPTER_REFERENCE_NORMALS": "1"})
                 out["config"]["adapter_host_ms"] = {"extraction": tm[0], "solve_call": tm[1], "write_back": tm[2],
+                                                    "write_back_with_the_reference_normal_update": tm_ref[2],
                                                     "note": "Optimizer::LocalBundleAdjustment over mock KeyFrame/MapPoint classes (taking the reference's locks), fourth call of the process "
                                                             "on a fresh copy of the map (buffers, arena and handle warm, as in a running system): one "
-                                                            "GetObservations() copy per point, normal/depth stored from the GPU result"}
+                                                            "GetObservations() copy per point, normal/depth stored from the GPU result — which needs the one-line SetMinMaxDistance "
+                                                            "accessor INTEGRATION.md 1.4 adds to MoV-SLAM's MapPoint.h; write_back_with_the_reference_normal_update is the "
+                                                            "figure for an unpatched MapPoint (MapPoint::UpdateNormalAndDepth per point)"}
             except Exception as exc:                        # context only
                 out["config"]["adapter_host_ms"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:

@@ -170,7 +170,13 @@ int  movba_lba_download(movba_handle *h, movba_lba_result *res);      /* D2H + c
  * GPU): every kernel of an LM trial is one launch over the concatenated windows, with per-window LM state, so each window
  * takes exactly the steps of its solo run and returns bit-identical results; download each handle as usual.  The handles
  * must have been created on the same device and the same stream, and hold either stereo or monocular windows.  Windows
- * that end before the solve (MOVBA_EMPTY / MOVBA_NO_FIXED / stop flag up) report that through their own download. */
+ * that end before the solve (MOVBA_EMPTY / MOVBA_NO_FIXED / stop flag up) report that through their own download.
+ * The windows run in two groups half a trial out of phase; the second group's launches go to the device's COPY stream,
+ * which every handle's upload also uses (one stream per device for all handles: each further stream of the process
+ * competes for the few hardware queues).  Results never depend on it (tested with another handle uploading and solving
+ * meanwhile), but an upload on ANOTHER handle of the device queues behind the running batch, and its copies between the
+ * second group's kernels cost the batch its out-of-phase schedule for that trial: for the quoted batch throughput, upload
+ * the windows first, then run.  Windows without an on-chip PCG are run one by one behind the batched launches. */
 int  movba_lba_run_batch(movba_handle *const *handles, int32_t n);
 
 /* Copy the optimised poses (n_poses x 7 f64) into a caller-owned DEVICE buffer on the
