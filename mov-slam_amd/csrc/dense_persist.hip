@@ -38,6 +38,8 @@ namespace {
 constexpr int kPT = 256;                        // threads: 4 waves, one per SIMD
 constexpr int kTileLds = NB * LD;               // doubles of one LDS tile image
 constexpr unsigned long long kWaitTicks = 2000000ull;      // 20 ms of the 100 MHz clock
+constexpr int kTaskCache = 128;                 // tasks of the workgroup's list held in LDS at a time (32 bytes each)
+__host__ __device__ constexpr int kTaskOff(int nslots) { return (2 + nslots) * kTileLds + 672; }       // (doubles) behind the carve
 __host__ __device__ constexpr int kBadOff(int nslots) { return (2 + nslots) * kTileLds + 660; }     // LDS word of sweep_tiles' bad-pivot flag (in the carve's spare doubles)
 
 // every word that travels between workgroups is a GLOBAL agent-scope access (global_load / global_store ... sc1, never flat_)
@@ -77,22 +79,33 @@ __device__ __forceinline__ Lds carve(double *sm, int nslots)
 // buffer descriptor of the tile, all of a thread's accesses in flight (a tile is 1 152 x 16 bytes: 4.5 per thread)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileBytes = NB * NB * 8, kTileVec = kTileBytes / 16;
+// TRI = 2: an upper triangular tile (the inverse factor W_K) travels without its three 16 x 16 blocks below the diagonal
+// (TRI = 1: without those above)
+template <int TRI>
+__device__ __forceinline__ bool tri_skip(int row, int c) { return TRI == 1 ? (c >> 4) > (row >> 4) : (TRI == 2 ? (c >> 4) < (row >> 4) : false); }
+template <int TRI = 0>
 __device__ __forceinline__ void fetch_tile(const double *g, double *lds, int tid)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(g), 0, kTileBytes, 0x00020000);
     u32x4 v[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { const int e = tid + kPT * q; v[q] = __builtin_amdgcn_raw_buffer_load_b128(r, (e < kTileVec ? e : 0) * 16, 0, 16); }
+    for (int q = 0; q < 5; ++q) {
+        const int e = tid + kPT * q, row = (2 * e) / NB, c = 2 * e - row * NB;
+        const bool want = e < kTileVec && !tri_skip<TRI>(row, c);
+        v[q] = __builtin_amdgcn_raw_buffer_load_b128(r, want ? e * 16 : kTileBytes, 0, 16);       // (past the descriptor's range: no memory access)
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         const int e = tid + kPT * q;
         if (e < kTileVec) {
             const int row = (2 * e) / NB, c = 2 * e - row * NB;
+            if (tri_skip<TRI>(row, c)) continue;
             lds[row * LD + c] = __hiloint2double((int)v[q].y, (int)v[q].x); lds[row * LD + c + 1] = __hiloint2double((int)v[q].w, (int)v[q].z);
         }
     }
 }
 
+template <int TRI = 0>
 __device__ __forceinline__ void publish_tile(double *g, const double *lds, int tid)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(g, 0, kTileBytes, 0x00020000);
@@ -101,6 +114,7 @@ __device__ __forceinline__ void publish_tile(double *g, const double *lds, int t
         const int e = tid + kPT * q;
         if (e < kTileVec) {
             const int row = (2 * e) / NB, c = 2 * e - row * NB;
+            if (tri_skip<TRI>(row, c)) continue;
             const double a = lds[row * LD + c], b = lds[row * LD + c + 1];
             const u32x4 v = { (unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b) };
             __builtin_amdgcn_raw_buffer_store_b128(v, r, e * 16, 0, 16);
@@ -141,14 +155,91 @@ __device__ __forceinline__ bool wg_wait(const unsigned *flags, unsigned epoch, i
     return *l.abort == 0;
 }
 
-// slot -= A B^T, the nine 16 x 16 MFMA tiles dealt round-robin to the four waves
+// two flags, the first one awaited: 0 = gave up, 1 = the first is set, 3 = both are (the caller fetches both operands at once;
+// otherwise the first operand travels while the second is still being produced)
+__device__ __forceinline__ int wg_wait2(const unsigned *flags, unsigned epoch, int fa, int fb, const Lds &l, int tid)
+{
+    if (tid < 64) {
+        const unsigned *f = flags + (tid == 1 ? fb : fa);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long m;
+        bool good = true;
+        for (;;) {
+            m = __ballot(ld_flag(f) == epoch);
+            if (m & 1) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) { good = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (tid == 0) { if (!good) *l.abort = 1; l.abort[1] = (int)(m & 3); }
+    }
+    __syncthreads();
+    return *l.abort == 0 ? l.abort[1] : 0;
+}
+
+// r -= L y for one 48 x 48 tile (LDS image) and y in xs: five column groups, combined in fixed order
+__device__ __forceinline__ void rhs_minus_tile_times(const double *L, const Lds &l, int tid)
+{
+    const int g = tid / NB, cc = tid - g * NB;
+    if (g < 5) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { const int col = g + 5 * q; if (col < NB) s += L[cc * LD + col] * l.xs[col]; }
+        l.ps[g * NB + cc] = s;
+    }
+    __syncthreads();
+    if (tid < NB) l.rrow[tid] -= (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid];
+    __syncthreads();
+}
+
+// tile <- tile W with W upper triangular (blocks (kb, cb), kb <= cb): wave rb < 3 takes row block rb, all three products in
+// registers before the first of them is written back (in place: the row block is read and written by this wave only)
+__device__ __forceinline__ void tile_times_upper(double *U, const double *W, int wv, int lane)
+{
+    if (wv >= 3) return;
+    const double *ap = U + (wv * 16 + (lane & 15)) * LD + (lane >> 4);          // A[i = lane & 15][k = lane >> 4]
+    const double *bp = W + (lane >> 4) * LD + (lane & 15);                      // B[k = lane >> 4][j = lane & 15]
+    dbl4 x0 = dbl4{ 0.0, 0.0, 0.0, 0.0 }, x1 = x0, x2 = x0;
+#pragma unroll
+    for (int k = 0; k < NB; k += 4) {
+        const double a = ap[k];
+        const int kb = k >> 4;
+        if (kb <= 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LD], x0, 0, 0, 0);
+        if (kb <= 1) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LD + 16], x1, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LD + 32], x2, 0, 0, 0);
+    }
+    double *cp = U + (wv * 16 + (lane >> 4)) * LD + (lane & 15);                // C: col = lane & 15, row = (lane >> 4) + 4 reg
+    cp[0] = x0.x; cp[4 * LD] = x0.y; cp[8 * LD] = x0.z; cp[12 * LD] = x0.w;
+    cp[16] = x1.x; cp[4 * LD + 16] = x1.y; cp[8 * LD + 16] = x1.z; cp[12 * LD + 16] = x1.w;
+    cp[32] = x2.x; cp[4 * LD + 32] = x2.y; cp[8 * LD + 32] = x2.z; cp[12 * LD + 32] = x2.w;
+}
+
+// out[c] = sum_r T[r][c] v[r] (TRANSPOSED) or sum_c' T[c][c'] v[c'] for a 48 x 48 LDS tile and v in xs: five groups of 48
+// threads, partial sums combined in fixed order; the result to every thread below 48 (after the barriers inside)
+template <bool TRANSPOSED>
+__device__ __forceinline__ double tile_matvec(const double *T, const Lds &l, int tid)
+{
+    const int g = tid / NB, cc = tid - g * NB;
+    if (g < 5) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) { const int r = g + 5 * q; if (r < NB) s += (TRANSPOSED ? T[r * LD + cc] : T[cc * LD + r]) * l.xs[r]; }
+        l.ps[g * NB + cc] = s;
+    }
+    __syncthreads();
+    return tid < NB ? (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid] : 0.0;
+}
+
+// slot -= A B^T, the nine 16 x 16 MFMA tiles dealt round-robin to the four waves; LOWER (a diagonal tile, A == B): the six
+// tiles on and below the diagonal only
+template <bool LOWER>
 __device__ __forceinline__ void tile_update(double *C, const double *As, const double *Bs, int wv, int lane)
 {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int q = wv + 4 * u;
-        if (q < 9) {
-            const int mt = q / 3, ntc = q - mt * 3;
+        if (q < (LOWER ? 6 : 9)) {
+            // (lower: tiles (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) in that order)
+            const int mt = LOWER ? (q >= 3 ? 2 : (q >= 1 ? 1 : 0)) : q / 3, ntc = LOWER ? q - mt * (mt + 1) / 2 : q - mt * 3;
             double *cp = C + (mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
             dbl4 acc = dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
             acc = tile_mfma(As, Bs, mt, ntc, lane, acc);
@@ -159,17 +250,17 @@ __device__ __forceinline__ void tile_update(double *C, const double *As, const d
 
 // S (damped) of tile (I, K) from the schur work-item partials into an LDS image: the element map and the item order of
 // k_dense_assemble (dense_solve.hip), so both direct solvers and the PCG see the same matrix to the last bit
-__device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int I, int K, double lambda, int dst_off, int rrow_off, int tid)
+struct AsmView { const double *part; const int32_t *pid, *pis; double *bp; int32_t nf, n; };      // (by value: the kernel's argument block stays out of scratch)
+__device__ __attribute__((noinline)) void assemble_tile(AsmView av, int I, int K, double lambda, int dst_off, int rrow_off, int tid)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];     // (LDS addressed from its own symbol: ds_ instructions, not flat_)
     double *dst = sm + dst_off;
-    const DenseSys &ds = w.dense;
-    const int nf = w.nfree, n = ds.n;
+    const int nf = av.nf, n = av.n;
     // (global pointers said to be global: plain global_load instead of flat_load)
     typedef const __attribute__((address_space(1))) double *gdp;
     typedef const __attribute__((address_space(1))) int32_t *gip;
-    const gdp part = (gdp)w.part;
-    const gip pid = (gip)ds.pid, pis = (gip)w.pair_item_start;
+    const gdp part = (gdp)av.part;
+    const gip pid = (gip)av.pid, pis = (gip)av.pis;
     // A diagonal tile holds eight diagonal pairs, each cut into several work items (five at cfg3) whose records are summed
     // for 57 of the tile's elements and for the right-hand side: their records (contiguous: the diagonal pairs come first, in
     // order) are staged in the two scratch tiles by one coalesced pass and summed from LDS — element by element from
@@ -204,24 +295,31 @@ __device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int 
     for (int q = 0; q < kPer; ++q) {
         i0[q] = pr[q] >= 0 ? pis[pr[q]] : 0; i1[q] = pr[q] >= 0 ? pis[pr[q] + 1] : 0;
     }
-    // sums in item order, the loads of four items of every element in flight together (a diagonal pair of cfg3 is cut into
-    // five work items: one item after the other the tile took five dependent memory round trips more)
+    // sums in item order; the thread's nine elements advance through their item lists TOGETHER (step s = the s-th item of
+    // every element, nine loads in flight): one list after the other the tile took nine dependent memory round trips
     double sacc[kPer], hpp[kPer];
+    int maxlen = 0;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) { sacc[q] = 0.0; hpp[q] = 0.0; }
+    for (int q = 0; q < kPer; ++q) { sacc[q] = 0.0; hpp[q] = 0.0; maxlen = max(maxlen, i1[q] - i0[q]); }
+    for (int st = 0; st < maxlen; ++st) {
+        double va[kPer], vh[kPer];
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        if (uu[q] >= 0 && nstage > 0) {
-            for (int itx = i0[q]; itx < i1[q]; ++itx) {
-                sacc[q] += sm[(itx - item0) * kPartStride + kk[q]];
-                hpp[q] += sm[(itx - item0) * kPartStride + uu[q]];
-            }
-        } else {
-            for (int itx = i0[q]; itx < i1[q]; ++itx) {
-                sacc[q] += part[(size_t)itx * kPartStride + kk[q]];
-                if (uu[q] >= 0) hpp[q] += part[(size_t)itx * kPartStride + uu[q]];
+        for (int q = 0; q < kPer; ++q) {
+            const int itx = i0[q] + st;
+            const bool on = itx < i1[q];
+            const bool staged = uu[q] >= 0 && nstage > 0;
+            va[q] = 0.0; vh[q] = 0.0;
+            if (staged) {
+                if (on) { va[q] = sm[(itx - item0) * kPartStride + kk[q]]; vh[q] = sm[(itx - item0) * kPartStride + uu[q]]; }
+            } else {
+                const size_t base = (size_t)(on ? itx : 0) * kPartStride;      // (item 0 exists: an address that is always valid)
+                va[q] = part[base + kk[q]];
+                if (uu[q] >= 0) vh[q] = part[base + uu[q]];
             }
         }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+            if (i0[q] + st < i1[q]) { sacc[q] += va[q]; hpp[q] += vh[q]; }
     }
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
@@ -243,7 +341,7 @@ __device__ __attribute__((noinline)) void assemble_tile(const DevWindow &w, int 
             } else {
                 for (int itx = j0; itx < j1; ++itx) { bb += part[(size_t)itx * kPartStride + 63 + a]; cb += part[(size_t)itx * kPartStride + 36 + a]; }
             }
-            st_sc1(w.bp + gc, bb);
+            st_sc1(av.bp + gc, bb);
             v = bb - cb;
         }
         sm[rrow_off + tid] = v;
@@ -295,6 +393,13 @@ __device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int 
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_ublk = (n_urows + 15) >> 4;
     if (tid == 0) *s_bad = 0;
+#ifdef MOVBA_SWEEP_PROFILE
+    unsigned long long *prof = reinterpret_cast<unsigned long long *>(sm + flag_off - 660 + 256);      // (Lds::ps: idle during a sweep)
+#define SWEEP_MARK(i) do { if (tid == 64) prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SWEEP_MARK(i) do { } while (0)
+#endif
+    SWEEP_MARK(0);
 #pragma unroll 1
     for (int pn = 0; pn < 3; ++pn) {
         const int c0 = 16 * pn;
@@ -314,9 +419,12 @@ __device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int 
         if (chain) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) pr[c] = rowp[c];
+            SWEEP_MARK(1 + 5 * pn);
             PanelStep<0>::run(pr, pk, bad);
+            SWEEP_MARK(2 + 5 * pn);
         }
         __syncthreads();                                // wave 1 has read the diagonal block before wave 0 stores its factor over it
+        SWEEP_MARK(3 + 5 * pn);
         if (chain) {
             if (bad && lane == 0) *s_bad = 1;
             if (writes) {
@@ -331,6 +439,7 @@ __device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int 
             }
         }
         __syncthreads();
+        SWEEP_MARK(4 + 5 * pn);
         if (pn == 2) break;
         // ---- trailing blocks of this panel: D blocks (rb, cb), rb >= cb > pn, then U blocks (ub, cb) ----
         const int ncb = 2 - pn;                         // column blocks right of the panel
@@ -357,43 +466,11 @@ __device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int 
             cp[0] = acc.x; cp[4 * LD] = acc.y; cp[8 * LD] = acc.z; cp[12 * LD] = acc.w;
         }
         __syncthreads();
+        SWEEP_MARK(5 + 5 * pn);
     }
     return *s_bad != 0;
 }
 
-
-// L^T x = s for one 48 x 48 factor (LDS image at l_off) by ONE wave, unknown t on lane t, from the last unknown up: x_k is
-// broadcast from lane k (v_readlane), every lane above the diagonal subtracts its L[k][t] x_k.  Fully unrolled with the
-// factor's column t in registers (static indices): the chain per unknown is readlane -> multiply -> fused update; as a loop
-// over k with a select per step it took 4.5 us per block row, most of the back substitution's chain.
-template <int K>
-struct BackStep {
-    static __device__ __forceinline__ void run(double &sv, const double (&lk)[NB], const double (&rd)[NB])
-    {
-        const double xk = readlane_f64(sv, K) * rd[K];
-        sv -= lk[K] * xk;
-        BackStep<K - 1>::run(sv, lk, rd);
-    }
-};
-template <>
-struct BackStep<-1> {
-    static __device__ __forceinline__ void run(double &, const double (&)[NB], const double (&)[NB]) {}
-};
-
-__device__ __attribute__((noinline)) double back_solve48(int l_off, double sv, int lane)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const double *L = sm + l_off;
-    const int t = lane < NB ? lane : NB - 1;
-    double lk[NB], rd[NB];
-    const double rdl = fast_rcp(L[t * LD + t]);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) { const double v = L[k * LD + t]; lk[k] = (k > lane) ? v : 0.0; }      // only the rows below the diagonal act on unknown t
-#pragma unroll
-    for (int k = 0; k < NB; ++k) rd[k] = readlane_f64(rdl, k);
-    BackStep<NB - 1>::run(sv, lk, rd);
-    return sv * rdl;
-}
 
 }  // namespace
 
@@ -402,27 +479,46 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
     if (c->done == 1) return;
-    const DenseSys &ds = w.dense;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = ds.ntile, n = ds.n;
-    const Lds l = carve(sm, ds.slots);
-    unsigned *flags = ds.flags;
+    // everything the task loop needs from the argument block, once, in registers
+    const int nt = w.dense.ntile, n = w.dense.n, nslots = w.dense.slots;
+    double *const tiles = w.dense.tiles, *const contrib = w.dense.contrib, *const xsol = w.dense.xsol;
+    unsigned *const flags = w.dense.flags, *const failw = w.dense.failw;
+    unsigned long long *const stamps = w.dense.stamps;
+    const DenseTask *const gtasks = w.dense.tasks;
+    const AsmView av = { w.part, w.dense.pid, w.pair_item_start, w.bp, w.nfree, w.dense.n };
+    const Lds l = carve(sm, nslots);
     const double lambda = c->lambda;
     if (tid == 0) { *l.abort = 0; *l.prog = 0; }
     __syncthreads();
     bool aborted = false;
+    // a tile's publication whose flag is still to be set: the stores are issued, the drain + flag follow behind the next piece of
+    // work that needs nothing from memory (set before any wait, any further publication, and at the end)
+    int pending = -1;
+    auto flush = [&]() { if (pending >= 0) { set_flag(flags, pending, epoch, tid); pending = -1; } };
 
-    const int t0 = ds.task_ptr[blockIdx.x], t1 = ds.task_ptr[blockIdx.x + 1];
+    const int t0 = w.dense.task_ptr[blockIdx.x], t1 = w.dense.task_ptr[blockIdx.x + 1];
+    int32_t *tcache = reinterpret_cast<int32_t *>(sm + kTaskOff(nslots));       // the next kTaskCache tasks of this workgroup, in LDS
     for (int t = t0; t < t1 && !aborted; ++t) {
-        const DenseTask tk = ds.tasks[t];
+        if ((t - t0) % kTaskCache == 0) {
+            __syncthreads();
+            const int nload = min(kTaskCache, t1 - t) * 8;
+            for (int q = tid; q < nload; q += kPT) tcache[q] = reinterpret_cast<const int32_t *>(gtasks + t)[q];
+            __syncthreads();
+        }
+        const int32_t *tw = tcache + ((t - t0) % kTaskCache) * 8;
+        DenseTask tk;
+        tk.op = __builtin_amdgcn_readfirstlane(tw[0]); tk.slot = __builtin_amdgcn_readfirstlane(tw[1]); tk.I = __builtin_amdgcn_readfirstlane(tw[2]);
+        tk.K = __builtin_amdgcn_readfirstlane(tw[3]); tk.k = __builtin_amdgcn_readfirstlane(tw[4]);
+        tk.pad[0] = __builtin_amdgcn_readfirstlane(tw[5]); tk.pad[1] = __builtin_amdgcn_readfirstlane(tw[6]); tk.pad[2] = __builtin_amdgcn_readfirstlane(tw[7]);
         const int I = tk.I, K = tk.K, k = tk.k;
-        if (ds.stamps && tid == 0) { ds.stamps[6 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); for (int q = 1; q < 5; ++q) ds.stamps[6 * (size_t)t + q] = 0; }
+        if (stamps && tid == 0) { stamps[6 * (size_t)t] = __builtin_amdgcn_s_memrealtime(); for (int q = 1; q < 5; ++q) stamps[6 * (size_t)t + q] = 0; }
         const int slot_off = (2 + tk.slot) * kTileLds;
         double *slot = sm + slot_off;
         switch (tk.op) {
         case DT_ASM: {
-            assemble_tile(w, I, K, lambda, slot_off, (2 + ds.slots) * kTileLds, tid);      // (the right-hand side row into Lds::rrow)
+            assemble_tile(av, I, K, lambda, slot_off, (2 + nslots) * kTileLds, tid);      // (the right-hand side row into Lds::rrow)
             __syncthreads();
             break;
         }
@@ -430,99 +526,158 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             // operands this workgroup produced itself are read where they lie (its own LDS slots: pad[0] / pad[1] of the task);
             // the others are waited for and fetched
             const int sa = tk.pad[0], sb = I == K ? tk.pad[0] : tk.pad[1];
-            const int fa = sa < 0 ? dense_flag_F(nt, I, k) : -1, fb = (I != K && sb < 0) ? dense_flag_F(nt, K, k) : -1;
-            const int nw = (fa >= 0) + (fb >= 0);
-            if (nw > 0 && !wg_wait(flags, epoch, nw, [&](int i) { return (i == 0 && fa >= 0) ? fa : fb; }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
-            if (sa < 0) fetch_tile(ds.tiles + tile_off(I, k), l.A, tid);
-            if (I != K && sb < 0) fetch_tile(ds.tiles + tile_off(K, k), l.B, tid);
-            if (sa < 0 || (I != K && sb < 0)) __syncthreads();
+            const bool getA = sa == -1, getB = I != K && sb == -1;          // (-2: in the scratch tile since the update before)
+            const int fa = dense_flag_F(nt, I, k), fb = dense_flag_F(nt, K, k);
+            if (getA || getB) flush();
+            if (getA && getB) {
+                const int m = wg_wait2(flags, epoch, fa, fb, l, tid);
+                if (m == 0) { aborted = true; break; }
+                if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                fetch_tile(tiles + tile_off(I, k), l.A, tid);
+                if (m != 3 && !wg_wait(flags, epoch, 1, [&](int) { return fb; }, l, tid)) { aborted = true; break; }
+                fetch_tile(tiles + tile_off(K, k), l.B, tid);
+            } else if (getA || getB) {
+                if (!wg_wait(flags, epoch, 1, [&](int) { return getA ? fa : fb; }, l, tid)) { aborted = true; break; }
+                if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                if (getA) fetch_tile(tiles + tile_off(I, k), l.A, tid); else fetch_tile(tiles + tile_off(K, k), l.B, tid);
+            }
+            if (getA || getB) __syncthreads();
             const double *Ap = sa < 0 ? l.A : sm + (2 + sa) * kTileLds;
             const double *Bp = I == K ? Ap : (sb < 0 ? l.B : sm + (2 + sb) * kTileLds);
-            tile_update(slot, Ap, Bp, wv, lane);
+            if (I == K) tile_update<true>(slot, Ap, Bp, wv, lane); else tile_update<false>(slot, Ap, Bp, wv, lane);
+            __syncthreads();
+            break;
+        }
+        case DT_UPD2: {
+            // block column k into the diagonal tile (six blocks on and below the diagonal) and the tile to its left (nine)
+            const int sa = tk.pad[0], sb = tk.pad[1];
+            const int fa = dense_flag_F(nt, K, k), fb = dense_flag_F(nt, K - 1, k);
+            if (sa < 0 || sb < 0) flush();
+            if (sa < 0 && sb < 0) {
+                if (!wg_wait(flags, epoch, 2, [&](int i) { return i == 0 ? fa : fb; }, l, tid)) { aborted = true; break; }
+            } else if (sa < 0 || sb < 0) {
+                if (!wg_wait(flags, epoch, 1, [&](int) { return sa < 0 ? fa : fb; }, l, tid)) { aborted = true; break; }
+            }
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (sa < 0) fetch_tile(tiles + tile_off(K, k), l.A, tid);
+            if (sb < 0) fetch_tile(tiles + tile_off(K - 1, k), l.B, tid);
+            if (sa < 0 || sb < 0) __syncthreads();
+            const double *Ap = sa < 0 ? l.A : sm + (2 + sa) * kTileLds;
+            const double *Bp = sb < 0 ? l.B : sm + (2 + sb) * kTileLds;
+            double *sub = sm + (2 + tk.pad[2]) * kTileLds;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = wv + 4 * u;
+                if (q < 15) {
+                    const bool dg = q < 6;
+                    const int qq = dg ? q : q - 6;
+                    const int mt = dg ? (qq >= 3 ? 2 : (qq >= 1 ? 1 : 0)) : qq / 3, ntc = dg ? qq - mt * (mt + 1) / 2 : qq - mt * 3;
+                    double *cp = (dg ? slot : sub) + (mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
+                    dbl4 acc = dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
+                    acc = tile_mfma(Ap, dg ? Ap : Bp, mt, ntc, lane, acc);
+                    cp[0] = acc.x; cp[4 * LD] = acc.y; cp[8 * LD] = acc.z; cp[12 * LD] = acc.w;
+                }
+            }
             __syncthreads();
             break;
         }
         case DT_DIAG: {
-            publish_tile(ds.tiles + tile_off(K, K), slot, tid);
+            // D_K -> L(K, K) and W_K = L(K, K)^-T: the stacked sweep of D_K over the identity (scratch tile A).  W_K is what
+            // travels - the tiles below take  L(I, K) = S(I, K) W_K  as one matrix product instead of factoring D_K once more
+            // each - and what this workgroup keeps, in D_K's slot: both substitutions are products with it.
+            flush();
+            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; l.A[r * LD + cc] = r == cc ? 1.0 : 0.0; }
+            __syncthreads();
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
+            if (sweep_tiles(slot_off, 0, NB, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+            publish_tile<2>(tiles + tile_off(K, K), l.A, tid);
+            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; slot[r * LD + cc] = l.A[r * LD + cc]; }     // (behind the stores: their drain is on the chain)
             set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
             break;
         }
         case DT_OFF: {
+            flush();
             if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_PD(nt, K); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
-            fetch_tile(ds.tiles + tile_off(K, K), l.B, tid);      // D_K, factored in place in the scratch tile
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            fetch_tile<2>(tiles + tile_off(K, K), l.B, tid);      // W_K
             __syncthreads();
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
-            if (sweep_tiles(kTileLds, slot_off, NB, kBadOff(ds.slots)) && tid == 0) st_flag(ds.failw, epoch);
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
-            // (published BEFORE this workgroup goes on to its diagonal tile: the next block column's owner needs L(I, K) for
-            //  the update of its own sub-diagonal tile as much as it needs D_I; deferring it behind D_I was measured slower)
-            publish_tile(ds.tiles + tile_off(I, K), slot, tid);
-            set_flag(flags, dense_flag_F(nt, I, K), epoch, tid);
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
+            tile_times_upper(slot, l.B, wv, lane);
+            __syncthreads();
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+            // Its stores are issued here; the drain and the flag follow behind the next piece of work (for the diagonal owner: the
+            // update of D_I from its own LDS slots), so the write acknowledgements are not waited for on the chain.
+            publish_tile(tiles + tile_off(I, K), slot, tid);
+            pending = dense_flag_F(nt, I, K);
             break;
         }
         case DT_RHS: {
-            // r_K -= L(K, k) y_k for every block column to the left, then the workgroup's own factorisation of D_K with the
-            // right-hand side as row 48: L(K, K) stays in the slot for the back substitution, y_K is published
-            for (int kk = 0; kk < K && !aborted; ++kk) {
-                if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_F(nt, nt, kk); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
-                fetch_tile(ds.tiles + tile_off(K, kk), l.A, tid);
-                if (tid < NB) l.xs[tid] = ld_sc1(ds.tiles + tile_off(nt, kk) + tid);
+            // r_K -= L(K, K-1) y_(K-1) (the block columns up to K - 2 were applied by the DT_RUP tasks), then y_K = W_K^T r_K
+            flush();
+            if (K >= 1) {
+                if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_F(nt, nt, K - 1); }, l, tid)) { aborted = true; break; }
+                if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                if (tid < NB) l.xs[tid] = ld_sc1(tiles + tile_off(nt, K - 1) + tid);
                 __syncthreads();
-                const int g = tid / NB, cc = tid - g * NB;
-                if (g < 5) {
-                    double s = 0.0;
-#pragma unroll
-                    for (int q = 0; q < 10; ++q) { const int col = g + 5 * q; if (col < NB) s += l.A[cc * LD + col] * l.xs[col]; }
-                    l.ps[g * NB + cc] = s;
-                }
-                __syncthreads();
-                if (tid < NB) l.rrow[tid] -= (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid];
-                __syncthreads();
+                rhs_minus_tile_times(sm + (2 + tk.pad[0]) * kTileLds, l, tid);       // L(K, K-1): the workgroup's own tile (pad[0] = its slot)
             }
-            if (aborted) break;
-            // the right-hand side as the one row of a 16-row block of U (scratch tile A: free now)
-            if (tid < NB) l.A[tid] = l.rrow[tid];
+            if (tid < NB) l.xs[tid] = l.rrow[tid];
             __syncthreads();
-            if (sweep_tiles(slot_off, 0, 1, kBadOff(ds.slots)) && tid == 0) st_flag(ds.failw, epoch);
-            if (tid < NB) l.yv[tid] = l.A[tid];
-            __syncthreads();
-            if (tid < NB) st_sc1(ds.tiles + tile_off(nt, K) + tid, l.yv[tid]);
+            const double yk = tile_matvec<true>(slot, l, tid);
+            if (tid < NB) { l.yv[tid] = yk; st_sc1(tiles + tile_off(nt, K) + tid, yk); }
             set_flag(flags, dense_flag_F(nt, nt, K), epoch, tid);
             break;
         }
+        case DT_RUP: {
+            flush();
+            if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_F(nt, nt, k); }, l, tid)) { aborted = true; break; }
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            fetch_tile(tiles + tile_off(K, k), l.A, tid);
+            if (tid < NB) l.xs[tid] = ld_sc1(tiles + tile_off(nt, k) + tid);
+            __syncthreads();
+            rhs_minus_tile_times(l.A, l, tid);
+            break;
+        }
         case DT_BSX: {
+            // the contributions of the block rows from J + 2 down were ready long ago: summed first, so that the chain
+            // x_(J+1) -> c(J+1, J) -> x_J carries one flag and one 48-vector
             const int J = K, nc = nt - 1 - J;
-            if (nc > 0 && !wg_wait(flags, epoch, nc, [&](int i) { return dense_flag_FC(nt, J + 1 + i, J); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
-            if (tid < 64) {
-                double sv = 0.0;
-                if (tid < NB) {
-                    double acc = 0.0;
-                    for (int i0 = J + 1; i0 < nt; i0 += 8) {
+            flush();
+            double acc = 0.0;
+            if (nc > 1) {
+                if (!wg_wait(flags, epoch, nc - 1, [&](int i) { return dense_flag_FC(nt, J + 2 + i, J); }, l, tid)) { aborted = true; break; }
+                if (tid < NB)
+                    for (int i0 = J + 2; i0 < nt; i0 += 8) {
                         double v[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) v[u] = i0 + u < nt ? ld_sc1(ds.contrib + ((size_t)(i0 + u) * nt + J) * NB + tid) : 0.0;
+                        for (int u = 0; u < 8; ++u) v[u] = i0 + u < nt ? ld_sc1(contrib + ((size_t)(i0 + u) * nt + J) * NB + tid) : 0.0;
 #pragma unroll
                         for (int u = 0; u < 8; ++u) acc += v[u];
                     }
-                    sv = l.yv[tid] - acc;
-                }
-                sv = back_solve48(slot_off, sv, tid);
-                if (tid < NB) { l.xv[tid] = sv; st_sc1(ds.xsol + J * NB + tid, sv); }
             }
-            set_flag(flags, dense_flag_FX(nt, J), epoch, tid);
+            if (nc > 0 && !wg_wait(flags, epoch, 1, [&](int) { return dense_flag_FC(nt, J + 1, J); }, l, tid)) { aborted = true; break; }
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (tid < NB) {
+                if (nc > 0) acc += ld_sc1(contrib + ((size_t)(J + 1) * nt + J) * NB + tid);
+                l.xs[tid] = l.yv[tid] - acc;
+            }
+            __syncthreads();
+            const double xj = tile_matvec<false>(slot, l, tid);       // x_J = W_J (y_J - sum c(I, J))
+            if (tid < NB) { l.xv[tid] = xj; st_sc1(xsol + J * NB + tid, xj); }
+            // (flagged behind the next task when that is the contribution of this workgroup's own tile (J, J-1): one drain for
+            //  x_J and c(J, J-1) on the chain of the back substitution instead of two)
+            pending = dense_flag_FX(nt, J);
             break;
         }
         case DT_BSC: {
             // c(I, J) = L(I, J)^T x_I with J = K: column sums over the tile's rows in five row groups, combined in fixed order
             // (x_I of the workgroup's own diagonal tile is still in LDS: pad[0] of the task)
             if (tk.pad[0] != 1) {
+                flush();
                 if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_FX(nt, I); }, l, tid)) { aborted = true; break; }
-                if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
-                if (tid < NB) l.xs[tid] = ld_sc1(ds.xsol + I * NB + tid);
+                if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+                if (tid < NB) l.xs[tid] = ld_sc1(xsol + I * NB + tid);
             } else if (tid < NB) l.xs[tid] = l.xv[tid];
             __syncthreads();
             const int g = tid / NB, cc = tid - g * NB;
@@ -533,33 +688,35 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
                 l.ps[g * NB + cc] = s;
             }
             __syncthreads();
-            if (tid < NB) st_sc1(ds.contrib + ((size_t)I * nt + K) * NB + tid, (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid]);
+            if (tid < NB) st_sc1(contrib + ((size_t)I * nt + K) * NB + tid, (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid]);
             set_flag(flags, dense_flag_FC(nt, I, K), epoch, tid);
+            if (pending >= 0) { if (tid == 0) st_flag(flags + pending, epoch); pending = -1; }      // (x_I's stores were drained by the same wait)
             break;
         }
         case DT_EPI: {
+            flush();
             if (!wg_wait(flags, epoch, nt, [&](int i) { return dense_flag_FX(nt, i); }, l, tid)) { aborted = true; break; }
-            if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
             break;      // (the outputs follow the loop)
         }
         default: break;
         }
-        if (ds.stamps && tid == 0) ds.stamps[6 * (size_t)t + 5] = __builtin_amdgcn_s_memrealtime();
+        if (stamps && tid == 0) stamps[6 * (size_t)t + 5] = __builtin_amdgcn_s_memrealtime();
     }
+    flush();
     if (blockIdx.x != 0) {
-        if (aborted && tid == 0) st_flag(ds.failw + 1, epoch);
+        if (aborted && tid == 0) st_flag(failw + 1, epoch);
         return;
     }
 
     // ---- workgroup 0: increment, pose part of computeScale(), trial poses (VertexSE3Expmap::oplusImpl); releases a parked
     // solve (Ctrl::done 2 -> 0).  A solve that gave up on a wait is reported as a failed factorisation AND counted. ----
     __syncthreads();
-    const bool fail = aborted || ld_flag(ds.failw) == epoch ||
-                      ld_flag(ds.failw + 1) == epoch;
+    const bool fail = aborted || ld_flag(failw) == epoch || ld_flag(failw + 1) == epoch;
     double *x = l.A;                                // n <= 2 tiles of scratch (dense_persist_supported)
     double sc = 0.0;
     for (int idx = tid; idx < n; idx += kPT) {
-        const double xv = fail ? 0.0 : ld_sc1(ds.xsol + idx);
+        const double xv = fail ? 0.0 : ld_sc1(xsol + idx);
         const double bpv = fail ? 0.0 : ld_sc1(w.bp + idx);
         w.xp[idx] = xv;
         sc += xv * (lambda * xv + bpv);
@@ -597,12 +754,12 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
         c->pcg_last_iters = -1;                     // trace marker: this trial was solved directly
         c->n_direct += 1;
         if (fail) c->n_chol_fail += 1;
-        if (aborted || ld_flag(ds.failw + 1) == epoch) c->n_sync_timeouts += 1;
+        if (aborted || ld_flag(failw + 1) == epoch) c->n_sync_timeouts += 1;
         if (c->done == 2) c->done = 0;              // the solve was parked for this: the kernels behind run again
     }
 }
 
-size_t dense_persist_lds_bytes(int slots) { return ((size_t)(2 + slots) * kTileLds + 672) * sizeof(double); }
+size_t dense_persist_lds_bytes(int slots) { return ((size_t)(2 + slots) * kTileLds + 672 + kTaskCache * 4) * sizeof(double); }
 
 bool dense_persist_supported(const DensePlan &p)
 {

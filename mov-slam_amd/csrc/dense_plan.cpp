@@ -23,6 +23,14 @@ inline uint64_t mk_key(int stage, int cls, int a, int b)
 // updates), to the least loaded workgroup with a free slot.
 // Task order inside a workgroup: ascending key (stage, class, ...) with stage = block column + 1 for the factorisation and
 // nt + 1 + (nt - 1 - J) for the back substitution of block row J; every dependency points to a smaller key (dense_plan.h).
+// Inside a stage the keys follow the critical path  L(K, K-1) published -> [workgroup K+1] tile (K+1, K) -= L(K+1, K-1) L(K, K-1)^T
+// -> L(K+1, K):
+//   * the diagonal owner applies block column k to its diagonal tile and to its sub-diagonal tile in ONE task (DT_UPD2: both
+//     operands arrive together, L(K-1, k) from the chain's workgroup): one wait, one round of fetches, fifteen MFMA blocks;
+//   * consecutive updates that share an operand keep it in the scratch tile (pad = -2);
+//   * D_K is published straight behind its last update, ahead of the same stage's updates of the workgroup's other tiles;
+//   * the right-hand side row takes the block columns up to K - 2 one stage behind their y_k (DT_RUP, where the workgroup
+//     would otherwise wait): DT_RHS is left with the last column and the factorisation of D_K.
 void build_dense_plan(int nt, DensePlan &p, int max_groups, int max_slots)
 {
     p = DensePlan{};
@@ -67,12 +75,23 @@ void build_dense_plan(int nt, DensePlan &p, int max_groups, int max_slots)
             const int g = p.owner[tix(I, K)], s = p.slot[tix(I, K)];
             add(g, mk_key(0, 0, K, I), DT_ASM, s, I, K, 0);
             for (int k = 0; k < K; ++k) {
-                add(g, mk_key(k + 1, 3, K - k, I - K), DT_UPD, s, I, K, k);
+                if (I == K + 1 && k <= K - 1 && p.owner[tix(I, I)] == g) continue;     // (the sub-diagonal tile: updated by the owner's DT_UPD2 tasks)
+                if (I == K && k <= K - 2) {
+                    add(g, mk_key(k + 1, 3, K - 1 - k, 0), DT_UPD2, s, K, K, k);
+                    DenseTask &t = per[g].back().t;
+                    t.pad[0] = own_slot(g, K, k); t.pad[1] = own_slot(g, K - 1, k); t.pad[2] = p.slot[tix(K, K - 1)];
+                    continue;
+                }
+                add(g, I == K ? mk_key(k + 1, 3, K - 1 - k, 0) : mk_key(k + 1, 3, K - k, I - K), DT_UPD, s, I, K, k);
                 per[g].back().t.pad[0] = own_slot(g, I, k); per[g].back().t.pad[1] = own_slot(g, K, k);
             }
             if (I == K) {
-                add(g, mk_key(K + 1, 0, 0, 0), DT_DIAG, s, K, K, 0);
+                add(g, mk_key(K, 3, 0, 1), DT_DIAG, s, K, K, 0);
+                // (behind the pair of updates of block column k + 1, where the workgroup would wait for column k + 2; not behind
+                //  the pair of column K - 2, the one in front of L(K, K-1): those two follow D_K's publication)
+                for (int k = 0; k + 2 <= K; ++k) add(g, k + 4 <= K ? mk_key(k + 2, 3, K - 2 - k, 2) : mk_key(K, 3, 0, 2 + k), DT_RUP, s, K, K, k);
                 add(g, mk_key(K + 1, 2, 0, 0), DT_RHS, s, K, K, 0);
+                per[g].back().t.pad[0] = K >= 1 ? p.slot[tix(K, K - 1)] : -1;
                 add(g, mk_key(nt + 1 + (nt - 1 - K), 0, 0, 0), DT_BSX, s, K, K, 0);
             } else {
                 add(g, mk_key(K + 1, 1, I - K, 0), DT_OFF, s, I, K, 0);
@@ -85,6 +104,14 @@ void build_dense_plan(int nt, DensePlan &p, int max_groups, int max_slots)
     for (int g = 0; g < G; ++g) {
         std::sort(per[g].begin(), per[g].end(), [](const Keyed &a, const Keyed &b) { return a.key < b.key; });
         p.task_ptr[g + 1] = p.task_ptr[g] + (int32_t)per[g].size();
+        // an operand the update before fetched into the same scratch tile is not fetched again
+        for (size_t q = 1; q < per[g].size(); ++q) {
+            const DenseTask &a = per[g][q - 1].t;
+            DenseTask &b = per[g][q].t;
+            if (a.op != DT_UPD || b.op != DT_UPD || a.k != b.k) continue;
+            if (a.I == b.I && a.pad[0] < 0 && b.pad[0] == -1) b.pad[0] = -2;
+            if (a.I != a.K && b.I != b.K && a.K == b.K && a.pad[1] < 0 && b.pad[1] == -1) b.pad[1] = -2;
+        }
     }
     p.tasks.reserve(p.task_ptr[G]);
     for (int g = 0; g < G; ++g) for (const Keyed &kt : per[g]) p.tasks.push_back(kt.t);

@@ -25,10 +25,14 @@ enum DenseOp : int32_t {
     DT_BSX = 5,     // diagonal owner: x_J = L(J, J)^-T (y_J - sum_I c(I, J))   waits FC(I, J), I > J, sets FX(J)
     DT_BSC = 6,     // owner of (I, J): c(I, J) = L(I, J)^T x_I               waits FX(I), sets FC(I, J)
     DT_EPI = 7,     // increments, computeScale's pose part, trial poses      waits FX(*)
+    DT_UPD2 = 9,    // diagonal owner, block column k <= K - 2: D_K -= L(K, k) L(K, k)^T and tile (K, K-1) -= L(K, k) L(K-1, k)^T in one
+                    // task (one wait, both operands fetched together, fifteen MFMA blocks over the four waves): slot = D_K's,
+                    // pad[2] = the sub-diagonal tile's, pad[0] / pad[1] = own slot of L(K, k) / L(K-1, k) or -1       waits F(K, k), F(K-1, k)
+    DT_RUP = 8,     // diagonal owner: r_K -= L(K, k) y_k, k <= K - 2 (ahead of DT_RHS, in the shadow of the factorisation)  waits FY(k)
 };
 
-struct DenseTask { int32_t op, slot, I, K, k, pad[3]; };       // 32 bytes: one scalar load; DT_UPD: pad[0] / pad[1] = own LDS slot of L(I, k) / L(K, k), -1 = fetch;
-                                                                // DT_BSC: pad[0] = 1: x_I is in this workgroup's LDS
+struct DenseTask { int32_t op, slot, I, K, k, pad[3]; };       // 32 bytes; DT_UPD: pad[0] / pad[1] = own LDS slot of L(I, k) / L(K, k), -1 = fetch, -2 = still in
+                                                                // the scratch tile from the task before; DT_BSC: pad[0] = 1: x_I is in this workgroup's LDS
 
 constexpr int kDenseMaxSlots = 6;       // tiles a workgroup keeps in LDS (2 scratch tiles beside them: 150 KB)
 constexpr int kDenseMaxGroups = 248;    // workgroups of the launch (one per CU, a few CUs to spare)

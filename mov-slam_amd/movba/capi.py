@@ -203,10 +203,10 @@ def dense_plan(nt: int, max_groups: int = 0, max_slots: int = 0):
     info = np.zeros(4, np.int32)
     lib().movba_dense_plan_probe(nt, max_groups, max_slots, _p(info, _i), None, 0, None, 0)
     if not info[0]:
-        return dict(ok=False, G=0, slots=0, task_ptr=np.zeros(1, np.int32), tasks=np.zeros((0, 7), np.int32))
+        return dict(ok=False, G=0, slots=0, task_ptr=np.zeros(1, np.int32), tasks=np.zeros((0, 7), np.int32), tasks8=np.zeros((0, 8), np.int32))
     tp = np.zeros(info[1] + 1, np.int32); tk = np.zeros((info[3], 8), np.int32)
     lib().movba_dense_plan_probe(nt, max_groups, max_slots, _p(info, _i), _p(tp, _i), len(tp), _p(tk, _i), info[3])
-    return dict(ok=True, G=int(info[1]), slots=int(info[2]), task_ptr=tp, tasks=tk[:, :7])
+    return dict(ok=True, G=int(info[1]), slots=int(info[2]), task_ptr=tp, tasks=tk[:, :7], tasks8=tk)
 
 
 def ransac_samples(n: int, n_hyp: int, seed: int) -> np.ndarray:

@@ -6,17 +6,20 @@ leave some workgroup able to run — whatever the speeds of the workgroups."""
 import numpy as np
 import pytest
 
-ASM, UPD, DIAG, OFF, RHS, BSX, BSC, EPI = range(8)
+ASM, UPD, DIAG, OFF, RHS, BSX, BSC, EPI, RUP, UPD2 = range(10)
 
 
 def waits_and_sets(op, I, K, k, p0, p1, nt):
     """(flags a task waits for, flag it sets)"""
     if op == ASM: return [], []
-    if op == UPD:       # operands the workgroup owns itself (p0 / p1 = their LDS slots) are not waited for: program order
-        return ([("F", I, k)] if p0 < 0 else []) + ([("F", K, k)] if I != K and p1 < 0 else []), []
+    if op == UPD:       # operands the workgroup owns itself (p0 / p1 = their LDS slots) are not waited for: program order;
+        # nor are those the update before left in the scratch tiles (-2)
+        return ([("F", I, k)] if p0 == -1 else []) + ([("F", K, k)] if I != K and p1 == -1 else []), []
+    if op == UPD2: return ([("F", K, k)] if p0 < 0 else []) + ([("F", K - 1, k)] if p1 < 0 else []), []
     if op == DIAG: return [], [("PD", K)]
     if op == OFF: return [("PD", K)], [("F", I, K)]
-    if op == RHS: return [("FY", q) for q in range(K)], [("FY", K)]
+    if op == RHS: return ([("FY", K - 1)] if K >= 1 else []), [("FY", K)]
+    if op == RUP: return [("FY", k)], []
     if op == BSX: return [("FY", K)] + [("FC", i, K) for i in range(K + 1, nt)], [("FX", K)]
     if op == BSC: return ([] if p0 == 1 else [("FX", I)]), [("FC", I, K)]
     if op == EPI: return [("FX", j) for j in range(nt)], []
@@ -31,12 +34,15 @@ def replay(plan, nt, order_rng):
     upd_seen = {}                         # tile -> columns applied so far (must be 0, 1, 2, ... in order)
     state = {}                            # tile -> "asm" / "final"
     slots = {}                            # (workgroup, slot) -> tile
+    rup_seen = {}                         # block row -> columns applied to its right-hand side row by RUP tasks
+    scratch = {}                          # workgroup -> [tile in scratch A, tile in scratch B] as the device leaves them
     while True:
         runnable = [g for g in range(plan["G"]) if pc[g] < tp[g + 1] and all(f in flags for f in waits_and_sets(*tk[pc[g], [0, 2, 3, 4, 5, 6]], nt)[0])]
         if not runnable:
             break
         g = int(order_rng.choice(runnable))
         op, slot, I, K, k, p0, p1 = (int(v) for v in tk[pc[g]])
+        p2 = int(plan["tasks8"][pc[g], 7])
         tile = (I, K)
         if op == ASM:
             assert tile not in state and slots.setdefault((g, slot), tile) == tile
@@ -44,11 +50,42 @@ def replay(plan, nt, order_rng):
         elif op == UPD:
             assert state[tile] == "asm" and upd_seen[tile] == k and slots[(g, slot)] == tile
             upd_seen[tile] += 1
+            sc = scratch.setdefault(g, [None, None])
+            # an operand marked "still in scratch" must be what the device has there; both operands must be final tiles
+            if p0 == -1: sc[0] = (I, k)
+            elif p0 == -2: assert sc[0] == (I, k)
+            else: assert slots[(g, p0)] == (I, k)
+            if I != K:
+                if p1 == -1: sc[1] = (K, k)
+                elif p1 == -2: assert sc[1] == (K, k)
+                else: assert slots[(g, p1)] == (K, k)
+            assert state[(I, k)] == "final" and state[(K, k)] == "final"
+        elif op == UPD2:
+            # the diagonal tile and the tile to its left take block column k together (k <= K - 2)
+            sub = (K, K - 1)
+            assert I == K == g and k <= K - 2 and slots[(g, slot)] == tile and slots[(g, p2)] == sub
+            assert state[tile] == "asm" and state[sub] == "asm" and upd_seen[tile] == k and upd_seen[sub] == k
+            upd_seen[tile] += 1; upd_seen[sub] += 1
+            assert state[(K, k)] == "final" and state[(K - 1, k)] == "final"
+            sc = scratch.setdefault(g, [None, None])
+            if p0 < 0: sc[0] = (K, k)
+            else: assert slots[(g, p0)] == (K, k)
+            if p1 < 0: sc[1] = (K - 1, k)
+            else: assert slots[(g, p1)] == (K - 1, k)
         elif op in (DIAG, OFF):
             assert state[tile] == "asm" and upd_seen[tile] == K and slots[(g, slot)] == tile    # every column to the left applied
             state[tile] = "final"
+            if op == OFF: scratch.setdefault(g, [None, None])[1] = None                         # (D_K is fetched into scratch B)
+        elif op == RUP:
+            assert g == K and rup_seen.get(K, 0) == k and k <= K - 2 and state[(K, k)] == "final" and upd_seen[(K, K)] > k
+            rup_seen[K] = k + 1
+            scratch.setdefault(g, [None, None])[0] = None
         elif op in (RHS, BSX):
             assert state[(K, K)] == "final" and slots[(g, slot)] == (K, K)
+            if op == RHS:
+                assert rup_seen.get(K, 0) == max(K - 1, 0)       # RHS itself applies block column K - 1, from the workgroup's own tile
+                assert K == 0 or (slots[(g, p0)] == (K, K - 1) and state[(K, K - 1)] == "final")
+                scratch.setdefault(g, [None, None])[0] = None
         elif op == BSC:
             assert state[tile] == "final" and slots[(g, slot)] == tile
         for s in waits_and_sets(op, I, K, k, p0, p1, nt)[1]:
