@@ -198,14 +198,20 @@ __device__ __forceinline__ void tile_times_upper(double *U, const double *W, int
     if (wv >= 3) return;
     const double *ap = U + (wv * 16 + (lane & 15)) * LD + (lane >> 4);          // A[i = lane & 15][k = lane >> 4]
     const double *bp = W + (lane >> 4) * LD + (lane & 15);                      // B[k = lane >> 4][j = lane & 15]
+    // every operand in registers first (36 LDS reads in flight), then the 24 matrix instructions back to back
+    double a[12], b0[4], b1[8], b2[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) { a[q] = ap[4 * q]; b2[q] = bp[4 * q * LD + 32]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b1[q] = bp[4 * q * LD + 16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b0[q] = bp[4 * q * LD];
     dbl4 x0 = dbl4{ 0.0, 0.0, 0.0, 0.0 }, x1 = x0, x2 = x0;
 #pragma unroll
-    for (int k = 0; k < NB; k += 4) {
-        const double a = ap[k];
-        const int kb = k >> 4;
-        if (kb <= 0) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LD], x0, 0, 0, 0);
-        if (kb <= 1) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LD + 16], x1, 0, 0, 0);
-        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[k * LD + 32], x2, 0, 0, 0);
+    for (int q = 0; q < 12; ++q) {
+        if (q < 4) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b0[q], x0, 0, 0, 0);
+        if (q < 8) x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b1[q], x1, 0, 0, 0);
+        x2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b2[q], x2, 0, 0, 0);
     }
     double *cp = U + (wv * 16 + (lane >> 4)) * LD + (lane & 15);                // C: col = lane & 15, row = (lane >> 4) + 4 reg
     cp[0] = x0.x; cp[4 * LD] = x0.y; cp[8 * LD] = x0.z; cp[12 * LD] = x0.w;
@@ -349,49 +355,89 @@ __device__ __attribute__((noinline)) void assemble_tile(AsmView av, int I, int K
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The stacked sweep  [D; U] -> [L(K, K); U L(K, K)^-T]  of a diagonal tile D (48 x 48, LDS image at d_off) and up to 48 more
-// rows U (the workgroup's own tile, or the right-hand side row), in three panels of 16 columns:
+// D (48 x 48, LDS image at d_off, overwritten) -> W = L^-T (upper triangular, LDS image at w_off; its blocks below the
+// diagonal are NOT written) with D = L L^T: the stacked sweep [D; I] -> [L; L^-T] in three panels of 16 columns.
 //   chain   the panel's 16 pivots with one ROW PER LANE and the panel's 16 entries of the row in registers; pivot row k is
 //           lane k, broadcast entry by entry with v_readlane (no LDS round trip, no barrier inside the chain):
 //           p_rc -= (p_rk / p_kk) p_kc for c > k.  Wave 0 holds the rows of D from the panel's diagonal block down; wave 1
-//           holds that diagonal block ONCE MORE on its lanes 0..15 (the same arithmetic, bit for bit) and the rows of U on
-//           lanes 16..63, so neither wave needs anything from the other inside a panel;
-//   trail   [D22; U2] -= [L21; U1] L21^T on the fp64 matrix cores, 16 x 16 blocks dealt to the four waves.
-// 48 dependent pivots of ~100 cycles each instead of 48 LDS round trips of ~900 (the single-wave sweeps of dense_tile.h
-// took 18 us of a 25 us block column).  The upper triangle of a diagonal block is carried as its symmetric image.
+//           holds that diagonal block ONCE MORE on its lanes 0..15 (the same arithmetic, bit for bit) and behind it the rows
+//           of the identity's image: row blocks 0 .. panel, the last of them still the identity itself (made in registers:
+//           nothing below the diagonal of [I] is ever touched), so neither wave needs anything from the other in a panel;
+//   trail   one round of three 16 x 16 blocks on the fp64 matrix cores, column block by column block (left-looking: block
+//           column 2 takes both panels' updates at once): D(1,1), D(2,1), W(0,1) after panel 0; D(2,2), W(0,2), W(1,2)
+//           after panel 1.
+// L itself is not kept (only the rows below a panel, which the trailing products read): the substitutions and the tiles
+// below use W.  The upper triangle of a diagonal block of D is carried as its symmetric image.
 // Returns true (to every thread) when a pivot was not positive: the caller marks the factorisation failed.
 // ---------------------------------------------------------------------------------------------------------------------
+// One pivot of the chain.  What limits a panel is the dependent sequence
+//     entry (K, K) final -> v_readlane (pivot) -> v_rcp_f64 -> e -> t -> td = p_K / pivot -> p_(K+1) -= td s_(K+1) -> next pivot
+// so everything else is issued INTO that sequence's latency, in an order pinned by scheduling barriers (left to itself the
+// scheduler put the thirty broadcasts and fifteen updates of a pivot in front of the reciprocal's refinement):
+//   * pivot K's remaining updates (columns K + 2 ...) are deferred into pivot K + 1's reciprocal chain (tdp, sp = the previous
+//     pivot's multiplier and row), two between each pair of dependent operations;
+//   * p_K / pivot by ONE cubic step from the hardware reciprocal (relative error 2^-24 -> 2^-72): three dependent operations;
+//   * the pivots are collected on their own lanes (mine): 1 / sqrt(pivot) is computed ONCE behind the chain, lane-parallel.
+// A pivot that is not positive and finite is only recorded: the numbers that follow are garbage, the caller marks the
+// factorisation failed and nothing of it is used.
+#ifdef MOVBA_CHAIN_PINNED
+#define CHAIN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CHAIN_FENCE() do { } while (0)
+#endif
+// lane LANE of old <- the wave-uniform v (two v_writelane_b32 from scalar registers)
+template <int LANE>
+__device__ __forceinline__ double writelane_f64(double v, double old)
+{
+    int lo = __double2loint(old), hi = __double2hiint(old);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(__double2loint(v)), "n"(LANE));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(__double2hiint(v)), "n"(LANE));
+    return __hiloint2double(hi, lo);
+}
 template <int K>
 struct PanelStep {
-    static __device__ __forceinline__ void run(double (&p)[16], double (&pk)[16], bool &bad)
+    static __device__ __forceinline__ void run(double (&p)[16], double &mine, bool &bad, int lane, double piv, double r0, double tdp, const double (&sp)[16])
     {
-        double piv = readlane_f64(p[K], K);
-        if (!(piv > 0.0) || !isfinite(piv)) { bad = true; piv = 1.0; }
-        pk[K] = piv;
-        const double td = p[K] * fast_rcp(piv);
-        // the pivot row's entries first, each into scalar registers of its own, then the updates: read one by one in front of
-        // its update every v_readlane pair was followed by the wait states of the scalar-to-vector hazard
+        const double e = __builtin_fma(-piv, r0, 1.0);
+        const double q0 = p[K] * r0;
+        CHAIN_FENCE();
+        if constexpr (K >= 1 && K + 1 < 16) p[K + 1] -= tdp * sp[K + 1];
+        if constexpr (K >= 1 && K + 2 < 16) p[K + 2] -= tdp * sp[K + 2];
+        CHAIN_FENCE();
+        const double t = __builtin_fma(e, e, e);
+        CHAIN_FENCE();
+        if constexpr (K >= 1 && K + 3 < 16) p[K + 3] -= tdp * sp[K + 3];
+        if constexpr (K >= 1 && K + 4 < 16) p[K + 4] -= tdp * sp[K + 4];
+        CHAIN_FENCE();
+        const double td = __builtin_fma(q0, t, q0);
+        CHAIN_FENCE();
+        if constexpr (K >= 1) {
+#pragma unroll
+            for (int c = K + 5; c < 16; ++c) p[c] -= tdp * sp[c];
+        }
+        mine = writelane_f64<K>(piv, mine);           // (two v_writelane from the pivot's scalar registers)
         double s[16];
 #pragma unroll
         for (int c = K + 1; c < 16; ++c) s[c] = readlane_f64(p[c], K);
-#pragma unroll
-        for (int c = K + 1; c < 16; ++c) p[c] -= td * s[c];
-        PanelStep<K + 1>::run(p, pk, bad);
+        CHAIN_FENCE();
+        if constexpr (K < 15) {
+            p[K + 1] -= td * s[K + 1];
+            CHAIN_FENCE();
+            const double pivn = readlane_f64(p[K + 1], K + 1);
+            const double r0n = __builtin_amdgcn_rcp(pivn);
+            CHAIN_FENCE();
+            PanelStep<K + 1>::run(p, mine, bad, lane, pivn, r0n, td, s);
+        }
     }
 };
-template <>
-struct PanelStep<16> {
-    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], bool &) {}
-};
 
-__device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int n_urows, int flag_off)
+__device__ __attribute__((noinline)) bool sweep_inverse(int d_off, int w_off, int flag_off)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];     // (LDS addressed from its own symbol: ds_ instructions, not flat_)
-    double *D = sm + d_off, *U = sm + u_off;
+    double *D = sm + d_off, *W = sm + w_off;
     int *s_bad = reinterpret_cast<int *>(sm + flag_off);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_ublk = (n_urows + 15) >> 4;
     if (tid == 0) *s_bad = 0;
 #ifdef MOVBA_SWEEP_PROFILE
     unsigned long long *prof = reinterpret_cast<unsigned long long *>(sm + flag_off - 660 + 256);      // (Lds::ps: idle during a sweep)
@@ -400,74 +446,84 @@ __device__ __attribute__((noinline)) bool sweep_tiles(int d_off, int u_off, int 
 #define SWEEP_MARK(i) do { } while (0)
 #endif
     SWEEP_MARK(0);
+    bool bad_any = false;
 #pragma unroll 1
     for (int pn = 0; pn < 3; ++pn) {
         const int c0 = 16 * pn;
         double pr[16], pk[16];
-        double *rowp = D;
-        bool writes = false, chain = false;
-        int diag_i = 16;                                // lanes of wave 0 below 16 hold a row of the diagonal block: entries right of the diagonal are not stored
+        double *rowp = D + c0 * LD + c0;                // (lanes without a row of their own shadow the pivot block's first row)
+        bool writes = false;
+        int ident_c = -1;
+        const bool chain = wv < 2;
         if (wv == 0) {
-            const int nr = NB - c0, i = lane < nr ? lane : nr - 1;      // (lanes past the last row shadow it; nothing of theirs is stored)
-            rowp = D + (c0 + i) * LD + c0; writes = lane < nr; chain = true; diag_i = lane;
-        } else if (wv == 1 && n_urows > 0) {
-            const int r = lane - 16 < n_urows ? lane - 16 : n_urows - 1;
-            rowp = lane < 16 ? D + (c0 + lane) * LD + c0 : U + r * LD + c0;
-            writes = lane >= 16 && lane - 16 < n_urows; chain = true;
+            const int nr = NB - c0;
+            if (lane < nr) rowp = D + (c0 + lane) * LD + c0;
+            writes = lane >= 16 && lane < nr;           // (the rows below the pivot block: L21, read by the trailing products)
+        } else if (wv == 1) {
+            const int r = lane - 16;
+            if (lane < 16) rowp = D + (c0 + lane) * LD + c0;
+            else if (r < c0 + 16) { rowp = W + r * LD + c0; writes = true; if (r >= c0) ident_c = r - c0; }
         }
-        bool bad = false;
         if (chain) {
 #pragma unroll
-            for (int c = 0; c < 16; ++c) pr[c] = rowp[c];
-            SWEEP_MARK(1 + 5 * pn);
-            PanelStep<0>::run(pr, pk, bad);
-            SWEEP_MARK(2 + 5 * pn);
-        }
-        __syncthreads();                                // wave 1 has read the diagonal block before wave 0 stores its factor over it
-        SWEEP_MARK(3 + 5 * pn);
-        if (chain) {
-            if (bad && lane == 0) *s_bad = 1;
-            if (writes) {
+            for (int c = 0; c < 16; ++c) pr[c] = rowp[c];               // (all sixteen reads in flight; an identity row reads and drops)
+            if (__any(ident_c >= 0)) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
-                    // 1 / sqrt(pivot) by v_rsq_f64 and two Newton steps
-                    double rs = __builtin_amdgcn_rsq(pk[c]);
-                    rs = rs * (1.5 - 0.5 * pk[c] * rs * rs);
-                    rs = rs * (1.5 - 0.5 * pk[c] * rs * rs);
-                    rowp[c] = c <= diag_i ? pr[c] * rs : 0.0;
+                    // (bitwise selects: the value read may be anything)
+                    const long long keep = ident_c >= 0 ? 0ll : -1ll, one = c == ident_c ? 0x3ff0000000000000ll : 0ll;
+                    pr[c] = __longlong_as_double((__double_as_longlong(pr[c]) & keep) | one);
                 }
+            }
+            SWEEP_MARK(1 + 4 * pn);
+            {
+                const double piv0 = readlane_f64(pr[0], 0);
+                const double s0[16] = {};
+                double mine = 1.0;
+                bool bad = false;
+                PanelStep<0>::run(pr, mine, bad, lane, piv0, __builtin_amdgcn_rcp(piv0), 0.0, s0);
+                bad_any |= __any(!(mine > 0.0 && mine < __builtin_inf()));
+                // 1 / sqrt(pivot) by v_rsq_f64 and two Newton steps, pivot c on lane c; broadcast for the scaling below
+                double rs = __builtin_amdgcn_rsq(mine);
+                const double hp = 0.5 * mine;
+                rs = rs * __builtin_fma(-hp * rs, rs, 1.5);
+                rs = rs * __builtin_fma(-hp * rs, rs, 1.5);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) pk[c] = readlane_f64(rs, c);
+            }
+            SWEEP_MARK(2 + 4 * pn);
+            if (writes) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) rowp[c] = pr[c] * pk[c];
             }
         }
         __syncthreads();
-        SWEEP_MARK(4 + 5 * pn);
+        SWEEP_MARK(3 + 4 * pn);
         if (pn == 2) break;
-        // ---- trailing blocks of this panel: D blocks (rb, cb), rb >= cb > pn, then U blocks (ub, cb) ----
-        const int ncb = 2 - pn;                         // column blocks right of the panel
-        const int nD = ncb * (ncb + 1) / 2, nblk = nD + n_ublk * ncb;
-        for (int q = wv; q < nblk; q += 4) {
-            int rb, cb;
-            const double *Arow;
-            double *Cbase;
-            if (q < nD) {
-                // (pn == 0: blocks (1,1), (2,1), (2,2); pn == 1: block (2,2))
-                if (pn == 0) { cb = q < 2 ? 1 : 2; rb = q == 0 ? 1 : 2; } else { cb = 2; rb = 2; }
-                Arow = D + (16 * rb) * LD; Cbase = D + (16 * rb) * LD + 16 * cb;
-            } else {
-                const int qq = q - nD;
-                rb = qq / ncb; cb = pn + 1 + (qq - rb * ncb);
-                Arow = U + (16 * rb) * LD; Cbase = U + (16 * rb) * LD + 16 * cb;
-            }
-            const double *ap = Arow + (lane & 15) * LD + c0 + (lane >> 4);
-            const double *bp = D + (16 * cb + (lane & 15)) * LD + c0 + (lane >> 4);
-            double *cp = Cbase + (lane >> 4) * LD + (lane & 15);
-            dbl4 acc = dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
+        if (wv < 3) {
+            // pn == 0: D(1,1), D(2,1), W(0,1) over the panel's columns;  pn == 1: D(2,2), W(0,2) over both panels', W(1,2) over this one's
+            const int cb = pn + 1;
+            const bool isW = pn == 0 ? wv == 2 : wv >= 1;
+            const int rb = pn == 0 ? (wv == 0 ? 1 : (wv == 1 ? 2 : 0)) : (wv == 0 ? 2 : wv - 1);
+            const int k0 = (pn == 1 && wv < 2) ? 0 : c0, k1 = c0 + 16;
+            const double *Ab = (isW ? W : D) + (16 * rb) * LD;
+            double *Cb = (isW ? W : D) + (16 * rb) * LD + 16 * cb;
+            const double *ap = Ab + (lane & 15) * LD + (lane >> 4);
+            const double *bp = D + (16 * cb + (lane & 15)) * LD + (lane >> 4);
+            double *cp = Cb + (lane >> 4) * LD + (lane & 15);
+            dbl4 acc = isW ? dbl4{ 0.0, 0.0, 0.0, 0.0 } : dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
+            double av[8], bv[8];
 #pragma unroll
-            for (int k4 = 0; k4 < 16; k4 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-ap[k4], bp[k4], acc, 0, 0, 0);
+            for (int q = 0; q < 8; ++q) { const int k = k0 + 4 * q; av[q] = k < k1 ? -ap[k] : 0.0; bv[q] = k < k1 ? bp[k] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (k0 + 4 * q < k1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
             cp[0] = acc.x; cp[4 * LD] = acc.y; cp[8 * LD] = acc.z; cp[12 * LD] = acc.w;
         }
         __syncthreads();
-        SWEEP_MARK(5 + 5 * pn);
+        SWEEP_MARK(4 + 4 * pn);
     }
+    if (bad_any && lane == 0) *s_bad = 1;
+    __syncthreads();
     return *s_bad != 0;
 }
 
@@ -586,13 +642,18 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             // travels - the tiles below take  L(I, K) = S(I, K) W_K  as one matrix product instead of factoring D_K once more
             // each - and what this workgroup keeps, in D_K's slot: both substitutions are products with it.
             flush();
-            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; l.A[r * LD + cc] = r == cc ? 1.0 : 0.0; }
-            __syncthreads();
             if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
-            if (sweep_tiles(slot_off, 0, NB, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
+            if (sweep_inverse(slot_off, 0, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
             if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+#ifdef MOVBA_SWEEP_PROFILE
+            if (stamps && tid == 0 && K == 1) {
+                const unsigned long long *pf = reinterpret_cast<const unsigned long long *>(l.ps);
+                printf("sweep D_1: p0 load %llu chain %llu store+sync %llu trail %llu | p1 load %llu chain %llu store+sync %llu trail %llu | p2 load %llu chain %llu store+sync %llu  (x10 ns)\n",
+                       pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8] - pf[7], pf[9] - pf[8], pf[10] - pf[9], pf[11] - pf[10]);
+            }
+#endif
             publish_tile<2>(tiles + tile_off(K, K), l.A, tid);
-            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; slot[r * LD + cc] = l.A[r * LD + cc]; }     // (behind the stores: their drain is on the chain)
+            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; slot[r * LD + cc] = tri_skip<2>(r, cc) ? 0.0 : l.A[r * LD + cc]; }     // (behind the stores: their drain is on the chain)
             set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
             break;
         }

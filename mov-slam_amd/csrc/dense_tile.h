@@ -41,8 +41,11 @@ __device__ __forceinline__ dbl4 tile_mfma(const double *As, const double *Bs, in
 {
     const double *ap = As + (mt * 16 + (lane & 15)) * LD + (lane >> 4);
     const double *bp = Bs + (nt * 16 + (lane & 15)) * LD + (lane >> 4);
+    double a[NB / 4], b[NB / 4];                    // (operands in registers first: 24 LDS reads in flight, then the chain)
 #pragma unroll
-    for (int k = 0; k < NB; k += 4) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-ap[k], bp[k], c, 0, 0, 0);
+    for (int q = 0; q < NB / 4; ++q) { a[q] = -ap[4 * q]; b[q] = bp[4 * q]; }
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], c, 0, 0, 0);
     return c;
 }
 
