@@ -238,18 +238,21 @@ __device__ __forceinline__ double tile_matvec(const double *T, const Lds &l, int
 // slot -= A B^T, the nine 16 x 16 MFMA tiles dealt round-robin to the four waves; LOWER (a diagonal tile, A == B): the six
 // tiles on and below the diagonal only
 template <bool LOWER>
-__device__ __forceinline__ void tile_update(double *C, const double *As, const double *Bs, int wv, int lane)
+__device__ __forceinline__ void tile_update(double *C, const double *As, const double *Bs, int wv, int lane, double *Cout = nullptr)
 {
+    if (!Cout) Cout = C;                // (the last update of a diagonal tile lands in scratch tile B, where the sweep takes it from)
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int q = wv + 4 * u;
         if (q < (LOWER ? 6 : 9)) {
             // (lower: tiles (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) in that order)
             const int mt = LOWER ? (q >= 3 ? 2 : (q >= 1 ? 1 : 0)) : q / 3, ntc = LOWER ? q - mt * (mt + 1) / 2 : q - mt * 3;
-            double *cp = C + (mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
+            const int off = (mt * 16 + (lane >> 4)) * LD + ntc * 16 + (lane & 15);
+            const double *cp = C + off;
             dbl4 acc = dbl4{ cp[0], cp[4 * LD], cp[8 * LD], cp[12 * LD] };
             acc = tile_mfma(As, Bs, mt, ntc, lane, acc);
-            cp[0] = acc.x; cp[4 * LD] = acc.y; cp[8 * LD] = acc.z; cp[12 * LD] = acc.w;
+            double *op = Cout + off;
+            op[0] = acc.x; op[4 * LD] = acc.y; op[8 * LD] = acc.z; op[12 * LD] = acc.w;
         }
     }
 }
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             if (getA || getB) __syncthreads();
             const double *Ap = sa < 0 ? l.A : sm + (2 + sa) * kTileLds;
             const double *Bp = I == K ? Ap : (sb < 0 ? l.B : sm + (2 + sb) * kTileLds);
-            if (I == K) tile_update<true>(slot, Ap, Bp, wv, lane); else tile_update<false>(slot, Ap, Bp, wv, lane);
+            if (I == K) tile_update<true>(slot, Ap, Bp, wv, lane, k == K - 1 ? l.B : nullptr); else tile_update<false>(slot, Ap, Bp, wv, lane);
             __syncthreads();
             break;
         }
@@ -638,12 +641,18 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             break;
         }
         case DT_DIAG: {
-            // D_K -> L(K, K) and W_K = L(K, K)^-T: the stacked sweep of D_K over the identity (scratch tile A).  W_K is what
+            // D_K -> W_K = L(K, K)^-T: the stacked sweep of D_K over the identity (sweep_inverse).  W_K is what
             // travels - the tiles below take  L(I, K) = S(I, K) W_K  as one matrix product instead of factoring D_K once more
             // each - and what this workgroup keeps, in D_K's slot: both substitutions are products with it.
             flush();
+            // (D_K lies in scratch tile B: its last update wrote it there - block column 0's is copied - so that W_K can be
+            //  written straight into the slot)
+            if (K == 0) {
+                for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; l.B[r * LD + cc] = slot[r * LD + cc]; }
+                __syncthreads();
+            }
             if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
-            if (sweep_inverse(slot_off, 0, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
+            if (sweep_inverse(kTileLds, slot_off, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
             if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
 #ifdef MOVBA_SWEEP_PROFILE
             if (stamps && tid == 0 && K == 1) {
@@ -652,9 +661,11 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
                        pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8] - pf[7], pf[9] - pf[8], pf[10] - pf[9], pf[11] - pf[10]);
             }
 #endif
-            publish_tile<2>(tiles + tile_off(K, K), l.A, tid);
-            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; slot[r * LD + cc] = tri_skip<2>(r, cc) ? 0.0 : l.A[r * LD + cc]; }     // (behind the stores: their drain is on the chain)
+            publish_tile<2>(tiles + tile_off(K, K), slot, tid);
             set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
+            // (behind the flag: what is left of D_K below the diagonal blocks goes, the substitutions multiply with the whole slot)
+            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; if (tri_skip<2>(r, cc)) slot[r * LD + cc] = 0.0; }
+            __syncthreads();
             break;
         }
         case DT_OFF: {
