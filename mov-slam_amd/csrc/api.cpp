@@ -807,16 +807,17 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (!edge_b_queued) { const int rq = queue_edge_b(); if (rq) return rq; }
     h->pp = PcgParams{};
     h->rows_kernel = pcg_rows_supported(s.nfree, s.row_ptr.data(), &h->pp);
-    // A reduced matrix far beyond the PCG workgroup's registers (dense covisibility: every keyframe pair shares points, as in
-    // the reference's own windows, KeyFrame.cc:227-231) is not iterated over from L2: the one-launch direct solver takes the
-    // window from the first trial, whatever its pattern.  Measured (profiles/r03*_patterns.json): hub 50 keyframes, 2 550 gather
-    // entries against the 1 024 the registers hold: PCG 283 us per trial, direct 195; 80 keyframes with cfg3's band, 1 580
-    // entries: PCG 220, direct 274 — so the switch sits at twice the register capacity.
+    // A reduced matrix beyond the PCG workgroup's registers (dense covisibility: every keyframe pair shares points, as in the
+    // reference's own windows, KeyFrame.cc:227-231; or simply more keyframes) is not iterated over from L2: the one-launch
+    // direct solver takes the window from the first trial, whatever its pattern.  Measured (profiles/r03zd_solver_switch.log,
+    // solve kernels per window solve): 50 keyframes, 900 gather entries, all in registers: PCG 0.71 ms, direct 1.30; 56
+    // keyframes, 1 020 entries, the first to overflow: PCG 1.35, direct 1.26; 80 keyframes, 1 500 entries: 2.21 / 1.74; 50
+    // keyframes with tracks of up to 20, 1 600 entries: 1.88 / 1.38 - the PCG's cost doubles the moment it spills, so that is
+    // where the switch sits.
     // (movba_options::pcg_spill = 1 keeps the spilling PCG whatever the size; ::solver = 1 takes every window direct.)
     {
-        const int cap = 2 * 64 * (kPcgRowsThreads / 64);        // gather entries the PCG workgroup keeps in VGPRs
-        const bool far_over = h->rows_kernel && h->pp.overflow && (int)s.row_ent.size() > 2 * cap;
-        if (h->rows_kernel && ((far_over && !h->opt.pcg_spill) || h->opt.solver == 1)) h->rows_kernel = false;
+        const bool over = h->rows_kernel && h->pp.overflow;
+        if (h->rows_kernel && ((over && !h->opt.pcg_spill) || h->opt.solver == 1)) h->rows_kernel = false;
     }
     if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     lap("pcg plan + coarse lists");

@@ -82,16 +82,16 @@ def test_baseline_configs_full_size(solver, oracle_mod, name):
 
 def test_dense_covisibility_window_spills_list_tails_to_l2(solver, oracle_mod, built_lib):
     """Long tracks (10-30 keyframes per point): the reduced matrix is nearly dense and exceeds what the PCG workgroup keeps
-    in VGPRs.  Up to twice the register capacity the PCG still runs, reading its list tails from the L2 copy of S; beyond
-    (the 50-keyframe hub window of test_covisibility_patterns_...) the one-launch direct solver takes the window.  Both
-    solvers on this window, each against the oracle."""
+    in VGPRs.  By default the one-launch direct solver takes such a window from the first trial (the PCG's cost doubles the
+    moment it reads list tails from the L2 copy of S: profiles/r03zd_solver_switch.log); movba_options::pcg_spill keeps the
+    PCG.  Both solvers on this window, each against the oracle."""
     w = synth.make_window(40, 4, 3000, seed=5, run_lo=10, run_hi=30)
     plan = built_lib.structure_probe(w)
     assert plan["pcg_on_chip"] and plan["pcg_overflow"] and plan["max_degree"] >= 25
     o = oracle_mod.solve(w)
     r = solver.solve(w)
     check_against(r, o, w)
-    assert (r["n_direct"] == r["n_solves"]) == (plan["n_row_entries"] > 2048) and r["n_sync_timeouts"] == 0
+    assert r["n_direct"] == r["n_solves"] and r["n_sync_timeouts"] == 0
     for kw in (dict(pcg_spill=True), dict(direct=True)):
         s = built_lib.Solver(**kw)
         try:
