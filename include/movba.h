@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOVBA_VERSION 3
+#define MOVBA_VERSION 4
 
 /* status codes */
 #define MOVBA_OK              0
@@ -77,6 +77,11 @@ typedef struct {
      * mvuRight[idx] of a stereo observation (third residual u_r - (u - bf/z)); < 0 or NULL: monocular */
     const double  *obs_right;   /* E or NULL                                                  */
     double bf;                  /* KeyFrame::mbf (Optimizer.cc:695)                           */
+    /* intrinsics by keyframe: the reference gives every edge the camera of ITS keyframe (e->pCamera = pKFi->mpCamera,
+     * Optimizer.cc:664; e->fx .. e->bf = pKFi->fx .. pKFi->mbf, :690-695).  NULL (every shipped MoV-SLAM configuration has
+     * one camera): fx, fy, cx, cy / bf above hold for every keyframe.  Either may be given without the other.        */
+    const double  *cam_kf;      /* n_poses x 4 (fx fy cx cy) or NULL                          */
+    const double  *bf_kf;       /* n_poses or NULL                                            */
 } movba_lba_desc;
 
 #define MOVBA_MAX_TRACE 128

@@ -522,6 +522,8 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
     const size_t o_obsr = c.take<double>(d->obs_right ? E : 0);
     const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
+    const bool has_kcam = d->cam_kf || d->bf_kf;               // intrinsics by keyframe (src/Optimizer.cc:664, 690-695)
+    const size_t o_kcam = c.take<double>(has_kcam ? 8 * (size_t)NP : 0);
     const size_t edge_bytes_grouped = c.off;
     const size_t o_perm = c.take<int32_t>(E);                   // only travels when the caller's edges are not grouped by point
     const size_t edge_bytes_max = c.off;
@@ -569,6 +571,14 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         if (d->obs_right) std::memcpy(sg + o_obsr, d->obs_right, sizeof(double) * (size_t)E);
         std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
         std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
+        if (has_kcam) {
+            double *kc = reinterpret_cast<double *>(sg + o_kcam);
+            for (int i = 0; i < NP; ++i) {
+                const double *ck = d->cam_kf ? d->cam_kf + 4 * (size_t)i : &d->fx;      // (fx, fy, cx, cy are contiguous in the descriptor)
+                kc[8 * i] = ck[0]; kc[8 * i + 1] = ck[1]; kc[8 * i + 2] = ck[2]; kc[8 * i + 3] = ck[3];
+                kc[8 * i + 4] = d->bf_kf ? d->bf_kf[i] : d->bf; kc[8 * i + 5] = kc[8 * i + 6] = kc[8 * i + 7] = 0.0;
+            }
+        }
         send(o_isig, edge_bytes_grouped);
         if (raw_copy_err == hipSuccess) raw_copy_err = hipEventRecord(h->copy_event, h->copy_stream);
     });
@@ -959,6 +969,7 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
     w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
     w.obs_r = d->obs_right ? reinterpret_cast<double *>(a + o_obsr) : nullptr; w.bf = d->bf; w.stereo = stereo ? 1 : 0;
+    w.kcam = has_kcam ? reinterpret_cast<const double *>(a + o_kcam) : nullptr;
     w.slot = reinterpret_cast<int32_t *>(a + o_slot);
     w.obs_pm = reinterpret_cast<double *>(a + o_obspm); w.obsr_pm = reinterpret_cast<double *>(a + o_obsrpm);
     {
@@ -1246,7 +1257,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
         h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false;
         if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
         if (caller_stop(h->stop)) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
-        if (!h->rows_kernel) { solo.push_back(h); continue; }
+        if (!h->rows_kernel || h->win.kcam) { solo.push_back(h); continue; }      // (direct-solver windows and windows with intrinsics by keyframe run on their own)
         act.push_back(h);
     }
     const int na = (int)act.size();

@@ -117,6 +117,8 @@ struct DevWindow {
                             // edge record instead of reading a second per-edge record that every trial would have to write
     double *obsr_pm;        // E_free: right-image u by slot (stereo windows only)
     double bf;              // KeyFrame::mbf
+    const double *kcam;     // per-keyframe intrinsics, NP x 8 (fx fy cx cy bf 0 0 0), or nullptr: fx .. cy / bf above hold for every keyframe
+                            // (the reference gives every edge its keyframe's camera: src/Optimizer.cc:664, 690-695)
     int32_t stereo, pad2;   // window has >= 1 stereo edge: 3-row kernels
     const int32_t *slot;    // E: pose-major slot of a grouped edge (-1: edge of a fixed pose)
     // k_schur entry lists.  Diagonal pair of free pose h: its entry k IS pose-major slot k (the diagonal pairs come first

@@ -68,6 +68,22 @@ __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int 
     w.st[0].Rt[12 * i + 9] = q[4]; w.st[0].Rt[12 * i + 10] = q[5]; w.st[0].Rt[12 * i + 11] = q[6];
 }
 
+// The camera of an edge is its keyframe's (src/Optimizer.cc:664: e->pCamera = pKFi->mpCamera; :690-695: e->fx .. e->bf from
+// pKFi): one set of intrinsics for the whole window in every shipped MoV-SLAM configuration (DevWindow::fx ..), a table by
+// keyframe when the caller hands one (movba_lba_desc::cam_kf / bf_kf).  The choice is a wave-uniform branch.
+struct Cam { double fx, fy, cx, cy, bf; };
+// PERKF = false: the window's one camera, straight from the kernel's scalar arguments (the instantiations every shipped
+// configuration runs: carried as a runtime choice the table's values took vector registers in k_schur, which has none to
+// spare - 17 -> 22 us per launch at cfg3); PERKF = true: row ip of DevWindow::kcam
+template <bool PERKF>
+__device__ __forceinline__ Cam cam_of(const DevWindow &w, int ip)
+{
+    if (!PERKF) return Cam{ w.fx, w.fy, w.cx, w.cy, w.bf };
+    const double *k = w.kcam + 8 * (size_t)ip;
+    return Cam{ k[0], k[1], k[2], k[3], k[4] };
+}
+__device__ __forceinline__ Cam cam_of_rt(const DevWindow &w, int ip) { return w.kcam ? cam_of<true>(w, ip) : cam_of<false>(w, ip); }
+
 __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim.x); }
 
 // --------------------------------------------------------------------------------
@@ -79,7 +95,7 @@ __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim
 // --------------------------------------------------------------------------------
 // LDSP: the keyframe rotations (and, for BACKSUB, the pose increments and hessian indices) are staged in LDS; windows
 // with more keyframes than fit (~850) read them through L2 instead (same arithmetic, same results).
-template <bool BACKSUB, bool STEREO, bool LDSP>
+template <bool BACKSUB, bool STEREO, bool LDSP, bool PERKF = false>
 __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -163,16 +179,17 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
             // (one reciprocal per edge and multiplications: an fp64 division is a ~25-instruction sequence, and the projection
             //  and its Jacobian would take six of them)
-            const double iz = fast_rcp_zero_safe(z), u = w.fx * x * iz, v = w.fy * y * iz;
-            const double e0 = ob.x - (u + w.cx);
-            const double e1 = ob.y - (v + w.cy);
+            const Cam cm = cam_of<PERKF>(w, ip);
+            const double iz = fast_rcp_zero_safe(z), u = cm.fx * x * iz, v = cm.fy * y * iz;
+            const double e0 = ob.x - (u + cm.cx);
+            const double e1 = ob.y - (v + cm.cy);
             double chi2 = e0 * (om * e0) + e1 * (om * e1);
-            if (STEREO && ur >= 0.0) { const double e2 = ur - (u + w.cx - w.bf * iz); chi2 += e2 * (om * e2); }
+            if (STEREO && ur >= 0.0) { const double e2 = ur - (u + cm.cx - cm.bf * iz); chi2 += e2 * (om * e2); }
             double rho1 = 1.0;
             if (w.huber_delta > 0.0 && !(chi2 <= dsq0)) rho1 = w.huber_delta * rsqrt(chi2);
             const double wg = rho1 * om;
-            const double a00 = -(w.fx * iz), a02 = u * iz;
-            const double a11 = -(w.fy * iz), a12 = v * iz;
+            const double a00 = -(cm.fx * iz), a02 = u * iz;
+            const double a11 = -(cm.fy * iz), a12 = v * iz;
             const double *xp = pxp + 6 * h;
             // t = J_c xp  (rows of -Jpi [ -[Xc]x | I ])
             const double t0 = (a02 * y) * xp[0] + (a00 * z - a02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + a02 * xp[5];
@@ -184,7 +201,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             a2 += (a00 * R[2] + a02 * R[8]) * g0 + (a11 * R[5] + a12 * R[8]) * g1;
             if (STEREO && ur >= 0.0) {
                 // stereo row (g2o::EdgeStereoSE3ProjectXYZ): like row 0 with a02 -> a02 - bf/z^2
-                const double c02 = a02 - w.bf * iz * iz;
+                const double c02 = a02 - cm.bf * iz * iz;
                 const double t2 = (c02 * y) * xp[0] + (a00 * z - c02 * x) * xp[1] + (-a00 * y) * xp[2] + a00 * xp[3] + c02 * xp[5];
                 const double g2 = wg * t2;
                 a0 += (a00 * R[0] + c02 * R[6]) * g2; a1 += (a00 * R[1] + c02 * R[7]) * g2; a2 += (a00 * R[2] + c02 * R[8]) * g2;
@@ -222,15 +239,16 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + R[9];
         const double y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + R[10];
         const double z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + R[11];
-        const double iz = fast_rcp_zero_safe(z), u = w.fx * x * iz, v = w.fy * y * iz;      // (one reciprocal per edge: see back_edge)
-        const double e0 = ob.x - (u + w.cx);
-        const double e1 = ob.y - (v + w.cy);
+        const Cam cm = cam_of<PERKF>(w, ip);
+        const double iz = fast_rcp_zero_safe(z), u = cm.fx * x * iz, v = cm.fy * y * iz;      // (one reciprocal per edge: see back_edge)
+        const double e0 = ob.x - (u + cm.cx);
+        const double e1 = ob.y - (v + cm.cy);
         double chi2 = e0 * (om * e0) + e1 * (om * e1);
         bool st = false;
         double e2 = 0.0;
         if (STEREO) {
             st = ur >= 0.0;
-            if (st) { e2 = ur - (u + w.cx - w.bf * iz); chi2 += e2 * (om * e2); }
+            if (st) { e2 = ur - (u + cm.cx - cm.bf * iz); chi2 += e2 * (om * e2); }
         }
         double rho0 = chi2, rho1 = 1.0;
         if (w.huber_delta > 0.0 && !(chi2 <= dsqr)) {
@@ -248,8 +266,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             }
         }
         F += rho0;
-        const double a00 = -(w.fx * iz), a02 = u * iz;
-        const double a11 = -(w.fy * iz), a12 = v * iz;
+        const double a00 = -(cm.fx * iz), a02 = u * iz;
+        const double a11 = -(cm.fy * iz), a12 = v * iz;
         const double p00 = a00 * R[0] + a02 * R[6], p01 = a00 * R[1] + a02 * R[7], p02 = a00 * R[2] + a02 * R[8];
         const double p10 = a11 * R[3] + a12 * R[6], p11 = a11 * R[4] + a12 * R[7], p12 = a11 * R[5] + a12 * R[8];
         h0 += wg * (p00 * p00 + p10 * p10); h1 += wg * (p00 * p01 + p10 * p11); h2 += wg * (p00 * p02 + p10 * p12);
@@ -258,7 +276,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         if (STEREO) {
             const double r2 = -wg * e2;
             if (st) {
-                const double c02 = a02 - w.bf * iz * iz;
+                const double c02 = a02 - cm.bf * iz * iz;
                 const double p20 = a00 * R[0] + c02 * R[6], p21 = a00 * R[1] + c02 * R[7], p22 = a00 * R[2] + c02 * R[8];
                 h0 += wg * p20 * p20; h1 += wg * p20 * p21; h2 += wg * p20 * p22;
                 h3 += wg * p21 * p21; h4 += wg * p21 * p22; h5 += wg * p22 * p22;
@@ -295,6 +313,9 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
 
 template <bool BACKSUB, bool STEREO, bool LDSP>
 __global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w) { point_body<BACKSUB, STEREO, LDSP>(w, blockIdx.x); }
+// intrinsics by keyframe (DevWindow::kcam): the variant that reads the keyframes' data through L2
+template <bool BACKSUB, bool STEREO>
+__global__ __launch_bounds__(kPointBlock) void k_point_kf(DevWindow w) { point_body<BACKSUB, STEREO, false, true>(w, blockIdx.x); }
 
 // Batched launches (movba_lba_run_batch): one grid over the concatenated windows; `pre` is the prefix of the windows'
 // block counts for this kernel.  Every window runs exactly the code of its solo launch, so results are bit-identical.
@@ -365,18 +386,18 @@ __device__ __forceinline__ double wave_reduce(double (&v)[NV], double *strip, in
 // (A division-free variant on normalised records (x / z, y / z, 1 / z) with the structural zeros of C skipped was 20 %
 //  SLOWER, solo and batched: the kernel then needs all 256 registers and the compiler schedules its gathers worse.)
 template <int NR>
-__device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y, double z, const double R[9], bool stereo,
+__device__ __forceinline__ void edge_rows(const Cam &cm, double x, double y, double z, const double R[9], bool stereo,
                                           double (&P)[NR][3], double (&C)[NR][6])
 {
     const double iz = fast_rcp(z);
-    const double a00 = -w.fx * iz, a02 = w.fx * x * iz * iz, a11 = -w.fy * iz, a12 = w.fy * y * iz * iz;
+    const double a00 = -cm.fx * iz, a02 = cm.fx * x * iz * iz, a11 = -cm.fy * iz, a12 = cm.fy * y * iz * iz;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { P[0][q] = a00 * R[q] + a02 * R[6 + q]; P[1][q] = a11 * R[3 + q] + a12 * R[6 + q]; }
     C[0][0] = a02 * y; C[0][1] = a00 * z - a02 * x; C[0][2] = -a00 * y; C[0][3] = a00; C[0][4] = 0.0; C[0][5] = a02;
     C[1][0] = -a11 * z + a12 * y; C[1][1] = -a12 * x; C[1][2] = a11 * x; C[1][3] = 0.0; C[1][4] = a11; C[1][5] = a12;
     if (NR == 3) {
         const double m = stereo ? 1.0 : 0.0;
-        const double c00 = m * a00, c02 = m * (a02 - w.bf * iz * iz);
+        const double c00 = m * a00, c02 = m * (a02 - cm.bf * iz * iz);
 #pragma unroll
         for (int q = 0; q < 3; ++q) P[NR - 1][q] = c00 * R[q] + c02 * R[6 + q];
         C[NR - 1][0] = c02 * y; C[NR - 1][1] = c00 * z - c02 * x; C[NR - 1][2] = -c00 * y;
@@ -387,12 +408,12 @@ __device__ __forceinline__ void edge_rows(const DevWindow &w, double x, double y
 // accumulates one diagonal-pair entry: ha += w C^T C (Hpp), ba += C^T (-w e) (b_p) and, unless HPP_ONLY, the Schur
 // terms sa += B Dinv B^T, ca += B Dinv b_l.  `wg` = 0 masks the entry out (all its contributions are exact zeros).
 template <int NR, bool HPP_ONLY>
-__device__ __forceinline__ void schur_diag_entry(const DevWindow &w, const double4 &rc, double wg, const double (&rv)[NR], bool st,
+__device__ __forceinline__ void schur_diag_entry(const Cam &cm, const double4 &rc, double wg, const double (&rv)[NR], bool st,
                                                  const double (&Ri)[9], const double2 (&h)[3], const double (&bl)[3], double lambda,
                                                  double (&sa)[21], double (&ha)[21], double (&ca)[6], double (&ba)[6])
 {
     double P[NR][3], C[NR][6];
-    edge_rows<NR>(w, rc.x, rc.y, rc.z, Ri, st, P, C);
+    edge_rows<NR>(cm, rc.x, rc.y, rc.z, Ri, st, P, C);
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
@@ -443,7 +464,7 @@ __device__ __forceinline__ void schur_diag_entry(const DevWindow &w, const doubl
 
 // accumulates one off-diagonal entry: acc += w_i w_j Jc_i^T (Jp_i Dinv Jp_j^T) Jc_j; `ww` = 0 masks the entry out
 template <int NR>
-__device__ __forceinline__ void schur_offdiag_entry(const DevWindow &w, const double4 &ri, const double4 &rj, double ww, bool sti, bool stj,
+__device__ __forceinline__ void schur_offdiag_entry(const Cam &cmi, const Cam &cmj, const double4 &ri, const double4 &rj, double ww, bool sti, bool stj,
                                                     const double (&Ri)[9], const double (&Rj)[9], const double2 (&h)[3], double lambda,
                                                     double (&acc)[36])
 {
@@ -451,8 +472,8 @@ __device__ __forceinline__ void schur_offdiag_entry(const DevWindow &w, const do
     H[0] = h[0].x + lambda; H[1] = h[0].y; H[2] = h[1].x; H[3] = h[1].y + lambda; H[4] = h[2].x; H[5] = h[2].y + lambda;
     inv3sym(H, D);
     double P[NR][3], C[NR][6], Q[NR][3], Ec[NR][6];
-    edge_rows<NR>(w, ri.x, ri.y, ri.z, Ri, sti, P, C);
-    edge_rows<NR>(w, rj.x, rj.y, rj.z, Rj, stj, Q, Ec);
+    edge_rows<NR>(cmi, ri.x, ri.y, ri.z, Ri, sti, P, C);
+    edge_rows<NR>(cmj, rj.x, rj.y, rj.z, Rj, stj, Q, Ec);
     double M[NR][NR];
 #pragma unroll
     for (int m = 0; m < NR; ++m) {
@@ -487,7 +508,7 @@ constexpr int kSchurBatchDiag = MOVBA_SCHUR_BD;     // entries per lane whose ga
 constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
 
 // HPP_ONLY: diagonal pairs only, Hpp and b_p only (one launch per solve, seeds lambda)
-template <int NR, bool HPP_ONLY>
+template <int NR, bool HPP_ONLY, bool PERKF = false>
 __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
 {
 #ifdef MOVBA_CLOCK_STAMP
@@ -523,6 +544,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
     double Ri[9], Rj[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) { Ri[k] = S0.Rt[12 * ip + k]; Rj[k] = S0.Rt[12 * jp + k]; }
+    const Cam cmi = cam_of<PERKF>(w, ip), cmj = cam_of<PERKF>(w, jp);
     double *out = w.part + (size_t)item * kPartStride;
     WSTAMP(1);
 
@@ -561,9 +583,9 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
                 // -w e, e = observation - projection of the recorded camera-frame point (include/OptimizableTypes.h: computeError)
                 const double iz = fast_rcp(rc[u].z), mw = -(m * rc[u].w);
                 double rv[NR];
-                rv[0] = mw * (ob[u].x - (w.fx * rc[u].x * iz + w.cx)); rv[1] = mw * (ob[u].y - (w.fy * rc[u].y * iz + w.cy));
-                if (NR == 3) rv[NR - 1] = st ? mw * (ur[u] - (w.fx * rc[u].x * iz + w.cx - w.bf * iz)) : 0.0;
-                schur_diag_entry<NR, HPP_ONLY>(w, rc[u], m * rc[u].w, rv, st, Ri, h[u], bl[u], lambda, sa, ha, ca, ba);
+                rv[0] = mw * (ob[u].x - (cmi.fx * rc[u].x * iz + cmi.cx)); rv[1] = mw * (ob[u].y - (cmi.fy * rc[u].y * iz + cmi.cy));
+                if (NR == 3) rv[NR - 1] = st ? mw * (ur[u] - (cmi.fx * rc[u].x * iz + cmi.cx - cmi.bf * iz)) : 0.0;
+                schur_diag_entry<NR, HPP_ONLY>(cmi, rc[u], m * rc[u].w, rv, st, Ri, h[u], bl[u], lambda, sa, ha, ca, ba);
             }
         }
         // 54 sums: [0,21) upper triangle of sum B Dinv B^T, [21,27) B Dinv b_l, [27,48) upper Hpp, [48,54) b_p
@@ -601,7 +623,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
             }
 #pragma unroll
             for (int u = 0; u < B; ++u)
-                schur_offdiag_entry<NR>(w, ri[u], rj[u], ok[u] ? ri[u].w * rj[u].w : 0.0, sti[u], stj[u], Ri, Rj, h[u], lambda, acc);
+                schur_offdiag_entry<NR>(cmi, cmj, ri[u], rj[u], ok[u] ? ri[u].w * rj[u].w : 0.0, sti[u], stj[u], Ri, Rj, h[u], lambda, acc);
         }
         WSTAMP(2);
         wsum[wv][lane] = wave_reduce<36>(acc, strip, lane);
@@ -634,6 +656,10 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
 
 template <int NR, bool HPP_ONLY>
 __global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w) { schur_body<NR, HPP_ONLY>(w, blockIdx.x); }
+
+// (a window with intrinsics by keyframe: solved on its own, never in a batch - api.cpp)
+template <int NR, bool HPP_ONLY>
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur_kf(DevWindow w) { schur_body<NR, HPP_ONLY, true>(w, blockIdx.x); }
 
 template <int NR, bool HPP_ONLY>
 __global__ __launch_bounds__(kSchurWaves * 64) void k_schur_b(BatchDev b)
@@ -801,11 +827,12 @@ __device__ __forceinline__ void finalize_body(const DevWindow &w, int bid, int n
             const double y = Rs[3] * Xs[0] + Rs[4] * Xs[1] + Rs[5] * Xs[2] + Rs[10];
             const double z = Rs[6] * Xs[0] + Rs[7] * Xs[1] + Rs[8] * Xs[2] + Rs[11];
             const double om = w.isig[g];
-            const double e0 = w.obs[2 * g] - (w.fx * x / z + w.cx), e1 = w.obs[2 * g + 1] - (w.fy * y / z + w.cy);
+            const Cam cm = cam_of_rt(w, w.g_pose[g]);
+            const double e0 = w.obs[2 * g] - (cm.fx * x / z + cm.cx), e1 = w.obs[2 * g + 1] - (cm.fy * y / z + cm.cy);
             chi2 = e0 * (om * e0) + e1 * (om * e1);
             if (w.stereo) {
                 const double ur = w.obs_r[g];
-                if (ur >= 0.0) { const double e2 = ur - (w.fx * x / z + w.cx - w.bf / z); chi2 += e2 * (om * e2); }
+                if (ur >= 0.0) { const double e2 = ur - (cm.fx * x / z + cm.cx - cm.bf / z); chi2 += e2 * (om * e2); }
             }
         }
         // isDepthPositive() at the final estimates (include/OptimizableTypes.h:111-116)
@@ -892,7 +919,10 @@ hipError_t launch_init(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 {
-    if (!w.lds_poses) {
+    if (w.kcam) {
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w);
+        else hipLaunchKernelGGL((k_point_kf<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w);
+    } else if (!w.lds_poses) {
         if (w.stereo) hipLaunchKernelGGL((k_point<false, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
         else hipLaunchKernelGGL((k_point<false, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
     } else if (w.stereo) hipLaunchKernelGGL((k_point<false, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
@@ -904,7 +934,15 @@ hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
     const int nblk = 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI));                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
     (void)trial;
-    if (mode == 1) {
+    if (w.kcam) {
+        if (mode == 1) {
+            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+            else hipLaunchKernelGGL((k_schur_kf<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        } else {
+            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+            else hipLaunchKernelGGL((k_schur_kf<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        }
+    } else if (mode == 1) {
         if (w.stereo) hipLaunchKernelGGL((k_schur<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
         else hipLaunchKernelGGL((k_schur<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
     } else {
@@ -922,7 +960,10 @@ hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
 {
-    if (!w.lds_poses) {
+    if (w.kcam) {
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
+        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
+    } else if (!w.lds_poses) {
         if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
         else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
     } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);

@@ -105,7 +105,8 @@ namespace MOV_SLAM
             int32_t vertex;                         // index of the keyframe's vertex in the window (-1: none), filled by push_point
         };
 
-        // What the edges of a window must agree on: ONE pinhole (and one stereo baseline) per window (see emit_point).
+        // The window's camera: ONE pinhole (and one stereo baseline) in every shipped MoV-SLAM configuration; a window whose
+        // keyframes disagree is handed over with intrinsics by keyframe (see emit_point, solve).
         struct CamState
         {
             double cam[4] = {0, 0, 0, 0};
@@ -120,6 +121,7 @@ namespace MOV_SLAM
         // One instance per calling thread, reused from call to call (the vectors keep their capacity).
         struct Flat : CamState
         {
+            std::vector<double> cam_kf, bf_kf;      // intrinsics / baselines by vertex, filled only for a mixed-camera window
             std::vector<ObsRef> obs_all;            // observation lists of the local map points, back to back (map order)
             std::vector<size_t> obs_start;          // first observation of local map point k; one more entry at the end
             std::vector<int32_t> point_edge0;       // first edge of problem point k (its edges are contiguous, in observation order); +1 entry
@@ -204,9 +206,9 @@ namespace MOV_SLAM
                     cs.bf = pKFi->mbf;
                 }
                 f.obs_right[e] = kp_ur >= 0 ? (double)kp_ur : -1.0;
-                // e->pCamera = pKFi->mpCamera per edge (Optimizer.cc:664): the kernels take ONE pinhole for the window, which
-                // is what every MoV-SLAM configuration has (one camera, Tracking.cc builds a single mpCamera); a window
-                // whose keyframes disagree is refused by the callers below instead of being solved with the wrong intrinsics
+                // e->pCamera = pKFi->mpCamera per edge (Optimizer.cc:664): ONE pinhole for the window is what every MoV-SLAM
+                // configuration has (one camera, Tracking.cc builds a single mpCamera) and what the descriptor's scalars say;
+                // a window whose keyframes disagree goes over with movba_lba_desc::cam_kf / bf_kf (solve() below)
                 if (!cs.cam_set)
                 {
                     for (int k = 0; k < 4; ++k) cs.cam[k] = pKFi->mpCamera->getParameter(k);
@@ -253,12 +255,6 @@ namespace MOV_SLAM
             const int n = push_point(f, pMP, f.obs_all.data() + o0, f.obs_all.data() + f.obs_all.size(), kfIndex, pCurrentMap, requireSameMap);
             f.obs_all.resize(o0);
             return n;
-        }
-
-        void report_mixed_cameras(const char *who)
-        {
-            std::fprintf(stderr, "MOV_SLAM::Optimizer::%s: keyframes of the window carry different camera intrinsics or baselines "
-                                 "(per-edge cameras, Optimizer.cc:664, 690-695): not supported by the GPU path, optimisation skipped\n", who);
         }
 
         double now_ms()
@@ -364,6 +360,17 @@ namespace MOV_SLAM
             d.obs_right = f.any_stereo ? f.obs_right.data() : nullptr;
             d.bf = f.bf;
             d.fx = f.cam[0]; d.fy = f.cam[1]; d.cx = f.cam[2]; d.cy = f.cam[3];
+            if (f.cam_mixed)
+            {
+                // every edge its keyframe's camera and baseline (Optimizer.cc:664, 690-695): tables by vertex
+                f.cam_kf.resize(4 * f.kfs.size()); f.bf_kf.resize(f.kfs.size());
+                for (size_t i = 0; i < f.kfs.size(); ++i)
+                {
+                    for (int k = 0; k < 4; ++k) f.cam_kf[4 * i + k] = f.kfs[i]->mpCamera->getParameter(k);
+                    f.bf_kf[i] = f.kfs[i]->mbf;
+                }
+                d.cam_kf = f.cam_kf.data(); d.bf_kf = f.bf_kf.data();
+            }
             const float thHuber = std::sqrt(delta);              // const float thHuberMono = sqrt(delta)  (Optimizer.cc:616)
             d.huber_delta = bRobust ? (double)thHuber : 0.0;
             d.chi2_gate = delta;
@@ -430,12 +437,6 @@ namespace MOV_SLAM
         }
         if (f.edge_pose.empty())
             return;
-        if (f.cam_mixed)
-        {
-            report_mixed_cameras("BundleAdjustment");
-            note_status("BundleAdjustment", MOVBA_ERR_ARG);
-            return;
-        }
 
         const Solved &s = solve(f, nIterations, bRobust, pbStopFlag);
         note_status("BundleAdjustment", s.status);
@@ -632,12 +633,6 @@ namespace MOV_SLAM
         }
         num_edges = nEdges;
         lap("points and edges");
-        if (f.cam_mixed)
-        {
-            report_mixed_cameras("LocalBundleAdjustment");
-            note_status("LocalBundleAdjustment", MOVBA_ERR_ARG);
-            return;
-        }
 
         if (pbStopFlag)
             if (*pbStopFlag)

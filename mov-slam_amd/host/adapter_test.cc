@@ -37,6 +37,11 @@ static int run_lba(const char *in, const char *out, bool global)
     double bf = 0.0;
     std::vector<double> obs_right;
     if (fread(&bf, sizeof(double), 1, f) == 1) obs_right = rd<double>(f, E);
+    // optional camera trailer (behind the stereo one): the word 0x43414d31, then fx fy cx cy per keyframe and mbf per keyframe -
+    // every keyframe then has a GeometricCamera of its own (e->pCamera = pKFi->mpCamera, Optimizer.cc:664)
+    std::vector<double> cam_kf, bf_kf;
+    int32_t magic = 0;
+    if (fread(&magic, sizeof(int32_t), 1, f) == 1 && magic == 0x43414d31) { cam_kf = rd<double>(f, 4 * (size_t)NP); bf_kf = rd<double>(f, NP); }
     fclose(f);
 
     // $MOVBA_ADAPTER_REPS: the call repeated on a freshly built copy of the map; the LAST repetition is written out (its
@@ -46,11 +51,14 @@ static int run_lba(const char *in, const char *out, bool global)
     for (int rep = 0; rep < reps; ++rep) {
     Map map;
     GeometricCamera cam({320.f, 320.f, 320.f, 240.f});
+    std::vector<GeometricCamera> cams;             // (one per keyframe when the window file carries a camera trailer)
+    for (int i = 0; i < NP && !cam_kf.empty(); ++i)
+        cams.emplace_back(std::vector<float>{(float)cam_kf[4 * i], (float)cam_kf[4 * i + 1], (float)cam_kf[4 * i + 2], (float)cam_kf[4 * i + 3]});
     std::vector<KeyFrame> kfs(NP);                 // contiguous: pointer order == id order == std::map order
     std::vector<MapPoint> mps(P);
     for (int i = 0; i < NP; ++i) {
         KeyFrame &k = kfs[i];
-        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = &cam; k.mbf = (float)bf;
+        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = cams.empty() ? &cam : &cams[i]; k.mbf = (float)(bf_kf.empty() ? bf : bf_kf[i]);
         k.mTcw = Sophus::SE3f(Eigen::Quaternionf((float)poses[7 * i + 3], (float)poses[7 * i], (float)poses[7 * i + 1], (float)poses[7 * i + 2]),
                               Eigen::Vector3f((float)poses[7 * i + 4], (float)poses[7 * i + 5], (float)poses[7 * i + 6]));
         map.mvKFs.push_back(&k);

@@ -36,7 +36,7 @@ class LbaDesc(C.Structure):
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
                 ("max_iters", C.c_int32), ("max_trials", C.c_int32), ("flags", C.c_uint32), ("stop", _u),
-                ("obs_right", _d), ("bf", C.c_double)]
+                ("obs_right", _d), ("bf", C.c_double), ("cam_kf", _d), ("bf_kf", _d)]
 
 
 class LbaResult(C.Structure):
@@ -180,6 +180,14 @@ def make_desc(w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_tr
         keep["obs_right"] = np.ascontiguousarray(w.obs_right, np.float64)
         d.obs_right = _p(keep["obs_right"], _d)
         d.bf = float(w.bf)
+    if getattr(w, "cam_kf", None) is not None:           # intrinsics by keyframe (n_poses x 4)
+        keep["cam_kf"] = np.ascontiguousarray(w.cam_kf, np.float64)
+        assert keep["cam_kf"].shape == (d.n_poses, 4)
+        d.cam_kf = _p(keep["cam_kf"], _d)
+    if getattr(w, "bf_kf", None) is not None:
+        keep["bf_kf"] = np.ascontiguousarray(w.bf_kf, np.float64)
+        assert keep["bf_kf"].shape == (d.n_poses,)
+        d.bf_kf = _p(keep["bf_kf"], _d)
     return d, keep
 
 

@@ -40,6 +40,8 @@ class Window:
     meta: dict = field(default_factory=dict)
     obs_right: np.ndarray | None = None   # (E,) f64: right-image u of stereo observations, < 0 = monocular edge
     bf: float = 0.0                       # KeyFrame::mbf (baseline * fx)
+    cam_kf: np.ndarray | None = None      # (NP,4) f64: fx fy cx cy by keyframe (None: `cam` for all, every shipped configuration)
+    bf_kf: np.ndarray | None = None       # (NP,)  f64: mbf by keyframe
 
     @property
     def n_poses(self): return int(self.poses.shape[0])
@@ -344,6 +346,32 @@ def shuffle_ids(w: Window, seed: int) -> Window:
                   cam=w.cam, huber_delta=w.huber_delta, chi2_gate=w.chi2_gate, max_iters=w.max_iters,
                   truth_poses=None if w.truth_poses is None else w.truth_poses[old_of_new], truth_points=w.truth_points,
                   meta=meta, obs_right=None if w.obs_right is None else w.obs_right[order], bf=w.bf)
+
+
+def mixed_cameras(w: Window, seed: int, models=((320.0, 320.0, 320.0, 240.0), (400.0, 410.0, 330.0, 250.0), (281.5, 279.25, 311.0, 236.5)),
+                  bf_scale=(1.0, 1.25, 0.8)) -> Window:
+    """The same window seen through DIFFERENT cameras: every keyframe draws one of `models` (and a baseline factor), its
+    observations are mapped pixel by pixel - u' = fx' (u - cx) / fx + cx', u_r' = u' - (bf' / bf) (u - u_r) - so geometry,
+    noise and outliers carry over.  The reference gives every edge its keyframe's camera (src/Optimizer.cc:664, 690-695);
+    `cam` / `bf` of the result are deliberately useless (the first model / 0) so that a path reading them shows up."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    NP = w.n_poses
+    pick = rng.integers(0, len(models), NP)
+    pick[: len(models)] = np.arange(len(models))[: min(len(models), NP)]            # every model occurs
+    cam_kf = _f32(np.asarray(models)[pick])
+    fx, fy, cx, cy = w.cam
+    k = cam_kf[w.edge_pose]
+    obs = np.stack([k[:, 0] * (w.obs[:, 0] - cx) / fx + k[:, 2], k[:, 1] * (w.obs[:, 1] - cy) / fy + k[:, 3]], axis=1)
+    out = dataclasses.replace(w, obs=_f32(obs), cam=tuple(float(v) for v in cam_kf[0]), cam_kf=cam_kf)
+    if w.obs_right is not None:
+        bf_kf = _f32(w.bf * np.asarray(bf_scale)[pick])
+        st = w.obs_right >= 0
+        ur = np.where(st, obs[:, 0] - (bf_kf[w.edge_pose] / w.bf) * (w.obs[:, 0] - w.obs_right), -1.0)
+        # (a disparity that leaves the image on the left is no stereo observation any more)
+        ur = np.where(st & (ur >= 0), ur, -1.0)
+        out = dataclasses.replace(out, obs_right=np.where(ur >= 0, _f32(ur), -1.0), bf=0.0, bf_kf=bf_kf)
+    return out
 
 
 def pattern_cfg(name: str, seed: int | None = None) -> Window:

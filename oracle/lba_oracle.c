@@ -341,6 +341,14 @@ static void ws_init(ws_t *w, const lba_oracle_problem *pb)
     w->Dinv = (double *)calloc(9 * (size_t)P + 9, sizeof(double));
 }
 
+/* the camera of edge e: its keyframe's (src/Optimizer.cc:664, 690-695) */
+static inline const double *edge_cam(const ws_t *w, int e)
+{
+    const lba_oracle_problem *pb = w->pb;
+    return pb->cam_kf ? pb->cam_kf + 4 * (size_t)pb->edge_pose[e] : w->cam;
+}
+static inline double edge_bf(const lba_oracle_problem *pb, int e) { return pb->bf_kf ? pb->bf_kf[pb->edge_pose[e]] : pb->bf; }
+
 /* computeActiveErrors + activeRobustChi2 */
 static double ws_errors(ws_t *w)
 {
@@ -352,9 +360,9 @@ static double ws_errors(ws_t *w)
     for (int e = 0; e < pb->n_edges; ++e) {
         double Xc[3];
         lba_oracle_se3_map(w->poses + 7 * pb->edge_pose[e], w->points + 3 * pb->edge_point[e], Xc);
-        edge_error(Xc, pb->obs + 2 * e, w->cam, w->err + 3 * e);
+        edge_error(Xc, pb->obs + 2 * e, edge_cam(w, e), w->err + 3 * e);
         double *er = w->err + 3 * e;
-        er[2] = is_stereo(pb, e) ? stereo_error(Xc, pb->obs_right[e], w->cam, pb->bf) : 0.0;
+        er[2] = is_stereo(pb, e) ? stereo_error(Xc, pb->obs_right[e], edge_cam(w, e), edge_bf(pb, e)) : 0.0;
         const double chi2 = pb->inv_sigma2[e] * (er[0] * er[0] + er[1] * er[1] + er[2] * er[2]);
         if (pb->huber_delta > 0.0) {
             double rho[3];
@@ -380,9 +388,9 @@ static inline void ws_build_edge(ws_t *w, int e, double *Hpp, double *bp)
         double Xc[3], R[9], A[6], B[12];
         lba_oracle_se3_map(qt, w->points + 3 * l, Xc);
         quat_to_R(qt, R);
-        edge_jacobians(R, Xc, w->cam, A, B);
+        edge_jacobians(R, Xc, edge_cam(w, e), A, B);
         double A2[3] = { 0, 0, 0 }, B2[6] = { 0, 0, 0, 0, 0, 0 };      /* third row: stereo edges only */
-        if (is_stereo(pb, e)) stereo_rows(R, Xc, pb->bf, A, B, A2, B2);
+        if (is_stereo(pb, e)) stereo_rows(R, Xc, edge_bf(pb, e), A, B, A2, B2);
         const double *er = w->err + 3 * e;
         const double om = pb->inv_sigma2[e];
         double wgt = 1.0;

@@ -52,6 +52,10 @@ typedef struct {
      * < 0 (or obs_right == NULL): monocular edge. */
     const double *obs_right;     /* E or NULL                                      */
     double bf;                   /* KeyFrame::mbf                                  */
+    /* intrinsics by keyframe: every edge carries ITS keyframe's camera (e->pCamera = pKFi->mpCamera, src/Optimizer.cc:664;
+     * e->fx .. e->bf from pKFi, :690-695).  NULL: fx .. cy / bf above for every keyframe. */
+    const double *cam_kf;        /* n_poses x 4 or NULL                            */
+    const double *bf_kf;         /* n_poses or NULL                                */
 } lba_oracle_problem;
 
 #define LBA_ORACLE_MAX_TRACE 128

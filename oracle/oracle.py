@@ -28,7 +28,7 @@ class _Problem(C.Structure):
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("huber_delta", C.c_double), ("chi2_gate", C.c_double),
                 ("max_iters", C.c_int), ("stale_error_quirk", C.c_int), ("max_trials", C.c_int), ("stop", _u),
-                ("obs_right", _d), ("bf", C.c_double)]
+                ("obs_right", _d), ("bf", C.c_double), ("cam_kf", _d), ("bf_kf", _d)]
 
 
 class _Result(C.Structure):
@@ -124,6 +124,12 @@ def _problem(w, stale_error_quirk=True, stop=None, max_iters=None, max_trials=0)
         keep["obs_right"] = np.ascontiguousarray(w.obs_right, np.float64)
         pb.obs_right = _p(keep["obs_right"], _d)
         pb.bf = float(w.bf)
+    if getattr(w, "cam_kf", None) is not None:
+        keep["cam_kf"] = np.ascontiguousarray(w.cam_kf, np.float64)
+        pb.cam_kf = _p(keep["cam_kf"], _d)
+    if getattr(w, "bf_kf", None) is not None:
+        keep["bf_kf"] = np.ascontiguousarray(w.bf_kf, np.float64)
+        pb.bf_kf = _p(keep["bf_kf"], _d)
     return pb, keep
 
 

@@ -18,13 +18,13 @@ def test_library_exports_every_symbol_declared_in_header(built_lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(built_lib.EXPORTS) == declared
-    assert lib.movba_version() == 3
+    assert lib.movba_version() == 4
     assert built_lib.status_string(0) == "ok" and built_lib.status_string(-2) == "HIP runtime error"
 
 
 def test_ctypes_struct_sizes_match_header_layout(built_lib):
     # int32 x3 (+pad) | 7 pointers | 6 doubles | 2 int32 + u32 (+pad) | pointer
-    assert ctypes.sizeof(built_lib.LbaDesc) == 16 + 7 * 8 + 6 * 8 + 16 + 8 + 16
+    assert ctypes.sizeof(built_lib.LbaDesc) == 16 + 7 * 8 + 6 * 8 + 16 + 8 + 16 + 16
     assert ctypes.sizeof(built_lib.Options) == 48
     assert ctypes.sizeof(built_lib.StructureInfo) == 72
 

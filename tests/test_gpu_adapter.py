@@ -44,8 +44,15 @@ def _write_window(path, w, bad_kf=-1):
         f.write(np.ascontiguousarray(w.edge_pose, np.int32).tobytes())
         f.write(np.ascontiguousarray(w.edge_point, np.int32).tobytes())
         f.write(np.ascontiguousarray(w.obs, np.float64).tobytes())
+        has_cams = getattr(w, "cam_kf", None) is not None
         if getattr(w, "obs_right", None) is not None:
             f.write(struct.pack("d", w.bf)); f.write(np.ascontiguousarray(w.obs_right, np.float64).tobytes())
+        elif has_cams:                                # (the camera trailer sits behind the stereo one)
+            f.write(struct.pack("d", 0.0)); f.write(np.full(w.n_edges, -1.0).tobytes())
+        if has_cams:
+            f.write(struct.pack("i", 0x43414d31)); f.write(np.ascontiguousarray(w.cam_kf, np.float64).tobytes())
+            bfk = w.bf_kf if getattr(w, "bf_kf", None) is not None else np.zeros(w.n_poses)
+            f.write(np.ascontiguousarray(bfk, np.float64).tobytes())
 
 
 def _read_out(path, w):
@@ -89,13 +96,23 @@ def _local_subwindow(w):
                        chi2_gate=w.chi2_gate, max_iters=w.max_iters)
     if getattr(w, "obs_right", None) is not None:
         sub.obs_right, sub.bf = w.obs_right[keep_e], w.bf
+    if getattr(w, "cam_kf", None) is not None:
+        sub.cam_kf = w.cam_kf[used_pose]
+        sub.bf_kf = w.bf_kf[used_pose] if getattr(w, "bf_kf", None) is not None else None
     return sub, used_pose, local_pt, keep_e
 
 
-@pytest.mark.parametrize("name", ["small", "cfg2", "stereo"])
+@pytest.mark.parametrize("name", ["small", "cfg2", "stereo", "cameras", "stereo-cameras"])
 def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tmp_path, name):
     # "stereo": a window whose keyframes hold stereo observations (mvuRight >= 0, Optimizer.cc:673-705)
-    w = synth.make_window(6, 2, 150, seed=43, run_lo=2, run_hi=5, stereo_frac=0.7) if name == "stereo" else synth.cfg(name)
+    # "cameras": every keyframe with a GeometricCamera (and mbf) of its own, three different ones in the window
+    # (e->pCamera = pKFi->mpCamera, Optimizer.cc:664; e->bf = pKFi->mbf, :695)
+    if name.startswith("stereo"):
+        w = synth.make_window(6, 2, 150, seed=43, run_lo=2, run_hi=5, stereo_frac=0.7)
+    else:
+        w = synth.cfg("small" if name == "cameras" else name)
+    if name.endswith("cameras"):
+        w = synth.mixed_cameras(w, seed=44)
     w.poses = _f32_pose(w.poses)                     # the doubles the adapter derives from the float map
     fin, fout = str(tmp_path / "w.bin"), str(tmp_path / "o.bin")
     _write_window(fin, w)

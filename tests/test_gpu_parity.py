@@ -930,3 +930,42 @@ def test_packed_and_unpacked_schur_entries_give_the_same_bits(built_lib, monkeyp
         np.testing.assert_array_equal(a["trace"]["f1"], b["trace"]["f1"])
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stereo", [0.0, 0.5])
+def test_intrinsics_by_keyframe(solver, oracle_mod, stereo):
+    """Every edge carries the camera of ITS keyframe (e->pCamera = pKFi->mpCamera, /root/reference/src/Optimizer.cc:664;
+    e->fx .. e->bf from pKFi, :690-695): a window whose keyframes have three different cameras (and baselines) against the
+    oracle; and a table that repeats the window's one camera gives the bits of the scalar path."""
+    base = synth.make_window(14, 3, 1800, seed=91, run_lo=2, run_hi=8, stereo_frac=stereo)
+    w = synth.mixed_cameras(base, seed=92)
+    assert len({tuple(c) for c in w.cam_kf}) == 3 and (stereo == 0.0 or len(set(w.bf_kf)) == 3)
+    o = oracle_mod.solve(w)
+    r = solver.solve(w)
+    check_against(r, o, w)
+    fr = w.pose_fixed == 0
+    assert np.abs(r["poses"][fr, 4:] - w.truth_poses[fr, 4:]).max() < 0.6 * np.abs(w.poses[fr, 4:] - w.truth_poses[fr, 4:]).max()
+    # the window's own camera ignored: the same table with a wrong `cam` / `bf` changes nothing
+    import dataclasses
+    r2 = solver.solve(dataclasses.replace(w, cam=(1.0, 1.0, 0.0, 0.0), bf=123.0))
+    assert np.array_equal(r2["poses"], r["poses"]) and np.array_equal(r2["points"], r["points"]) and np.array_equal(r2["chi2"], r["chi2"])
+    # one camera, given as a table: the bits of the scalar path
+    rs = solver.solve(base)
+    tab = dataclasses.replace(base, cam_kf=np.tile(np.asarray(base.cam), (base.n_poses, 1)),
+                              bf_kf=(np.full(base.n_poses, base.bf) if stereo else None))
+    rt = solver.solve(tab)
+    assert np.array_equal(rt["poses"], rs["poses"]) and np.array_equal(rt["points"], rs["points"]) and np.array_equal(rt["chi2"], rs["chi2"])
+    assert np.array_equal(rt["outlier"], rs["outlier"])
+
+
+@pytest.mark.gpu
+def test_intrinsics_by_keyframe_at_cfg3_size_and_on_the_direct_solver(solver, oracle_mod, built_lib):
+    w = synth.mixed_cameras(synth.cfg("cfg3"), seed=93)
+    o = oracle_mod.solve(w)
+    check_against(solver.solve(w), o, w)
+    s = built_lib.Solver(direct=True)
+    try:
+        check_against(s.solve(w), o, w)
+    finally:
+        s.close()

@@ -175,3 +175,28 @@ def test_pose_ransac_p3p_recovers_the_generating_pose_from_any_start(oracle_mod,
     obs = np.stack([320 * Xc[:, 0] / Xc[:, 2] + 320, 320 * Xc[:, 1] / Xc[:, 2] + 240], 1)
     e = oracle_mod.pose_ransac(g["Xw"], obs, g["pose0"], g["cam"], 1e-6, built_lib.ransac_samples(60, 8, 1))
     assert e["n_inliers"] == 60 and np.abs(e["pose"] - g["truth"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("stereo", [0.0, 0.5])
+def test_intrinsics_by_keyframe_in_the_oracle(oracle_mod, stereo):
+    """Every edge carries its keyframe's camera (/root/reference/src/Optimizer.cc:664, 690-695): a table that repeats the
+    window's one camera gives the scalar path's bits; a window seen through three cameras (observations mapped pixel by pixel,
+    movba.synth.mixed_cameras) walks the same LM path as the one-camera window it was made from when the noise is off."""
+    import dataclasses
+    base = synth.make_window(8, 2, 500, seed=71, run_lo=2, run_hi=6, stereo_frac=stereo)
+    o = oracle_mod.solve(base)
+    tab = dataclasses.replace(base, cam_kf=np.tile(np.asarray(base.cam), (base.n_poses, 1)),
+                              bf_kf=(np.full(base.n_poses, base.bf) if stereo else None))
+    ot = oracle_mod.solve(tab)
+    assert np.array_equal(ot["poses"], o["poses"]) and np.array_equal(ot["points"], o["points"]) and np.array_equal(ot["chi2"], o["chi2"])
+    # noise-free, outlier-free: both windows describe the same geometry and converge to the same truth
+    clean = synth.make_window(8, 2, 500, seed=72, run_lo=2, run_hi=6, stereo_frac=stereo, pix_sigma=0.0, outlier_frac=0.0)
+    mixed = synth.mixed_cameras(clean, seed=73)
+    assert len({tuple(c) for c in mixed.cam_kf}) == 3
+    om = oracle_mod.solve(mixed)
+    fr = clean.pose_fixed == 0
+    assert om["cost"] < 1e-3 * om["cost0"]
+    assert np.abs(om["poses"][fr, 4:] - clean.truth_poses[fr, 4:]).max() < 0.05 * np.abs(clean.poses[fr, 4:] - clean.truth_poses[fr, 4:]).max()
+    # and with the window's own `cam` / `bf` wrong, nothing changes: they are not read when the tables are given
+    om2 = oracle_mod.solve(dataclasses.replace(mixed, cam=(1.0, 1.0, 0.0, 0.0), bf=55.0))
+    assert np.array_equal(om2["poses"], om["poses"])
