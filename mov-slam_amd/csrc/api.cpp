@@ -492,167 +492,306 @@ int movba_dense_plan_probe(int32_t n_block_cols, int32_t max_groups, int32_t max
     return MOVBA_OK;
 }
 
-int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
+// =====================================================================================================================
+// movba_lba_upload, in phases.  One Upload object lives for the duration of one call; its members say who owns what.
+//
+//   threads     the CALLER's thread runs every phase below; the handle's HELPER thread (movba_handle::packer) runs exactly
+//               one closure per call, posted by post_helper(), which copies the caller's big arrays into the staging buffer
+//               and sends them to the arena on the copy stream.
+//   hand-off    HelperHandOff: the two things the helper produces for the caller (idx_ready, copy_err) and the things
+//               fixed before it is posted.  Everything else in Upload belongs to the caller's thread alone.
+//   staging     the pinned buffer is laid out like the edge region of the arena (EdgeLayout): the helper writes
+//               [gpose, gpoint) index copies and [raw_begin, grouped_end) there, the caller everything else - and the
+//               helper's parts only after join_helper() (+ copy_event, when they are to be rewritten).
+//   streams     h->stream: structure kernels, derived arrays, pair region, and later the solve.  h->copy_stream: the
+//               caller's arrays (helper) and the early copy of the derived edge arrays.
+//   events      copy_event  (copy stream -> stream): the caller's arrays have arrived; recorded by the helper, waited for
+//                           by the stream before the solve's first kernel (send_pairs) and by the host before the staging
+//                           copy of those arrays is rewritten (ungrouped windows);
+//               edgeb_event (copy stream -> stream): the derived edge arrays sent early have arrived; waited for by the
+//                           stream ahead of the slot-completion / fill kernels (queue_edge_b).
+//   arena       may be reallocated by ensure_arena() in lay_out_rest(): its generation (arena_gen) at the time something
+//               was queued tells whether that something has to be queued again.
+// =====================================================================================================================
+namespace {
+
+// byte offsets of the edge region's arrays, the same in the arena and in the staging buffer; fixed by the caller's counts
+struct EdgeLayout {
+    // (what the device structure pass reads comes first: it is copied ahead of the rest)
+    size_t gpose = 0, ptstart = 0, hidx = 0;
+    size_t a_end = 0;                   // end of that first part
+    size_t gpoint = 0, free_pose = 0, slot = 0;
+    size_t base = 0;                    // first pose-major slot of every keyframe (slots are completed on the device)
+    // (the caller's own arrays, contiguous: they cross the bus on the copy stream, straight from the helper thread)
+    size_t raw_begin = 0, obs = 0, isig = 0, obsr = 0, pose0 = 0, point0 = 0, kcam = 0;
+    size_t grouped_end = 0;             // end of the region when the caller's edges come grouped by map point
+    size_t perm = 0;                    // only travels when they do not
+    size_t max_end = 0;
+    bool has_kcam = false;              // intrinsics by keyframe (src/Optimizer.cc:664, 690-695)
+};
+
+struct HelperHandOff {
+    // helper -> caller
+    std::atomic<int> idx_ready{0};      // the caller's index arrays are in the staging buffer (release / acquire): what the
+                                        // structure pass on the device waits for
+    hipError_t copy_err = hipSuccess;   // read by the caller only after Worker::wait()
+    // fixed before the helper is posted, read by both
+    char *arena = nullptr;              // the arena the helper sends to ...
+    uint64_t arena_gen = 0;             // ... and its generation: a reallocation later on is told by it
+    // caller only
+    bool joined = false;
+};
+
+struct Upload {
+    movba_handle *const h;
+    const movba_lba_desc *const d;
+    const int NP, P, E;
+    Carver c;                           // the arena's layout, carved phase by phase
+    EdgeLayout L;
+    HelperHandOff ho;
+    char *sg = nullptr;                 // staging buffer
+    size_t misc_bytes = 0;              // its tail: counts back / pair ids out (device structure pass)
+    bool stereo = false;
+    bool done = false;                  // the call is complete (early status): run() returns rc as it stands
+    // --- grouping ---
+    bool rank_mode = true;              // the staging buffer's slot array holds ranks; pose_slot0 the keyframes' first slots
+    int nf = 0, nb = 0, nbins = 0;
+    size_t edge_bytes = 0;
+    // --- edge copies ---
+    uint64_t arena_gen_at_edge_copy = 0;
+    bool edge_b_early = false, edge_b_stale = false, edge_b_queued = false;
+    double upload_host_ms = 0.0;
+    // --- structure ---
+    StructDev sd{};
+    bool dev_structure = false, ent_packed = false, filled_early = false;
+    uint64_t fill_gen = 0;
+    size_t noff = 0, o_ent = 0, o_slotpt = 0;
+    // --- pair region / device-only region ---
+    size_t pair_begin = 0, hole = 0, h2d = 0, total = 0;
+    size_t o_items = 0, o_sched = 0, o_pi = 0, o_pj = 0, o_pis = 0, o_rowptr = 0, o_rowent = 0, o_plan = 0;
+    size_t o_cg = 0, o_ch = 0, o_cp = 0, o_ce = 0, o_cij = 0, o_multi = 0, o_pid = 0, o_dtp = 0, o_dtk = 0;
+    size_t o_st[2][11] = {};
+    size_t o_obspm = 0, o_obsrpm = 0, o_part = 0, o_blocks = 0, o_blocks_ov = 0, o_blocks_c = 0, o_aci = 0, o_acitag = 0;
+    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
+    size_t o_dtiles = 0, o_ddiag = 0, o_dfail = 0, o_dx = 0, o_dflags = 0, o_dcontrib = 0, o_dstamps = 0;
+    std::vector<int32_t> lane_plan;
+    size_t ncb = 0;
+    int ntile = 0;
+    bool dense_one = false, dense_stamps = false;
+    // --- timing ---
+    double t0 = 0.0, lap_t = 0.0;
+    bool lap_on = false;
+
+    Upload(movba_handle *h_, const movba_lba_desc *d_) : h(h_), d(d_), NP(d_->n_poses), P(d_->n_points), E(d_->n_edges) {}
+    // (every way out waits for the helper first: it reads the caller's arrays and writes to this object)
+    ~Upload() { h->packer.wait(); }
+
+    const Structure &s() const { return h->st; }
+    void lap(const char *what)
+    {
+        if (!lap_on) return;
+        const double t = now_ms();
+        std::fprintf(stderr, "libmovba[upload]: %-28s %.3f ms\n", what, t - lap_t);
+        lap_t = t;
+    }
+    int join_helper()
+    {
+        if (ho.joined) return MOVBA_OK;
+        h->packer.wait();
+        ho.joined = true;
+        if (ho.copy_err != hipSuccess) { std::fprintf(stderr, "libmovba: upload copy failed: %s\n", hipGetErrorString(ho.copy_err)); return MOVBA_ERR_HIP; }
+        return MOVBA_OK;
+    }
+
+    int run();
+    // phases, in the order run() takes them
+    int begin();                        // arguments, edge layout, buffers, streams drained
+    void post_helper();                 // the caller's arrays: staging buffer + copy stream, on the helper thread
+    int group();                        // build_basic (grouping / validation); the early ways out
+    int pack_derived();                 // derived edge arrays into the staging buffer
+    int send_edge_a();                  // what the device structure pass reads -> stream; the rest early -> copy stream
+    int structure_on_host();
+    int structure_on_device();
+    void choose_solver();
+    int lay_out_rest();                 // pair region + device-only region; arena / staging buffer sized
+    void pack_pairs();
+    int send_pairs();
+    void device_view();
+    // pieces several phases share
+    void pack_a(bool raw_too);          // what the device structure pass reads (first part of the edge region) ...
+    void pack_b(bool raw_too);          // ... and the rest of the derived arrays
+    void pack_edges(bool raw_too) { pack_a(raw_too); pack_b(raw_too); }
+    int queue_edge_b();
+    int launch_fill();
+    int launch_slotpt();
+    size_t ent_words() const { return (ent_packed ? 2 : 3) * noff + 4; }       // int32 words of the entry region
+    char *sp(size_t o) const { return sg + (o - hole); }                        // staging address of a pair-region offset
+};
+
+int Upload::begin()
 {
-    if (!h || !d) return MOVBA_ERR_ARG;
     HIP_TRY(hipSetDevice(h->device));
     h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK;
-    const double t0 = now_ms();
-    static const bool lap_on = std::getenv("MOVBA_TIME_UPLOAD") != nullptr;
-    double lap_t = t0;
-    auto lap = [&](const char *what) { if (lap_on) { const double t = now_ms(); std::fprintf(stderr, "libmovba[upload]: %-28s %.3f ms\n", what, t - lap_t); lap_t = t; } };
+    t0 = lap_t = now_ms();
+    static const bool lap_env = std::getenv("MOVBA_TIME_UPLOAD") != nullptr;
+    lap_on = lap_env;
     // ---- edge region of the arena, laid out from the caller's counts alone so that the helper thread can start copying the
     // caller's big arrays (observations, information, initial estimates: 3/4 of the region) into the pinned staging buffer
     // while this thread runs the grouping / validation pass.  Its H2D copies are queued as soon as it is packed, so that
     // the transfer runs while the pair structure is still being worked out ----
-    if (d->n_poses < 0 || d->n_points < 0 || d->n_edges < 0) return MOVBA_ERR_ARG;
-    if ((d->n_poses && (!d->poses || !d->pose_fixed)) || (d->n_points && !d->points)) return MOVBA_ERR_ARG;
-    if (d->n_edges && (!d->edge_pose || !d->edge_point || !d->obs || !d->inv_sigma2)) return MOVBA_ERR_ARG;
-    const int NP = d->n_poses, P = d->n_points, E = d->n_edges;
-    Carver c;
-    // (what the device structure pass reads comes first: it is copied ahead of the rest)
-    const size_t o_gpose = c.take<int32_t>(E), o_ptstart = c.take<int32_t>(P + 1), o_hidx = c.take<int32_t>(NP);
-    const size_t edge_a_bytes = c.off;
-    const size_t o_gpoint = c.take<int32_t>(E);
-    const size_t o_free = c.take<int32_t>(NP + 1);
-    const size_t o_slot = c.take<int32_t>(E);
-    const size_t o_base = c.take<int32_t>(NP + 1);             // first pose-major slot of every keyframe (slots are completed on the device)
-    // (the caller's own arrays, contiguous: they cross the bus on the copy stream, straight from the helper thread)
-    const size_t raw_begin = c.off;
-    const size_t o_obs = c.take<double>(2 * (size_t)E), o_isig = c.take<double>(E);
-    const size_t o_obsr = c.take<double>(d->obs_right ? E : 0);
-    const size_t o_pose0 = c.take<double>(7 * (size_t)NP), o_point0 = c.take<double>(3 * (size_t)P);
-    const bool has_kcam = d->cam_kf || d->bf_kf;               // intrinsics by keyframe (src/Optimizer.cc:664, 690-695)
-    const size_t o_kcam = c.take<double>(has_kcam ? 8 * (size_t)NP : 0);
-    const size_t edge_bytes_grouped = c.off;
-    const size_t o_perm = c.take<int32_t>(E);                   // only travels when the caller's edges are not grouped by point
-    const size_t edge_bytes_max = c.off;
+    if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
+    if ((NP && (!d->poses || !d->pose_fixed)) || (P && !d->points)) return MOVBA_ERR_ARG;
+    if (E && (!d->edge_pose || !d->edge_point || !d->obs || !d->inv_sigma2)) return MOVBA_ERR_ARG;
+    L.gpose = c.take<int32_t>(E); L.ptstart = c.take<int32_t>(P + 1); L.hidx = c.take<int32_t>(NP);
+    L.a_end = c.off;
+    L.gpoint = c.take<int32_t>(E);
+    L.free_pose = c.take<int32_t>(NP + 1);
+    L.slot = c.take<int32_t>(E);
+    L.base = c.take<int32_t>(NP + 1);
+    L.raw_begin = c.off;
+    L.obs = c.take<double>(2 * (size_t)E); L.isig = c.take<double>(E);
+    L.obsr = c.take<double>(d->obs_right ? E : 0);
+    L.pose0 = c.take<double>(7 * (size_t)NP); L.point0 = c.take<double>(3 * (size_t)P);
+    L.has_kcam = d->cam_kf || d->bf_kf;
+    L.kcam = c.take<double>(L.has_kcam ? 8 * (size_t)NP : 0);
+    L.grouped_end = c.off;
+    L.perm = c.take<int32_t>(E);
+    L.max_end = c.off;
     const size_t nf_dev = (size_t)std::min(NP, 80);             // the device structure pass takes windows of up to 80 free keyframes
-    const size_t misc_bytes = (nf_dev * nf_dev + 8) * sizeof(int32_t) * 2 + 4096;        // counts back / pair ids out (device structure pass)
-    int rc2 = ensure_stage(h, edge_bytes_max + misc_bytes); if (rc2) return rc2;
+    misc_bytes = (nf_dev * nf_dev + 8) * sizeof(int32_t) * 2 + 4096;
+    int rc = ensure_stage(h, L.max_end + misc_bytes); if (rc) return rc;
     // first sizing of the arena: room for the states and pair lists too, so that it is not reallocated a moment later
-    if (edge_bytes_max > h->arena_cap) { rc2 = ensure_arena(h, 10 * edge_bytes_max); if (rc2) return rc2; }
+    if (L.max_end > h->arena_cap) { rc = ensure_arena(h, 10 * L.max_end); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(h->stream));     // staging buffer may still be in flight from a previous call
     HIP_TRY(hipStreamSynchronize(h->copy_stream));
-    char *sg = h->stage;
+    sg = h->stage;
     // (a window is a stereo window when any observation carries a right-image coordinate; looked up on this thread — the first
     //  stereo observation ends the scan — so that nothing the layout below depends on is produced by the helper thread)
-    bool stereo = false;
     if (d->obs_right) for (int e = 0; e < E && !stereo; ++e) stereo = d->obs_right[e] >= 0.0;
-    // helper: straight copies of the caller's arrays (valid as they are when the edges come grouped by map point, the
-    // reference's own order; an ungrouped window has them permuted again below) and the scan for stereo observations
-    char *const arena_at_post = h->arena;
-    const uint64_t arena_gen_at_post = h->arena_gen;
-    hipError_t raw_copy_err = hipSuccess;
-    std::atomic<int> idx_ready{0};
-    // (every way out of this function waits for the helper first: it reads the caller's arrays and writes to this frame)
-    struct HelperGuard { Worker &w; ~HelperGuard() { w.wait(); } } helper_guard{h->packer};
+    return MOVBA_OK;
+}
+
+// helper: straight copies of the caller's arrays (valid as they are when the edges come grouped by map point, the
+// reference's own order; an ungrouped window has them permuted again by pack_b) on their way to the arena
+void Upload::post_helper()
+{
+    ho.arena = h->arena;
+    ho.arena_gen = h->arena_gen;
     // (MOVBA_HELPER_DELAY_US: the helper starts that much later — for tests: whatever this thread takes from the helper
     //  without waiting for it shows up as a wrong result instead of hiding behind the usual timing)
     const char *delay_env = std::getenv("MOVBA_HELPER_DELAY_US");
     const int helper_delay_us = delay_env ? std::atoi(delay_env) : 0;
-    h->packer.post([=, &raw_copy_err, &idx_ready]() {
+    // (by value: the layout, the buffers and the handle's streams; by reference: the hand-off object alone)
+    const EdgeLayout lay = L;
+    char *const stage = sg;
+    movba_handle *const hh = h;
+    const movba_lba_desc *const dd = d;
+    const int np = NP, p = P, e = E;
+    HelperHandOff *const out = &ho;
+    h->packer.post([=]() {
         if (helper_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(helper_delay_us));
-        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_edges otherwise)
-        std::memcpy(sg + o_gpose, d->edge_pose, sizeof(int32_t) * (size_t)E);
-        std::memcpy(sg + o_gpoint, d->edge_point, sizeof(int32_t) * (size_t)E);
-        idx_ready.store(1, std::memory_order_release);       // what the structure pass on the device waits for
+        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_a otherwise)
+        std::memcpy(stage + lay.gpose, dd->edge_pose, sizeof(int32_t) * (size_t)e);
+        std::memcpy(stage + lay.gpoint, dd->edge_point, sizeof(int32_t) * (size_t)e);
+        out->idx_ready.store(1, std::memory_order_release);
         // ... each part straight on to the device on the copy stream while the next one is being staged: most of the upload
         // is across the bus before the calling thread has finished its pass over the edges (the solve's first kernels wait
         // for copy_event, nothing else does)
-        raw_copy_err = hipSetDevice(h->device);
+        hipError_t err = hipSetDevice(hh->device);
         auto send = [&](size_t from, size_t to) {
-            if (raw_copy_err == hipSuccess && to > from)
-                raw_copy_err = hipMemcpyAsync(arena_at_post + from, sg + from, to - from, hipMemcpyHostToDevice, h->copy_stream);
+            if (err == hipSuccess && to > from)
+                err = hipMemcpyAsync(out->arena + from, stage + from, to - from, hipMemcpyHostToDevice, hh->copy_stream);
         };
-        std::memcpy(sg + o_obs, d->obs, sizeof(double) * 2 * (size_t)E);
-        send(o_obs, o_isig);
-        std::memcpy(sg + o_isig, d->inv_sigma2, sizeof(double) * (size_t)E);
-        if (d->obs_right) std::memcpy(sg + o_obsr, d->obs_right, sizeof(double) * (size_t)E);
-        std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
-        std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
-        if (has_kcam) {
-            double *kc = reinterpret_cast<double *>(sg + o_kcam);
-            for (int i = 0; i < NP; ++i) {
-                const double *ck = d->cam_kf ? d->cam_kf + 4 * (size_t)i : &d->fx;      // (fx, fy, cx, cy are contiguous in the descriptor)
+        std::memcpy(stage + lay.obs, dd->obs, sizeof(double) * 2 * (size_t)e);
+        send(lay.obs, lay.isig);
+        std::memcpy(stage + lay.isig, dd->inv_sigma2, sizeof(double) * (size_t)e);
+        if (dd->obs_right) std::memcpy(stage + lay.obsr, dd->obs_right, sizeof(double) * (size_t)e);
+        std::memcpy(stage + lay.pose0, dd->poses, sizeof(double) * 7 * (size_t)np);
+        std::memcpy(stage + lay.point0, dd->points, sizeof(double) * 3 * (size_t)p);
+        if (lay.has_kcam) {
+            double *kc = reinterpret_cast<double *>(stage + lay.kcam);
+            for (int i = 0; i < np; ++i) {
+                const double *ck = dd->cam_kf ? dd->cam_kf + 4 * (size_t)i : &dd->fx;      // (fx, fy, cx, cy are contiguous in the descriptor)
                 kc[8 * i] = ck[0]; kc[8 * i + 1] = ck[1]; kc[8 * i + 2] = ck[2]; kc[8 * i + 3] = ck[3];
-                kc[8 * i + 4] = d->bf_kf ? d->bf_kf[i] : d->bf; kc[8 * i + 5] = kc[8 * i + 6] = kc[8 * i + 7] = 0.0;
+                kc[8 * i + 4] = dd->bf_kf ? dd->bf_kf[i] : dd->bf; kc[8 * i + 5] = kc[8 * i + 6] = kc[8 * i + 7] = 0.0;
             }
         }
-        send(o_isig, edge_bytes_grouped);
-        if (raw_copy_err == hipSuccess) raw_copy_err = hipEventRecord(h->copy_event, h->copy_stream);
+        send(lay.isig, lay.grouped_end);
+        if (err == hipSuccess) err = hipEventRecord(hh->copy_event, hh->copy_stream);
+        out->copy_err = err;
     });
+}
+
+int Upload::group()
+{
     // (the pose-major slots are left to the device when the edges come grouped by point: the pass leaves each edge's rank
     // among its keyframe's edges where the slots go)
     h->st.no_reorder = h->opt.reorder == -1;
-    int rc = build_basic(*d, h->st, reinterpret_cast<int32_t *>(sg + o_slot));
-    bool rank_mode = true;              // the staging buffer's slot array holds ranks; pose_slot0 the keyframes' first slots
+    const int rc = build_basic(*d, h->st, reinterpret_cast<int32_t *>(sg + L.slot));
+    rank_mode = true;
     lap("build_basic");
-    bool helper_done = false;
-    auto wait_helper = [&]() -> int {
-        if (helper_done) return MOVBA_OK;
-        h->packer.wait();
-        helper_done = true;
-        if (raw_copy_err != hipSuccess) { std::fprintf(stderr, "libmovba: upload copy failed: %s\n", hipGetErrorString(raw_copy_err)); return MOVBA_ERR_HIP; }
-        return MOVBA_OK;
-    };
-    if (rc < 0) { (void)wait_helper(); (void)hipStreamSynchronize(h->copy_stream); return rc; }
-    const Structure &s = h->st;
+    if (rc < 0) { (void)join_helper(); (void)hipStreamSynchronize(h->copy_stream); return rc; }
     h->stop = d->stop;
-    if (rc == MOVBA_EMPTY || s.P == 0) { h->early_status = MOVBA_EMPTY; }
-    else if (s.n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
+    if (rc == MOVBA_EMPTY || s().P == 0) { h->early_status = MOVBA_EMPTY; }
+    else if (s().n_fixed == 0) { h->early_status = MOVBA_NO_FIXED; }
     if (h->early_status != MOVBA_OK) {
-        const int rw = wait_helper(); if (rw) return rw;
-        h->prof.structure_ms += now_ms() - t0; h->uploaded = true; return MOVBA_OK;
+        const int rw = join_helper(); if (rw) return rw;
+        h->prof.structure_ms += now_ms() - t0; h->uploaded = true; done = true; return MOVBA_OK;
     }
-    const int nf = s.nfree;
+    nf = s().nfree;
     // beyond the one-launch direct solver (dense_plan.h) the multi-launch one holds the solution vector in LDS and the lower
     // block triangle in HBM: refused by name past that, instead of failing in a launch
     if (nf > MOVBA_MAX_FREE_KEYFRAMES) {
-        (void)wait_helper();
+        (void)join_helper();
         std::fprintf(stderr, "libmovba: %d free keyframes: the reduced system exceeds the direct solver's capacity (%d)\n", nf, MOVBA_MAX_FREE_KEYFRAMES);
         return MOVBA_ERR_TOO_LARGE;
     }
-    const int nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
-    const size_t edge_bytes = s.already_grouped ? edge_bytes_grouped : edge_bytes_max;
-    const int nbins = nf * nf;
-    // what the device structure pass reads (first part of the edge region) ...
-    auto pack_a = [&](bool raw_too) {
-        if (!s.already_grouped || raw_too) {         // (grouped order: the helper thread copied the caller's index arrays)
-            std::memcpy(sg + o_gpose, s.gp, sizeof(int32_t) * E);
-            std::memcpy(sg + o_gpoint, s.gl, sizeof(int32_t) * E);
+    nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
+    edge_bytes = s().already_grouped ? L.grouped_end : L.max_end;
+    nbins = nf * nf;
+    return MOVBA_OK;
+}
+
+void Upload::pack_a(bool raw_too)
+{
+    if (!s().already_grouped || raw_too) {         // (grouped order: the helper thread copied the caller's index arrays)
+        std::memcpy(sg + L.gpose, s().gp, sizeof(int32_t) * E);
+        std::memcpy(sg + L.gpoint, s().gl, sizeof(int32_t) * E);
+    }
+    std::memcpy(sg + L.ptstart, s().pt_start.data(), sizeof(int32_t) * (P + 1));
+    std::memcpy(sg + L.hidx, s().hidx.data(), sizeof(int32_t) * NP);
+}
+
+void Upload::pack_b(bool raw_too)
+{
+    if (!s().already_grouped) std::memcpy(sg + L.perm, s().perm.data(), sizeof(int32_t) * E);
+    if (!rank_mode) std::memcpy(sg + L.slot, s().slot.data(), sizeof(int32_t) * E);
+    else std::memcpy(sg + L.base, s().pose_slot0.data(), sizeof(int32_t) * NP);
+    std::memcpy(sg + L.free_pose, s().free_pose.data(), sizeof(int32_t) * nf);
+    double *obs = reinterpret_cast<double *>(sg + L.obs), *isg = reinterpret_cast<double *>(sg + L.isig);
+    double *obr = reinterpret_cast<double *>(sg + L.obsr);
+    if (!s().already_grouped) {       // the helper's straight copies are in caller order: permute into grouped order
+        for (int g = 0; g < E; ++g) {
+            const int e = s().perm[g];
+            obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
         }
-        std::memcpy(sg + o_ptstart, s.pt_start.data(), sizeof(int32_t) * (P + 1));
-        std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
-    };
-    // ... and the rest of the derived arrays
-    auto pack_b = [&](bool raw_too) {
-        if (!s.already_grouped) std::memcpy(sg + o_perm, s.perm.data(), sizeof(int32_t) * E);
-        if (!rank_mode) std::memcpy(sg + o_slot, s.slot.data(), sizeof(int32_t) * E);
-        else std::memcpy(sg + o_base, s.pose_slot0.data(), sizeof(int32_t) * NP);
-        std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
-        double *obs = reinterpret_cast<double *>(sg + o_obs), *isg = reinterpret_cast<double *>(sg + o_isig);
-        double *obr = reinterpret_cast<double *>(sg + o_obsr);
-        if (!s.already_grouped) {       // the helper's straight copies are in caller order: permute into grouped order
-            for (int g = 0; g < E; ++g) {
-                const int e = s.perm[g];
-                obs[2 * g] = d->obs[2 * e]; obs[2 * g + 1] = d->obs[2 * e + 1]; isg[g] = d->inv_sigma2[e];
-            }
-            if (d->obs_right) for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s.perm[g]];
-        } else if (raw_too) {
-            std::memcpy(obs, d->obs, sizeof(double) * 2 * (size_t)E);
-            std::memcpy(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
-            if (d->obs_right) std::memcpy(obr, d->obs_right, sizeof(double) * (size_t)E);
-        }
-        if (raw_too) {
-            std::memcpy(sg + o_pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
-            std::memcpy(sg + o_point0, d->points, sizeof(double) * 3 * (size_t)P);
-        }
-    };
-    auto pack_edges = [&](bool raw_too) { pack_a(raw_too); pack_b(raw_too); };
-    if (!s.already_grouped) {
+        if (d->obs_right) for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s().perm[g]];
+    } else if (raw_too) {
+        std::memcpy(obs, d->obs, sizeof(double) * 2 * (size_t)E);
+        std::memcpy(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
+        if (d->obs_right) std::memcpy(obr, d->obs_right, sizeof(double) * (size_t)E);
+    }
+    if (raw_too) {
+        std::memcpy(sg + L.pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
+        std::memcpy(sg + L.point0, d->points, sizeof(double) * 3 * (size_t)P);
+    }
+}
+
+int Upload::pack_derived()
+{
+    if (!s().already_grouped) {
         // (rare: the helper's straight copies get permuted below, so it has to be through with them)
-        const int rw = wait_helper(); if (rw) return rw;
+        const int rw = join_helper(); if (rw) return rw;
         // ... and so do its transfers out of the staging buffer (found by ThreadSanitizer over the fake device, tests/hipstub: the
         // copy engine was still reading the caller-order observations while they were being permuted; harmless for the result —
         // the permuted region is sent again behind that copy — but a torn first copy is nothing to rely on)
@@ -660,163 +799,170 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         build_slots(h->st); rank_mode = false;
         pack_edges(false);
     } else {
-        while (idx_ready.load(std::memory_order_acquire) == 0) host_relax(h->opt.host_wait);
+        while (ho.idx_ready.load(std::memory_order_acquire) == 0) host_relax(h->opt.host_wait);
         pack_a(false);
         pack_b(false);      // (ranks where the slots go, the keyframes' first slots, the free keyframes)
     }
     lap("pack derived arrays");
+    return MOVBA_OK;
+}
+
+int Upload::send_edge_a()
+{
     const double t_up0 = now_ms();
-    HIP_TRY(hipMemcpyAsync(h->arena, sg, edge_a_bytes, hipMemcpyHostToDevice, h->stream));
-    const uint64_t arena_gen_at_edge_copy = arena_gen_at_post;
+    HIP_TRY(hipMemcpyAsync(h->arena, sg, L.a_end, hipMemcpyHostToDevice, h->stream));
+    arena_gen_at_edge_copy = ho.arena_gen;
     // grouped edges: the rest of the derived arrays (point ids, ranks / slots, first slots) leaves at once on the copy
     // stream, beside the structure kernels of this stream; what needs it (slot completion, fill) waits for edgeb_event
-    bool edge_b_early = false, edge_b_stale = false;
-    if (s.already_grouped && h->arena_gen == arena_gen_at_post) {
-        HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, raw_begin - edge_a_bytes, hipMemcpyHostToDevice, h->copy_stream));
+    if (s().already_grouped && h->arena_gen == ho.arena_gen) {
+        HIP_TRY(hipMemcpyAsync(h->arena + L.a_end, sg + L.a_end, L.raw_begin - L.a_end, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipEventRecord(h->edgeb_event, h->copy_stream));
         edge_b_early = true;
     }
-    double upload_host_ms = now_ms() - t_up0;
-    bool edge_b_queued = false;
-    auto queue_edge_b = [&]() -> int {
-        if (edge_b_early) HIP_TRY(hipStreamWaitEvent(h->stream, h->edgeb_event, 0));
-        if (!edge_b_early || edge_b_stale) {
-            // (not sent yet, or packed again since: host-built slots instead of ranks)
-            HIP_TRY(hipMemcpyAsync(h->arena + edge_a_bytes, sg + edge_a_bytes, raw_begin - edge_a_bytes, hipMemcpyHostToDevice, h->stream));
-        }
-        if (!s.already_grouped) {
-            // the helper's straight copies were permuted again by pack_edges: that part travels once more, behind the first copy
-            { const int rw = wait_helper(); if (rw) return rw; }      // (its copy_event must have been recorded)
-            HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
-            HIP_TRY(hipMemcpyAsync(h->arena + raw_begin, sg + raw_begin, edge_bytes - raw_begin, hipMemcpyHostToDevice, h->stream));
-        }
-        edge_b_queued = true;
-        return MOVBA_OK;
-    };
+    upload_host_ms = now_ms() - t_up0;
+    return MOVBA_OK;
+}
 
-    // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
-    // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
-    StructDev sd{};
-    // (on the device: up to 80 free keyframes, and as many keyframes in all as the kernels' LDS image has room for)
-    const bool dev_structure = s.already_grouped && s.nfree > 0 && s.nfree <= 80 && struct_lds_fits(s.nfree, NP) && !std::getenv("MOVBA_HOST_STRUCTURE");
-    size_t so_cntw = 0, so_cnt = 0, so_err = 0, so_ent0 = 0;
-    // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
-    // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
-    size_t noff = 0, o_ent = 0, o_slotpt = 0;
-    // 8-byte packed entries when slots and point ids fit (any realistic window; MOVBA_ENTRIES_UNPACKED=1 keeps the 12-byte form, for tests)
-    const bool ent_packed = s.E_free < kEntPackSlots && P < kEntPackPoints && !std::getenv("MOVBA_ENTRIES_UNPACKED");
-    auto ent_words = [&]() { return (ent_packed ? 2 : 3) * noff + 4; };       // int32 words of the entry region
-    bool filled_early = false;
-    uint64_t fill_gen = 0;
-    auto launch_fill = [&]() -> int {
-        int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
-        sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff;
-        sd.ent64 = ent_packed ? reinterpret_cast<unsigned long long *>(h->arena + o_ent) : nullptr;
-        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
-        sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
-        sd.slot = reinterpret_cast<const int32_t *>(h->arena + o_slot);
-        HIP_TRY(launch_struct_fill(sd, h->stream));
-        return MOVBA_OK;
-    };
-    auto launch_slotpt = [&]() -> int {
-        HIP_TRY(launch_slot_point(reinterpret_cast<int32_t *>(h->arena + o_slot), reinterpret_cast<const int32_t *>(h->arena + o_gpose),
-                                  rank_mode ? reinterpret_cast<const int32_t *>(h->arena + o_base) : nullptr,
-                                  reinterpret_cast<const int32_t *>(h->arena + o_gpoint), reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
-        return MOVBA_OK;
-    };
-    if (!dev_structure) {
-        rc = build_structure(*d, h->st);         // (runs build_basic again, with the slots this time)
-        if (rc < 0) return rc;
-        rank_mode = false;
-        pack_b(false); edge_b_stale = true;      // (slots instead of ranks in the staging buffer now)
-        noff = (size_t)(s.nentries - s.E_free);
-        o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
-    } else {
-        const int nchunks = (s.P + 63) / 64;
-        Carver sc;
-        so_cnt = sc.take<int32_t>(nbins); so_err = sc.take<int32_t>(4);
-        so_ent0 = sc.take<int32_t>(nbins);
-        so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
-        if (sc.off > h->scratch_cap) {
-            if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
-            const size_t cap = align_up(sc.off + sc.off / 4, 1 << 20);
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch), cap));
-            h->scratch_cap = cap;
-        }
-        char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;    // tail of the staging buffer: the pair region is packed in front of it
-        HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));        // bin totals and the error word
-        sd.P = s.P; sd.nfree = nf; sd.nchunks = nchunks; sd.NP = NP;
-        // grouped edges, point ranges and hessian indices are read where the edge copy just put them
-        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + o_gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + o_ptstart);
-        sd.hidx = reinterpret_cast<int32_t *>(h->arena + o_hidx);
-        sd.cntw = reinterpret_cast<int32_t *>(sa + so_cntw); sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt);
-        sd.error = reinterpret_cast<int32_t *>(sa + so_err);
-        sd.ent0 = reinterpret_cast<int32_t *>(sa + so_ent0);
-        HIP_TRY(launch_struct_count(sd, h->stream));
-        // cnt and the error word are adjacent in the scratch carve: one D2H copy; the host waits for exactly that copy, the
-        // stream goes on to the entry offsets of the fill kernel
-        // (misc: nbins totals, the error word, the sequence number of this upload)
-        volatile int32_t *misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
-        const int32_t seq = (int32_t)(++h->count_seq & 0x7fffffff);
-        __atomic_store_n(misc_seq, seq - 1, __ATOMIC_RELAXED);
-        HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
-        HIP_TRY(launch_struct_scan(sd, h->stream));
-        lap("edge H2D + count launches");
-        {
-            const double t_wait = now_ms();
-            while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
-                host_relax(h->opt.host_wait);
-                if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) return MOVBA_ERR_HIP; }
-            }
-        }
-        if (reinterpret_cast<const int32_t *>(misc)[nbins] != 0) return MOVBA_ERR_ARG;     // duplicate observation
-        lap("wait for the pair counts");
-        // covisibility ordering (structure.h): a window whose keyframe ids do not follow its covisibility graph is renumbered
-        // here, from the counts: hessian indices, free-pose list and first slots are sent again (a few hundred bytes) and the
-        // count / scan kernels run once more in the new numbering (the host permutes its copy of the counts itself)
-        if (!h->st.no_reorder) {
-            std::vector<int32_t> new_of_old;
-            if (covisibility_order(nf, reinterpret_cast<const int32_t *>(misc), new_of_old)) {
-                apply_pose_order(h->st, new_of_old, reinterpret_cast<int32_t *>(misc));
-                h->st.reordered = true;
-                std::memcpy(sg + o_hidx, s.hidx.data(), sizeof(int32_t) * NP);
-                std::memcpy(sg + o_base, s.pose_slot0.data(), sizeof(int32_t) * NP);
-                std::memcpy(sg + o_free, s.free_pose.data(), sizeof(int32_t) * nf);
-                HIP_TRY(hipMemcpyAsync(h->arena + o_hidx, sg + o_hidx, sizeof(int32_t) * NP, hipMemcpyHostToDevice, h->stream));
-                edge_b_stale = true;
-                HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));
-                HIP_TRY(launch_struct_count(sd, h->stream));
-                HIP_TRY(launch_struct_counts_out(sd, nullptr, 0, h->stream));
-                HIP_TRY(launch_struct_scan(sd, h->stream));
-                lap("covisibility reorder + recount");
-            }
-        }
-        // slots, point ids, observations and initial estimates cross the bus, then the entry lists are filled, while the
-        // host lays out the pairs
-        { const int rq = queue_edge_b(); if (rq) return rq; }
-        {
-            const int32_t *cnt = reinterpret_cast<const int32_t *>(misc);
-            int64_t n = 0;
-            for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) n += cnt[(size_t)i * nf + j];
-            if (n > (int64_t)0x7fffffff / 4) return MOVBA_ERR_ARG;
-            noff = (size_t)n;
-        }
-        o_ent = c.take<int32_t>(ent_words());
-        o_slotpt = c.take<int32_t>((size_t)s.E_free + 1);
-        if (c.off <= h->arena_cap && h->arena_gen == arena_gen_at_post) {
-            int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
-            rq = launch_fill(); if (rq) return rq;
-            filled_early = true; fill_gen = h->arena_gen;
-        }
-        lap("edge B H2D + fill kernel (queued)");
-        rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
-        lap("finish_pairs");
-        if (rc < 0) return rc;
-        if ((size_t)(s.nentries - s.E_free) != noff) return MOVBA_ERR_ARG;
+int Upload::queue_edge_b()
+{
+    if (edge_b_early) HIP_TRY(hipStreamWaitEvent(h->stream, h->edgeb_event, 0));
+    if (!edge_b_early || edge_b_stale) {
+        // (not sent yet, or packed again since: host-built slots instead of ranks)
+        HIP_TRY(hipMemcpyAsync(h->arena + L.a_end, sg + L.a_end, L.raw_begin - L.a_end, hipMemcpyHostToDevice, h->stream));
     }
-    if (!edge_b_queued) { const int rq = queue_edge_b(); if (rq) return rq; }
+    if (!s().already_grouped) {
+        // the helper's straight copies were permuted again by pack_edges: that part travels once more, behind the first copy
+        { const int rw = join_helper(); if (rw) return rw; }      // (its copy_event must have been recorded)
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
+        HIP_TRY(hipMemcpyAsync(h->arena + L.raw_begin, sg + L.raw_begin, edge_bytes - L.raw_begin, hipMemcpyHostToDevice, h->stream));
+    }
+    edge_b_queued = true;
+    return MOVBA_OK;
+}
+
+int Upload::launch_fill()
+{
+    int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
+    sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff;
+    sd.ent64 = ent_packed ? reinterpret_cast<unsigned long long *>(h->arena + o_ent) : nullptr;
+    sd.g_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart);
+    sd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx);
+    sd.slot = reinterpret_cast<const int32_t *>(h->arena + L.slot);
+    HIP_TRY(launch_struct_fill(sd, h->stream));
+    return MOVBA_OK;
+}
+
+int Upload::launch_slotpt()
+{
+    HIP_TRY(launch_slot_point(reinterpret_cast<int32_t *>(h->arena + L.slot), reinterpret_cast<const int32_t *>(h->arena + L.gpose),
+                              rank_mode ? reinterpret_cast<const int32_t *>(h->arena + L.base) : nullptr,
+                              reinterpret_cast<const int32_t *>(h->arena + L.gpoint), reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
+    return MOVBA_OK;
+}
+
+// the per-pair entry lists built on the host (ungrouped edges, more than 80 free keyframes, or a pair-bin mask beyond LDS)
+int Upload::structure_on_host()
+{
+    const int rc = build_structure(*d, h->st);         // (runs build_basic again, with the slots this time)
+    if (rc < 0) return rc;
+    rank_mode = false;
+    pack_b(false); edge_b_stale = true;      // (slots instead of ranks in the staging buffer now)
+    noff = (size_t)(s().nentries - s().E_free);
+    o_slotpt = c.take<int32_t>((size_t)s().E_free + 1);
+    return MOVBA_OK;
+}
+
+// ... counted and filled on the GPU (struct_kernels.hip): the reference's own edge order, up to 80 free keyframes
+int Upload::structure_on_device()
+{
+    const int nchunks = (s().P + 63) / 64;
+    Carver sc;
+    const size_t so_cnt = sc.take<int32_t>(nbins), so_err = sc.take<int32_t>(4);
+    const size_t so_ent0 = sc.take<int32_t>(nbins);
+    const size_t so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
+    if (sc.off > h->scratch_cap) {
+        if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
+        const size_t cap = align_up(sc.off + sc.off / 4, 1 << 20);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch), cap));
+        h->scratch_cap = cap;
+    }
+    char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;    // tail of the staging buffer: the pair region is packed in front of it
+    HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));        // bin totals and the error word
+    sd.P = s().P; sd.nfree = nf; sd.nchunks = nchunks; sd.NP = NP;
+    // grouped edges, point ranges and hessian indices are read where the edge copy just put them
+    sd.g_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart);
+    sd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx);
+    sd.cntw = reinterpret_cast<int32_t *>(sa + so_cntw); sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt);
+    sd.error = reinterpret_cast<int32_t *>(sa + so_err);
+    sd.ent0 = reinterpret_cast<int32_t *>(sa + so_ent0);
+    HIP_TRY(launch_struct_count(sd, h->stream));
+    // cnt and the error word are adjacent in the scratch carve: one D2H copy; the host waits for exactly that copy, the
+    // stream goes on to the entry offsets of the fill kernel
+    // (misc: nbins totals, the error word, the sequence number of this upload)
+    volatile int32_t *misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
+    const int32_t seq = (int32_t)(++h->count_seq & 0x7fffffff);
+    __atomic_store_n(misc_seq, seq - 1, __ATOMIC_RELAXED);
+    HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
+    HIP_TRY(launch_struct_scan(sd, h->stream));
+    lap("edge H2D + count launches");
+    {
+        const double t_wait = now_ms();
+        while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
+            host_relax(h->opt.host_wait);
+            if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) return MOVBA_ERR_HIP; }
+        }
+    }
+    if (reinterpret_cast<const int32_t *>(misc)[nbins] != 0) return MOVBA_ERR_ARG;     // duplicate observation
+    lap("wait for the pair counts");
+    // covisibility ordering (structure.h): a window whose keyframe ids do not follow its covisibility graph is renumbered
+    // here, from the counts: hessian indices, free-pose list and first slots are sent again (a few hundred bytes) and the
+    // count / scan kernels run once more in the new numbering (the host permutes its copy of the counts itself)
+    if (!h->st.no_reorder) {
+        std::vector<int32_t> new_of_old;
+        if (covisibility_order(nf, reinterpret_cast<const int32_t *>(misc), new_of_old)) {
+            apply_pose_order(h->st, new_of_old, reinterpret_cast<int32_t *>(misc));
+            h->st.reordered = true;
+            std::memcpy(sg + L.hidx, s().hidx.data(), sizeof(int32_t) * NP);
+            std::memcpy(sg + L.base, s().pose_slot0.data(), sizeof(int32_t) * NP);
+            std::memcpy(sg + L.free_pose, s().free_pose.data(), sizeof(int32_t) * nf);
+            HIP_TRY(hipMemcpyAsync(h->arena + L.hidx, sg + L.hidx, sizeof(int32_t) * NP, hipMemcpyHostToDevice, h->stream));
+            edge_b_stale = true;
+            HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));
+            HIP_TRY(launch_struct_count(sd, h->stream));
+            HIP_TRY(launch_struct_counts_out(sd, nullptr, 0, h->stream));
+            HIP_TRY(launch_struct_scan(sd, h->stream));
+            lap("covisibility reorder + recount");
+        }
+    }
+    // slots, point ids, observations and initial estimates cross the bus, then the entry lists are filled, while the
+    // host lays out the pairs
+    { const int rq = queue_edge_b(); if (rq) return rq; }
+    {
+        const int32_t *cnt = reinterpret_cast<const int32_t *>(misc);
+        int64_t n = 0;
+        for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) n += cnt[(size_t)i * nf + j];
+        if (n > (int64_t)0x7fffffff / 4) return MOVBA_ERR_ARG;
+        noff = (size_t)n;
+    }
+    o_ent = c.take<int32_t>(ent_words());
+    o_slotpt = c.take<int32_t>((size_t)s().E_free + 1);
+    if (c.off <= h->arena_cap && h->arena_gen == ho.arena_gen) {
+        int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
+        rq = launch_fill(); if (rq) return rq;
+        filled_early = true; fill_gen = h->arena_gen;
+    }
+    lap("edge B H2D + fill kernel (queued)");
+    const int rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
+    lap("finish_pairs");
+    if (rc < 0) return rc;
+    if ((size_t)(s().nentries - s().E_free) != noff) return MOVBA_ERR_ARG;
+    return MOVBA_OK;
+}
+
+void Upload::choose_solver()
+{
     h->pp = PcgParams{};
-    h->rows_kernel = pcg_rows_supported(s.nfree, s.row_ptr.data(), &h->pp);
+    h->rows_kernel = pcg_rows_supported(s().nfree, s().row_ptr.data(), &h->pp);
     // A reduced matrix beyond the PCG workgroup's registers (dense covisibility: every keyframe pair shares points, as in the
     // reference's own windows, KeyFrame.cc:227-231; or simply more keyframes) is not iterated over from L2: the one-launch
     // direct solver takes the window from the first trial, whatever its pattern.  Measured (profiles/r03zd_solver_switch.log,
@@ -831,44 +977,46 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     }
     if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     lap("pcg plan + coarse lists");
+}
 
+int Upload::lay_out_rest()
+{
     // ---- pair region (second H2D copy): packed in the staging buffer right behind the edge region, `hole` bytes before
     // its place in the arena (the device-only arrays carved above sit in between) ----
-    const size_t pair_begin = c.off, hole = pair_begin - edge_bytes_max;
-    auto sp = [&](size_t o) { return sg + (o - hole); };
-    const size_t o_items = c.take<Item>((size_t)s.nitems + 1), o_sched = c.take<SchedItem>(s.sched.size() + 1);
-    const size_t o_pi = c.take<int32_t>(s.npairs + 1), o_pj = c.take<int32_t>(s.npairs + 1), o_pis = c.take<int32_t>(s.npairs + 1);
-    const size_t o_rowptr = c.take<int32_t>(nf + 1), o_rowent = c.take<RowEnt>(s.row_ent.size() + 1);
-    std::vector<int32_t> lane_plan;
+    pair_begin = c.off; hole = pair_begin - L.max_end;
+    o_items = c.take<Item>((size_t)s().nitems + 1); o_sched = c.take<SchedItem>(s().sched.size() + 1);
+    o_pi = c.take<int32_t>(s().npairs + 1); o_pj = c.take<int32_t>(s().npairs + 1); o_pis = c.take<int32_t>(s().npairs + 1);
+    o_rowptr = c.take<int32_t>(nf + 1); o_rowent = c.take<RowEnt>(s().row_ent.size() + 1);
+    lane_plan.clear();
     if (h->rows_kernel) {
         // which two oriented blocks every lane of k_pcg_rows holds, and where their partial items are
         lane_plan.assign((size_t)kPcgRowsThreads * 8, -1);
         for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) {
-            const int P0 = s.row_ptr[h->pp.wave_row0[wv]] >> 1, P1 = s.row_ptr[h->pp.wave_row0[wv + 1]] >> 1;
+            const int P0 = s().row_ptr[h->pp.wave_row0[wv]] >> 1, P1 = s().row_ptr[h->pp.wave_row0[wv + 1]] >> 1;
             for (int ln = 0; ln < 64 && P0 + ln < P1; ++ln)
                 for (int k = 0; k < 2; ++k) {
-                    const RowEnt &re = s.row_ent[2 * (P0 + ln) + k];
+                    const RowEnt &re = s().row_ent[2 * (P0 + ln) + k];
                     int32_t *pl = &lane_plan[((size_t)(wv * 64 + ln) * 2 + k) * 4];
                     if (re.block < 0) continue;
                     pl[0] = re.block; pl[1] = (re.col * 6) | (re.transposed ? (1 << 30) : 0);
-                    pl[2] = s.pair_item_start[re.block]; pl[3] = s.pair_item_start[re.block + 1];
+                    pl[2] = s().pair_item_start[re.block]; pl[3] = s().pair_item_start[re.block + 1];
                 }
         }
     }
-    const size_t ncb = s.cblk_g.size();
-    const size_t o_plan = c.take<int32_t>(lane_plan.size() + 4);
-    const size_t o_cg = c.take<int32_t>(ncb + 1), o_ch = c.take<int32_t>(ncb + 1), o_cp = c.take<int32_t>(ncb + 2), o_ce = c.take<int32_t>(s.cblk_ent.size() + 1), o_cij = c.take<int32_t>(s.cblk_ij.size() + 1), o_multi = c.take<int32_t>(s.multi_pairs.size() + 1);
-    const size_t o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
+    ncb = s().cblk_g.size();
+    o_plan = c.take<int32_t>(lane_plan.size() + 4);
+    o_cg = c.take<int32_t>(ncb + 1); o_ch = c.take<int32_t>(ncb + 1); o_cp = c.take<int32_t>(ncb + 2); o_ce = c.take<int32_t>(s().cblk_ent.size() + 1);
+    o_cij = c.take<int32_t>(s().cblk_ij.size() + 1); o_multi = c.take<int32_t>(s().multi_pairs.size() + 1);
+    o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
     // one-launch direct solver: the static schedule depends on the number of block columns only (rebuilt when that changes)
-    const int ntile = dense_ntile(nf);
+    ntile = dense_ntile(nf);
     static const bool dense_multi = std::getenv("MOVBA_DENSE_MULTILAUNCH") != nullptr;
     if (h->dplan_nt != ntile) { build_dense_plan(ntile, h->dplan); h->dplan_nt = ntile; }
-    const bool dense_one = !dense_multi && dense_persist_supported(h->dplan);
-    const size_t o_dtp = c.take<int32_t>(dense_one ? h->dplan.task_ptr.size() : 1), o_dtk = c.take<DenseTask>(dense_one ? h->dplan.tasks.size() : 1);
+    dense_one = !dense_multi && dense_persist_supported(h->dplan);
+    o_dtp = c.take<int32_t>(dense_one ? h->dplan.task_ptr.size() : 1); o_dtk = c.take<DenseTask>(dense_one ? h->dplan.tasks.size() : 1);
     if (!dev_structure) o_ent = c.take<int32_t>(ent_words());       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
-    const size_t h2d = c.off;
+    h2d = c.off;
     // ---- device-only region ----
-    size_t o_st[2][11];
     for (int b = 0; b < 2; ++b) {
         o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
         o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
@@ -878,27 +1026,28 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
         o_st[b][9] = 0;
         o_st[b][10] = 0;
     }
-    const size_t o_obspm = c.take<double>(2 * (size_t)s.E_free + 2), o_obsrpm = c.take<double>(stereo ? (size_t)s.E_free + 1 : 1);
-    const size_t part_stride = ((size_t)s.nitems * kPartStride + 31) / 32 * 32;
-    const size_t o_part = c.take<double>(part_stride + 1), o_blocks = c.take<double>((size_t)s.npairs * 36 + 1);
-    const size_t o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s.row_ent.size() * 36 + 2 : 2);
-    const size_t o_blocks_c = c.take<double>((size_t)s.npairs * 36 + 1), o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2), o_acitag = c.take<int32_t>(2);
-    const size_t o_bp = c.take<double>(6 * (size_t)nf + 1), o_xp = c.take<double>(6 * (size_t)nf + 1);
-    const size_t o_scale = c.take<double>(nb + 1), o_hmax = c.take<double>(nb);
-    const size_t o_ctrl = c.take<Ctrl>(1), o_chi2 = c.take<double>(E), o_outl = c.take<uint8_t>(E);
+    o_obspm = c.take<double>(2 * (size_t)s().E_free + 2); o_obsrpm = c.take<double>(stereo ? (size_t)s().E_free + 1 : 1);
+    const size_t part_stride = ((size_t)s().nitems * kPartStride + 31) / 32 * 32;
+    o_part = c.take<double>(part_stride + 1); o_blocks = c.take<double>((size_t)s().npairs * 36 + 1);
+    o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s().row_ent.size() * 36 + 2 : 2);
+    o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
+    o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
+    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb);
+    o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
-    const size_t o_dtiles = c.take<double>(dense_tiles_doubles(nf)), o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1), o_dfail = c.take<int32_t>(4);
-    const size_t o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
-    const size_t o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_count(ntile) + 8 : 8);
-    const size_t o_dcontrib = c.take<double>(dense_one ? (size_t)ntile * ntile * kDenseNB : 1);
-    static const bool dense_stamps = std::getenv("MOVBA_DENSE_STAMPS") != nullptr;
-    const size_t o_dstamps = c.take<unsigned long long>(dense_one && dense_stamps ? 6 * h->dplan.tasks.size() : 1);
-    const size_t total = c.off;
+    o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
+    o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
+    o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_count(ntile) + 8 : 8);
+    o_dcontrib = c.take<double>(dense_one ? (size_t)ntile * ntile * kDenseNB : 1);
+    static const bool dense_stamps_env = std::getenv("MOVBA_DENSE_STAMPS") != nullptr;
+    dense_stamps = dense_stamps_env;
+    o_dstamps = c.take<unsigned long long>(dense_one && dense_stamps ? 6 * h->dplan.tasks.size() : 1);
+    total = c.off;
 
     // (a reallocation of the arena or of the staging buffer below must find the helper thread through with both: it reads
     //  the caller's arrays into the staging buffer and sends them to the arena it was given at the start)
-    if (total > h->arena_cap || h2d - hole + misc_bytes > h->stage_cap) { const int rw = wait_helper(); if (rw) return rw; }
-    rc2 = ensure_arena(h, total); if (rc2) return rc2;
+    if (total > h->arena_cap || h2d - hole + misc_bytes > h->stage_cap) { const int rw = join_helper(); if (rw) return rw; }
+    int rc = ensure_arena(h, total); if (rc) return rc;
     if (h->arena_gen != arena_gen_at_edge_copy) {
         // the arena was reallocated (told by its generation: the new allocation may sit at the old address): queue the
         // edge region again (the staging copy is intact); the fill below then runs on the new arena
@@ -907,89 +1056,99 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     if (h2d - hole + misc_bytes > h->stage_cap) {
         // (rare: huge host-built entry lists) a bigger staging buffer: ensure_stage drains the stream first, so the edge copy
         // has landed; the edge region is packed again only to keep the buffer self-consistent
-        rc2 = ensure_stage(h, h2d - hole + misc_bytes); if (rc2) return rc2;
+        rc = ensure_stage(h, h2d - hole + misc_bytes); if (rc) return rc;
         sg = h->stage;
         pack_edges(true);
     }
+    return MOVBA_OK;
+}
 
-    // ---- pack the pair region ----
+void Upload::pack_pairs()
+{
     if (!dev_structure && noff) {
         int32_t *eh = reinterpret_cast<int32_t *>(sp(o_ent));
         if (ent_packed) {
             unsigned long long *e64 = reinterpret_cast<unsigned long long *>(eh);
-            for (size_t k = 0; k < noff; ++k) e64[k] = ent_pack(s.ent_i[k], s.ent_j[k], s.ent_l[k]);
+            for (size_t k = 0; k < noff; ++k) e64[k] = ent_pack(s().ent_i[k], s().ent_j[k], s().ent_l[k]);
         } else {
-            std::memcpy(eh, s.ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s.ent_j.data(), sizeof(int32_t) * noff);
-            std::memcpy(eh + 2 * noff, s.ent_l.data(), sizeof(int32_t) * noff);
+            std::memcpy(eh, s().ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s().ent_j.data(), sizeof(int32_t) * noff);
+            std::memcpy(eh + 2 * noff, s().ent_l.data(), sizeof(int32_t) * noff);
         }
     }
-    std::memcpy(sp(o_items), s.items.data(), sizeof(Item) * (size_t)s.nitems);
-    std::memcpy(sp(o_sched), s.sched.data(), sizeof(SchedItem) * s.sched.size());
-    std::memcpy(sp(o_pi), s.pair_i.data(), sizeof(int32_t) * s.npairs);
-    std::memcpy(sp(o_pj), s.pair_j.data(), sizeof(int32_t) * s.npairs);
-    std::memcpy(sp(o_pis), s.pair_item_start.data(), sizeof(int32_t) * (s.npairs + 1));
-    std::memcpy(sp(o_rowptr), s.row_ptr.data(), sizeof(int32_t) * (nf + 1));
-    std::memcpy(sp(o_rowent), s.row_ent.data(), sizeof(RowEnt) * s.row_ent.size());
+    std::memcpy(sp(o_items), s().items.data(), sizeof(Item) * (size_t)s().nitems);
+    std::memcpy(sp(o_sched), s().sched.data(), sizeof(SchedItem) * s().sched.size());
+    std::memcpy(sp(o_pi), s().pair_i.data(), sizeof(int32_t) * s().npairs);
+    std::memcpy(sp(o_pj), s().pair_j.data(), sizeof(int32_t) * s().npairs);
+    std::memcpy(sp(o_pis), s().pair_item_start.data(), sizeof(int32_t) * (s().npairs + 1));
+    std::memcpy(sp(o_rowptr), s().row_ptr.data(), sizeof(int32_t) * (nf + 1));
+    std::memcpy(sp(o_rowent), s().row_ent.data(), sizeof(RowEnt) * s().row_ent.size());
     if (!lane_plan.empty()) std::memcpy(sp(o_plan), lane_plan.data(), sizeof(int32_t) * lane_plan.size());
-    std::memcpy(sp(o_cg), s.cblk_g.data(), sizeof(int32_t) * ncb);
-    std::memcpy(sp(o_ch), s.cblk_h.data(), sizeof(int32_t) * ncb);
-    std::memcpy(sp(o_cp), s.cblk_ptr.data(), sizeof(int32_t) * s.cblk_ptr.size());
-    std::memcpy(sp(o_ce), s.cblk_ent.data(), sizeof(int32_t) * s.cblk_ent.size());
-    std::memcpy(sp(o_cij), s.cblk_ij.data(), sizeof(int32_t) * s.cblk_ij.size());
-    std::memcpy(sp(o_multi), s.multi_pairs.data(), sizeof(int32_t) * s.multi_pairs.size());
-    std::memcpy(sp(o_pid), s.pid.data(), sizeof(int32_t) * (size_t)nf * nf);
+    std::memcpy(sp(o_cg), s().cblk_g.data(), sizeof(int32_t) * ncb);
+    std::memcpy(sp(o_ch), s().cblk_h.data(), sizeof(int32_t) * ncb);
+    std::memcpy(sp(o_cp), s().cblk_ptr.data(), sizeof(int32_t) * s().cblk_ptr.size());
+    std::memcpy(sp(o_ce), s().cblk_ent.data(), sizeof(int32_t) * s().cblk_ent.size());
+    std::memcpy(sp(o_cij), s().cblk_ij.data(), sizeof(int32_t) * s().cblk_ij.size());
+    std::memcpy(sp(o_multi), s().multi_pairs.data(), sizeof(int32_t) * s().multi_pairs.size());
+    std::memcpy(sp(o_pid), s().pid.data(), sizeof(int32_t) * (size_t)nf * nf);
     if (dense_one) {
         std::memcpy(sp(o_dtp), h->dplan.task_ptr.data(), sizeof(int32_t) * h->dplan.task_ptr.size());
         std::memcpy(sp(o_dtk), h->dplan.tasks.data(), sizeof(DenseTask) * h->dplan.tasks.size());
     }
     lap("carve + pack pair region");
+}
+
+int Upload::send_pairs()
+{
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
-    HIP_TRY(hipMemcpyAsync(h->arena + pair_begin, sg + edge_bytes_max, h2d - pair_begin, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->arena + pair_begin, sg + L.max_end, h2d - pair_begin, hipMemcpyHostToDevice, h->stream));
     if (!(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_slotpt(); if (rq) return rq; }
     if (dev_structure && !(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_fill(); if (rq) return rq; }
     // the solve's kernels start behind the caller's arrays on the copy stream (the structure pass above did not need them)
-    { const int rw = wait_helper(); if (rw) return rw; }          // (the helper has recorded copy_event by now)
+    { const int rw = join_helper(); if (rw) return rw; }          // (the helper has recorded copy_event by now)
     HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
     // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were
     // copied to the staging buffer already (the next upload synchronises before it refills it)
     lap("pair H2D (queued)");
     h->prof.upload_ms += now_ms() - t2 + upload_host_ms;
     h->h2d_bytes = h2d;
+    return MOVBA_OK;
+}
 
-    // ---- device view ----
+void Upload::device_view()
+{
     DevWindow &w = h->win;
     char *a = h->arena;
     w = DevWindow{};
-    w.NP = NP; w.P = P; w.E = E; w.nfree = nf; w.npairs = s.npairs; w.nitems = s.nitems; w.n_pt_blocks = nb;
+    w.NP = NP; w.P = P; w.E = E; w.nfree = nf; w.npairs = s().npairs; w.nitems = s().nitems; w.n_pt_blocks = nb;
     w.max_iters = d->max_iters; w.flags = d->flags; w.max_trials = d->max_trials > 0 ? d->max_trials : 10;
     w.fx = d->fx; w.fy = d->fy; w.cx = d->cx; w.cy = d->cy; w.huber_delta = d->huber_delta; w.chi2_gate = d->chi2_gate;
-    w.g_pose = reinterpret_cast<int32_t *>(a + o_gpose); w.g_point = reinterpret_cast<int32_t *>(a + o_gpoint);
-    w.pt_start = reinterpret_cast<int32_t *>(a + o_ptstart); w.perm = s.already_grouped ? nullptr : reinterpret_cast<int32_t *>(a + o_perm);
-    w.hidx = reinterpret_cast<int32_t *>(a + o_hidx); w.free_pose = reinterpret_cast<int32_t *>(a + o_free);
-    w.obs = reinterpret_cast<double *>(a + o_obs); w.isig = reinterpret_cast<double *>(a + o_isig);
-    w.obs_r = d->obs_right ? reinterpret_cast<double *>(a + o_obsr) : nullptr; w.bf = d->bf; w.stereo = stereo ? 1 : 0;
-    w.kcam = has_kcam ? reinterpret_cast<const double *>(a + o_kcam) : nullptr;
-    w.slot = reinterpret_cast<int32_t *>(a + o_slot);
+    w.g_pose = reinterpret_cast<int32_t *>(a + L.gpose); w.g_point = reinterpret_cast<int32_t *>(a + L.gpoint);
+    w.pt_start = reinterpret_cast<int32_t *>(a + L.ptstart); w.perm = s().already_grouped ? nullptr : reinterpret_cast<int32_t *>(a + L.perm);
+    w.hidx = reinterpret_cast<int32_t *>(a + L.hidx); w.free_pose = reinterpret_cast<int32_t *>(a + L.free_pose);
+    w.obs = reinterpret_cast<double *>(a + L.obs); w.isig = reinterpret_cast<double *>(a + L.isig);
+    w.obs_r = d->obs_right ? reinterpret_cast<double *>(a + L.obsr) : nullptr; w.bf = d->bf; w.stereo = stereo ? 1 : 0;
+    w.kcam = L.has_kcam ? reinterpret_cast<const double *>(a + L.kcam) : nullptr;
+    w.slot = reinterpret_cast<int32_t *>(a + L.slot);
     w.obs_pm = reinterpret_cast<double *>(a + o_obspm); w.obsr_pm = reinterpret_cast<double *>(a + o_obsrpm);
     {
         const int32_t *ed = reinterpret_cast<const int32_t *>(a + o_ent);
         w.ent_i = ed; w.ent_j = ed + noff; w.ent_l = ed + 2 * noff;
         w.ent64 = ent_packed ? reinterpret_cast<const unsigned long long *>(a + o_ent) : nullptr;
-        w.slot_point = reinterpret_cast<const int32_t *>(a + o_slotpt); w.n_diag = s.E_free;
+        w.slot_point = reinterpret_cast<const int32_t *>(a + o_slotpt); w.n_diag = s().E_free;
     }
     w.items = reinterpret_cast<Item *>(a + o_items);
-    w.sched = reinterpret_cast<SchedItem *>(a + o_sched); w.sched_per_xcd = s.sched_per_xcd;
+    w.sched = reinterpret_cast<SchedItem *>(a + o_sched); w.sched_per_xcd = s().sched_per_xcd;
     w.pair_i = reinterpret_cast<int32_t *>(a + o_pi); w.pair_j = reinterpret_cast<int32_t *>(a + o_pj);
     w.pair_item_start = reinterpret_cast<int32_t *>(a + o_pis); w.row_ptr = reinterpret_cast<int32_t *>(a + o_rowptr);
     w.row_ent = reinterpret_cast<RowEnt *>(a + o_rowent);
     w.lane_plan = reinterpret_cast<int32_t *>(a + o_plan);
-    w.n_agg = s.n_agg; w.n_cblk = (int32_t)ncb;
+    w.n_agg = s().n_agg; w.n_cblk = (int32_t)ncb;
     w.cblk_g = reinterpret_cast<int32_t *>(a + o_cg); w.cblk_h = reinterpret_cast<int32_t *>(a + o_ch);
     w.cblk_ptr = reinterpret_cast<int32_t *>(a + o_cp); w.cblk_ent = reinterpret_cast<int32_t *>(a + o_ce);
     w.cblk_ij = reinterpret_cast<int32_t *>(a + o_cij);
-    w.multi_pairs = reinterpret_cast<int32_t *>(a + o_multi); w.n_multi = (int32_t)s.multi_pairs.size();
-    w.pose0 = reinterpret_cast<double *>(a + o_pose0); w.point0 = reinterpret_cast<double *>(a + o_point0);
+    w.multi_pairs = reinterpret_cast<int32_t *>(a + o_multi); w.n_multi = (int32_t)s().multi_pairs.size();
+    w.pose0 = reinterpret_cast<double *>(a + L.pose0); w.point0 = reinterpret_cast<double *>(a + L.point0);
     for (int b = 0; b < 2; ++b) {
         DevState &S = w.st[b];
         S.pose = reinterpret_cast<double *>(a + o_st[b][0]); S.Rt = reinterpret_cast<double *>(a + o_st[b][1]);
@@ -1016,7 +1175,40 @@ int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
     w.direct_only = h->rows_kernel ? 0 : 1;
     w.lds_poses = point_lds_need(NP, nf) <= kPointLdsLimit ? 1 : 0;
     h->uploaded = true;
+}
+
+int Upload::run()
+{
+    int rc = begin(); if (rc) return rc;
+    post_helper();
+    rc = group(); if (rc || done) return rc;
+    rc = pack_derived(); if (rc) return rc;
+    rc = send_edge_a(); if (rc) return rc;
+    // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
+    // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
+    // (on the device: up to 80 free keyframes, and as many keyframes in all as the kernels' LDS image has room for)
+    dev_structure = s().already_grouped && s().nfree > 0 && s().nfree <= 80 && struct_lds_fits(s().nfree, NP) && !std::getenv("MOVBA_HOST_STRUCTURE");
+    // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
+    // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
+    // 8-byte packed entries when slots and point ids fit (any realistic window; MOVBA_ENTRIES_UNPACKED=1 keeps the 12-byte form, for tests)
+    ent_packed = s().E_free < kEntPackSlots && P < kEntPackPoints && !std::getenv("MOVBA_ENTRIES_UNPACKED");
+    rc = dev_structure ? structure_on_device() : structure_on_host(); if (rc) return rc;
+    if (!edge_b_queued) { rc = queue_edge_b(); if (rc) return rc; }
+    choose_solver();
+    rc = lay_out_rest(); if (rc) return rc;
+    pack_pairs();
+    rc = send_pairs(); if (rc) return rc;
+    device_view();
     return MOVBA_OK;
+}
+
+}  // namespace
+
+int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
+{
+    if (!h || !d) return MOVBA_ERR_ARG;
+    Upload u(h, d);
+    return u.run();
 }
 
 int movba_lba_reset(movba_handle *h)
