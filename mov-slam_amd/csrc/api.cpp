@@ -1257,7 +1257,7 @@ hipError_t queue_direct(movba_handle *h)
         if (hipStreamSynchronize(h->stream) == hipSuccess && hipMemcpy(st.data(), w.dense.stamps, sizeof(unsigned long long) * 6 * nt_, hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long t0 = ~0ull;
             for (size_t k = 0; k < nt_; ++k) if (st[6 * k] && st[6 * k] < t0) t0 = st[6 * k];
-            static const char *names[] = { "ASM", "UPD", "DIAG", "OFF", "RHS", "BSX", "BSC", "EPI", "RUP", "UPD2" };
+            static const char *names[] = { "ASM", "UPD", "DIAG", "OFF", "RHS", "BSX", "BSC", "EPI", "RUP", "UPD2", "COL" };
             for (int g = 0; g < h->dplan.G; ++g)
                 for (int t = h->dplan.task_ptr[g]; t < h->dplan.task_ptr[g + 1]; ++t) {
                     const DenseTask &tk = h->dplan.tasks[t];

@@ -668,6 +668,28 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             __syncthreads();
             break;
         }
+        case DT_COL: {
+            // the diagonal owner's chain of one block column: L(K, K-1) = S(K, K-1) W_(K-1), D_K -= L L^T, D_K -> W_K
+            flush();
+            if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_PD(nt, K - 1); }, l, tid)) { aborted = true; break; }
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
+            fetch_tile<2>(tiles + tile_off(K - 1, K - 1), l.B, tid);      // W_(K-1)
+            __syncthreads();
+            double *sub = sm + (2 + tk.pad[2]) * kTileLds;
+            tile_times_upper(sub, l.B, wv, lane);
+            __syncthreads();
+            publish_tile(tiles + tile_off(K, K - 1), sub, tid);         // (stores issued; drained behind the update below)
+            tile_update<true>(slot, sub, sub, wv, lane, l.B);           // D_K into scratch tile B (W_(K-1) is through)
+            set_flag(flags, dense_flag_F(nt, K, K - 1), epoch, tid);
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
+            if (sweep_inverse(kTileLds, slot_off, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
+            if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+            publish_tile<2>(tiles + tile_off(K, K), slot, tid);
+            set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
+            for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; if (tri_skip<2>(r, cc)) slot[r * LD + cc] = 0.0; }
+            __syncthreads();
+            break;
+        }
         case DT_OFF: {
             flush();
             if (!wg_wait(flags, epoch, 1, [&](int) { return dense_flag_PD(nt, K); }, l, tid)) { aborted = true; break; }

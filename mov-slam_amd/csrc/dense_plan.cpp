@@ -82,11 +82,17 @@ void build_dense_plan(int nt, DensePlan &p, int max_groups, int max_slots)
                     t.pad[0] = own_slot(g, K, k); t.pad[1] = own_slot(g, K - 1, k); t.pad[2] = p.slot[tix(K, K - 1)];
                     continue;
                 }
+                if (I == K && k == K - 1) continue;         // (the diagonal tile's last update: part of the owner's DT_COL)
                 add(g, I == K ? mk_key(k + 1, 3, K - 1 - k, 0) : mk_key(k + 1, 3, K - k, I - K), DT_UPD, s, I, K, k);
                 per[g].back().t.pad[0] = own_slot(g, I, k); per[g].back().t.pad[1] = own_slot(g, K, k);
             }
             if (I == K) {
-                add(g, mk_key(K, 3, 0, 1), DT_DIAG, s, K, K, 0);
+                if (K == 0) add(g, mk_key(0, 3, 0, 1), DT_DIAG, s, 0, 0, 0);
+                else {
+                    // the owner's own chain of block column K - 1 in one task, where its DT_OFF stood
+                    add(g, mk_key(K, 1, 1, 0), DT_COL, s, K, K, 0);
+                    per[g].back().t.pad[2] = p.slot[tix(K, K - 1)];
+                }
                 // (behind the pair of updates of block column k + 1, where the workgroup would wait for column k + 2; not behind
                 //  the pair of column K - 2, the one in front of L(K, K-1): those two follow D_K's publication)
                 for (int k = 0; k + 2 <= K; ++k) add(g, k + 4 <= K ? mk_key(k + 2, 3, K - 2 - k, 2) : mk_key(K, 3, 0, 2 + k), DT_RUP, s, K, K, k);
@@ -94,7 +100,7 @@ void build_dense_plan(int nt, DensePlan &p, int max_groups, int max_slots)
                 per[g].back().t.pad[0] = K >= 1 ? p.slot[tix(K, K - 1)] : -1;
                 add(g, mk_key(nt + 1 + (nt - 1 - K), 0, 0, 0), DT_BSX, s, K, K, 0);
             } else {
-                add(g, mk_key(K + 1, 1, I - K, 0), DT_OFF, s, I, K, 0);
+                if (!(I == K + 1 && p.owner[tix(I, I)] == g)) add(g, mk_key(K + 1, 1, I - K, 0), DT_OFF, s, I, K, 0);       // (else: the owner's DT_COL)
                 add(g, mk_key(nt + 1 + (nt - 1 - I), 1, I - K, 0), DT_BSC, s, I, K, 0);
                 per[g].back().t.pad[0] = p.owner[tix(I, I)] == g ? 1 : 0;      // x_I was solved by this workgroup: still in its LDS
             }

@@ -28,6 +28,9 @@ enum DenseOp : int32_t {
     DT_UPD2 = 9,    // diagonal owner, block column k <= K - 2: D_K -= L(K, k) L(K, k)^T and tile (K, K-1) -= L(K, k) L(K-1, k)^T in one
                     // task (one wait, both operands fetched together, fifteen MFMA blocks over the four waves): slot = D_K's,
                     // pad[2] = the sub-diagonal tile's, pad[0] / pad[1] = own slot of L(K, k) / L(K-1, k) or -1       waits F(K, k), F(K-1, k)
+    DT_COL = 10,    // diagonal owner K >= 1, block column K - 1 published: L(K, K-1) = tile W_(K-1), D_K -= L L^T, D_K -> W_K in ONE task
+                    // (DT_OFF + the last DT_UPD + DT_DIAG of the owner without the task boundaries between them): slot = D_K's,
+                    // pad[2] = the sub-diagonal tile's       waits PD(K-1), sets F(K, K-1) and PD(K)
     DT_RUP = 8,     // diagonal owner: r_K -= L(K, k) y_k, k <= K - 2 (ahead of DT_RHS, in the shadow of the factorisation)  waits FY(k)
 };
 

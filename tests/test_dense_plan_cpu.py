@@ -6,7 +6,7 @@ leave some workgroup able to run — whatever the speeds of the workgroups."""
 import numpy as np
 import pytest
 
-ASM, UPD, DIAG, OFF, RHS, BSX, BSC, EPI, RUP, UPD2 = range(10)
+ASM, UPD, DIAG, OFF, RHS, BSX, BSC, EPI, RUP, UPD2, COL = range(11)
 
 
 def waits_and_sets(op, I, K, k, p0, p1, nt):
@@ -16,6 +16,7 @@ def waits_and_sets(op, I, K, k, p0, p1, nt):
         # nor are those the update before left in the scratch tiles (-2)
         return ([("F", I, k)] if p0 == -1 else []) + ([("F", K, k)] if I != K and p1 == -1 else []), []
     if op == UPD2: return ([("F", K, k)] if p0 < 0 else []) + ([("F", K - 1, k)] if p1 < 0 else []), []
+    if op == COL: return [("PD", K - 1)], [("F", K, K - 1), ("PD", K)]
     if op == DIAG: return [], [("PD", K)]
     if op == OFF: return [("PD", K)], [("F", I, K)]
     if op == RHS: return ([("FY", K - 1)] if K >= 1 else []), [("FY", K)]
@@ -72,6 +73,14 @@ def replay(plan, nt, order_rng):
             else: assert slots[(g, p0)] == (K, k)
             if p1 < 0: sc[1] = (K - 1, k)
             else: assert slots[(g, p1)] == (K - 1, k)
+        elif op == COL:
+            # the diagonal owner's chain of block column K - 1: its sub-diagonal tile finished, the diagonal tile's last update, W_K
+            sub = (K, K - 1)
+            assert I == K == g and K >= 1 and slots[(g, slot)] == tile and slots[(g, p2)] == sub
+            assert state[sub] == "asm" and upd_seen[sub] == K - 1 and state[tile] == "asm" and upd_seen[tile] == K - 1
+            upd_seen[tile] += 1
+            state[sub] = "final"; state[tile] = "final"
+            scratch.setdefault(g, [None, None])[1] = None
         elif op in (DIAG, OFF):
             assert state[tile] == "asm" and upd_seen[tile] == K and slots[(g, slot)] == tile    # every column to the left applied
             state[tile] = "final"

@@ -618,9 +618,11 @@ def test_batched_run_beside_uploads_and_solves_on_another_handle(built_lib):
 def test_batched_run_with_windows_that_leave_the_batch(built_lib, oracle_mod):
     """A batch may hold windows that do not take the batched kernels to the end: one whose PCG gives up (it parks itself and
     finishes on the direct solver), one beyond the on-chip PCG (direct solver throughout), an empty one, one without a
-    fixed keyframe and one whose stop flag is up; the others are not disturbed."""
+    fixed keyframe, one whose stop flag is up and one with intrinsics by keyframe (kernel variants of its own: solved on its
+    own behind the batched launches); the others are not disturbed."""
     ws = [synth.cfg("cfg2"), synth.make_window(50, 2, 30, seed=101, run_lo=2, run_hi=6), synth.make_window(90, 6, 4000, seed=9, run_lo=2, run_hi=8),
-          synth.cfg("small"), synth.cfg("small"), synth.cfg("small"), synth.make_window(12, 3, 1500, seed=58, run_lo=2, run_hi=7)]
+          synth.cfg("small"), synth.cfg("small"), synth.cfg("small"), synth.make_window(12, 3, 1500, seed=58, run_lo=2, run_hi=7),
+          synth.mixed_cameras(synth.make_window(12, 3, 1500, seed=59, run_lo=2, run_hi=7), seed=60)]
     for f in ("edge_pose", "edge_point", "obs", "inv_sigma2"):
         setattr(ws[3], f, getattr(ws[3], f)[:0])                      # empty
     ws[4].pose_fixed = np.zeros_like(ws[4].pose_fixed)              # no fixed keyframe
@@ -632,7 +634,7 @@ def test_batched_run_with_windows_that_leave_the_batch(built_lib, oracle_mod):
             s.upload(w, stop=stop if i == 5 else None)
         assert built_lib.run_batch(solvers) == 0
         res = [s.download() for s in solvers]
-        assert [r["status"] for r in res] == [0, 0, 0, built_lib.EMPTY, built_lib.NO_FIXED, built_lib.STOPPED, 0]
+        assert [r["status"] for r in res] == [0, 0, 0, built_lib.EMPTY, built_lib.NO_FIXED, built_lib.STOPPED, 0, 0]
         for a, b in zip(solo, res):
             assert a["status"] == b["status"]
             for k in ("poses", "points", "chi2", "outlier"):
@@ -640,6 +642,7 @@ def test_batched_run_with_windows_that_leave_the_batch(built_lib, oracle_mod):
         assert res[1]["n_pcg_giveups"] == 1 and res[1]["n_direct"] > 0 and res[2]["direct_from"] == 0
         check_against(res[0], oracle_mod.solve(ws[0]), ws[0])
         check_against(res[1], oracle_mod.solve(ws[1]), ws[1], noise_guard=True, **WEAK_TOL)
+        check_against(res[7], oracle_mod.solve(ws[7]), ws[7])
     finally:
         for s in solvers:
             s.close()
