@@ -1037,7 +1037,7 @@ int Upload::lay_out_rest()
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
     o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
-    o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_count(ntile) + 8 : 8);
+    o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_words(ntile) : 8);
     o_dcontrib = c.take<double>(dense_one ? (size_t)ntile * ntile * kDenseNB : 1);
     static const bool dense_stamps_env = std::getenv("MOVBA_DENSE_STAMPS") != nullptr;
     dense_stamps = dense_stamps_env;
@@ -1168,6 +1168,7 @@ void Upload::device_view()
     w.dense.ntile = ntile; w.dense.n = 6 * nf; w.dense.xsol = reinterpret_cast<double *>(a + o_dx);
     w.dense.task_ptr = reinterpret_cast<const int32_t *>(a + o_dtp); w.dense.tasks = reinterpret_cast<const DenseTask *>(a + o_dtk);
     w.dense.flags = reinterpret_cast<unsigned *>(a + o_dflags); w.dense.failw = w.dense.flags + dense_flag_count(ntile);
+    w.dense.ctag = w.dense.flags + dense_ctag_word(ntile);
     w.dense.contrib = reinterpret_cast<double *>(a + o_dcontrib);
     w.dense.stamps = dense_one && dense_stamps ? reinterpret_cast<unsigned long long *>(a + o_dstamps) : nullptr;
     w.dense.G = dense_one ? h->dplan.G : 0; w.dense.slots = dense_one ? h->dplan.slots : 0;
@@ -1245,7 +1246,7 @@ hipError_t queue_direct(movba_handle *h)
     const DevWindow &w = h->win;
     if (w.dense.G <= 0) return launch_dense_solve(w, h->stream);
     if (!h->dense_flags_clean) {
-        const hipError_t e = hipMemsetAsync(w.dense.flags, 0, sizeof(uint32_t) * ((size_t)dense_flag_count(w.dense.ntile) + 8), h->stream);
+        const hipError_t e = hipMemsetAsync(w.dense.flags, 0, sizeof(uint32_t) * (size_t)dense_flag_words(w.dense.ntile), h->stream);
         if (e != hipSuccess) return e;
         h->dense_flags_clean = true; h->dense_epoch = 0;
     }

@@ -122,6 +122,40 @@ __device__ __forceinline__ void publish_tile(double *g, const double *lds, int t
     }
 }
 
+// A 48-vector handed over as 48 self-announcing 16-byte records (value, the launch's epoch, a check word): one sc1 store per
+// lane, no drain, no flag; the consumer's lanes poll their own record until epoch and check word fit.  (A 16-byte store of one
+// lane is one request to one cache line; the check word is there so that a torn read could only ever cause another look.)
+constexpr unsigned kTagSalt = 0x9e3779b9u;
+__device__ __forceinline__ void st_tagged(unsigned *rec_base, int nrec_bytes, int t, double v, unsigned epoch)
+{
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(rec_base, 0, nrec_bytes, 0x00020000);
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const u32x4 q = { lo, hi, epoch, epoch ^ lo ^ hi ^ kTagSalt };
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, t * 16, 0, 16);
+}
+// wave 0, lanes below 48: false (to the whole workgroup, through Lds::abort) when the records did not come within kWaitTicks
+__device__ __forceinline__ bool ld_tagged(const unsigned *rec_base, int nrec_bytes, int tid, unsigned epoch, double &v, const Lds &l)
+{
+    if (tid < 64) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(rec_base), 0, nrec_bytes, 0x00020000);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const bool mine = tid < NB;
+        bool good = true;
+        u32x4 q;
+        for (;;) {
+            q = __builtin_amdgcn_raw_buffer_load_b128(r, mine ? tid * 16 : 0, 0, 16);
+            const bool ok = q.z == epoch && q.w == (epoch ^ q.x ^ q.y ^ kTagSalt);
+            if (__all(ok || !mine)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) { good = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        v = __hiloint2double((int)q.y, (int)q.x);
+        if (!good && tid == 0) *l.abort = 1;
+    }
+    __syncthreads();
+    return *l.abort == 0;
+}
+
 // every storing wave drains its stores, the workgroup meets, ONE lane stores the flag
 __device__ __forceinline__ void set_flag(unsigned *flags, int idx, unsigned epoch, int tid)
 {
@@ -543,7 +577,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
     // everything the task loop needs from the argument block, once, in registers
     const int nt = w.dense.ntile, n = w.dense.n, nslots = w.dense.slots;
     double *const tiles = w.dense.tiles, *const contrib = w.dense.contrib, *const xsol = w.dense.xsol;
-    unsigned *const flags = w.dense.flags, *const failw = w.dense.failw;
+    unsigned *const flags = w.dense.flags, *const failw = w.dense.failw, *const ctag = w.dense.ctag;
     unsigned long long *const stamps = w.dense.stamps;
     const DenseTask *const gtasks = w.dense.tasks;
     const AsmView av = { w.part, w.dense.pid, w.pair_item_start, w.bp, w.nfree, w.dense.n };
@@ -750,18 +784,26 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
                         for (int u = 0; u < 8; ++u) acc += v[u];
                     }
             }
-            if (nc > 0 && !wg_wait(flags, epoch, 1, [&](int) { return dense_flag_FC(nt, J + 1, J); }, l, tid)) { aborted = true; break; }
+            // (the one contribution on the chain, c(J+1, J), comes as tagged records: no flag, no separate load)
+            double cj = 0.0;
+            if (nc > 0 && !ld_tagged(ctag + (size_t)J * NB * 4, NB * 16, tid, epoch, cj, l)) { aborted = true; break; }
             if (stamps && tid == 0) stamps[6 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime();
             if (tid < NB) {
-                if (nc > 0) acc += ld_sc1(contrib + ((size_t)(J + 1) * nt + J) * NB + tid);
+                if (nc > 0) acc += cj;
                 l.xs[tid] = l.yv[tid] - acc;
             }
             __syncthreads();
             const double xj = tile_matvec<false>(slot, l, tid);       // x_J = W_J (y_J - sum c(I, J))
-            if (tid < NB) { l.xv[tid] = xj; st_sc1(xsol + J * NB + tid, xj); }
-            // (flagged behind the next task when that is the contribution of this workgroup's own tile (J, J-1): one drain for
-            //  x_J and c(J, J-1) on the chain of the back substitution instead of two)
-            pending = dense_flag_FX(nt, J);
+            __syncthreads();                                                   // (every thread is through with xs and ps)
+            if (tid < NB) { l.xv[tid] = xj; l.xs[tid] = xj; st_sc1(xsol + J * NB + tid, xj); }
+            if (J >= 1) {
+                // c(J, J-1) = L(J, J-1)^T x_J straight away (the owner's own tile), handed to block row J - 1 as tagged records
+                __syncthreads();
+                const double cv = tile_matvec<true>(sm + (2 + tk.pad[0]) * kTileLds, l, tid);
+                if (tid < NB) st_tagged(ctag + (size_t)(J - 1) * NB * 4, NB * 16, tid, cv, epoch);
+            }
+            // x_J's flag, for the other tiles of block row J: behind the tagged records (not on the chain)
+            set_flag(flags, dense_flag_FX(nt, J), epoch, tid);
             break;
         }
         case DT_BSC: {
@@ -782,7 +824,8 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
                 l.ps[g * NB + cc] = s;
             }
             __syncthreads();
-            if (tid < NB) st_sc1(contrib + ((size_t)I * nt + K) * NB + tid, (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid]);
+            const double cv = tid < NB ? (((l.ps[tid] + l.ps[NB + tid]) + l.ps[2 * NB + tid]) + l.ps[3 * NB + tid]) + l.ps[4 * NB + tid] : 0.0;
+            if (tid < NB) st_sc1(contrib + ((size_t)I * nt + K) * NB + tid, cv);
             set_flag(flags, dense_flag_FC(nt, I, K), epoch, tid);
             if (pending >= 0) { if (tid == 0) st_flag(flags + pending, epoch); pending = -1; }      // (x_I's stores were drained by the same wait)
             break;

@@ -99,8 +99,10 @@ void build_dense_plan(int nt, DensePlan &p, int max_groups, int max_slots)
                 add(g, mk_key(K + 1, 2, 0, 0), DT_RHS, s, K, K, 0);
                 per[g].back().t.pad[0] = K >= 1 ? p.slot[tix(K, K - 1)] : -1;
                 add(g, mk_key(nt + 1 + (nt - 1 - K), 0, 0, 0), DT_BSX, s, K, K, 0);
+                per[g].back().t.pad[0] = K >= 1 ? p.slot[tix(K, K - 1)] : -1;      // (x_K's solve also takes c(K, K-1): the owner's own tile)
             } else {
                 if (!(I == K + 1 && p.owner[tix(I, I)] == g)) add(g, mk_key(K + 1, 1, I - K, 0), DT_OFF, s, I, K, 0);       // (else: the owner's DT_COL)
+                if (I == K + 1 && p.owner[tix(I, I)] == g) continue;           // (the sub-diagonal tile's contribution: inside the owner's DT_BSX)
                 add(g, mk_key(nt + 1 + (nt - 1 - I), 1, I - K, 0), DT_BSC, s, I, K, 0);
                 per[g].back().t.pad[0] = p.owner[tix(I, I)] == g ? 1 : 0;      // x_I was solved by this workgroup: still in its LDS
             }

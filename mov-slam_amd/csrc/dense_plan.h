@@ -22,7 +22,8 @@ enum DenseOp : int32_t {
     DT_DIAG = 2,    // publish the updated diagonal tile D_K                  sets PD(K)
     DT_OFF = 3,     // L(I, K) = tile (I, K) L(K, K)^-T (sweep against D_K)   waits PD(K), sets F(I, K)
     DT_RHS = 4,     // diagonal owner: y_K (forward substitution) and L(K, K) waits FY(k), k < K, sets FY(K)
-    DT_BSX = 5,     // diagonal owner: x_J = L(J, J)^-T (y_J - sum_I c(I, J))   waits FC(I, J), I > J, sets FX(J)
+    DT_BSX = 5,     // diagonal owner: x_J = L(J, J)^-T (y_J - sum_I c(I, J)), then c(J, J-1) of its own sub-diagonal tile (pad[0] = its
+                    // slot)                                               waits FC(I, J), I > J, sets FX(J), FC(J, J-1)
     DT_BSC = 6,     // owner of (I, J): c(I, J) = L(I, J)^T x_I               waits FX(I), sets FC(I, J)
     DT_EPI = 7,     // increments, computeScale's pose part, trial poses      waits FX(*)
     DT_UPD2 = 9,    // diagonal owner, block column k <= K - 2: D_K -= L(K, k) L(K, k)^T and tile (K, K-1) -= L(K, k) L(K-1, k)^T in one
@@ -54,6 +55,9 @@ constexpr inline int dense_flag_PD(int nt, int K) { return (nt + 1) * nt + K; }
 constexpr inline int dense_flag_FX(int nt, int J) { return (nt + 2) * nt + J; }
 constexpr inline int dense_flag_FC(int nt, int I, int J) { return (nt + 3) * nt + I * nt + J; }
 constexpr inline int dense_flag_count(int nt) { return (2 * nt + 3) * nt + 8; }
+// (behind the flags and the two failure words, 16-byte aligned: the tagged sub-diagonal contributions, 4 words x 48 per block row)
+constexpr inline int dense_ctag_word(int nt) { return (dense_flag_count(nt) + 8 + 3) / 4 * 4; }
+constexpr inline int dense_flag_words(int nt) { return dense_ctag_word(nt) + nt * 48 * 4; }
 
 void build_dense_plan(int nt, DensePlan &p, int max_groups = kDenseMaxGroups, int max_slots = kDenseMaxSlots);
 

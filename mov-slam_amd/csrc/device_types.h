@@ -98,6 +98,8 @@ struct DenseSys {
     const DenseTask *tasks;
     unsigned *flags, *failw;
     double *contrib;            // ntile x ntile x NB
+    unsigned *ctag;             // ntile x NB x 4 words: the sub-diagonal contributions c(J+1, J) as self-announcing 16-byte records
+                                // (value, epoch, check word), behind the flags: zeroed with them
     unsigned long long *stamps; // diagnostic (MOVBA_DENSE_STAMPS=1): per task 3 readings of the 100 MHz clock (start, wait over, end), else null
     int32_t G, slots;           // workgroups of the launch, LDS tile slots per workgroup (G == 0: multi-launch path only)
 };

@@ -21,7 +21,7 @@ def waits_and_sets(op, I, K, k, p0, p1, nt):
     if op == OFF: return [("PD", K)], [("F", I, K)]
     if op == RHS: return ([("FY", K - 1)] if K >= 1 else []), [("FY", K)]
     if op == RUP: return [("FY", k)], []
-    if op == BSX: return [("FY", K)] + [("FC", i, K) for i in range(K + 1, nt)], [("FX", K)]
+    if op == BSX: return [("FY", K)] + [("FC", i, K) for i in range(K + 1, nt)], [("FX", K)] + ([("FC", K, K - 1)] if K >= 1 else [])
     if op == BSC: return ([] if p0 == 1 else [("FX", I)]), [("FC", I, K)]
     if op == EPI: return [("FX", j) for j in range(nt)], []
     raise AssertionError(op)
@@ -91,6 +91,8 @@ def replay(plan, nt, order_rng):
             scratch.setdefault(g, [None, None])[0] = None
         elif op in (RHS, BSX):
             assert state[(K, K)] == "final" and slots[(g, slot)] == (K, K)
+            if op == BSX:                            # ... and the contribution of the owner's own sub-diagonal tile
+                assert K == 0 or (slots[(g, p0)] == (K, K - 1) and state[(K, K - 1)] == "final")
             if op == RHS:
                 assert rup_seen.get(K, 0) == max(K - 1, 0)       # RHS itself applies block column K - 1, from the workgroup's own tile
                 assert K == 0 or (slots[(g, p0)] == (K, K - 1) and state[(K, K - 1)] == "final")
