@@ -569,7 +569,7 @@ struct Upload {
     // --- pair region / device-only region ---
     size_t pair_begin = 0, hole = 0, h2d = 0, total = 0;
     size_t o_items = 0, o_sched = 0, o_pi = 0, o_pj = 0, o_pis = 0, o_rowptr = 0, o_rowent = 0, o_plan = 0;
-    size_t o_cg = 0, o_ch = 0, o_cp = 0, o_ce = 0, o_cij = 0, o_multi = 0, o_pid = 0, o_dtp = 0, o_dtk = 0;
+    size_t o_cg = 0, o_ch = 0, o_cp = 0, o_ce = 0, o_cij = 0, o_multi = 0, o_pid = 0, o_prange = 0, o_dtp = 0, o_dtk = 0;
     size_t o_st[2][11] = {};
     size_t o_obspm = 0, o_obsrpm = 0, o_part = 0, o_blocks = 0, o_blocks_ov = 0, o_blocks_c = 0, o_aci = 0, o_acitag = 0;
     size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
@@ -1014,6 +1014,7 @@ int Upload::lay_out_rest()
     if (h->dplan_nt != ntile) { build_dense_plan(ntile, h->dplan); h->dplan_nt = ntile; }
     dense_one = !dense_multi && dense_persist_supported(h->dplan);
     o_dtp = c.take<int32_t>(dense_one ? h->dplan.task_ptr.size() : 1); o_dtk = c.take<DenseTask>(dense_one ? h->dplan.tasks.size() : 1);
+    o_prange = c.take<int32_t>(dense_one ? 2 * (size_t)nf * nf : 1);
     if (!dev_structure) o_ent = c.take<int32_t>(ent_words());       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
     h2d = c.off;
     // ---- device-only region ----
@@ -1093,6 +1094,12 @@ void Upload::pack_pairs()
     if (dense_one) {
         std::memcpy(sp(o_dtp), h->dplan.task_ptr.data(), sizeof(int32_t) * h->dplan.task_ptr.size());
         std::memcpy(sp(o_dtk), h->dplan.tasks.data(), sizeof(DenseTask) * h->dplan.tasks.size());
+        int32_t *pr = reinterpret_cast<int32_t *>(sp(o_prange));
+        for (size_t q = 0; q < (size_t)nf * nf; ++q) {
+            const int32_t pair = s().pid[q];
+            pr[2 * q] = pair >= 0 ? s().pair_item_start[pair] : 0;
+            pr[2 * q + 1] = pair >= 0 ? s().pair_item_start[pair + 1] : 0;
+        }
     }
     lap("carve + pack pair region");
 }
@@ -1165,6 +1172,7 @@ void Upload::device_view()
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
     w.dense.pid = reinterpret_cast<const int32_t *>(a + o_pid); w.dense.fail = reinterpret_cast<int32_t *>(a + o_dfail);
+    w.dense.prange = dense_one ? reinterpret_cast<const int32_t *>(a + o_prange) : nullptr;
     w.dense.ntile = ntile; w.dense.n = 6 * nf; w.dense.xsol = reinterpret_cast<double *>(a + o_dx);
     w.dense.task_ptr = reinterpret_cast<const int32_t *>(a + o_dtp); w.dense.tasks = reinterpret_cast<const DenseTask *>(a + o_dtk);
     w.dense.flags = reinterpret_cast<unsigned *>(a + o_dflags); w.dense.failw = w.dense.flags + dense_flag_count(ntile);

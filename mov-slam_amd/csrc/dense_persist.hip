@@ -293,7 +293,7 @@ __device__ __forceinline__ void tile_update(double *C, const double *As, const d
 
 // S (damped) of tile (I, K) from the schur work-item partials into an LDS image: the element map and the item order of
 // k_dense_assemble (dense_solve.hip), so both direct solvers and the PCG see the same matrix to the last bit
-struct AsmView { const double *part; const int32_t *pid, *pis; double *bp; int32_t nf, n; };      // (by value: the kernel's argument block stays out of scratch)
+struct AsmView { const double *part; const int32_t *prange; double *bp; int32_t nf, n; unsigned long long *st; };      // (by value: the kernel's argument block stays out of scratch)
 __device__ __attribute__((noinline)) void assemble_tile(AsmView av, int I, int K, double lambda, int dst_off, int rrow_off, int tid)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];     // (LDS addressed from its own symbol: ds_ instructions, not flat_)
@@ -301,76 +301,125 @@ __device__ __attribute__((noinline)) void assemble_tile(AsmView av, int I, int K
     const int nf = av.nf, n = av.n;
     // (global pointers said to be global: plain global_load instead of flat_load)
     typedef const __attribute__((address_space(1))) double *gdp;
-    typedef const __attribute__((address_space(1))) int32_t *gip;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) i32x2 *grp;
     const gdp part = (gdp)av.part;
-    const gip pid = (gip)av.pid, pis = (gip)av.pis;
-    // A diagonal tile holds eight diagonal pairs, each cut into several work items (five at cfg3) whose records are summed
-    // for 57 of the tile's elements and for the right-hand side: their records (contiguous: the diagonal pairs come first, in
-    // order) are staged in the two scratch tiles by one coalesced pass and summed from LDS — element by element from
-    // memory the tile took five dependent round trips more (12 us at the head of the solve's chain).
-    int item0 = 0, nstage = 0;
-    if (I == K) {
-        const int b0 = K * (NB / 6), b1 = min(b0 + NB / 6, nf);
-        item0 = pis[b0];
-        nstage = pis[b1] - item0;
-        if (nstage * kPartStride > 2 * kTileLds) nstage = 0;       // (a keyframe with tens of thousands of edges: summed from memory)
-        for (int e = tid; e < nstage * kPartStride; e += kPT) sm[e] = part[(size_t)item0 * kPartStride + e];
-        __syncthreads();
-    }
+    const grp prange = (grp)av.prange;
+    // Two levels of dependent loads in all (these come right behind a launch boundary: ~2.5 us each, cold): the item ranges
+    // of the thread's nine elements and of the tile's diagonal pairs, then the partial records themselves.  Everything is
+    // loaded unconditionally from an address that is always valid and masked afterwards: written with a branch per element
+    // the compiler serialised the nine round trips of every level (11 us per diagonal tile).
     constexpr int kPer = NB * NB / kPT;
-    int pr[kPer], kk[kPer], uu[kPer], i0[kPer], i1[kPer];
+    int kk[kPer], uu[kPer], i0[kPer], i1[kPer];
+    bool live[kPer];                    // the element lies inside the system (not in the padding of the last tile)
     double pad[kPer];
+    i32x2 rg[kPer];
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         const int e = tid + kPT * q, r = e / NB, cc = e - r * NB;
         const int gr = I * NB + r, gc = K * NB + cc;
-        pr[q] = -1; kk[q] = 0; uu[q] = -1; pad[q] = 0.0;
-        if (gr >= n || gc >= n) pad[q] = (gr == gc) ? 1.0 : 0.0;
-        else {
-            const int bi = gr / 6, a = gr - bi * 6, bj = gc / 6, b = gc - bj * 6;
-            const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
-            pr[q] = pid[(size_t)lo * nf + hi];
-            kk[q] = bi <= bj ? a * 6 + b : b * 6 + a;
-            if (bi == bj) { uu[q] = 42 + (a <= b ? ut6(a, b) : ut6(b, a)); pad[q] = a == b ? lambda : 0.0; }
+        live[q] = gr < n && gc < n;
+        const int bi = live[q] ? gr / 6 : 0, bj = live[q] ? gc / 6 : 0;
+        const int a = gr - (gr / 6) * 6, b = gc - (gc / 6) * 6;
+        const int lo = bi < bj ? bi : bj, hi = bi < bj ? bj : bi;
+        rg[q] = prange[(size_t)lo * nf + hi];
+        kk[q] = bi <= bj ? a * 6 + b : b * 6 + a;
+        const bool dg = live[q] && bi == bj;
+        uu[q] = dg ? 42 + (a <= b ? ut6(a, b) : ut6(b, a)) : -1;
+        pad[q] = live[q] ? (dg && a == b ? lambda : 0.0) : (gr == gc ? 1.0 : 0.0);
+    }
+    // A diagonal tile holds eight diagonal pairs, each cut into several work items (four or five at cfg3) whose records are
+    // summed for 57 of the tile's elements and for the right-hand side: their records (contiguous: the diagonal pairs come
+    // first, in order) are staged in the two scratch tiles by one coalesced pass and summed from LDS.
+    int item0 = 0, nstage = 0;
+    const int b0 = K * (NB / 6), b1 = min(b0 + NB / 6, nf);
+    if (I == K) {
+        item0 = prange[(size_t)b0 * nf + b0].x;
+        nstage = prange[(size_t)(b1 - 1) * nf + (b1 - 1)].y - item0;
+        if (nstage * kPartStride > 2 * kTileLds) nstage = 0;       // (a keyframe with tens of thousands of edges: summed from memory)
+    }
+    bool staged[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        i0[q] = live[q] ? rg[q].x : 0; i1[q] = live[q] ? rg[q].y : 0;
+        staged[q] = uu[q] >= 0 && nstage > 0;
+    }
+    if (av.st && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); av.st[1] = __builtin_amdgcn_s_memrealtime(); }
+    // the first item of every element that is not staged, issued beside the staging pass
+    double sacc[kPer], hpp[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const size_t base = (size_t)(staged[q] ? 0 : i0[q]) * kPartStride;           // (item 0 exists; read and dropped where not wanted)
+        sacc[q] = part[base + kk[q]];
+        hpp[q] = part[base + (uu[q] >= 0 ? uu[q] : 0)];
+    }
+    if (I == K) {
+        // (eight loads in flight per thread: one at a time the pass took a memory round trip per 256 doubles)
+        const int ntot = nstage * kPartStride;
+        for (int base = 0; base < ntot; base += 8 * kPT) {
+            double tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = base + tid + u * kPT; tmp[u] = part[(size_t)item0 * kPartStride + (e < ntot ? e : 0)]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int e = base + tid + u * kPT; if (e < ntot) sm[e] = tmp[u]; }
         }
+        __syncthreads();
     }
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
-        i0[q] = pr[q] >= 0 ? pis[pr[q]] : 0; i1[q] = pr[q] >= 0 ? pis[pr[q] + 1] : 0;
+        const bool first = !staged[q] && i1[q] > i0[q];
+        sacc[q] = first ? 0.0 + sacc[q] : 0.0;                     // (0 + v: the sum as k_dense_assemble forms it, to the sign of a zero)
+        hpp[q] = (first && uu[q] >= 0) ? 0.0 + hpp[q] : 0.0;
     }
-    // sums in item order; the thread's nine elements advance through their item lists TOGETHER (step s = the s-th item of
-    // every element, nine loads in flight): one list after the other the tile took nine dependent memory round trips
-    double sacc[kPer], hpp[kPer];
-    int maxlen = 0;
+    if (av.st && tid == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); av.st[2] = __builtin_amdgcn_s_memrealtime(); }
+    // sums in item order.  Staged elements: from LDS, the thread's elements step by step together (reads unconditional,
+    // adds masked) ...
+    if (nstage > 0) {
+        int len = 0;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) { sacc[q] = 0.0; hpp[q] = 0.0; maxlen = max(maxlen, i1[q] - i0[q]); }
-    for (int st = 0; st < maxlen; ++st) {
-        double va[kPer], vh[kPer];
+        for (int q = 0; q < kPer; ++q) len = max(len, staged[q] ? i1[q] - i0[q] : 0);
+        for (int st = 0; st < len; ++st) {
+            double va[kPer], vh[kPer];
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const int itx = i0[q] + st;
-            const bool on = itx < i1[q];
-            const bool staged = uu[q] >= 0 && nstage > 0;
-            va[q] = 0.0; vh[q] = 0.0;
-            if (staged) {
-                if (on) { va[q] = sm[(itx - item0) * kPartStride + kk[q]]; vh[q] = sm[(itx - item0) * kPartStride + uu[q]]; }
-            } else {
-                const size_t base = (size_t)(on ? itx : 0) * kPartStride;      // (item 0 exists: an address that is always valid)
-                va[q] = part[base + kk[q]];
-                if (uu[q] >= 0) vh[q] = part[base + uu[q]];
+            for (int q = 0; q < kPer; ++q) {
+                const bool on = staged[q] && i0[q] + st < i1[q];
+                const int it = on ? i0[q] + st - item0 : 0;
+                va[q] = sm[it * kPartStride + kk[q]];
+                vh[q] = sm[it * kPartStride + (uu[q] >= 0 ? uu[q] : 0)];
             }
-        }
 #pragma unroll
-        for (int q = 0; q < kPer; ++q)
-            if (i0[q] + st < i1[q]) { sacc[q] += va[q]; hpp[q] += vh[q]; }
+            for (int q = 0; q < kPer; ++q)
+                if (staged[q] && i0[q] + st < i1[q]) { sacc[q] += va[q]; hpp[q] += vh[q]; }
+        }
+    }
+    // ... the further items of an element summed from memory (rare: an off-diagonal pair of more than 2 048 shared points, or
+    // a diagonal tile too large to stage), step by step as well
+    {
+        int len = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) len = max(len, staged[q] ? 0 : i1[q] - i0[q]);
+        for (int st = 1; st < len; ++st) {
+            double va[kPer], vh[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+                const bool on = !staged[q] && i0[q] + st < i1[q];
+                const size_t base = (size_t)(on ? i0[q] + st : 0) * kPartStride;
+                va[q] = part[base + kk[q]];
+                vh[q] = part[base + (uu[q] >= 0 ? uu[q] : 0)];
+            }
+#pragma unroll
+            for (int q = 0; q < kPer; ++q)
+                if (!staged[q] && i0[q] + st < i1[q]) { sacc[q] += va[q]; if (uu[q] >= 0) hpp[q] += vh[q]; }
+        }
     }
 #pragma unroll
     for (int q = 0; q < kPer; ++q) {
         double v = pad[q];
-        if (pr[q] >= 0) v = uu[q] >= 0 ? (hpp[q] + pad[q]) - sacc[q] : -sacc[q];
+        if (live[q] && i1[q] > i0[q]) v = uu[q] >= 0 ? (hpp[q] + pad[q]) - sacc[q] : -sacc[q];
         const int e = tid + kPT * q, r = e / NB, cc = e - r * NB;
         dst[r * LD + cc] = v;
     }
+    if (av.st && tid == 0) av.st[3] = __builtin_amdgcn_s_memrealtime();
     if (I == K && tid < NB) {
         // right-hand side b_S = b_p - sum B Dinv b_l of this block column; b_p is kept for computeScale
         const int gc = K * NB + tid;
@@ -378,7 +427,8 @@ __device__ __attribute__((noinline)) void assemble_tile(AsmView av, int I, int K
         if (gc < n) {
             const int bj = gc / 6, a = gc - bj * 6;
             double bb = 0.0, cb = 0.0;
-            const int j0 = pis[bj], j1 = pis[bj + 1];
+            const i32x2 jr = prange[(size_t)bj * nf + bj];
+            const int j0 = jr.x, j1 = jr.y;
             if (nstage > 0) {
                 for (int itx = j0; itx < j1; ++itx) { bb += sm[(itx - item0) * kPartStride + 63 + a]; cb += sm[(itx - item0) * kPartStride + 36 + a]; }
             } else {
@@ -580,7 +630,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
     unsigned *const flags = w.dense.flags, *const failw = w.dense.failw, *const ctag = w.dense.ctag;
     unsigned long long *const stamps = w.dense.stamps;
     const DenseTask *const gtasks = w.dense.tasks;
-    const AsmView av = { w.part, w.dense.pid, w.pair_item_start, w.bp, w.nfree, w.dense.n };
+    AsmView av = { w.part, w.dense.prange, w.bp, w.nfree, w.dense.n, nullptr };
     const Lds l = carve(sm, nslots);
     const double lambda = c->lambda;
     if (tid == 0) { *l.abort = 0; *l.prog = 0; }
@@ -611,6 +661,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
         double *slot = sm + slot_off;
         switch (tk.op) {
         case DT_ASM: {
+            av.st = stamps ? stamps + 6 * (size_t)t : nullptr;
             assemble_tile(av, I, K, lambda, slot_off, (2 + nslots) * kTileLds, tid);      // (the right-hand side row into Lds::rrow)
             __syncthreads();
             break;

@@ -90,6 +90,8 @@ struct DenseSys {
     double *diagL;              // ntile x NB x NB: Cholesky factors of the diagonal tiles
     double *xsol;               // ntile x NB: solution of the multi-launch back substitution (large systems)
     const int32_t *pid;         // nfree x nfree: pair id of block (i <= j) or -1
+    const int32_t *prange;      // nfree x nfree x 2: first / one-past-last schur work item of block (i <= j), (0, 0) where there is no pair
+                                // (pid and pair_item_start folded into one load level for the one-launch solver's assembly)
     int32_t *fail;              // != 0: a pivot was not positive (the trial is rejected like a failed CSparse factorisation)
     int32_t ntile, n;           // column tiles; unknowns (6 nfree)
     // one-launch form (dense_persist.hip): the static schedule (dense_plan.h), the hand-off flags (compared with the launch's
