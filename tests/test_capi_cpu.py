@@ -173,3 +173,9 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".cc", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "lba_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_graft_entry_build_runs_clean():
+    """The driver's build check (__graft_entry__.build): every native piece compiles and the library matches the header."""
+    import __graft_entry__ as g
+    g.build()
