@@ -688,7 +688,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             if (getA || getB) __syncthreads();
             const double *Ap = sa < 0 ? l.A : sm + (2 + sa) * kTileLds;
             const double *Bp = I == K ? Ap : (sb < 0 ? l.B : sm + (2 + sb) * kTileLds);
-            if (I == K) tile_update<true>(slot, Ap, Bp, wv, lane, k == K - 1 ? l.B : nullptr); else tile_update<false>(slot, Ap, Bp, wv, lane);
+            if (I == K) tile_update<true>(slot, Ap, Bp, wv, lane); else tile_update<false>(slot, Ap, Bp, wv, lane);
             __syncthreads();
             break;
         }
@@ -739,13 +739,6 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
             if (sweep_inverse(kTileLds, slot_off, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
             if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
-#ifdef MOVBA_SWEEP_PROFILE
-            if (stamps && tid == 0 && K == 1) {
-                const unsigned long long *pf = reinterpret_cast<const unsigned long long *>(l.ps);
-                printf("sweep D_1: p0 load %llu chain %llu store+sync %llu trail %llu | p1 load %llu chain %llu store+sync %llu trail %llu | p2 load %llu chain %llu store+sync %llu  (x10 ns)\n",
-                       pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8] - pf[7], pf[9] - pf[8], pf[10] - pf[9], pf[11] - pf[10]);
-            }
-#endif
             publish_tile<2>(tiles + tile_off(K, K), slot, tid);
             set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
             // (behind the flag: what is left of D_K below the diagonal blocks goes, the substitutions multiply with the whole slot)
@@ -769,6 +762,13 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
             if (stamps && tid == 0) stamps[6 * (size_t)t + 2] = __builtin_amdgcn_s_memrealtime();
             if (sweep_inverse(kTileLds, slot_off, kBadOff(nslots)) && tid == 0) st_flag(failw, epoch);
             if (stamps && tid == 0) stamps[6 * (size_t)t + 3] = __builtin_amdgcn_s_memrealtime();
+#ifdef MOVBA_SWEEP_PROFILE
+            if (stamps && tid == 0 && K == 1) {
+                const unsigned long long *pf = reinterpret_cast<const unsigned long long *>(l.ps);
+                printf("sweep D_1: p0 load %llu chain %llu store+sync %llu trail %llu | p1 load %llu chain %llu store+sync %llu trail %llu | p2 load %llu chain %llu store+sync %llu  (x10 ns)\n",
+                       pf[1] - pf[0], pf[2] - pf[1], pf[3] - pf[2], pf[4] - pf[3], pf[5] - pf[4], pf[6] - pf[5], pf[7] - pf[6], pf[8] - pf[7], pf[9] - pf[8], pf[10] - pf[9], pf[11] - pf[10]);
+            }
+#endif
             publish_tile<2>(tiles + tile_off(K, K), slot, tid);
             set_flag(flags, dense_flag_PD(nt, K), epoch, tid);
             for (int e = tid; e < NB * NB; e += kPT) { const int r = e / NB, cc = e - r * NB; if (tri_skip<2>(r, cc)) slot[r * LD + cc] = 0.0; }
