@@ -181,6 +181,20 @@ struct movba_handle {
 
 namespace {
 
+// One launch of the one-launch direct solver at a time per device.  Its workgroups wait for one another, which is safe while all
+// of them are resident (<= 248 of the 256 CUs); two such launches dispatched at the same moment from two streams could each get
+// part of the chip and wait for workgroups that cannot start until the other gives way - until the 20 ms clock ends both with
+// MOVBA_ERR_DEVICE_WAIT.  As long as ONE stream uses the solver on a device (MoV-SLAM: the LocalMapping thread) nothing is
+// added; from the moment a second stream does, every launch waits for the one before it through an event.
+struct DenseGate {
+    std::mutex mu;
+    hipStream_t only_stream = nullptr;      // single mode: the one stream that has launched the solver on this device
+    bool multi = false;
+    hipEvent_t ev = nullptr;                // multi mode: completion of the latest launch, whichever stream it was on
+    bool ev_recorded = false;
+};
+DenseGate &dense_gate(int device) { static DenseGate gates[32]; return gates[device & 31]; }
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // one copy stream per device for all handles (created on first use, kept for the life of the process)
@@ -430,6 +444,11 @@ void movba_destroy(movba_handle *h)
     if (h->stage) (void)hipHostFree(h->stage);
     if (h->hstat) (void)hipHostFree((void *)h->hstat);
     if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
+    {
+        DenseGate &g = dense_gate(h->device);       // (queue_direct: the gate must not keep a stream that is about to go)
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.only_stream == h->stream && h->own_stream) g.only_stream = nullptr;
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1258,7 +1277,22 @@ hipError_t queue_direct(movba_handle *h)
         if (e != hipSuccess) return e;
         h->dense_flags_clean = true; h->dense_epoch = 0;
     }
-    const hipError_t el = launch_dense_persist(w, ++h->dense_epoch, h->stream);
+    hipError_t el;
+    {
+        DenseGate &g = dense_gate(h->device);
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (!g.multi && g.only_stream && g.only_stream != h->stream) {
+            // a second stream: what the first one has in flight is waited for once, on the host; the event chain takes over
+            hipError_t e = hipStreamSynchronize(g.only_stream);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&g.ev, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+            g.multi = true; g.ev_recorded = false;
+        }
+        if (g.multi && g.ev_recorded) { const hipError_t e = hipStreamWaitEvent(h->stream, g.ev, 0); if (e != hipSuccess) return e; }
+        el = launch_dense_persist(w, ++h->dense_epoch, h->stream);
+        if (g.multi) { if (el == hipSuccess) { el = hipEventRecord(g.ev, h->stream); g.ev_recorded = el == hipSuccess; } }
+        else g.only_stream = h->stream;
+    }
     if (w.dense.stamps && el == hipSuccess && h->dense_epoch == 3) {
         // diagnostic (MOVBA_DENSE_STAMPS=1): the third direct launch of a window, task by task, in 10 ns ticks from the first start
         const size_t nt_ = h->dplan.tasks.size();

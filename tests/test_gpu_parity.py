@@ -972,3 +972,42 @@ def test_intrinsics_by_keyframe_at_cfg3_size_and_on_the_direct_solver(solver, or
         check_against(s.solve(w), o, w)
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+def test_two_handles_on_the_one_launch_direct_solver_at_once(built_lib):
+    """Two sessions on one GPU, both with windows the one-launch direct solver takes (each launch wants up to 248 of the 256
+    CUs for workgroups that wait for one another): their launches must not interleave on the device - two half-resident
+    launches would wait for workgroups that cannot start until the 20 ms clock gives up (MOVBA_ERR_DEVICE_WAIT).  Both get
+    the bits of their solo runs, no wait is given up, and nothing takes milliseconds longer than it should."""
+    import threading, time
+    wa = synth.make_window(150, 6, 6000, 9, run_lo=2, run_hi=10)
+    wb = synth.make_window(140, 6, 5000, 10, run_lo=2, run_hi=10)      # (172 + 154 workgroups: the two launches do not fit the chip together)
+    a, b = built_lib.Solver(), built_lib.Solver()
+    try:
+        ra, rb = a.solve(wa), b.solve(wb)
+        assert ra["n_direct"] == ra["n_solves"] and rb["n_direct"] == rb["n_solves"]
+        errs, times = [], {"a": [], "b": []}
+
+        def run(s, w, ref, key, n):
+            try:
+                s.prepare(w, pinned=True)
+                for _ in range(n):
+                    t = time.perf_counter()
+                    r = s.solve_prepared()
+                    times[key].append(time.perf_counter() - t)
+                    if r["status"] != 0 or r["n_sync_timeouts"] != 0:
+                        errs.append(f"{key}: status {r['status']} timeouts {r['n_sync_timeouts']}")
+                    elif not (np.array_equal(r["poses"], ref["poses"]) and np.array_equal(r["chi2"], ref["chi2"])):
+                        errs.append(f"{key}: result changed")
+            except Exception as exc:            # noqa: BLE001
+                errs.append(f"{key}: {exc!r}")
+
+        ts = [threading.Thread(target=run, args=(a, wa, ra, "a", 12)), threading.Thread(target=run, args=(b, wb, rb, "b", 12))]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        assert not errs, errs[:3]
+        # a given-up wait costs 20 ms per trial: the slowest concurrent solve stays far below that
+        assert max(times["a"]) < 0.060 and max(times["b"]) < 0.060, (max(times["a"]), max(times["b"]))
+    finally:
+        a.close(); b.close()
