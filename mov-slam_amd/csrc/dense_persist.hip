@@ -2,24 +2,28 @@
 //
 // The reference's step is an exact sparse Cholesky (LinearSolverCSparse, /root/reference/src/Optimizer.cc:535; a failed
 // factorisation rejects the LM trial).  dense_solve.hip does the same arithmetic with one launch per 48-wide block column
-// (28 us each, whatever the size); here the whole solve — assembly of S from the schur partials, blocked Cholesky,
-// forward and back substitution, pose update — is one launch of up to 248 workgroups that hand finished tiles to each
+// (28 us each, whatever the size); here the whole solve - assembly of S from the schur partials, blocked Cholesky,
+// forward and back substitution, pose update - is one launch of up to 248 workgroups that hand finished tiles to each
 // other through L2:
 //   * every 48 x 48 tile of the lower block triangle has an OWNER workgroup (dense_plan.h) that keeps it in LDS from
 //     assembly to the end: tile (I, K) -= L(I, k) L(K, k)^T for every block column k < K as soon as that column's tiles
-//     are published (fp64 matrix cores), then L(I, K) = tile L(K, K)^-T by a panel sweep against the published diagonal
-//     tile D_K (every owner of column K factors D_K for itself: nobody waits for a factor), then L(I, K) is published;
-//   * workgroup K owns the diagonal tile (K, K) and the one to its left, so the dependent chain
-//     D_(K-1) -> L(K, K-1) -> D_K crosses workgroups once per block column;
-//   * the right-hand side rides along as row 48 of the diagonal owner's own factorisation of D_K (forward substitution by
-//     augmentation), the back substitution L^T x = y runs from the last block row up with one 48-vector per tile in flight;
-//   * hand-offs follow cdna_hip_programming.md Guideline 16 in its write-through form: payload by sc1 stores, every storing
-//     wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the flag (= the launch's epoch, so flags are
-//     never reset between launches); the consumer's wave 0 polls the flag with sc1 loads, the workgroup barrier behind the
-//     match releases the other waves, and EVERY load of handed-off bytes is an sc1 load (no acquire fence needed: one
-//     workgroup per CU, hipMalloc memory, 8-byte accesses — the first row of MI355X_MICROARCH.md's hand-off table);
+//     are published (fp64 matrix cores);
+//   * workgroup K owns the diagonal tile (K, K) and the one to its left.  It factors D_K ONCE, over the identity
+//     (sweep_inverse: [D; I] -> [L; L^-T]), and publishes the inverse factor W_K = L(K, K)^-T: the tiles below take
+//     L(I, K) = tile W_K as a matrix product, the forward substitution is y_K = W_K^T r_K, the back substitution
+//     x_J = W_J (y_J - sum c(I, J)).  L(K, K) itself is never stored.  The dependent chain
+//         W_(K-1) -> L(K, K-1) -> D_K -> W_K
+//     crosses workgroups once per block column and is one task of the owner (DT_COL);
+//   * the right-hand side row r_K follows the factorisation one block column behind (DT_RUP), the back substitution runs
+//     from the last block row up with one 48-vector per tile in flight, the one on its chain as tagged records;
+//   * hand-offs of tiles follow cdna_hip_programming.md Guideline 16 in its write-through form: payload by sc1 stores, every
+//     storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane stores the flag (= the launch's epoch, so flags
+//     are never reset between launches); the consumer's wave 0 polls the flag with sc1 loads, the workgroup barrier behind
+//     the match releases the other waves, and EVERY load of handed-off bytes is an sc1 load (no acquire fence needed: one
+//     workgroup per CU, hipMalloc memory, 8- / 16-byte accesses - the first row of MI355X_MICROARCH.md's hand-off table);
 //   * every wait is bounded by the 100 MHz clock: a workgroup that waits 20 ms gives up, marks the solve failed (the LM
-//     trial is rejected and the host reports MOVBA_ERR_HIP through Ctrl::n_sync_timeouts) and leaves; so do the others.
+//     trial is rejected, the download returns MOVBA_ERR_DEVICE_WAIT through Ctrl::n_sync_timeouts) and leaves; so do the
+//     others.  The host keeps two such launches from sharing the device (DenseGate, api.cpp).
 // Fixed summation order everywhere (each tile has one owner, updates in column order): bit-reproducible run to run.
 #include <hip/hip_runtime.h>
 
@@ -40,7 +44,7 @@ constexpr int kTileLds = NB * LD;               // doubles of one LDS tile image
 constexpr unsigned long long kWaitTicks = 2000000ull;      // 20 ms of the 100 MHz clock
 constexpr int kTaskCache = 128;                 // tasks of the workgroup's list held in LDS at a time (32 bytes each)
 __host__ __device__ constexpr int kTaskOff(int nslots) { return (2 + nslots) * kTileLds + 672; }       // (doubles) behind the carve
-__host__ __device__ constexpr int kBadOff(int nslots) { return (2 + nslots) * kTileLds + 660; }     // LDS word of sweep_tiles' bad-pivot flag (in the carve's spare doubles)
+__host__ __device__ constexpr int kBadOff(int nslots) { return (2 + nslots) * kTileLds + 660; }     // LDS word of sweep_inverse's bad-pivot flag (in the carve's spare doubles)
 
 // every word that travels between workgroups is a GLOBAL agent-scope access (global_load / global_store ... sc1, never flat_)
 typedef __attribute__((address_space(1))) long long g_i64;

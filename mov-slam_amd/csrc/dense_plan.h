@@ -5,7 +5,8 @@
 // /root/reference/src/Optimizer.cc:535).  Here S is factored as a dense blocked Cholesky in ONE launch: every tile of the
 // lower block triangle has an owner workgroup that keeps it in LDS for the whole factorisation and applies the updates
 // of the block columns to its left as those columns are published (right-looking, owner computes); the finished tiles
-// L(I, K) are the only data that travel between workgroups (write-through stores + one flag each).  The order of a
+// L(I, K) and the inverse factors W_K = L(K, K)^-T of the diagonal tiles are what travels between workgroups (write-through
+// stores + one flag each; the substitutions' 48-vectors likewise, the one on the back substitution's chain as tagged records).  The order of a
 // workgroup's tasks is a host-built list sorted by a key under which every task depends only on tasks of smaller keys:
 // the globally smallest unfinished task can always run, so the schedule cannot deadlock while its workgroups are
 // resident (and every device-side wait is bounded by a clock, dense_persist.hip).
@@ -19,10 +20,10 @@ namespace movba {
 enum DenseOp : int32_t {
     DT_ASM = 0,     // tile (I, K) <- S (and, for a diagonal tile, the right-hand side row) from the schur partials
     DT_UPD = 1,     // tile (I, K) -= L(I, k) L(K, k)^T                      waits F(I, k), F(K, k)
-    DT_DIAG = 2,    // publish the updated diagonal tile D_K                  sets PD(K)
-    DT_OFF = 3,     // L(I, K) = tile (I, K) L(K, K)^-T (sweep against D_K)   waits PD(K), sets F(I, K)
-    DT_RHS = 4,     // diagonal owner: y_K (forward substitution) and L(K, K) waits FY(k), k < K, sets FY(K)
-    DT_BSX = 5,     // diagonal owner: x_J = L(J, J)^-T (y_J - sum_I c(I, J)), then c(J, J-1) of its own sub-diagonal tile (pad[0] = its
+    DT_DIAG = 2,    // block column 0's owner: D_0 -> W_0 = L(0, 0)^-T (sweep over the identity), published   sets PD(0)   (K >= 1: DT_COL)
+    DT_OFF = 3,     // L(I, K) = tile (I, K) W_K (a matrix product)           waits PD(K), sets F(I, K)
+    DT_RHS = 4,     // diagonal owner: r_K -= L(K, K-1) y_(K-1) (own tile: pad[0] = its slot), y_K = W_K^T r_K   waits FY(K-1), sets FY(K)
+    DT_BSX = 5,     // diagonal owner: x_J = W_J (y_J - sum_I c(I, J)), then c(J, J-1) of its own sub-diagonal tile (pad[0] = its
                     // slot)                                               waits FC(I, J), I > J, sets FX(J), FC(J, J-1)
     DT_BSC = 6,     // owner of (I, J): c(I, J) = L(I, J)^T x_I               waits FX(I), sets FC(I, J)
     DT_EPI = 7,     // increments, computeScale's pose part, trial poses      waits FX(*)
