@@ -1,47 +1,38 @@
 """Randomised GPU-vs-oracle parity sweep over window shapes (run on a GPU box): free/fixed keyframe counts around every
 code-path boundary (one keyframe per wave, two rows per aggregate, VGPR overflow, generic PCG), track lengths, stereo,
-unobserved map points, edges that do not arrive grouped by map point."""
+unobserved map points, edges that do not arrive grouped by map point, intrinsics by keyframe.
+    python tests/dev/fuzz_parity.py <seed> <windows> [direct]      ("direct": every window on the one-launch direct solver)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 from movba import synth, capi
 from oracle import oracle
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_gen
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-s = capi.Solver()
+s = capi.Solver(direct=len(sys.argv) > 3 and sys.argv[3] == "direct")
 worst = dict(dq=0.0, dt=0.0, pt=0.0, outl=0)
 bad = 0
 for it in range(n):
-    K = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 10, 12, 15, 16, 17, 20, 24, 31, 40, 50, 64, 79, 81, 95, 130]))
-    F = int(rng.integers(1, 6))
-    P = int(rng.choice([30, 80, 200, 600, 1500, 5000]))
-    lo = int(rng.integers(2, 5)); hi = int(min(K + F, lo + rng.integers(0, 12)))
-    stereo = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
-    seed = int(rng.integers(1, 10 ** 6))
-    try:
-        w = synth.make_window(K, F, P, seed=seed, run_lo=lo, run_hi=max(lo, hi), stereo_frac=stereo)
-    except Exception as e:          # degenerate generator input
+    w, d = fuzz_gen.next_window(rng)
+    if w is None:
         continue
-    variant = int(rng.integers(0, 5))
-    if variant == 0 and w.n_edges > 40:                 # map points nobody observes: drop all edges of a few points
-        dead = rng.choice(w.n_points, size=max(1, w.n_points // 25), replace=False)
-        keep = ~np.isin(w.edge_point, dead)
-        kf_alive = np.bincount(w.edge_pose[keep], minlength=w.n_poses) > 0
-        if kf_alive.all():
-            w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[keep], w.edge_point[keep], w.obs[keep], w.inv_sigma2[keep]
-            if getattr(w, "obs_right", None) is not None: w.obs_right = w.obs_right[keep]
-    elif variant == 1:                                  # edges not grouped by map point (host structure pass, permuted arrays)
-        pm = rng.permutation(w.n_edges)
-        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[pm], w.edge_point[pm], w.obs[pm], w.inv_sigma2[pm]
-        if getattr(w, "obs_right", None) is not None: w.obs_right = w.obs_right[pm]
+    K, F, P, lo, hi, stereo, seed = d["K"], d["F"], d["P"], d["lo"], d["hi"], d["stereo"], d["seed"]
     # keyframes held by a handful of observations make the reduced system rank-deficient up to the LM damping: the PCG gives
     # up there and the direct solver takes over; they are held to SURVEY 8(d)'s float32-map tolerance (two exact solvers differ
     # by cond(S) * eps in the weak directions) and counted as mismatches like every other window when they exceed it
     per_kf = np.bincount(w.edge_pose, minlength=w.n_poses)[w.pose_fixed == 0]
     weak = per_kf.min() < 12 if len(per_kf) else True
     tol_q, tol_t, tol_p = (1e-6, 1e-6, 1e-4) if weak else (1e-8, 1e-8, 1e-6)
+    # a free keyframe with fewer than three observations has no unique pose at all (six unknowns from < 6 equations): the
+    # reduced matrix is singular but for the LM damping, two exact solvers land anywhere along the free directions
+    # (seed 21, window 474: 130 keyframes x 200 points, one observation on some keyframes: both direct solvers 1e-5 m from the
+    # oracle, costs equal to six digits).  Such windows are held to the cost trace instead of the poses.
+    degenerate = len(per_kf) > 0 and per_kf.min() < 3
+    if degenerate: tol_q, tol_t, tol_p = 1e-3, 1e-3, 1e-2
     ro = oracle.solve(w)
     try:
         rg = s.solve(w)
@@ -61,6 +52,7 @@ for it in range(n):
     k0 = int(nz[0]) if len(nz) else len(f0)
     same = np.array_equal(ro['trace']['accept'][:k0], rg['trace']['accept'][:k0]) and (k0 < len(f0) or ro['n_solves'] == rg['n_solves'])
     ok = dq < tol_q and dt < tol_t and pt < tol_p and outl == 0 and same
+    if degenerate: ok = ok and np.allclose(ro['trace']['f1'][:k0], rg['trace']['f1'][:k0], rtol=1e-4)
     worst['dq'] = max(worst['dq'], dq); worst['dt'] = max(worst['dt'], dt); worst['pt'] = max(worst['pt'], pt); worst['outl'] += outl
     if ok and not weak and (dt > 1e-9 or dq > 1e-10):
         print(f"[{it}] close to tolerance: K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} pcg {rg['pcg_iters']} per trial {rg['trace']['pcg'].tolist()}", flush=True)
