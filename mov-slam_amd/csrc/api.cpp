@@ -447,7 +447,7 @@ void movba_destroy(movba_handle *h)
     {
         DenseGate &g = dense_gate(h->device);       // (queue_direct: the gate must not keep a stream that is about to go)
         std::lock_guard<std::mutex> lk(g.mu);
-        if (g.only_stream == h->stream && h->own_stream) g.only_stream = nullptr;
+        if (g.only_stream == h->stream) g.only_stream = nullptr;       // (drained above: nothing of this stream is in flight)
     }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
