@@ -534,6 +534,10 @@ int movba_dense_plan_probe(int32_t n_block_cols, int32_t max_groups, int32_t max
 // =====================================================================================================================
 namespace {
 
+// memcpy that takes an empty source (a vector without storage has a null data()): copying nothing from nowhere is undefined
+// behaviour for memcpy itself (found by UBSan over the host build, tests/hipstub)
+inline void put(void *dst, const void *src, size_t bytes) { if (bytes) std::memcpy(dst, src, bytes); }
+
 // byte offsets of the edge region's arrays, the same in the arena and in the staging buffer; fixed by the caller's counts
 struct EdgeLayout {
     // (what the device structure pass reads comes first: it is copied ahead of the rest)
@@ -774,19 +778,19 @@ int Upload::group()
 void Upload::pack_a(bool raw_too)
 {
     if (!s().already_grouped || raw_too) {         // (grouped order: the helper thread copied the caller's index arrays)
-        std::memcpy(sg + L.gpose, s().gp, sizeof(int32_t) * E);
-        std::memcpy(sg + L.gpoint, s().gl, sizeof(int32_t) * E);
+        put(sg + L.gpose, s().gp, sizeof(int32_t) * E);
+        put(sg + L.gpoint, s().gl, sizeof(int32_t) * E);
     }
-    std::memcpy(sg + L.ptstart, s().pt_start.data(), sizeof(int32_t) * (P + 1));
-    std::memcpy(sg + L.hidx, s().hidx.data(), sizeof(int32_t) * NP);
+    put(sg + L.ptstart, s().pt_start.data(), sizeof(int32_t) * (P + 1));
+    put(sg + L.hidx, s().hidx.data(), sizeof(int32_t) * NP);
 }
 
 void Upload::pack_b(bool raw_too)
 {
-    if (!s().already_grouped) std::memcpy(sg + L.perm, s().perm.data(), sizeof(int32_t) * E);
-    if (!rank_mode) std::memcpy(sg + L.slot, s().slot.data(), sizeof(int32_t) * E);
-    else std::memcpy(sg + L.base, s().pose_slot0.data(), sizeof(int32_t) * NP);
-    std::memcpy(sg + L.free_pose, s().free_pose.data(), sizeof(int32_t) * nf);
+    if (!s().already_grouped) put(sg + L.perm, s().perm.data(), sizeof(int32_t) * E);
+    if (!rank_mode) put(sg + L.slot, s().slot.data(), sizeof(int32_t) * E);
+    else put(sg + L.base, s().pose_slot0.data(), sizeof(int32_t) * NP);
+    put(sg + L.free_pose, s().free_pose.data(), sizeof(int32_t) * nf);
     double *obs = reinterpret_cast<double *>(sg + L.obs), *isg = reinterpret_cast<double *>(sg + L.isig);
     double *obr = reinterpret_cast<double *>(sg + L.obsr);
     if (!s().already_grouped) {       // the helper's straight copies are in caller order: permute into grouped order
@@ -796,13 +800,13 @@ void Upload::pack_b(bool raw_too)
         }
         if (d->obs_right) for (int g = 0; g < E; ++g) obr[g] = d->obs_right[s().perm[g]];
     } else if (raw_too) {
-        std::memcpy(obs, d->obs, sizeof(double) * 2 * (size_t)E);
-        std::memcpy(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
-        if (d->obs_right) std::memcpy(obr, d->obs_right, sizeof(double) * (size_t)E);
+        put(obs, d->obs, sizeof(double) * 2 * (size_t)E);
+        put(isg, d->inv_sigma2, sizeof(double) * (size_t)E);
+        if (d->obs_right) put(obr, d->obs_right, sizeof(double) * (size_t)E);
     }
     if (raw_too) {
-        std::memcpy(sg + L.pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
-        std::memcpy(sg + L.point0, d->points, sizeof(double) * 3 * (size_t)P);
+        put(sg + L.pose0, d->poses, sizeof(double) * 7 * (size_t)NP);
+        put(sg + L.point0, d->points, sizeof(double) * 3 * (size_t)P);
     }
 }
 
@@ -1091,28 +1095,28 @@ void Upload::pack_pairs()
             unsigned long long *e64 = reinterpret_cast<unsigned long long *>(eh);
             for (size_t k = 0; k < noff; ++k) e64[k] = ent_pack(s().ent_i[k], s().ent_j[k], s().ent_l[k]);
         } else {
-            std::memcpy(eh, s().ent_i.data(), sizeof(int32_t) * noff); std::memcpy(eh + noff, s().ent_j.data(), sizeof(int32_t) * noff);
-            std::memcpy(eh + 2 * noff, s().ent_l.data(), sizeof(int32_t) * noff);
+            put(eh, s().ent_i.data(), sizeof(int32_t) * noff); put(eh + noff, s().ent_j.data(), sizeof(int32_t) * noff);
+            put(eh + 2 * noff, s().ent_l.data(), sizeof(int32_t) * noff);
         }
     }
-    std::memcpy(sp(o_items), s().items.data(), sizeof(Item) * (size_t)s().nitems);
-    std::memcpy(sp(o_sched), s().sched.data(), sizeof(SchedItem) * s().sched.size());
-    std::memcpy(sp(o_pi), s().pair_i.data(), sizeof(int32_t) * s().npairs);
-    std::memcpy(sp(o_pj), s().pair_j.data(), sizeof(int32_t) * s().npairs);
-    std::memcpy(sp(o_pis), s().pair_item_start.data(), sizeof(int32_t) * (s().npairs + 1));
-    std::memcpy(sp(o_rowptr), s().row_ptr.data(), sizeof(int32_t) * (nf + 1));
-    std::memcpy(sp(o_rowent), s().row_ent.data(), sizeof(RowEnt) * s().row_ent.size());
-    if (!lane_plan.empty()) std::memcpy(sp(o_plan), lane_plan.data(), sizeof(int32_t) * lane_plan.size());
-    std::memcpy(sp(o_cg), s().cblk_g.data(), sizeof(int32_t) * ncb);
-    std::memcpy(sp(o_ch), s().cblk_h.data(), sizeof(int32_t) * ncb);
-    std::memcpy(sp(o_cp), s().cblk_ptr.data(), sizeof(int32_t) * s().cblk_ptr.size());
-    std::memcpy(sp(o_ce), s().cblk_ent.data(), sizeof(int32_t) * s().cblk_ent.size());
-    std::memcpy(sp(o_cij), s().cblk_ij.data(), sizeof(int32_t) * s().cblk_ij.size());
-    std::memcpy(sp(o_multi), s().multi_pairs.data(), sizeof(int32_t) * s().multi_pairs.size());
-    std::memcpy(sp(o_pid), s().pid.data(), sizeof(int32_t) * (size_t)nf * nf);
+    put(sp(o_items), s().items.data(), sizeof(Item) * (size_t)s().nitems);
+    put(sp(o_sched), s().sched.data(), sizeof(SchedItem) * s().sched.size());
+    put(sp(o_pi), s().pair_i.data(), sizeof(int32_t) * s().npairs);
+    put(sp(o_pj), s().pair_j.data(), sizeof(int32_t) * s().npairs);
+    put(sp(o_pis), s().pair_item_start.data(), sizeof(int32_t) * (s().npairs + 1));
+    put(sp(o_rowptr), s().row_ptr.data(), sizeof(int32_t) * (nf + 1));
+    put(sp(o_rowent), s().row_ent.data(), sizeof(RowEnt) * s().row_ent.size());
+    if (!lane_plan.empty()) put(sp(o_plan), lane_plan.data(), sizeof(int32_t) * lane_plan.size());
+    put(sp(o_cg), s().cblk_g.data(), sizeof(int32_t) * ncb);
+    put(sp(o_ch), s().cblk_h.data(), sizeof(int32_t) * ncb);
+    put(sp(o_cp), s().cblk_ptr.data(), sizeof(int32_t) * s().cblk_ptr.size());
+    put(sp(o_ce), s().cblk_ent.data(), sizeof(int32_t) * s().cblk_ent.size());
+    put(sp(o_cij), s().cblk_ij.data(), sizeof(int32_t) * s().cblk_ij.size());
+    put(sp(o_multi), s().multi_pairs.data(), sizeof(int32_t) * s().multi_pairs.size());
+    put(sp(o_pid), s().pid.data(), sizeof(int32_t) * (size_t)nf * nf);
     if (dense_one) {
-        std::memcpy(sp(o_dtp), h->dplan.task_ptr.data(), sizeof(int32_t) * h->dplan.task_ptr.size());
-        std::memcpy(sp(o_dtk), h->dplan.tasks.data(), sizeof(DenseTask) * h->dplan.tasks.size());
+        put(sp(o_dtp), h->dplan.task_ptr.data(), sizeof(int32_t) * h->dplan.task_ptr.size());
+        put(sp(o_dtk), h->dplan.tasks.data(), sizeof(DenseTask) * h->dplan.tasks.size());
         int32_t *pr = reinterpret_cast<int32_t *>(sp(o_prange));
         for (size_t q = 0; q < (size_t)nf * nf; ++q) {
             const int32_t pair = s().pid[q];

@@ -19,3 +19,13 @@ def test_host_state_machine_is_race_free_and_the_watchdog_fires_on_a_stalled_dev
     assert p.returncode == 0 and p.stdout.strip().endswith("HOST-TSAN OK"), p.stderr[-2000:]
     # scenario 5 of the driver: a device that stops making progress gives the call back through the watchdog
     assert "device made no progress for 200 ms" in p.stderr
+
+
+def test_host_side_under_address_and_undefined_behaviour_sanitizers():
+    """The same driver (uploads from several threads, batches, park / resume, the stop flag, the watchdog) built with
+    -fsanitize=address,undefined: the host's layout carving, staging-buffer packing and schedule building overrun nothing."""
+    subprocess.check_call(["make", "-C", STUB, "-s", "host_asan_driver"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0 abort_on_error=0 exitcode=67", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([os.path.join(STUB, "host_asan_driver")], env=env, capture_output=True, text=True, timeout=600)
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error:" not in p.stderr, p.stderr[:4000]
+    assert p.returncode == 0 and p.stdout.strip().endswith("HOST-TSAN OK"), p.stderr[-2000:]
