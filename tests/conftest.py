@@ -28,6 +28,10 @@ def load_golden(name):
                      max_iters=int(g["in_max_iters"]))
     if "in_obs_right" in g.files and g["in_obs_right"].size:
         w.obs_right, w.bf = g["in_obs_right"], float(g["in_bf"])
+    if "in_cam_kf" in g.files:
+        w.cam_kf = g["in_cam_kf"]
+    if "in_bf_kf" in g.files:
+        w.bf_kf = g["in_bf_kf"]
     out = {k[4:]: g[k] for k in g.files if k.startswith("out_")}
     return w, out
 

@@ -55,7 +55,7 @@ def huber(c, delta):
 
 def errors(Ts, X, w):
     """(E,3) residuals; third component u_r - (u - bf/z) for stereo edges (g2o EdgeStereoSE3ProjectXYZ), else 0."""
-    fx, fy, cx, cy = w.cam
+    fx, fy, cx, cy, bf = edge_cameras(w)
     Xc = np.einsum("eij,ej->ei", Ts[w.edge_pose][:, :3, :3], X[w.edge_point]) + Ts[w.edge_pose][:, :3, 3]
     u = fx * Xc[:, 0] / Xc[:, 2] + cx
     e = np.zeros((w.n_edges, 3))
@@ -63,8 +63,21 @@ def errors(Ts, X, w):
     e[:, 1] = w.obs[:, 1] - (fy * Xc[:, 1] / Xc[:, 2] + cy)
     if w.obs_right is not None:
         st = w.obs_right >= 0
-        e[st, 2] = w.obs_right[st] - (u[st] - w.bf / Xc[st, 2])
+        e[st, 2] = w.obs_right[st] - (u[st] - bf[st] / Xc[st, 2])
     return e, Xc
+
+
+def edge_cameras(w):
+    """per-edge fx, fy, cx, cy, bf: the camera of the edge's keyframe (e->pCamera = pKFi->mpCamera, src/Optimizer.cc:664;
+    e->fx .. e->bf from pKFi, :690-695) when the window carries cameras by keyframe, the window's one camera otherwise"""
+    E = w.n_edges
+    if getattr(w, "cam_kf", None) is not None:
+        ck = np.asarray(w.cam_kf)[w.edge_pose]
+        fx, fy, cx, cy = ck[:, 0], ck[:, 1], ck[:, 2], ck[:, 3]
+    else:
+        fx, fy, cx, cy = (np.full(E, v) for v in w.cam)
+    bf = np.asarray(w.bf_kf)[w.edge_pose] if getattr(w, "bf_kf", None) is not None else np.full(E, w.bf)
+    return fx, fy, cx, cy, bf
 
 
 def robust_cost(e, w):
@@ -75,7 +88,7 @@ def robust_cost(e, w):
 def lm_dense(w, max_iters=10):
     """g2o Levenberg on the full un-Schur'd system."""
     NP, P, E = w.n_poses, w.n_points, w.n_edges
-    fx, fy, cx, cy = w.cam
+    efx, efy, ecx, ecy, ebf = edge_cameras(w)
     Ts = np.stack([T_from_qt(q) for q in w.poses])
     X = w.points.copy()
     free = np.flatnonzero(w.pose_fixed == 0)
@@ -96,9 +109,10 @@ def lm_dense(w, max_iters=10):
         for k in range(E):
             ip, l = w.edge_pose[k], w.edge_point[k]
             x, y, z = Xc[k]
+            fx, fy = efx[k], efy[k]
             Jpi = np.array([[fx / z, 0, -fx * x / z ** 2], [0, fy / z, -fy * y / z ** 2], [0, 0, 0]])
             if w.obs_right is not None and w.obs_right[k] >= 0:
-                Jpi[2] = [fx / z, 0, -fx * x / z ** 2 + w.bf / z ** 2]      # d(u - bf/z)/dXc
+                Jpi[2] = [fx / z, 0, -fx * x / z ** 2 + ebf[k] / z ** 2]      # d(u - bf/z)/dXc
             A = -Jpi @ Ts[ip][:3, :3]
             skew = np.array([[0, -z, y], [z, 0, -x], [-y, x, 0]])
             B = -Jpi @ np.hstack([-skew, np.eye(3)])
@@ -154,6 +168,8 @@ def save(name, w, out):
         in_edge_point=w.edge_point, in_obs=w.obs, in_inv_sigma2=w.inv_sigma2, in_cam=np.array(w.cam),
         in_huber_delta=w.huber_delta, in_chi2_gate=w.chi2_gate, in_max_iters=w.max_iters,
         in_obs_right=(w.obs_right if w.obs_right is not None else np.zeros(0)), in_bf=w.bf,
+        **({"in_cam_kf": w.cam_kf} if getattr(w, "cam_kf", None) is not None else {}),
+        **({"in_bf_kf": w.bf_kf} if getattr(w, "bf_kf", None) is not None else {}),
         **{"out_" + k: v for k, v in out.items()})
     print(name, w.meta, "iters", out["iters"], "trials", len(out["tr_lam"]),
           "accept", out["tr_accept"].tolist(), "outliers", int(out["outlier"].sum()))
@@ -174,7 +190,15 @@ def main():
     # stereo + monocular edges mixed (the reference's stereo branch, Optimizer.cc:673-705)
     w = synth.make_window(5, 2, 80, seed=41, run_lo=2, run_hi=5, stereo_frac=0.6)
     save("lba_stereo", w, lm_dense(w))
+    cameras()
+
+
+def cameras():
+    # every keyframe with a camera (and baseline) of its own, three different ones in the window, stereo + monocular edges
+    # (e->pCamera = pKFi->mpCamera, Optimizer.cc:664; e->fx .. e->bf from pKFi, :690-695)
+    w = synth.mixed_cameras(synth.make_window(5, 2, 80, seed=47, run_lo=2, run_hi=5, stereo_frac=0.6), seed=48)
+    save("lba_cameras", w, lm_dense(w))
 
 
 if __name__ == "__main__":
-    main()
+    cameras() if sys.argv[1:] == ["cameras"] else main()

@@ -47,7 +47,7 @@ def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_
     assert np.abs(r["poses"][fx] - o["poses"][fx]).max() < 1e-15
 
 
-@pytest.mark.parametrize("name", ["lba_tiny", "lba_small", "lba_hard", "lba_norobust", "lba_stereo"])
+@pytest.mark.parametrize("name", ["lba_tiny", "lba_small", "lba_hard", "lba_norobust", "lba_stereo", "lba_cameras"])
 def test_golden_fixtures(solver, oracle_mod, name):
     w, g = load_golden(name)
     r = solver.solve(w)

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import load_golden, quat_angle
 
-CASES = ["lba_tiny", "lba_small", "lba_hard", "lba_norobust", "lba_stereo"]
+CASES = ["lba_tiny", "lba_small", "lba_hard", "lba_norobust", "lba_stereo", "lba_cameras"]     # lba_cameras: a camera per keyframe
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -32,7 +32,7 @@ def test_hard_case_has_rejected_trials():
     assert (g["tr_accept"] == 0).sum() >= 3      # the fixture must exercise pop() / lambda growth
 
 
-@pytest.mark.parametrize("name", ["lba_small", "lba_hard", "lba_stereo"])
+@pytest.mark.parametrize("name", ["lba_small", "lba_hard", "lba_stereo", "lba_cameras"])
 def test_openmp_build_of_the_oracle_agrees_with_the_serial_one(oracle_mod, name):
     """bench.py times the OpenMP build for context only; its sums run in a different order, nothing else differs."""
     w, _ = load_golden(name)
