@@ -154,6 +154,8 @@ struct movba_handle {
     unsigned dense_epoch = 0;           // direct launches on this window so far: the value a flag of the current launch carries
     char *scratch = nullptr;            // structure-pass temporaries (struct_kernels.hip)
     size_t scratch_cap = 0;
+    char *scratch2 = nullptr;           // ... of the sort-based fill (struct_sort.hip): keys, values, rocPRIM's temporary storage
+    size_t scratch2_cap = 0;
     // movba_lba_run_batch (kept by the first handle of a batch): device views, PCG plans and block prefixes of the windows
     char *batch_host = nullptr, *batch_dev = nullptr;
     size_t batch_cap = 0;
@@ -441,6 +443,7 @@ void movba_destroy(movba_handle *h)
     if (h->batch_dev) (void)hipFree(h->batch_dev);
     if (h->batch_host) (void)hipHostFree(h->batch_host);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->scratch2) (void)hipFree(h->scratch2);
     if (h->stage) (void)hipHostFree(h->stage);
     if (h->hstat) (void)hipHostFree((void *)h->hstat);
     if (h->ctrl_host) (void)hipHostFree(h->ctrl_host);
@@ -553,6 +556,8 @@ struct EdgeLayout {
     bool has_kcam = false;              // intrinsics by keyframe (src/Optimizer.cc:664, 690-695)
 };
 
+constexpr int kSortedMaxPoses = 1024;   // windows the sort-based device structure pass takes (pair counts back: 4 NP^2 bytes of pinned memory)
+
 struct HelperHandOff {
     // helper -> caller
     std::atomic<int> idx_ready{0};      // the caller's index arrays are in the staging buffer (release / acquire): what the
@@ -587,6 +592,8 @@ struct Upload {
     // --- structure ---
     StructDev sd{};
     bool dev_structure = false, ent_packed = false, filled_early = false;
+    bool sorted_structure = false;      // the device pass of struct_sort.hip (beyond k_struct_pairs' 80 free keyframes)
+    size_t s2_off = 0, s2_keys_in = 0, s2_keys_out = 0, s2_vals_in = 0, s2_tmp = 0, s2_tmp_bytes = 0, so_cntpt = 0;
     uint64_t fill_gen = 0;
     size_t noff = 0, o_ent = 0, o_slotpt = 0;
     // --- pair region / device-only region ---
@@ -635,6 +642,7 @@ struct Upload {
     int send_edge_a();                  // what the device structure pass reads -> stream; the rest early -> copy stream
     int structure_on_host();
     int structure_on_device();
+    int structure_on_device_sorted();
     void choose_solver();
     int lay_out_rest();                 // pair region + device-only region; arena / staging buffer sized
     void pack_pairs();
@@ -680,7 +688,8 @@ int Upload::begin()
     L.grouped_end = c.off;
     L.perm = c.take<int32_t>(E);
     L.max_end = c.off;
-    const size_t nf_dev = (size_t)std::min(NP, 80);             // the device structure pass takes windows of up to 80 free keyframes
+    // (the device structure passes hand the pair counts back through the tail of the staging buffer: up to kSortedMaxPoses keyframes)
+    const size_t nf_dev = (size_t)(NP <= kSortedMaxPoses ? NP : 80);
     misc_bytes = (nf_dev * nf_dev + 8) * sizeof(int32_t) * 2 + 4096;
     int rc = ensure_stage(h, L.max_end + misc_bytes); if (rc) return rc;
     // first sizing of the arena: room for the states and pair lists too, so that it is not reallocated a moment later
@@ -865,6 +874,17 @@ int Upload::queue_edge_b()
 
 int Upload::launch_fill()
 {
+    if (sorted_structure) {
+        sd.ent64 = reinterpret_cast<unsigned long long *>(h->arena + o_ent);
+        sd.g_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart);
+        sd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx);
+        sd.slot = reinterpret_cast<const int32_t *>(h->arena + L.slot);
+        char *s2 = h->scratch2;
+        HIP_TRY(launch_sorted_fill(sd, reinterpret_cast<const int32_t *>(h->scratch + so_cntpt), reinterpret_cast<int32_t *>(s2 + s2_off),
+                                   reinterpret_cast<unsigned *>(s2 + s2_keys_in), reinterpret_cast<unsigned *>(s2 + s2_keys_out),
+                                   reinterpret_cast<unsigned long long *>(s2 + s2_vals_in), s2 + s2_tmp, s2_tmp_bytes, (long long)noff, h->stream));
+        return MOVBA_OK;
+    }
     int32_t *ed = reinterpret_cast<int32_t *>(h->arena + o_ent);
     sd.ent_i = ed; sd.ent_j = ed + noff; sd.ent_l = ed + 2 * noff;
     sd.ent64 = ent_packed ? reinterpret_cast<unsigned long long *>(h->arena + o_ent) : nullptr;
@@ -975,6 +995,82 @@ int Upload::structure_on_device()
         filled_early = true; fill_gen = h->arena_gen;
     }
     lap("edge B H2D + fill kernel (queued)");
+    const int rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
+    lap("finish_pairs");
+    if (rc < 0) return rc;
+    if ((size_t)(s().nentries - s().E_free) != noff) return MOVBA_ERR_ARG;
+    return MOVBA_OK;
+}
+
+// ... beyond k_struct_pairs' reach (more than 80 free keyframes, or a pair-bin mask that does not fit LDS): counted by atomics
+// and filled by a stable sort of the points' couples (struct_sort.hip); the same hand-offs with the host as above
+int Upload::structure_on_device_sorted()
+{
+    Carver sc;
+    const size_t so_cnt = sc.take<int32_t>(nbins), so_err = sc.take<int32_t>(4);
+    const size_t so_ent0 = sc.take<int32_t>(nbins);
+    so_cntpt = sc.take<int32_t>((size_t)P + 1);
+    if (sc.off > h->scratch_cap) {
+        if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
+        const size_t cap = align_up(sc.off + sc.off / 4, 1 << 20);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch), cap));
+        h->scratch_cap = cap;
+    }
+    char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;
+    HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));        // bin totals and the error word
+    sd = StructDev{};
+    sd.P = s().P; sd.nfree = nf; sd.nchunks = 0; sd.NP = NP;
+    sd.g_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart);
+    sd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx);
+    sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt); sd.error = reinterpret_cast<int32_t *>(sa + so_err);
+    sd.ent0 = reinterpret_cast<int32_t *>(sa + so_ent0);
+    HIP_TRY(launch_couple_count(sd, reinterpret_cast<int32_t *>(sa + so_cntpt), h->stream));
+    volatile int32_t *misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
+    const int32_t seq = (int32_t)(++h->count_seq & 0x7fffffff);
+    __atomic_store_n(misc_seq, seq - 1, __ATOMIC_RELAXED);
+    HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
+    lap("edge H2D + count launches");
+    {
+        const double t_wait = now_ms();
+        while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
+            host_relax(h->opt.host_wait);
+            if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) return MOVBA_ERR_HIP; }
+        }
+    }
+    if (reinterpret_cast<const int32_t *>(misc)[nbins] != 0) return MOVBA_ERR_ARG;     // duplicate observation
+    lap("wait for the pair counts");
+    { const int rq = queue_edge_b(); if (rq) return rq; }
+    {
+        const int32_t *cnt = reinterpret_cast<const int32_t *>(misc);
+        int64_t n = 0;
+        for (int i = 0; i < nf; ++i) for (int j = i + 1; j < nf; ++j) n += cnt[(size_t)i * nf + j];
+        if (n > (int64_t)0x7fffffff / 4) return MOVBA_ERR_ARG;
+        noff = (size_t)n;
+    }
+    o_ent = c.take<int32_t>(ent_words());
+    o_slotpt = c.take<int32_t>((size_t)s().E_free + 1);
+    // keys, values and rocPRIM's temporary storage of the fill
+    {
+        Carver s2;
+        s2_off = s2.take<int32_t>((size_t)P + 1);
+        s2_keys_in = s2.take<unsigned>(noff + 1); s2_keys_out = s2.take<unsigned>(noff + 1);
+        s2_vals_in = s2.take<unsigned long long>(noff + 1);
+        s2_tmp_bytes = sorted_fill_temp_bytes(P, (long long)noff, nf);
+        s2_tmp = s2.take<char>(s2_tmp_bytes);
+        if (s2.off > h->scratch2_cap) {
+            if (h->scratch2) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch2)); h->scratch2 = nullptr; h->scratch2_cap = 0; }
+            const size_t cap = align_up(s2.off + s2.off / 4, 1 << 20);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch2), cap));
+            h->scratch2_cap = cap;
+        }
+    }
+    sorted_structure = true;
+    if (c.off <= h->arena_cap && h->arena_gen == ho.arena_gen) {
+        int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
+        rq = launch_fill(); if (rq) return rq;
+        filled_early = true; fill_gen = h->arena_gen;
+    }
+    lap("edge B H2D + fill kernels (queued)");
     const int rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
     lap("finish_pairs");
     if (rc < 0) return rc;
@@ -1219,12 +1315,16 @@ int Upload::run()
     // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
     // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
     // (on the device: up to 80 free keyframes, and as many keyframes in all as the kernels' LDS image has room for)
-    dev_structure = s().already_grouped && s().nfree > 0 && s().nfree <= 80 && struct_lds_fits(s().nfree, NP) && !std::getenv("MOVBA_HOST_STRUCTURE");
+    const bool on_device = s().already_grouped && s().nfree > 0 && !std::getenv("MOVBA_HOST_STRUCTURE");
+    const bool masks_fit = s().nfree <= 80 && struct_lds_fits(s().nfree, NP);
     // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
     // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
     // 8-byte packed entries when slots and point ids fit (any realistic window; MOVBA_ENTRIES_UNPACKED=1 keeps the 12-byte form, for tests)
     ent_packed = s().E_free < kEntPackSlots && P < kEntPackPoints && !std::getenv("MOVBA_ENTRIES_UNPACKED");
-    rc = dev_structure ? structure_on_device() : structure_on_host(); if (rc) return rc;
+    // (beyond the pair-bin masks: the sort-based pass, for packed entries and up to kSortedMaxPoses keyframes)
+    const bool sorted = on_device && !masks_fit && ent_packed && NP <= kSortedMaxPoses && !std::getenv("MOVBA_NO_SORTED_STRUCTURE");
+    dev_structure = on_device && (masks_fit || sorted);
+    rc = !dev_structure ? structure_on_host() : (masks_fit ? structure_on_device() : structure_on_device_sorted()); if (rc) return rc;
     if (!edge_b_queued) { rc = queue_edge_b(); if (rc) return rc; }
     choose_solver();
     rc = lay_out_rest(); if (rc) return rc;

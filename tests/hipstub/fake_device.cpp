@@ -70,6 +70,41 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
     });
     return hipSuccess;
 }
+// (the sort-based pass of struct_sort.hip: the same counts, plus the couples per point; the fill touches its inputs)
+hipError_t launch_couple_count(const StructDev &sd, int32_t *cnt_pt, hipStream_t s)
+{
+    fake_enqueue(s, [sd, cnt_pt] {
+        const int nf = sd.nfree;
+        std::vector<int> hs;
+        for (int l = 0; l < sd.P; ++l) {
+            hs.clear();
+            for (int e = sd.pt_start[l]; e < sd.pt_start[l + 1]; ++e) { const int h = sd.hidx[sd.g_pose[e]]; if (h >= 0) hs.push_back(h); }
+            for (size_t a = 0; a < hs.size(); ++a)
+                for (size_t b = a; b < hs.size(); ++b) {
+                    if (a != b && hs[a] == hs[b]) { *sd.error = 1; continue; }
+                    const int lo = hs[a] < hs[b] ? hs[a] : hs[b], hi = hs[a] < hs[b] ? hs[b] : hs[a];
+                    sd.cnt[(size_t)lo * nf + hi] += 1;
+                }
+            cnt_pt[l] = (int32_t)(hs.size() * (hs.size() - (hs.empty() ? 0 : 1)) / 2);
+        }
+    });
+    return hipSuccess;
+}
+size_t sorted_fill_temp_bytes(int P, long long noff, int) { return (size_t)P * 4 + (size_t)noff * 16 + 256; }
+hipError_t launch_sorted_fill(const StructDev &sd, const int32_t *cnt_pt, int32_t *off, unsigned *keys_in, unsigned *keys_out,
+                              unsigned long long *vals_in, void *tmp, size_t tmp_bytes, long long noff, hipStream_t s)
+{
+    fake_enqueue(s, [=] {
+        if (noff <= 0) return;
+        const int E = sd.pt_start[sd.P];
+        g_sink += sum_bytes(sd.slot, sizeof(int32_t) * E) + sum_bytes(sd.g_pose, sizeof(int32_t) * E) + sum_bytes(sd.hidx, sizeof(int32_t) * sd.NP) + sum_bytes(cnt_pt, 4 * (size_t)sd.P);
+        off[0] = 0; keys_in[noff - 1] = 0; keys_out[noff - 1] = 0; vals_in[noff - 1] = 0;
+        if (tmp_bytes) static_cast<char *>(tmp)[tmp_bytes - 1] = 0;
+        sd.ent64[0] = 1; sd.ent64[noff - 1] = 1;
+    });
+    return hipSuccess;
+}
+
 hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt, int seq, hipStream_t s)
 {
     fake_enqueue(s, [sd, host_cnt, seq] {

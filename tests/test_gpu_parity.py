@@ -280,12 +280,19 @@ def test_stereo_edges(solver, oracle_mod, frac):
     assert np.abs(solver.solve(wm)["poses"] - r["poses"]).max() > 1e-6
 
 
-@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged"])
+@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged", "150kf", "descending-150kf", "400kf"])
 def test_device_structure_pass_equals_host_structure_pass(solver, name):
-    """The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip); MOVBA_HOST_STRUCTURE=1 forces the
-    host builder.  Same lists in the same order => bit-identical solves."""
+    """The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip up to 80 free keyframes, the sort-based
+    pass of struct_sort.hip beyond: "150kf", "400kf"); MOVBA_HOST_STRUCTURE=1 forces the host builder.  Same lists in the
+    same order => bit-identical solves."""
     import os
-    if name == "stereo":
+    if name in ("150kf", "descending-150kf", "400kf"):
+        w = synth.make_window(400, 8, 12000, 9, run_lo=2, run_hi=12) if name == "400kf" else synth.make_window(150, 6, 6000, 9, run_lo=2, run_hi=10)
+        w.max_iters = 3
+        if name.startswith("descending"):
+            order = np.lexsort((-w.edge_pose, w.edge_point))
+            w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[order], w.edge_point[order], w.obs[order], w.inv_sigma2[order]
+    elif name == "stereo":
         w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5)
     elif name == "ragged":
         w = synth.make_window(5, 2, 150, seed=77, run_lo=1, run_hi=7, min_obs=1)
