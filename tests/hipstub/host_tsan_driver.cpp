@@ -169,6 +169,30 @@ int main()
         check_solved(w, movba_lba_solve(h, &w.d, &w.r));
         movba_destroy(h);
     }
+    // ---- 6. windows beyond the on-chip PCG: the sort-based structure pass (more than 80 free keyframes, grouped edges), the host
+    //         pass (ungrouped edges), intrinsics by keyframe; two handles with direct-solver windows from two threads (the gate
+    //         that keeps their launches apart switches to its event chain) ----
+    {
+        auto worker = [](unsigned seed) {
+            movba_handle *h = nullptr;
+            EXPECT(movba_create(&h, 0, nullptr, nullptr) == MOVBA_OK);
+            Win w;
+            std::vector<double> cams, bfs;
+            for (int it = 0; it < 4; ++it) {
+                make(w, 95 + 20 * it, 3, 1500 + 300 * it, seed + it, it == 2, it == 1);
+                if (it == 3) {
+                    cams.assign(4 * (size_t)w.d.n_poses, 320.0); bfs.assign(w.d.n_poses, 40.0);
+                    for (int i = 0; i < w.d.n_poses; i += 2) cams[4 * i] = 400.0;
+                    w.d.cam_kf = cams.data(); w.d.bf_kf = bfs.data();
+                }
+                check_solved(w, movba_lba_solve(h, &w.d, &w.r));
+                EXPECT(w.r.n_direct == w.r.n_solves && w.r.n_sync_timeouts == 0);
+            }
+            movba_destroy(h);
+        };
+        std::thread a(worker, 300u), b(worker, 700u);
+        a.join(); b.join();
+    }
     if (fails) { std::fprintf(stderr, "HOST-TSAN FAILED: %d expectation(s)\n", fails); return 1; }
     std::printf("HOST-TSAN OK\n");
     return 0;
