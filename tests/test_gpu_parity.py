@@ -1014,7 +1014,7 @@ def test_two_handles_on_the_one_launch_direct_solver_at_once(built_lib):
         for t in ts: t.start()
         for t in ts: t.join()
         assert not errs, errs[:3]
-        # a given-up wait costs 20 ms per trial: the slowest concurrent solve stays far below that
-        assert max(times["a"]) < 0.060 and max(times["b"]) < 0.060, (max(times["a"]), max(times["b"]))
+        # a given-up wait costs 20 ms per trial, 0.2 s and more per solve: the slowest concurrent solve (~10 ms) stays far below
+        assert max(times["a"]) < 0.150 and max(times["b"]) < 0.150, (max(times["a"]), max(times["b"]))
     finally:
         a.close(); b.close()
