@@ -1,0 +1,11 @@
+#!/bin/bash
+# sq_counters.sh <tag> <name> <script> [args...]: SQ wave-cycle counters of one Python target (rocprofv3 --pmc, its own run:
+# no trace options beside it), summarised per kernel into profiles/<tag>_sq_counters_<name>.json by scripts/summarise_sq.py.
+# Run through gpurun from the repo root.
+TAG=$1; NAME=$2; shift 2
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/sq_${TAG}_$NAME; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
+    --output-format csv -d $OUT/pmc -- python3 $ROOT/scripts/"$@" > $OUT/run.log 2>&1 || exit 1
+cd $ROOT && python3 scripts/summarise_sq.py $OUT/pmc $TAG $NAME "$*"
