@@ -24,19 +24,40 @@ namespace {
 
 constexpr int kCoupleBlock = 256;
 
+// the hessian indices of a point's first kCache observers, fetched once with all their loads in flight (edge -> keyframe ->
+// hessian index: two dependent levels instead of two per couple); observers past the cache are read where they are needed
+constexpr int kCache = 16;
+
+__device__ __forceinline__ int obs_h(const StructDev &sd, const int (&hc)[kCache], int b, int g)
+{
+    const int k = g - b;
+    int h = -1;
+    if (k < kCache) {
+#pragma unroll
+        for (int q = 0; q < kCache; ++q) h = k == q ? hc[q] : h;
+        return h;
+    }
+    return sd.hidx[sd.g_pose[g]];
+}
+
 __global__ __launch_bounds__(kCoupleBlock) void k_couple_count(StructDev sd, int32_t *cnt_pt)
 {
     const int l = blockIdx.x * kCoupleBlock + threadIdx.x;
     if (l >= sd.P) return;
     const int b = sd.pt_start[l], e = sd.pt_start[l + 1], nf = sd.nfree;
+    int hc[kCache];
+#pragma unroll
+    for (int q = 0; q < kCache; ++q) hc[q] = b + q < e ? sd.g_pose[b + q] : -1;
+#pragma unroll
+    for (int q = 0; q < kCache; ++q) hc[q] = hc[q] >= 0 ? sd.hidx[hc[q]] : -1;
     int f = 0;
     for (int ga = b; ga < e; ++ga) {
-        const int ha = sd.hidx[sd.g_pose[ga]];
+        const int ha = obs_h(sd, hc, b, ga);
         if (ha < 0) continue;
         ++f;
         atomicAdd(&sd.cnt[(size_t)ha * nf + ha], 1);
         for (int gb = ga + 1; gb < e; ++gb) {
-            const int hb = sd.hidx[sd.g_pose[gb]];
+            const int hb = obs_h(sd, hc, b, gb);
             if (hb < 0) continue;
             if (hb == ha) { *sd.error = 1; continue; }          // a keyframe observes the point twice
             const int lo = ha < hb ? ha : hb, hi = ha < hb ? hb : ha;
@@ -51,13 +72,18 @@ __global__ __launch_bounds__(kCoupleBlock) void k_couple_emit(StructDev sd, cons
     const int l = blockIdx.x * kCoupleBlock + threadIdx.x;
     if (l >= sd.P) return;
     const int b = sd.pt_start[l], e = sd.pt_start[l + 1], nf = sd.nfree;
+    int hc[kCache];
+#pragma unroll
+    for (int q = 0; q < kCache; ++q) hc[q] = b + q < e ? sd.g_pose[b + q] : -1;
+#pragma unroll
+    for (int q = 0; q < kCache; ++q) hc[q] = hc[q] >= 0 ? sd.hidx[hc[q]] : -1;
     int k = off[l];
     for (int ga = b; ga < e; ++ga) {
-        const int ha = sd.hidx[sd.g_pose[ga]];
+        const int ha = obs_h(sd, hc, b, ga);
         if (ha < 0) continue;
         const int sa = sd.slot[ga];
         for (int gb = ga + 1; gb < e; ++gb) {
-            const int hb = sd.hidx[sd.g_pose[gb]];
+            const int hb = obs_h(sd, hc, b, gb);
             if (hb < 0 || hb == ha) continue;
             const int sb = sd.slot[gb];
             const bool up = ha < hb;
