@@ -602,7 +602,7 @@ struct Upload {
     size_t o_cg = 0, o_ch = 0, o_cp = 0, o_ce = 0, o_cij = 0, o_multi = 0, o_pid = 0, o_prange = 0, o_dtp = 0, o_dtk = 0;
     size_t o_st[2][11] = {};
     size_t o_obspm = 0, o_obsrpm = 0, o_part = 0, o_blocks = 0, o_blocks_ov = 0, o_blocks_c = 0, o_aci = 0, o_acitag = 0;
-    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
+    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_tick = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
     size_t o_dtiles = 0, o_ddiag = 0, o_dfail = 0, o_dx = 0, o_dflags = 0, o_dcontrib = 0, o_dstamps = 0;
     std::vector<int32_t> lane_plan;
     size_t ncb = 0;
@@ -1152,7 +1152,7 @@ int Upload::lay_out_rest()
     o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s().row_ent.size() * 36 + 2 : 2);
     o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
     o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
-    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb);
+    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(kTicketWords);
     o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
@@ -1287,6 +1287,7 @@ void Upload::device_view()
     w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
+    w.tickets = reinterpret_cast<unsigned *>(a + o_tick);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev; w.ctrl_out = h->ctrl_host_dev;
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
@@ -1458,8 +1459,7 @@ int lm_loop(movba_handle *h, bool parked)
         return MOVBA_OK;
     };
     auto queue_tail = [&]() -> int {
-        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
-        { ScopedEvents ev(h, KC_DECIDE); HIP_TRY(launch_decide(w, s)); }
+        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }      // (its last workgroup takes the LM decision: no launch of its own)
         return MOVBA_OK;
     };
     // The device parked the solve (k_pcg_rows gave up on trial `td`): every trial set queued behind has turned into no-ops.
@@ -1740,7 +1740,6 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 if (g + 1 < ngroups) HIP_TRY(hipEventRecord(h0->batch_phase_ev[g][G.t % kPhaseEvents], G.s));
                 HIP_TRY(launch_pcg_rows_batch(G.b, overflow, G.lds_pcg, G.t, G.s));
                 HIP_TRY(launch_point_batch(G.b, G.nb_point, true, stereo, ldsp, G.lds_back, G.s));
-                HIP_TRY(launch_decide_batch(G.b, G.s));
                 G.t += 1;
                 t_progress = now_ms();
             }

@@ -31,7 +31,6 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s);
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s);
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s);
-hipError_t launch_decide(const DevWindow &w, hipStream_t s);
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s);
 // destinations of k_export in the host's pinned staging buffer (device view; null = not wanted), as 64-bit words
 struct ExportDst { unsigned long long *poses, *points, *chi2, *outlier; };
@@ -44,7 +43,6 @@ size_t point_lds_bytes_for(const DevWindow &w, bool backsub, bool ldsp);
 int schur_blocks(const DevWindow &w);
 hipError_t launch_schur_batch(const BatchDev &b, int nblk, int mode, bool stereo, hipStream_t s);
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s);
-hipError_t launch_decide_batch(const BatchDev &b, hipStream_t s);
 hipError_t launch_finalize_batch(const BatchDev &b, int nblk, hipStream_t s);
 hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, size_t lds, int trial, hipStream_t s);
 size_t pcg_rows_lds_bytes(int nfree, int nrowent);

@@ -11,8 +11,8 @@
 //   k_schur  (one wave per pose-pair chunk)  -> partial 6x6 blocks of the reduced system
 //   k_pcg    (one workgroup)                 -> assemble S, block-Jacobi PCG, trial poses
 //   k_point<true> (8 lanes per map point)    -> back-substitution, trial points, errors and
-//                                               the linearisation (Hll, bl, weights) at the trial state
-//   k_decide (one wave)                      -> gain ratio, accept/reject, lambda schedule
+//                                               the linearisation (Hll, bl, weights) at the trial state; its last
+//                                               workgroup to arrive: gain ratio, accept/reject, lambda schedule
 // None of this is GEMM-shaped (block-sparse 6x3 / 3x3 / 6x6 products over a point
 // graph), so there is no MFMA: the kernels are gather/stream kernels bound by HBM/L2
 // traffic and launch latency.
@@ -23,6 +23,7 @@
 
 #include "device_math.h"
 #include "device_types.h"
+#include "handoff.h"
 #include "kernels.h"
 
 namespace movba {
@@ -34,6 +35,7 @@ namespace movba {
 __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int nblk)
 {
     const int i = bid * blockDim.x + threadIdx.x;
+    for (int k = i; k < kTicketWords; k += nblk * blockDim.x) w.tickets[k] = 0u;      // arrival counters of the point pass (its last workgroup takes the LM decision)
     {
         const double2 *src = reinterpret_cast<const double2 *>(w.point0);
         double2 *dst = reinterpret_cast<double2 *>(w.st[0].point);
@@ -87,6 +89,88 @@ __device__ __forceinline__ Cam cam_of_rt(const DevWindow &w, int ip) { return w.
 __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim.x); }
 
 // --------------------------------------------------------------------------------
+// decide_body: one wave - wave 0 of the LAST workgroup of the back-substitution pass to arrive (point_body).  The accept /
+// reject logic and lambda schedule of OptimizationAlgorithmLevenberg::solve plus the loop conditions of
+// SparseOptimizer::optimize, restated as a state machine that advances by one trial per
+// point pass.  Publishes progress to pinned host memory.
+// (A launch of its own until round 4: 4.6 us per trial plus a launch boundary.  The cost and scale partials it sums were
+// written by the other workgroups of THIS launch: sc1 stores there, sc1 loads here - handoff.h.)
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
+{
+    Ctrl *c = w.ctrl;
+    const int lane = threadIdx.x;
+    // Lane-strided partial sums, loads issued 10 deep (a plain loop would pay one round trip per term; 10 x 64 covers
+    // cfg3's 625 blocks in one round), added in a fixed order
+    constexpr int kDeep = 10;
+    const double *Fp = w.st[cur ^ 1].Fpart;         // the trial state's cost partials
+    double F1 = 0.0, scale = 0.0;
+    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * kDeep) {
+        double f1[kDeep], sv[kDeep];
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
+            f1[u] = hx_ld_f64(Fp + k); sv[u] = hx_ld_f64(w.scale_part + k);
+        }
+#pragma unroll
+        for (int u = 0; u < kDeep; ++u) {
+            const bool in = k0 + 64 * u < w.n_pt_blocks;
+            F1 += in ? f1[u] : 0.0; scale += in ? sv[u] : 0.0;
+        }
+    }
+    F1 = wave_sum(F1);
+    scale = wave_sum(scale);
+    if (lane != 0) return;
+    scale += w.scale_part[w.n_pt_blocks];
+    if (c->pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
+    scale += 1e-3;
+    const double F0 = c->F0;
+    const double rho = (F0 - F1) / scale;
+    const int stop = __hip_atomic_load(&w.hstat->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int tr = c->n_trace;
+    if (tr < kMaxTrace) {
+        c->tr_lambda[tr] = c->lambda; c->tr_f0[tr] = F0; c->tr_f1[tr] = F1; c->tr_rho[tr] = rho;
+        c->tr_pcg[tr] = c->pcg_last_iters;
+    }
+    bool lambda_ok = true;
+    int accepted = 0;
+    if (rho > 0.0 && isfinite(F1)) {
+        const double tr = 2.0 * rho - 1.0;
+        double alpha = 1.0 - tr * tr * tr;             // (pow(tmp, 3) in g2o: a library call of ~100 instructions here)
+        alpha = fmin(alpha, 2.0 / 3.0);
+        c->lambda *= fmax(1.0 / 3.0, alpha);
+        c->nu = 2.0;
+        c->F0 = F1;
+        c->cur = cur ^ 1;                    // discardTop(): the trial state becomes current
+        c->last_rejected = 0;
+        accepted = 1;
+    } else {
+        c->lambda *= c->nu;
+        c->nu *= 2.0;
+        c->last_rejected = 1;                // pop(): keep the current state
+        lambda_ok = isfinite(c->lambda);
+    }
+    if (tr < kMaxTrace) { c->tr_accept[tr] = accepted; c->n_trace = tr + 1; }
+    c->n_solves += 1;
+    c->qmax += 1;
+    const bool more_trials = lambda_ok && (rho < 0.0) && (c->qmax < w.max_trials) && !stop;
+    int done = 0;
+    if (!more_trials) {
+        c->iters_done = c->it + 1;
+        if (c->qmax == w.max_trials || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
+        else {
+            c->it += 1;
+            c->qmax = 0;
+            if (c->it >= w.max_iters || stop) done = 1;
+        }
+    }
+    c->done = done;
+    // one word, one store: the host sees a consistent (trials_done, it, done), and the launch ends behind ONE write
+    // acknowledgement from host memory instead of a chain of them
+    __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// --------------------------------------------------------------------------------
 // k_point<BACKSUB>: 8 lanes per map point, edges of a point are contiguous.
 //   BACKSUB=false : evaluate errors + linearise (Hll, bl, per-edge Xc/weight) at state cur
 //   BACKSUB=true  : x_l = Dinv (b_l - sum_i B_il^T xp_i)  (BlockSolver::solve back-substitution),
@@ -110,8 +194,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     double *sRt = sm;                               // NP x 12 at dst
     double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 12 at cur  (BACKSUB)
     double *sxp = sR0 + ((BACKSUB && LDSP) ? 12 * w.NP : 0);  // nfree x 6       (BACKSUB)
-    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4
-    int *shidx = reinterpret_cast<int *>(red + 4);  // NP              (BACKSUB)
+    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4, then the "last workgroup" word
+    int *shidx = reinterpret_cast<int *>(red + 6);  // NP              (BACKSUB)
     // where the pose data is read from: the LDS images, or the state buffers themselves
     const double *pRt = LDSP ? sRt : S1.Rt;
     const double *pR0 = LDSP ? sR0 : S0.Rt;
@@ -303,12 +387,21 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     const double Fsum = block_reduce<kPointBlock / 64, false>(F, red);
     if (BACKSUB) {
         const double ssum = block_reduce<kPointBlock / 64, false>(scale, red);
-        if (threadIdx.x == 0) w.scale_part[bid] = ssum;
+        // The LM decision needs every workgroup's partials: the last workgroup to arrive takes it, in this launch (a launch of
+        // its own cost 4.6 us plus a launch boundary per trial).  One lane publishes this workgroup's two partials write-through,
+        // drains and takes a ticket; the partials are summed by ONE wave in the fixed order of the old k_decide.
+        int *lastw = reinterpret_cast<int *>(red + 4);
+        if (threadIdx.x == 0) {
+            hx_st_f64(w.scale_part + bid, ssum); hx_st_f64(S1.Fpart + bid, Fsum);
+            hx_drain();
+            *lastw = hx_last_arriver(w.tickets, bid, w.n_pt_blocks) ? 1 : 0;
+        }
+        __syncthreads();
+        if (*lastw && threadIdx.x < 64) decide_body(w, cur);
     } else {
         const double m = block_reduce<kPointBlock / 64, true>(hmax, red);
-        if (threadIdx.x == 0) w.hmax_part[bid] = m;
+        if (threadIdx.x == 0) { w.hmax_part[bid] = m; S1.Fpart[bid] = Fsum; }
     }
-    if (threadIdx.x == 0) S1.Fpart[bid] = Fsum;
 }
 
 template <bool BACKSUB, bool STEREO, bool LDSP>
@@ -713,95 +806,6 @@ __device__ __forceinline__ void lambda_init_body(const DevWindow &w)
 __global__ __launch_bounds__(64) void k_lambda_init(DevWindow w) { lambda_init_body(w); }
 __global__ __launch_bounds__(64) void k_lambda_init_b(BatchDev b) { lambda_init_body(b.wins[blockIdx.x]); }
 
-// --------------------------------------------------------------------------------
-// k_decide: one wave.  The accept/reject logic and lambda schedule of
-// OptimizationAlgorithmLevenberg::solve plus the loop conditions of
-// SparseOptimizer::optimize, restated as a state machine that
-// advances by one trial per launch.  Publishes progress to pinned host memory.
-// --------------------------------------------------------------------------------
-__device__ __forceinline__ void decide_body(const DevWindow &w)
-{
-    Ctrl *c = w.ctrl;
-    const int lane = threadIdx.x;
-    // Lane-strided partial sums, loads issued 10 deep (a plain loop would pay one round trip per term; 10 x 64 covers
-    // cfg3's 625 blocks in one round).  The kernel is a chain of memory round trips (the launch boundary has just
-    // invalidated the L2), so the first round is requested before anything of Ctrl is known: the cost partials of BOTH
-    // states, and before the `done` test.
-    constexpr int kDeep = 10;
-    double f0[kDeep], f1[kDeep], sv[kDeep];
-    auto request = [&](int k0) {
-#pragma unroll
-        for (int u = 0; u < kDeep; ++u) {
-            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
-            f0[u] = w.st[0].Fpart[k]; f1[u] = w.st[1].Fpart[k]; sv[u] = w.scale_part[k];
-        }
-    };
-    request(lane);
-    if (c->done) return;
-    const int cur = c->cur;
-    double F1 = 0.0, scale = 0.0;
-    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * kDeep) {
-        if (k0 != lane) request(k0);
-#pragma unroll
-        for (int u = 0; u < kDeep; ++u) {
-            const bool in = k0 + 64 * u < w.n_pt_blocks;
-            F1 += in ? (cur ? f0[u] : f1[u]) : 0.0; scale += in ? sv[u] : 0.0;
-        }
-    }
-    F1 = wave_sum(F1);
-    scale = wave_sum(scale);
-    if (lane != 0) return;
-    scale += w.scale_part[w.n_pt_blocks];
-    if (c->pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
-    scale += 1e-3;
-    const double F0 = c->F0;
-    const double rho = (F0 - F1) / scale;
-    const int stop = __hip_atomic_load(&w.hstat->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const int tr = c->n_trace;
-    if (tr < kMaxTrace) {
-        c->tr_lambda[tr] = c->lambda; c->tr_f0[tr] = F0; c->tr_f1[tr] = F1; c->tr_rho[tr] = rho;
-        c->tr_pcg[tr] = c->pcg_last_iters;
-    }
-    bool lambda_ok = true;
-    int accepted = 0;
-    if (rho > 0.0 && isfinite(F1)) {
-        const double tr = 2.0 * rho - 1.0;
-        double alpha = 1.0 - tr * tr * tr;             // (pow(tmp, 3) in g2o: a library call of ~100 instructions here)
-        alpha = fmin(alpha, 2.0 / 3.0);
-        c->lambda *= fmax(1.0 / 3.0, alpha);
-        c->nu = 2.0;
-        c->F0 = F1;
-        c->cur = cur ^ 1;                    // discardTop(): the trial state becomes current
-        c->last_rejected = 0;
-        accepted = 1;
-    } else {
-        c->lambda *= c->nu;
-        c->nu *= 2.0;
-        c->last_rejected = 1;                // pop(): keep the current state
-        lambda_ok = isfinite(c->lambda);
-    }
-    if (tr < kMaxTrace) { c->tr_accept[tr] = accepted; c->n_trace = tr + 1; }
-    c->n_solves += 1;
-    c->qmax += 1;
-    const bool more_trials = lambda_ok && (rho < 0.0) && (c->qmax < w.max_trials) && !stop;
-    int done = 0;
-    if (!more_trials) {
-        c->iters_done = c->it + 1;
-        if (c->qmax == w.max_trials || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
-        else {
-            c->it += 1;
-            c->qmax = 0;
-            if (c->it >= w.max_iters || stop) done = 1;
-        }
-    }
-    c->done = done;
-    // one word, one store: the host sees a consistent (trials_done, it, done), and the launch ends behind ONE write
-    // acknowledgement from host memory instead of a chain of them
-    __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-__global__ __launch_bounds__(64) void k_decide(DevWindow w) { decide_body(w); }
-__global__ __launch_bounds__(64) void k_decide_b(BatchDev b) { decide_body(b.wins[blockIdx.x]); }
 
 // --------------------------------------------------------------------------------
 // k_finalize: chi2 / outlier flags in caller edge order (src/Optimizer.cc:757-775).
@@ -897,15 +901,15 @@ __global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
 // --------------------------------------------------------------------------------
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
-    if (!w.lds_poses) return 4 * sizeof(double) + 16;
-    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
+    if (!w.lds_poses) return 6 * sizeof(double) + 16;
+    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 6;
     return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
 // the largest LDS image the point kernels would stage for this window (decides DevWindow::lds_poses)
 size_t point_lds_need(int NP, int nfree)
 {
-    return (24 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
+    return (24 * (size_t)NP + 6 * (size_t)nfree + 6) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s)
@@ -971,12 +975,6 @@ hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_decide(const DevWindow &w, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, s, w);
-    return hipGetLastError();
-}
-
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s)
 {
     hipLaunchKernelGGL(k_finalize, dim3((w.E + 255) / 256), dim3(256), 0, s, w);
@@ -1038,12 +1036,6 @@ hipError_t launch_schur_batch(const BatchDev &b, int nblk, int mode, bool stereo
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lambda_init_b, dim3(b.n), dim3(64), 0, s, b);
-    return hipGetLastError();
-}
-
-hipError_t launch_decide_batch(const BatchDev &b, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_decide_b, dim3(b.n), dim3(64), 0, s, b);
     return hipGetLastError();
 }
 

@@ -157,6 +157,7 @@ void fake_init(const DevWindow &w)
     if (w.dense.G > 0) g_sink += sum_bytes(w.dense.tasks, 32) + sum_bytes(w.dense.task_ptr, 4 * ((size_t)w.dense.G + 1));
     std::memcpy(w.st[0].pose, w.pose0, 56 * (size_t)w.NP);
     std::memcpy(w.st[0].point, w.point0, 24 * (size_t)w.P);
+    std::memset(w.tickets, 0, sizeof(unsigned) * kTicketWords);
     Ctrl *c = w.ctrl;
     std::memset(c, 0, sizeof(Ctrl));
     c->nu = 2.0; c->done = (w.max_iters <= 0) ? 1 : 0; c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
@@ -204,8 +205,8 @@ hipError_t launch_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] 
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done; }); return hipSuccess; }
 hipError_t launch_schur(const DevWindow &w, int, int, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + (w.ent64 ? (long)w.ent64[0] : (long)w.ent_i[0]) + w.slot_point[0]; }); return hipSuccess; }
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->lambda = 1e-3; }); return hipSuccess; }
-hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done; }); return hipSuccess; }
-hipError_t launch_decide(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_decide(w); }); return hipSuccess; }
+// (the back-substitution pass takes the LM decision in its last workgroup: one launch)
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + w.tickets[0]; fake_decide(w); }); return hipSuccess; }
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_finalize(w); }); return hipSuccess; }
 hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
 {
@@ -223,10 +224,13 @@ hipError_t launch_dense_persist(const DevWindow &w, unsigned, hipStream_t s) { f
 
 // ---- batched launches: the same closures over the windows of the batch (the device arrays are read where the host put them) ----
 hipError_t launch_init_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_init(b.wins[i]); }); return hipSuccess; }
-hipError_t launch_point_batch(const BatchDev &b, int, bool, bool, bool, size_t, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) g_sink += b.wins[i].ctrl->done + b.blk_point[i]; }); return hipSuccess; }
+hipError_t launch_point_batch(const BatchDev &b, int, bool backsub, bool, bool, size_t, hipStream_t s)
+{
+    fake_enqueue(s, [b, backsub] { for (int i = 0; i < b.n; ++i) { g_sink += b.wins[i].ctrl->done + b.blk_point[i]; if (backsub) fake_decide(b.wins[i]); } });
+    return hipSuccess;
+}
 hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) g_sink += b.wins[i].ctrl->done + b.blk_schur[i]; }); return hipSuccess; }
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) b.wins[i].ctrl->lambda = 1e-3; }); return hipSuccess; }
-hipError_t launch_decide_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_decide(b.wins[i]); }); return hipSuccess; }
 hipError_t launch_finalize_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_finalize(b.wins[i]); }); return hipSuccess; }
 hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i]); } }); return hipSuccess; }
 
