@@ -1152,7 +1152,7 @@ int Upload::lay_out_rest()
     o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s().row_ent.size() * 36 + 2 : 2);
     o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
     o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
-    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(kTicketWords);
+    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(8 * (size_t)nb + 8);
     o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
@@ -1287,7 +1287,7 @@ void Upload::device_view()
     w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
-    w.tickets = reinterpret_cast<unsigned *>(a + o_tick);
+    w.dec_rec = reinterpret_cast<unsigned *>(a + o_tick);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev; w.ctrl_out = h->ctrl_host_dev;
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
@@ -1671,7 +1671,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
                 pps[i] = run_pcg_params(h);
                 const DevWindow &w = h->win;
-                bp[i + 1] = bp[i] + w.n_pt_blocks;
+                bp[i + 1] = bp[i] + w.n_pt_blocks + 1;          // (+ the deciding workgroup of the window's back-substitution pass)
                 bs[i + 1] = bs[i] + (w.nitems > 0 ? schur_blocks(w) : 0);
                 bf[i + 1] = bf[i] + (w.E + 255) / 256;
                 const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;

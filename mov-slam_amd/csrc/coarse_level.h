@@ -18,6 +18,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_math.h"
 #include "device_types.h"
 
@@ -27,13 +29,13 @@ namespace movba {
 #define MOVBA_COARSE_EXTRAPOLATE 1
 #endif
 
-// sm: >= kNC*kNC + 5*kNC + 8 doubles + 2 ints per coarse term (= gather-list entry) of LDS; 512 threads
+// sm: >= kNC*kNC + 9*kNC + 8 doubles + 2 ints per coarse term (= gather-list entry) of LDS; 512 threads
 template <int kT, int kNC, int kPA>
 __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm, bool extrapolate)
 {
     double *Ac = sm;
     double *gj = Ac + kNC * kNC;
-    int &s_bad = *reinterpret_cast<int *>(gj + 5 * kNC + 2);     // gj: 4 kNC snapshot + 2 pivots + kNC scaling, then the flag
+    int &s_bad = *reinterpret_cast<int *>(gj + 9 * kNC + 2);     // gj: 2 x 4 kNC snapshots + 2 pivots + kNC scaling, then the flag
     const int tid = threadIdx.x;
     const int nf = w.nfree;
 #ifdef MOVBA_CLOCK_STAMP
@@ -96,84 +98,54 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     __syncthreads();
     COARSE_STAMP(2);
     // ---- A_c = P^T S P.  Coarse dof (g, d, a): aggregate g, mode d (0: constant, 1: linear in the keyframe index,
-    // phi_1(i) = (i - c_g) / h_g), pose component a.  One thread per (coarse block, a, b): it walks the block's fine terms
-    // once, in list order, and accumulates the four mode combinations phi_d(i) phi_e(j) together. ----
+    // phi_1(i) = (i - c_g) / h_g), pose component a.  One WAVE per coarse block (g, h), lane (a, b) of its first 36 lanes one
+    // element of the 6 x 6 fine blocks: every fine term is ONE coalesced 288-byte load of the wave (16 terms in flight), its
+    // weights phi(i), phi(j) are wave-uniform, and a lane adds its element into the four mode combinations phi_d(i) phi_e(j)
+    // in list order.  (Until round 4 a thread owned a ROW of a coarse block and gathered six scattered doubles per term:
+    // 12 000 eight-byte requests per batch from one CU, 16 us per build - as long as 7 CG iterations, on a workgroup the
+    // launch waits for.) ----
     // centre and inverse half-width of every aggregate (the linear mode's phi), once, in LDS
     double *aggc = gj;                                      // 2 x (kNC / kPA) doubles; gj is not in use yet
     if (tid < kNC / kPA) {
         const int g0 = pp.wave_row0[tid], g1 = pp.wave_row0[tid + 1];
         aggc[tid] = g0 + 0.5 * (g1 - g0 - 1); aggc[kNC / kPA + tid] = 1.0 / fmax(1.0, 0.5 * (g1 - g0));
     }
-    // the term lists themselves go to LDS first (one coalesced pass): the gathers below then depend on ONE global
-    // round trip per batch instead of two
-    int *tent = reinterpret_cast<int *>(gj + 5 * kNC + 8), *tij = tent + w.cblk_ptr[w.n_cblk];
+    // the term lists themselves go to LDS first (one coalesced pass)
+    int *tent = reinterpret_cast<int *>(gj + 9 * kNC + 8), *tij = tent + w.cblk_ptr[w.n_cblk];
     for (int q = tid; q < w.cblk_ptr[w.n_cblk]; q += kT) { tent[q] = w.cblk_ent[q]; tij[q] = w.cblk_ij[q]; }
     __syncthreads();
-    // Thread (cb, a) owns row a of coarse block cb = (g, h) in all four mode combinations: it walks the block's term
-    // list once (8 terms = 48 gathers in flight), so no thread pads its list to a longer neighbour's.  When there are
-    // threads to spare (n_cblk * 12 <= 512: always with 8 aggregates) two threads share a row: the first takes the front
-    // of the list (whole batches of 8), the second the rest, and the second's sums are added after the first's are stored.
-    const int nw = w.n_cblk * 6;
-    const bool split = 2 * nw <= kT;
-    auto walk = [&](int cb, int a, int part, double (&s00)[6], double (&s01)[6], double (&s10)[6], double (&s11)[6]) {
-        const int g = w.cblk_g[cb], h = w.cblk_h[cb];
-        const double cg = aggc[g], ch = aggc[h], ig = aggc[kNC / kPA + g], ih = aggc[kNC / kPA + h];
-        int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
-        if (split) {
-            const int n = t1 - t0, front = min(n, (((n + 1) >> 1) + 7) & ~7);
-            if (part == 0) t1 = t0 + front; else t0 += front;
-        }
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+        const int ea = min(ln, 35) / 6, eb = min(ln, 35) - ea * 6;      // (lanes 36 .. 63 shadow lane 35 and store nothing)
+        constexpr int kFly = 16;
+        for (int cb = wv; cb < w.n_cblk; cb += kT / 64) {
+            const int g = w.cblk_g[cb], h = w.cblk_h[cb];
+            const double cg = aggc[g], ch = aggc[h], ig = aggc[kNC / kPA + g], ih = aggc[kNC / kPA + h];
+            const int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
+            double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+            for (int t = t0; t < t1; t += kFly) {
+                int pk[kFly], ij[kFly];
+                double v[kFly];
 #pragma unroll
-        for (int m = 0; m < 6; ++m) s00[m] = s01[m] = s10[m] = s11[m] = 0.0;
-        for (int t = t0; t < t1; t += 8) {
-            int pk[8], ij[8];
-            double v[8][6];
+                for (int u = 0; u < kFly; ++u) { const int tt = min(t + u, t1 - 1); pk[u] = tent[tt]; ij[u] = tij[tt]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int tt = min(t + u, t1 - 1); pk[u] = tent[tt]; ij[u] = tij[tt]; }
+                for (int u = 0; u < kFly; ++u) {
+                    const int e = pk[u];
+                    const double *src = (e & 1) ? part_ + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
+                    v[u] = src[(e & 2) ? eb * 6 + ea : ea * 6 + eb];       // element (a, b) of the (possibly transposed) fine block
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = pk[u];
-                const double *src = (e & 1) ? part_ + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
-                // row a of the (possibly transposed) fine block
-                const int o0 = (e & 2) ? a : a * 6, st = (e & 2) ? 6 : 1;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) v[u][m] = src[o0 + st * m];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = t + u < t1;
-                const double sgn = in ? ((pk[u] & 1) ? -1.0 : 1.0) : 0.0;
-                const double pi = ((ij[u] >> 16) - cg) * ig, pj = ((ij[u] & 0xffff) - ch) * ih;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    const double x = sgn * v[u][m];
-                    s00[m] += x; s01[m] += pj * x; s10[m] += pi * x; s11[m] += pi * pj * x;
+                for (int u = 0; u < kFly; ++u) {
+                    const bool in = t + u < t1;
+                    const double x = in ? ((pk[u] & 1) ? -v[u] : v[u]) : 0.0;
+                    const double pi = ((ij[u] >> 16) - cg) * ig, pj = ((ij[u] & 0xffff) - ch) * ih;
+                    s00 += x; s01 += pj * x; s10 += pi * x; s11 += pi * pj * x;
                 }
             }
-        }
-        return Ac + (g * kPA + a) * kNC + h * kPA;
-    };
-    if (split) {
-        const bool active = tid < 2 * nw;
-        const int half = tid >= nw, wi = tid - half * nw;
-        double s00[6], s01[6], s10[6], s11[6];
-        double *dst = nullptr;
-        if (active) dst = walk(wi / 6, wi - (wi / 6) * 6, half, s00, s01, s10, s11);
-        if (active && !half) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
-        }
-        __syncthreads();
-        if (active && half) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) { dst[m] += s00[m]; dst[6 + m] += s01[m]; dst[6 * kNC + m] += s10[m]; dst[6 * kNC + 6 + m] += s11[m]; }
-        }
-    } else {
-        for (int wi = tid; wi < nw; wi += kT) {
-            double s00[6], s01[6], s10[6], s11[6];
-            double *dst = walk(wi / 6, wi - (wi / 6) * 6, 0, s00, s01, s10, s11);
-#pragma unroll
-            for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
+            if (ln < 36) {
+                double *dst = Ac + (g * kPA + ea) * kNC + h * kPA + eb;
+                dst[0] = s00; dst[6] = s01; dst[6 * kNC] = s10; dst[6 * kNC + 6] = s11;
+            }
         }
     }
     __syncthreads();
@@ -225,12 +197,17 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     COARSE_STAMP(3);
     // ---- Gauss-Jordan inverse of the symmetrically scaled matrix D A_c D (unit diagonal), the matrix held in REGISTERS:
     // thread (rg, cg) owns rows 3 rg .. 3 rg + 2 x columns 6 cg .. 6 cg + 5 (32 x 16 threads x 18 elements = 96 x 96).
-    // Per pivot k every thread reads the snapshot of row k and column k (double-buffered in LDS) and updates its tile with
-    // ONE formula, a_ij -= c_i r_j / p: the snapshot is published with r_k = p + 1 and c_k = p - 1, which turns the pivot
-    // row into r_j / p, the pivot column into -c_i / p and the pivot into 1 / p (accurate because the scaled pivots are
-    // <= 1).  The pivot loop is unrolled by 6 so that the tile row / column holding pivot k + 1 are compile-time indices.
+    // TWO pivots per workgroup barrier (round 4; one until then: 975 cycles per pivot, 39 us per build, most of it the
+    // barrier, the LDS round trip of the snapshot and its publication).  For the pair (k, k + 1) the snapshot holds, from
+    // the state BEFORE pivot k: row k and column k published with r_k = p + 1 and c_k = p - 1 - which turns ONE formula,
+    // a_ij -= c_i r_j / p, into the whole in-place step (pivot row -> r_j / p, pivot column -> -c_i / p, pivot -> 1 / p;
+    // accurate because the scaled pivots are <= 1) - and row k + 1 and column k + 1 as they stand.  Every thread brings
+    // those two forward over pivot k itself (the same formula applied to them: r'_j = r_j - c_(k+1) r^k_j / p, ...), which
+    // also yields the second pivot, and applies both steps to its tile.  The groups of 6 pivots are unrolled so that the
+    // tile rows / columns holding the next pair are compile-time indices.
     static_assert(kNC == 96 && kT == 512, "tile layout written for 96 x 96 on 512 threads");
-    double *dsc = gj + 4 * kNC + 2;                         // kNC: 1 / sqrt(diagonal)
+    double *dsc = gj + 8 * kNC + 2;                         // kNC: 1 / sqrt(diagonal)
+    double *pvs = gj + 8 * kNC;                             // first pivot of the pair, per snapshot buffer
     if (tid < kNC) { const double d = Ac[tid * kNC + tid]; dsc[tid] = (d > 0.0 && isfinite(d)) ? rsqrt(d) : 0.0; if (!(d > 0.0) || !isfinite(d)) s_bad = 1; }
     __syncthreads();
     const int rg = tid >> 4, cg = tid & 15;
@@ -246,61 +223,81 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
         const int nrows = pp.wave_row0[(q >> 1) + 1] - pp.wave_row0[q >> 1];
         if (!(nrows == 0 || ((q & 1) && nrows < 2))) live |= 1u << q;
     }
+    __syncthreads();                                        // (aggc, which shares the snapshot area, has been read by everyone)
+    // publishes the snapshot of the pair (6 gq + C, 6 gq + C + 1) from the tiles as they stand
+    auto publish = [&](auto Ctag, int gq, int buf) {
+        constexpr int C = decltype(Ctag)::value;
+        constexpr int lr0 = C % 3, lr1 = (C + 1) % 3;      // tile rows of the two pivots (6 gq is a multiple of 3)
+        const int rg0 = 2 * gq + C / 3, rg1 = 2 * gq + (C + 1) / 3;
+        double *R1 = gj + buf * 4 * kNC, *C1 = R1 + kNC, *R2 = C1 + kNC, *C2 = R2 + kNC;
+        if (rg == rg0) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) R1[6 * cg + q] = t[lr0][q] + ((cg == gq && q == C) ? 1.0 : 0.0);
+        }
+        if (rg == rg1) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) R2[6 * cg + q] = t[lr1][q];
+        }
+        if (cg == gq) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { C1[3 * rg + r] = t[r][C] - ((rg == rg0 && r == lr0) ? 1.0 : 0.0); C2[3 * rg + r] = t[r][C + 1]; }
+        }
+        if (rg == rg0 && cg == gq) pvs[buf] = t[lr0][C];
+    };
     int kk = live ? __builtin_ctz(live) : kNC / 6;
-    // snapshot of the first live pivot
-    if (kk < kNC / 6) {
-        if (rg == 2 * kk) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q) gj[6 * cg + q] = t[0][q] + ((cg == kk && q == 0) ? 1.0 : 0.0);
-        }
-        if (cg == kk) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) gj[kNC + 3 * rg + r] = t[r][0] - ((rg == 2 * kk && r == 0) ? 1.0 : 0.0);
-        }
-        if (rg == 2 * kk && cg == kk) gj[4 * kNC] = t[0][0];
-    }
+    if (kk < kNC / 6) publish(std::integral_constant<int, 0>{}, kk, 0);
     __syncthreads();
     bool bad = s_bad != 0;
+    int buf = 0;
+    // one pair: both pivots applied to the tile; false when a pivot is not positive (the coarse level is then unusable for one trial)
+    auto pair_step = [&](auto Ctag, int gq) -> bool {
+        constexpr int C = decltype(Ctag)::value;
+        constexpr int lr1 = (C + 1) % 3;
+        const int k = 6 * gq + C, rg1 = 2 * gq + (C + 1) / 3;
+        const double *R1 = gj + buf * 4 * kNC, *C1 = R1 + kNC, *R2 = C1 + kNC, *C2 = R2 + kNC;
+        const double p1 = pvs[buf];
+        const double o12 = R1[k + 1], o21 = C1[k + 1], q22 = R2[k + 1];
+        double r1[6], r2[6], c1[3], c2[3];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { r1[q] = R1[6 * cg + q]; r2[q] = R2[6 * cg + q]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { c1[r] = C1[3 * rg + r]; c2[r] = C2[3 * rg + r]; }
+        if (!(p1 > 0.0) || !isfinite(p1)) return false;
+        // reciprocals by v_rcp_f64 and two Newton steps (the scaled pivots are in (0, 1]; this is a preconditioner)
+        double ip1 = __builtin_amdgcn_rcp(p1);
+        ip1 = ip1 * (2.0 - p1 * ip1);
+        ip1 = ip1 * (2.0 - p1 * ip1);
+        const double s12 = o12 * ip1;
+        const double p2 = q22 - o21 * s12;
+        if (!(p2 > 0.0) || !isfinite(p2)) return false;
+        double ip2 = __builtin_amdgcn_rcp(p2);
+        ip2 = ip2 * (2.0 - p2 * ip2);
+        ip2 = ip2 * (2.0 - p2 * ip2);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            r1[q] *= ip1;
+            r2[q] = ((r2[q] - o21 * r1[q]) + ((cg == gq && q == C + 1) ? 1.0 : 0.0)) * ip2;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) c2[r] = (c2[r] - c1[r] * s12) - ((rg == rg1 && r == lr1) ? 1.0 : 0.0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { t[r][q] -= c1[r] * r1[q]; t[r][q] -= c2[r] * r2[q]; }
+        return true;
+    };
     while (kk < kNC / 6 && !bad) {
         const unsigned later = kk < 31 ? (live & ~((2u << kk) - 1u)) : 0u;
         const int next = later ? __builtin_ctz(later) : kNC / 6;
-#pragma unroll
-        for (int c6 = 0; c6 < 6; ++c6) {
-            const int k = 6 * kk + c6;
-            const int k1 = c6 < 5 ? k + 1 : 6 * next;                             // the next live pivot (k is odd when it jumps, 6 next even)
-            const double *rk = gj + (k & 1) * 2 * kNC, *ck = rk + kNC;
-            double *rn = gj + (k1 & 1) * 2 * kNC, *cn = rn + kNC;
-            const double piv = gj[4 * kNC + (k & 1)];
-            if (!(piv > 0.0) || !isfinite(piv)) { bad = true; break; }
-            // reciprocal by v_rcp_f64 and two Newton steps (the scaled pivots are in (0, 1]; this is a preconditioner)
-            double pinv = __builtin_amdgcn_rcp(piv);
-            pinv = pinv * (2.0 - piv * pinv);
-            pinv = pinv * (2.0 - piv * pinv);
-            double rj[6], ci[3];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) rj[q] = rk[6 * cg + q] * pinv;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) ci[r] = ck[3 * rg + r];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) t[r][q] -= ci[r] * rj[q];
-            // publish row / column / pivot k1 (static tile indices: k1 = k + 1 inside a group, the first of a group after it)
-            if (k1 < kNC) {
-                const int rn_r = (c6 + 1) % 3, cn_c = (c6 + 1) % 6;
-                const int rgn = k1 / 3, cgn = k1 / 6;
-                if (rg == rgn) {
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) rn[6 * cg + q] = t[rn_r][q] + ((cg == cgn && q == cn_c) ? 1.0 : 0.0);
-                }
-                if (cg == cgn) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) cn[3 * rg + r] = t[r][cn_c] - ((rg == rgn && r == rn_r) ? 1.0 : 0.0);
-                }
-                if (rg == rgn && cg == cgn) gj[4 * kNC + (k1 & 1)] = t[rn_r][cn_c];
-            }
-            __syncthreads();
-        }
+        if (!pair_step(std::integral_constant<int, 0>{}, kk)) { bad = true; break; }
+        publish(std::integral_constant<int, 2>{}, kk, buf ^ 1);
+        __syncthreads(); buf ^= 1;
+        if (!pair_step(std::integral_constant<int, 2>{}, kk)) { bad = true; break; }
+        publish(std::integral_constant<int, 4>{}, kk, buf ^ 1);
+        __syncthreads(); buf ^= 1;
+        if (!pair_step(std::integral_constant<int, 4>{}, kk)) { bad = true; break; }
+        if (next < kNC / 6) publish(std::integral_constant<int, 0>{}, next, buf ^ 1);
+        __syncthreads(); buf ^= 1;
         kk = next;
     }
     if (bad && tid == 0) s_bad = 1;

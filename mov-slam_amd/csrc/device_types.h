@@ -26,9 +26,6 @@ constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-ite
 constexpr int kEntPackSlots = 1 << 22, kEntPackPoints = 1 << 20;
 __host__ __device__ inline unsigned long long ent_pack(int si, int sj, int l) { return (unsigned long long)(unsigned)si | ((unsigned long long)(unsigned)sj << 22) | ((unsigned long long)(unsigned)l << 44); }
 
-// two-level arrival counter of a launch's workgroups (handoff.h): word 0 = top, word kTicketStride (1 + s) = shard s
-constexpr int kTicketShards = 16, kTicketStride = 32, kTicketWords = (1 + kTicketShards) * kTicketStride;
-
 constexpr int kPointGroup = 8;      // lanes cooperating on one map point
 #ifndef MOVBA_POINT_BLOCK
 #define MOVBA_POINT_BLOCK 256
@@ -161,7 +158,8 @@ struct DevWindow {
     double *bp;         // 6 nfree
     double *xp;         // 6 nfree
     double *scale_part; // n_pt_blocks + 1
-    unsigned *tickets;  // kTicketWords (handoff.h): arrival counters of the back-substitution pass, whose last workgroup takes the LM decision
+    unsigned *dec_rec;  // 2 n_pt_blocks records of 16 bytes (handoff.h): every workgroup of the back-substitution pass hands its cost and scale
+                        // partials to the pass's deciding workgroup as tagged records (tag = trial + 1)
     double *hmax_part;  // n_pt_blocks
     Ctrl *ctrl;
     HostStatus *hstat;  // device view of the pinned status block

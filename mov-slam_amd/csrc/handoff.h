@@ -46,23 +46,23 @@ __device__ __forceinline__ void hx_st_f64x2(__amdgpu_buffer_rsrc_t r, unsigned b
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);
 }
 
-// ---- "who is last" among the workgroups of one launch: a two-level ticket.  Workgroup b adds to shard b % kTicketShards;
-// the last arriver of a shard adds to the top word; the workgroup whose top add comes last is the launch's last one and
-// resets every word for the next launch.  (One word takes ~88 adds per microsecond: 625 point blocks on one word would
-// queue for 7 us; 16 shards on lines of their own do not.)  Words: [0] top, [32 (1 + s)] shard s.
-// (kTicketShards, kTicketStride, kTicketWords: device_types.h)
-// ONE lane of the workgroup calls this behind hx_drain(); true in exactly one workgroup of the launch, after every other one's add
-__device__ __forceinline__ bool hx_last_arriver(unsigned *tickets, int b, int nblocks)
+// ---- a double handed over as ONE self-announcing 16-byte record (value, tag, check word): one sc1 store of one lane, no
+// drain, no flag; the consumer's lane polls the record itself until tag and check word fit (MI355X_MICROARCH.md's
+// "handoff-1to1" against "handoff-flag": 0.8 us against 1.3 and more).  A 16-byte store of one lane is one request to one
+// cache line; the check word is there so that a torn read could only ever cause another look.  Tags are never 0 and never
+// repeat within one run of a window; the records are zeroed when a run starts.
+constexpr unsigned kHxTagSalt = 0x9e3779b9u;
+__device__ __forceinline__ void hx_st_tagged(__amdgpu_buffer_rsrc_t r, unsigned rec, double v, unsigned tag)
 {
-    const int s = b % kTicketShards;
-    const unsigned in_shard = (unsigned)((nblocks - s + kTicketShards - 1) / kTicketShards);     // workgroups b' < nblocks with b' % shards == s
-    unsigned *ws = tickets + kTicketStride * (1 + s);
-    if (hx_add_u32(ws, 1u) + 1u != in_shard) return false;
-    hx_st_u32(ws, 0u);
-    const unsigned nshards = (unsigned)(nblocks < kTicketShards ? nblocks : kTicketShards);
-    if (hx_add_u32(tickets, 1u) + 1u != nshards) return false;
-    hx_st_u32(tickets, 0u);
-    return true;
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const hx_u32x4 q = { lo, hi, tag, tag ^ lo ^ hi ^ kHxTagSalt };
+    __builtin_amdgcn_raw_buffer_store_b128(q, r, (int)(rec * 16u), 0, 16);
+}
+__device__ __forceinline__ bool hx_ld_tagged(__amdgpu_buffer_rsrc_t r, unsigned rec, unsigned tag, double &v)
+{
+    const hx_u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(rec * 16u), 0, 16);
+    v = __hiloint2double((int)q.y, (int)q.x);
+    return q.z == tag && q.w == (tag ^ q.x ^ q.y ^ kHxTagSalt);
 }
 
 }  // namespace movba

@@ -35,7 +35,7 @@ namespace movba {
 __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int nblk)
 {
     const int i = bid * blockDim.x + threadIdx.x;
-    for (int k = i; k < kTicketWords; k += nblk * blockDim.x) w.tickets[k] = 0u;      // arrival counters of the point pass (its last workgroup takes the LM decision)
+    for (int k = i; k < 8 * w.n_pt_blocks; k += nblk * blockDim.x) w.dec_rec[k] = 0u;  // the point pass's hand-off records: no tag of an earlier run may fit
     {
         const double2 *src = reinterpret_cast<const double2 *>(w.point0);
         double2 *dst = reinterpret_cast<double2 *>(w.st[0].point);
@@ -89,34 +89,54 @@ __device__ __forceinline__ Cam cam_of_rt(const DevWindow &w, int ip) { return w.
 __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim.x); }
 
 // --------------------------------------------------------------------------------
-// decide_body: one wave - wave 0 of the LAST workgroup of the back-substitution pass to arrive (point_body).  The accept /
-// reject logic and lambda schedule of OptimizationAlgorithmLevenberg::solve plus the loop conditions of
+// decide_body: one wave - wave 0 of the extra workgroup of the back-substitution pass (block n_pt_blocks of point_body).
+// The accept / reject logic and lambda schedule of OptimizationAlgorithmLevenberg::solve plus the loop conditions of
 // SparseOptimizer::optimize, restated as a state machine that advances by one trial per
 // point pass.  Publishes progress to pinned host memory.
-// (A launch of its own until round 4: 4.6 us per trial plus a launch boundary.  The cost and scale partials it sums were
-// written by the other workgroups of THIS launch: sc1 stores there, sc1 loads here - handoff.h.)
+// (A launch of its own until round 4: 4.6 us per trial plus a launch boundary.  Now the pass's workgroups hand their cost
+// and scale partials to this wave INSIDE the launch, as tagged 16-byte records (handoff.h) which its lanes poll: the
+// decision is taken ~1 us behind the last workgroup's partials, and the launch ends with it.)
 // --------------------------------------------------------------------------------
 __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
 {
     Ctrl *c = w.ctrl;
     const int lane = threadIdx.x;
-    // Lane-strided partial sums, loads issued 10 deep (a plain loop would pay one round trip per term; 10 x 64 covers
-    // cfg3's 625 blocks in one round), added in a fixed order
+    // Lane-strided partial sums, records polled 10 blocks deep per lane (10 x 64 covers cfg3's 625 blocks in one round),
+    // added in a fixed order once a round is complete.  A producer that never shows up (it cannot: none of them waits for
+    // anything) ends the solve through the bounded wait instead of hanging the launch.
     constexpr int kDeep = 10;
-    const double *Fp = w.st[cur ^ 1].Fpart;         // the trial state's cost partials
+    const unsigned tag = (unsigned)c->n_solves + 1u;
+    const __amdgpu_buffer_rsrc_t rr = hx_rsrc(w.dec_rec, 32u * (unsigned)w.n_pt_blocks);
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     double F1 = 0.0, scale = 0.0;
-    for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * kDeep) {
+    bool good = true;
+    for (int base = 0; base < w.n_pt_blocks && good; base += 64 * kDeep) {
+        const int k0 = base + lane;
         double f1[kDeep], sv[kDeep];
+        for (;;) {
+            bool ok = true;
 #pragma unroll
-        for (int u = 0; u < kDeep; ++u) {
-            const int k = min(k0 + 64 * u, w.n_pt_blocks - 1);
-            f1[u] = hx_ld_f64(Fp + k); sv[u] = hx_ld_f64(w.scale_part + k);
+            for (int u = 0; u < kDeep; ++u) {
+                const unsigned k = (unsigned)min(k0 + 64 * u, w.n_pt_blocks - 1);
+                ok &= hx_ld_tagged(rr, 2u * k, tag, f1[u]);
+                ok &= hx_ld_tagged(rr, 2u * k + 1u, tag, sv[u]);
+            }
+            if (__all(ok)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t_start > 2000000ull) { good = false; break; }     // 20 ms of the 100 MHz clock
+            __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
         for (int u = 0; u < kDeep; ++u) {
             const bool in = k0 + 64 * u < w.n_pt_blocks;
             F1 += in ? f1[u] : 0.0; scale += in ? sv[u] : 0.0;
         }
+    }
+    if (!good) {        // (never seen; the download then reports MOVBA_ERR_DEVICE_WAIT through n_sync_timeouts)
+        if (lane == 0) {
+            c->n_sync_timeouts += 1; c->done = 1;
+            __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
     }
     F1 = wave_sum(F1);
     scale = wave_sum(scale);
@@ -186,6 +206,10 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     const Ctrl *c = w.ctrl;
     if (c->done) return;
     const int cur = c->cur;
+    if (bid >= w.n_pt_blocks) {         // the pass's extra workgroup: its first wave takes the LM decision (back-substitution passes only)
+        if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur);
+        return;
+    }
     const int dst = BACKSUB ? (cur ^ 1) : cur;
     const double lambda = c->lambda;
     const DevState &S0 = w.st[cur];
@@ -194,8 +218,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     double *sRt = sm;                               // NP x 12 at dst
     double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 12 at cur  (BACKSUB)
     double *sxp = sR0 + ((BACKSUB && LDSP) ? 12 * w.NP : 0);  // nfree x 6       (BACKSUB)
-    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4, then the "last workgroup" word
-    int *shidx = reinterpret_cast<int *>(red + 6);  // NP              (BACKSUB)
+    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4
+    int *shidx = reinterpret_cast<int *>(red + 4);  // NP              (BACKSUB)
     // where the pose data is read from: the LDS images, or the state buffers themselves
     const double *pRt = LDSP ? sRt : S1.Rt;
     const double *pR0 = LDSP ? sR0 : S0.Rt;
@@ -387,17 +411,13 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     const double Fsum = block_reduce<kPointBlock / 64, false>(F, red);
     if (BACKSUB) {
         const double ssum = block_reduce<kPointBlock / 64, false>(scale, red);
-        // The LM decision needs every workgroup's partials: the last workgroup to arrive takes it, in this launch (a launch of
-        // its own cost 4.6 us plus a launch boundary per trial).  One lane publishes this workgroup's two partials write-through,
-        // drains and takes a ticket; the partials are summed by ONE wave in the fixed order of the old k_decide.
-        int *lastw = reinterpret_cast<int *>(red + 4);
+        // the LM decision needs every workgroup's partials: handed to the pass's deciding wave (decide_body) as two tagged
+        // records, one 16-byte write-through store each, nothing to wait for
         if (threadIdx.x == 0) {
-            hx_st_f64(w.scale_part + bid, ssum); hx_st_f64(S1.Fpart + bid, Fsum);
-            hx_drain();
-            *lastw = hx_last_arriver(w.tickets, bid, w.n_pt_blocks) ? 1 : 0;
+            const unsigned tag = (unsigned)c->n_solves + 1u;
+            const __amdgpu_buffer_rsrc_t rr = hx_rsrc(w.dec_rec, 32u * (unsigned)w.n_pt_blocks);
+            hx_st_tagged(rr, 2u * (unsigned)bid, Fsum, tag); hx_st_tagged(rr, 2u * (unsigned)bid + 1u, ssum, tag);
         }
-        __syncthreads();
-        if (*lastw && threadIdx.x < 64) decide_body(w, cur);
     } else {
         const double m = block_reduce<kPointBlock / 64, true>(hmax, red);
         if (threadIdx.x == 0) { w.hmax_part[bid] = m; S1.Fpart[bid] = Fsum; }
@@ -901,15 +921,15 @@ __global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
 // --------------------------------------------------------------------------------
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
-    if (!w.lds_poses) return 6 * sizeof(double) + 16;
-    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 6;
+    if (!w.lds_poses) return 4 * sizeof(double) + 16;
+    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
     return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
 // the largest LDS image the point kernels would stage for this window (decides DevWindow::lds_poses)
 size_t point_lds_need(int NP, int nfree)
 {
-    return (24 * (size_t)NP + 6 * (size_t)nfree + 6) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
+    return (24 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s)
@@ -964,14 +984,15 @@ hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
 {
+    // (one workgroup more than the points need: its first wave takes the LM decision, decide_body)
     if (w.kcam) {
-        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
-        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
+        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
     } else if (!w.lds_poses) {
-        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
     return hipGetLastError();
 }
 

@@ -12,7 +12,7 @@ size_t pcg_rows_lds_bytes(int nfree, int nrowent)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
     const size_t solve = (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC / 2 + kNC + 32 * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
-    const size_t coarse = ((size_t)kNC * kNC + 5 * kNC + 8) * sizeof(double) + 2 * sizeof(int32_t) * ((size_t)nrowent + 2);   // the second workgroup (coarse_level.h)
+    const size_t coarse = ((size_t)kNC * kNC + 9 * kNC + 8) * sizeof(double) + 2 * sizeof(int32_t) * ((size_t)nrowent + 2);   // the second workgroup (coarse_level.h)
     return solve > coarse ? solve : coarse;
 }
 

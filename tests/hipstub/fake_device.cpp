@@ -157,7 +157,7 @@ void fake_init(const DevWindow &w)
     if (w.dense.G > 0) g_sink += sum_bytes(w.dense.tasks, 32) + sum_bytes(w.dense.task_ptr, 4 * ((size_t)w.dense.G + 1));
     std::memcpy(w.st[0].pose, w.pose0, 56 * (size_t)w.NP);
     std::memcpy(w.st[0].point, w.point0, 24 * (size_t)w.P);
-    std::memset(w.tickets, 0, sizeof(unsigned) * kTicketWords);
+    std::memset(w.dec_rec, 0, sizeof(unsigned) * 8 * (size_t)w.n_pt_blocks);
     Ctrl *c = w.ctrl;
     std::memset(c, 0, sizeof(Ctrl));
     c->nu = 2.0; c->done = (w.max_iters <= 0) ? 1 : 0; c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
@@ -206,7 +206,7 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s,
 hipError_t launch_schur(const DevWindow &w, int, int, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + (w.ent64 ? (long)w.ent64[0] : (long)w.ent_i[0]) + w.slot_point[0]; }); return hipSuccess; }
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->lambda = 1e-3; }); return hipSuccess; }
 // (the back-substitution pass takes the LM decision in its last workgroup: one launch)
-hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + w.tickets[0]; fake_decide(w); }); return hipSuccess; }
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + w.dec_rec[0]; fake_decide(w); }); return hipSuccess; }
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_finalize(w); }); return hipSuccess; }
 hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
 {
