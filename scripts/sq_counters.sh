@@ -9,3 +9,5 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $OUT/pmc -- python3 $ROOT/scripts/"$@" > $OUT/run.log 2>&1 || exit 1
 cd $ROOT && python3 scripts/summarise_sq.py $OUT/pmc $TAG $NAME "$*"
+# the summary is written on the GPU box: only gpurun_out/ comes back, so a copy goes there (commit it under profiles/ afterwards)
+cp $ROOT/profiles/${TAG}_sq_counters_$NAME.json $OUT/
