@@ -137,7 +137,10 @@ typedef struct {
     int32_t reorder;            /* 0 = default: free keyframes are renumbered by covisibility (reverse Cuthill-McKee on the pair
                                  * graph) when that shrinks the reduced matrix's envelope by a fifth or more; -1 = keep the
                                  * caller's order (KeyFrame::mnId order, as the reference numbers its vertices)             */
-    int32_t pad_o;
+    int32_t two_streams;        /* 0 = default: every kernel of a solve on the handle's stream, one after the other; 1 = the PCG launches of a
+                                 * solve go to a stream of the handle's own and run beside the schur and back-substitution passes of their
+                                 * trial, hand-offs through flags in device memory (also MOVBA_TWO_STREAMS=1).  Measured slower on MI355X
+                                 * (DESIGN.md, round 4): kept for boxes where launch boundaries cost more than device-scope round trips */
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */

@@ -114,6 +114,12 @@ struct movba_handle {
                                         // handles of a device: every extra stream of the process competes for the few hardware queues,
                                         // and two streams of a batched run that land on one queue run in turns)
     hipEvent_t copy_event = nullptr;
+    // The reduced solves of a solo LM loop (k_pcg_rows) run on a stream of their own, resident beside the schur pass of their
+    // trial, fed and answered through flags in device memory (DevWindow::xs; lm_loop): created on first use
+    hipStream_t pcg_stream = nullptr;
+    hipEvent_t xs_event = nullptr;      // the run's setup launches have ended (stream -> pcg_stream, once per run)
+    bool xs_run = false;                // this run's PCG launches are on pcg_stream
+    int sync_retries = 0;               // > 0: this run's first attempt gave up that many in-launch waits and was repeated on the paths without any
     hipEvent_t edgeb_event = nullptr;   // the derived edge arrays sent early on the copy stream have arrived
     uint64_t count_seq = 0;             // uploads that went through the device structure pass (what the host polls for in the counts buffer)
     movba_options opt{};
@@ -253,18 +259,18 @@ hipEvent_t get_event(movba_handle *h)
 }
 
 struct ScopedEvents {
-    movba_handle *h; EventPair p{}; bool on;
-    ScopedEvents(movba_handle *h_, int cls) : h(h_), on(((h_->opt.profile >> cls) & 1) != 0)
+    movba_handle *h; EventPair p{}; bool on; hipStream_t st;
+    ScopedEvents(movba_handle *h_, int cls, hipStream_t st_ = nullptr) : h(h_), on(((h_->opt.profile >> cls) & 1) != 0), st(st_ ? st_ : h_->stream)
     {
         if (!on) return;
         p.a = get_event(h); p.b = get_event(h); p.cls = cls;
         if (!p.a || !p.b) { on = false; return; }
-        (void)hipEventRecord(p.a, h->stream);
+        (void)hipEventRecord(p.a, st);
     }
     ~ScopedEvents()
     {
         if (!on) return;
-        (void)hipEventRecord(p.b, h->stream);
+        (void)hipEventRecord(p.b, st);
         h->ev_used.push_back(p);
     }
 };
@@ -387,7 +393,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     movba_handle *h = new (std::nothrow) movba_handle();
     if (!h) return MOVBA_ERR_HIP;
     h->device = device;
-    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0; h->opt.reorder = 0; h->opt.pad_o = 0;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0; h->opt.reorder = 0; h->opt.two_streams = 0;
     if (opt) {
         if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
         if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
@@ -398,7 +404,9 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         h->opt.pcg_spill = opt->pcg_spill == 1 ? 1 : 0;
         h->opt.solver = opt->solver == 1 ? 1 : 0;
         h->opt.reorder = opt->reorder == -1 ? -1 : 0;
+        h->opt.two_streams = opt->two_streams == 1 ? 1 : 0;
     }
+    if (std::getenv("MOVBA_TWO_STREAMS")) h->opt.two_streams = 1;
     if (h->opt.host_wait == 1) h->packer.spin_ms = 0;      // (a caller that asks for yielding waits does not want a spinning helper either)
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
     if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
@@ -432,6 +440,8 @@ void movba_destroy(movba_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);        // shared: stays
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
+    if (h->pcg_stream) { (void)hipStreamSynchronize(h->pcg_stream); (void)hipStreamDestroy(h->pcg_stream); }
+    if (h->xs_event) (void)hipEventDestroy(h->xs_event);
     if (h->edgeb_event) (void)hipEventDestroy(h->edgeb_event);
     harvest_events(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -602,7 +612,7 @@ struct Upload {
     size_t o_cg = 0, o_ch = 0, o_cp = 0, o_ce = 0, o_cij = 0, o_multi = 0, o_pid = 0, o_prange = 0, o_dtp = 0, o_dtk = 0;
     size_t o_st[2][11] = {};
     size_t o_obspm = 0, o_obsrpm = 0, o_part = 0, o_blocks = 0, o_blocks_ov = 0, o_blocks_c = 0, o_aci = 0, o_acitag = 0;
-    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_tick = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
+    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_tick = 0, o_xs = 0, o_recd = 0, o_imgb = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
     size_t o_dtiles = 0, o_ddiag = 0, o_dfail = 0, o_dx = 0, o_dflags = 0, o_dcontrib = 0, o_dstamps = 0;
     std::vector<int32_t> lane_plan;
     size_t ncb = 0;
@@ -1122,6 +1132,20 @@ int Upload::lay_out_rest()
                 }
         }
     }
+    // where the schur pass leaves the block of every single-item off-diagonal pair for those lanes (DevWindow::img_b)
+    for (SchedItem &si : h->st.sched) { si.dst_a = -1; si.dst_b = -1; }
+    if (h->rows_kernel && !h->pp.overflow) {
+        std::vector<int32_t> slot_of_item((size_t)s().nitems, -1);
+        for (size_t q = 0; q < s().sched.size(); ++q) if (s().sched[q].tag >= 0) slot_of_item[(size_t)(s().sched[q].tag >> 1)] = (int32_t)q;
+        for (int t = 0; t < kPcgRowsThreads; ++t)
+            for (int k = 0; k < 2; ++k) {
+                const int32_t *pl = &lane_plan[((size_t)t * 2 + k) * 4];
+                if (pl[0] < nf || pl[3] - pl[2] != 1) continue;         // no block, a diagonal one, or a pair cut into several items
+                SchedItem &si = h->st.sched[(size_t)slot_of_item[(size_t)pl[2]]];
+                const int32_t dst = 36 * k * kPcgRowsThreads + t;
+                if ((pl[1] >> 30) & 1) si.dst_b = dst; else si.dst_a = dst;
+            }
+    }
     ncb = s().cblk_g.size();
     o_plan = c.take<int32_t>(lane_plan.size() + 4);
     o_cg = c.take<int32_t>(ncb + 1); o_ch = c.take<int32_t>(ncb + 1); o_cp = c.take<int32_t>(ncb + 2); o_ce = c.take<int32_t>(s().cblk_ent.size() + 1);
@@ -1149,10 +1173,12 @@ int Upload::lay_out_rest()
     o_obspm = c.take<double>(2 * (size_t)s().E_free + 2); o_obsrpm = c.take<double>(stereo ? (size_t)s().E_free + 1 : 1);
     const size_t part_stride = ((size_t)s().nitems * kPartStride + 31) / 32 * 32;
     o_part = c.take<double>(part_stride + 1); o_blocks = c.take<double>((size_t)s().npairs * 36 + 1);
+    o_recd = c.take<double>((size_t)s().pair_item_start[nf] * 48 + 2); o_imgb = c.take<double>((size_t)72 * kPcgRowsThreads);
     o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s().row_ent.size() * 36 + 2 : 2);
     o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
     o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
     o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(8 * (size_t)nb + 8);
+    o_xs = c.take<uint32_t>((size_t)kXsItem0 + (size_t)s().nitems + 8);
     o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
@@ -1283,11 +1309,12 @@ void Upload::device_view()
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
+    w.rec_d = reinterpret_cast<double *>(a + o_recd); w.img_b = reinterpret_cast<double *>(a + o_imgb);
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c); w.blocks_ov = reinterpret_cast<double *>(a + o_blocks_ov);
     w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
-    w.dec_rec = reinterpret_cast<unsigned *>(a + o_tick);
+    w.dec_rec = reinterpret_cast<unsigned *>(a + o_tick); w.xs = reinterpret_cast<unsigned *>(a + o_xs);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev; w.ctrl_out = h->ctrl_host_dev;
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
@@ -1302,6 +1329,7 @@ void Upload::device_view()
     w.dense.G = dense_one ? h->dplan.G : 0; w.dense.slots = dense_one ? h->dplan.slots : 0;
     h->dense_flags_clean = false; h->dense_epoch = 0;
     w.direct_only = h->rows_kernel ? 0 : 1;
+    w.wait_ticks = 2000000ull;
     w.lds_poses = point_lds_need(NP, nf) <= kPointLdsLimit ? 1 : 0;
     h->uploaded = true;
 }
@@ -1430,6 +1458,14 @@ int lm_loop(movba_handle *h, bool parked)
     const int nrowent = (int)h->st.row_ent.size();
     // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
     bool direct = !h->rows_kernel;
+    // Two streams (h->xs_run): the PCG launch of trial t goes to h->pcg_stream and is resident while the schur pass of its trial
+    // still runs on `s` (it takes the pass's partials item by item behind their flags: what used to be 11 us of assembly
+    // behind a launch boundary); the back-substitution pass of trial t follows the schur pass on `s`, is resident while the
+    // solve still runs, and starts from the solve's word (DevWindow::xs).  Whatever the hardware queues do with the two
+    // streams, every kernel's inputs come from kernels queued before it: a device that runs them one after the other in
+    // queueing order behaves like the one-stream loop.
+    const bool xs = h->xs_run;
+    hipStream_t sp = xs ? h->pcg_stream : s;
     int pauses_seen = 0;
     if (!parked) __atomic_store_n(&h->hstat->pause_seq, 0, __ATOMIC_RELAXED);
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
@@ -1453,13 +1489,14 @@ int lm_loop(movba_handle *h, bool parked)
         return MOVBA_OK;
     };
     auto queue_solve = [&]() -> int {
-        ScopedEvents ev(h, KC_PCG);
-        if (direct) HIP_TRY(queue_direct(h));
-        else HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, s));
+        if (direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(queue_direct(h)); }
+        else { ScopedEvents ev(h, KC_PCG, sp); HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, xs, sp)); }
         return MOVBA_OK;
     };
     auto queue_tail = [&]() -> int {
-        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }      // (its last workgroup takes the LM decision: no launch of its own)
+        // (the pass's extra workgroup takes the LM decision: no launch of its own; with the solve on the other stream the pass
+        //  waits for the solve's word of this trial inside the launch)
+        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, (xs && !direct) ? (unsigned)t + 1u : 0u, s)); }
         return MOVBA_OK;
     };
     // The device parked the solve (k_pcg_rows gave up on trial `td`): every trial set queued behind has turned into no-ops.
@@ -1498,6 +1535,7 @@ int lm_loop(movba_handle *h, bool parked)
                     std::fprintf(stderr, "libmovba: device made no progress for %.0f ms, giving up\n", watchdog_ms());
                     wr_stop(h->hstat, 1); h->uploaded = false;
                     (void)hipStreamSynchronize(s);          // nothing of this solve is left queued when the caller gets the error
+                    if (xs) (void)hipStreamSynchronize(sp);
                     return MOVBA_ERR_HIP;
                 }
                 host_relax(h->opt.host_wait);
@@ -1506,12 +1544,14 @@ int lm_loop(movba_handle *h, bool parked)
             if (paused) { const int rq = answer_pause(); if (rq != MOVBA_OK) return rq; --t; continue; }
             if (caller_stop(h->stop)) wr_stop(h->hstat, 1);
             t_progress = now_ms();                          // (new work queued counts as progress)
-            if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, t, s)); }
+            if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, (xs && !direct) ? t : -1, s)); }
             { const int rq = queue_solve(); if (rq != MOVBA_OK) return rq; }
             { const int rq = queue_tail(); if (rq != MOVBA_OK) return rq; }
         }
         if (final_after != t) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
         HIP_TRY(hipStreamSynchronize(s));
+        // (every PCG launch still queued on the other stream has left through its schur pass's no-op word: cheap to wait for)
+        if (xs) HIP_TRY(hipStreamSynchronize(sp));
         // a park that happened behind the last queued set is only seen now
         if (rd_pause(h->hstat) == pauses_seen) break;
         const int rq = answer_pause(); if (rq != MOVBA_OK) return rq;
@@ -1537,11 +1577,27 @@ int movba_lba_run(movba_handle *h)
     h->win.pose_export = (h->pose_export && h->pose_export_cap >= (int64_t)sizeof(double) * 7 * h->win.NP) ? h->pose_export : nullptr;
     const DevWindow &w = h->win;
     hipStream_t s = h->stream;
-    __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0);
     // (the staging buffer is free once the upload's copies, queued ahead of every kernel of the run, have left it; it is as
     // large as the upload needed, which is more than the results take)
     h->export_in_run = h->export_hint && export_layout(w).end <= h->stage_cap;
     if (!h->export_in_run) for (int k = 0; k < 3; ++k) { h->user_dst[k] = nullptr; h->user_host[k] = nullptr; }
+
+    // Two kinds of kernels wait for other workgroups INSIDE a launch: the two-stream LM loop (the back-substitution pass waits
+    // for the reduced solve, the solve for the schur pass: lm_loop) and the one-launch direct solver (dense_persist.hip).
+    // Every such wait is bounded (DevWindow::wait_ticks, 20 ms) and none can deadlock on an otherwise idle device, but none is
+    // GUARANTEED its workgroups' residency either: another process on the GPU, a CU-masked or partitioned device, any other
+    // kernel holding the CUs.  A solve in which a wait was given up (Ctrl::n_sync_timeouts) is therefore run AGAIN from the
+    // uploaded state on the paths that wait for nothing - one stream, the direct solver one launch per block column
+    // (dense_solve.hip) - instead of handing the caller an error: the reference never skips a solve for such a reason
+    // (src/Optimizer.cc:535).  movba_lba_result::n_sync_timeouts reports that it happened.
+    static const unsigned long long test_ticks = [] { const char *e = std::getenv("MOVBA_TEST_WAIT_TICKS"); return e ? std::strtoull(e, nullptr, 10) : ~0ull; }();
+    h->sync_retries = 0;
+    const int32_t dense_G = h->win.dense.G;
+    for (int attempt = 0;; ++attempt) {
+    const bool careful = attempt > 0;
+    h->win.wait_ticks = (!careful && test_ticks != ~0ull) ? test_ticks : 2000000ull;
+    h->win.dense.G = careful ? 0 : dense_G;
+    __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0);
 
     {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
         ScopedEvents ev(h, KC_SETUP);
@@ -1550,8 +1606,29 @@ int movba_lba_run(movba_handle *h)
         if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, 0, s));
         HIP_TRY(launch_lambda_init(w, s));
     }
+    // the PCG launches of this run on a stream of their own (lm_loop): windows with an on-chip PCG whose lists fit its registers
+    h->xs_run = h->rows_kernel && !h->pp.overflow && w.nitems > 0 && h->opt.two_streams && !careful;
+    if (h->xs_run) {
+        if (!h->pcg_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->pcg_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->xs_event, hipEventDisableTiming));
+        }
+        // (k_init_pose has zeroed the hand-off words: no PCG launch of this run may look at them before that)
+        HIP_TRY(hipEventRecord(h->xs_event, s));
+        HIP_TRY(hipStreamWaitEvent(h->pcg_stream, h->xs_event, 0));
+    }
     const int rl = lm_loop(h, false);
+    h->win.dense.G = dense_G;
     if (rl != MOVBA_OK) return rl;
+    if (h->ctrl_host->n_sync_timeouts > 0 && !careful) {
+        std::fprintf(stderr, "libmovba: a workgroup gave up waiting for another in %d launch(es) of this solve: running it again on one stream, the direct solver launch by launch\n",
+                     h->ctrl_host->n_sync_timeouts);
+        h->sync_retries = h->ctrl_host->n_sync_timeouts;
+        h->dense_flags_clean = false;           // (hand-off flags of the abandoned launches: zeroed again before the next one-launch solve)
+        continue;
+    }
+    break;
+    }
 #ifdef MOVBA_CLOCK_STAMP
     std::fprintf(stderr, "libmovba[stamp]: k_pcg_rows %llu shader cycles in %llu x 10 ns -> %.3f GHz\n", h->ctrl_host->dbg_cycles,
                  h->ctrl_host->dbg_ticks, h->ctrl_host->dbg_ticks ? 0.1 * (double)h->ctrl_host->dbg_cycles / (double)h->ctrl_host->dbg_ticks : 0.0);
@@ -1560,6 +1637,11 @@ int movba_lba_run(movba_handle *h)
     for (int wv = 0; wv < 8; ++wv) {
         std::fprintf(stderr, "\nlibmovba[stamp]:   wave %d:", wv);
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_wseg[wv][k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
+    }
+    if (h->ctrl_host->dbg_xs[5]) {
+        const double n = (double)h->ctrl_host->dbg_xs[5];
+        std::fprintf(stderr, "\nlibmovba[stamp]: two streams, us behind the schur pass's last item flag: partials in registers %.2f, CG starts %.2f, CG ends %.2f, done word %.2f",
+                     0.01 * h->ctrl_host->dbg_xs[1] / n, 0.01 * h->ctrl_host->dbg_xs[2] / n, 0.01 * h->ctrl_host->dbg_xs[3] / n, 0.01 * h->ctrl_host->dbg_xs[4] / n);
     }
     std::fprintf(stderr, "\nlibmovba[stamp]: setup phases per launch (cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
@@ -1593,7 +1675,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
     std::vector<movba_handle *> act, solo;
     for (int i = 0; i < n; ++i) {
         movba_handle *h = hs[i];
-        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false;
+        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false; h->xs_run = false;
         if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
         if (caller_stop(h->stop)) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
         if (!h->rows_kernel || h->win.kcam) { solo.push_back(h); continue; }      // (direct-solver windows and windows with intrinsics by keyframe run on their own)
@@ -1829,9 +1911,9 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
         res->tr_lambda[k] = c.tr_lambda[k]; res->tr_f0[k] = c.tr_f0[k]; res->tr_f1[k] = c.tr_f1[k];
         res->tr_rho[k] = c.tr_rho[k]; res->tr_accept[k] = c.tr_accept[k]; res->tr_pcg_iters[k] = c.tr_pcg[k];
     }
-    res->n_sync_timeouts = c.n_sync_timeouts;
+    res->n_sync_timeouts = c.n_sync_timeouts + h->sync_retries;
     h->prof.download_ms += now_ms() - t0;
-    if (c.n_sync_timeouts > 0) {
+    if (c.n_sync_timeouts > 0) {        // (only a batched run, which has no second attempt, or a second attempt that met a wait of the decide wave)
         // (the trials concerned were rejected like failed factorisations, so the state is a valid LM state — but not the one the
         //  reference's exact solver would have reached: never handed out as a success)
         std::fprintf(stderr, "libmovba: the one-launch direct solver gave up waiting between workgroups in %d solve(s): results discarded\n", c.n_sync_timeouts);

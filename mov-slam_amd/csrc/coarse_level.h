@@ -22,6 +22,7 @@
 
 #include "device_math.h"
 #include "device_types.h"
+#include "handoff.h"
 
 namespace movba {
 
@@ -30,8 +31,10 @@ namespace movba {
 #endif
 
 // sm: >= kNC*kNC + 9*kNC + 8 doubles + 2 ints per coarse term (= gather-list entry) of LDS; 512 threads
+// signal_read: once the partials have been read for the last time, say so (DevWindow::xs: the solving workgroup holds the
+// word the next passes wait for until then)
 template <int kT, int kNC, int kPA>
-__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm, bool extrapolate)
+__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm, bool extrapolate, bool signal_read)
 {
     double *Ac = sm;
     double *gj = Ac + kNC * kNC;
@@ -44,6 +47,8 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
 #else
 #define COARSE_STAMP(k) do { } while (0)
 #endif
+    // (the schur partials: plain loads; on the two-stream path the caller's waves have made their agent-scope acquire behind
+    //  the pass's flags)
     const double *part = w.part, *part_ = part;
     double *blocks = w.blocks_c;
     if (tid == 0) s_bad = 0;
@@ -98,57 +103,88 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     __syncthreads();
     COARSE_STAMP(2);
     // ---- A_c = P^T S P.  Coarse dof (g, d, a): aggregate g, mode d (0: constant, 1: linear in the keyframe index,
-    // phi_1(i) = (i - c_g) / h_g), pose component a.  One WAVE per coarse block (g, h), lane (a, b) of its first 36 lanes one
-    // element of the 6 x 6 fine blocks: every fine term is ONE coalesced 288-byte load of the wave (16 terms in flight), its
-    // weights phi(i), phi(j) are wave-uniform, and a lane adds its element into the four mode combinations phi_d(i) phi_e(j)
-    // in list order.  (Until round 4 a thread owned a ROW of a coarse block and gathered six scattered doubles per term:
-    // 12 000 eight-byte requests per batch from one CU, 16 us per build - as long as 7 CG iterations, on a workgroup the
-    // launch waits for.) ----
+    // phi_1(i) = (i - c_g) / h_g), pose component a.  One thread per (coarse block, a, b): it walks the block's fine terms
+    // once, in list order, and accumulates the four mode combinations phi_d(i) phi_e(j) together. ----
     // centre and inverse half-width of every aggregate (the linear mode's phi), once, in LDS
     double *aggc = gj;                                      // 2 x (kNC / kPA) doubles; gj is not in use yet
     if (tid < kNC / kPA) {
         const int g0 = pp.wave_row0[tid], g1 = pp.wave_row0[tid + 1];
         aggc[tid] = g0 + 0.5 * (g1 - g0 - 1); aggc[kNC / kPA + tid] = 1.0 / fmax(1.0, 0.5 * (g1 - g0));
     }
-    // the term lists themselves go to LDS first (one coalesced pass)
+    // the term lists themselves go to LDS first (one coalesced pass): the gathers below then depend on ONE global
+    // round trip per batch instead of two
     int *tent = reinterpret_cast<int *>(gj + 9 * kNC + 8), *tij = tent + w.cblk_ptr[w.n_cblk];
     for (int q = tid; q < w.cblk_ptr[w.n_cblk]; q += kT) { tent[q] = w.cblk_ent[q]; tij[q] = w.cblk_ij[q]; }
     __syncthreads();
-    {
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
-        const int ea = min(ln, 35) / 6, eb = min(ln, 35) - ea * 6;      // (lanes 36 .. 63 shadow lane 35 and store nothing)
-        constexpr int kFly = 16;
-        for (int cb = wv; cb < w.n_cblk; cb += kT / 64) {
-            const int g = w.cblk_g[cb], h = w.cblk_h[cb];
-            const double cg = aggc[g], ch = aggc[h], ig = aggc[kNC / kPA + g], ih = aggc[kNC / kPA + h];
-            const int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
-            double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
-            for (int t = t0; t < t1; t += kFly) {
-                int pk[kFly], ij[kFly];
-                double v[kFly];
+    // Thread (cb, a) owns row a of coarse block cb = (g, h) in all four mode combinations: it walks the block's term
+    // list once (8 terms = 48 gathers in flight), so no thread pads its list to a longer neighbour's.  When there are
+    // threads to spare (n_cblk * 12 <= 512: always with 8 aggregates) two threads share a row: the first takes the front
+    // of the list (whole batches of 8), the second the rest, and the second's sums are added after the first's are stored.
+    const int nw = w.n_cblk * 6;
+    const bool split = 2 * nw <= kT;
+    auto walk = [&](int cb, int a, int part, double (&s00)[6], double (&s01)[6], double (&s10)[6], double (&s11)[6]) {
+        const int g = w.cblk_g[cb], h = w.cblk_h[cb];
+        const double cg = aggc[g], ch = aggc[h], ig = aggc[kNC / kPA + g], ih = aggc[kNC / kPA + h];
+        int t0 = w.cblk_ptr[cb], t1 = w.cblk_ptr[cb + 1];
+        if (split) {
+            const int n = t1 - t0, front = min(n, (((n + 1) >> 1) + 7) & ~7);
+            if (part == 0) t1 = t0 + front; else t0 += front;
+        }
 #pragma unroll
-                for (int u = 0; u < kFly; ++u) { const int tt = min(t + u, t1 - 1); pk[u] = tent[tt]; ij[u] = tij[tt]; }
+        for (int m = 0; m < 6; ++m) s00[m] = s01[m] = s10[m] = s11[m] = 0.0;
+        for (int t = t0; t < t1; t += 8) {
+            int pk[8], ij[8];
+            double v[8][6];
 #pragma unroll
-                for (int u = 0; u < kFly; ++u) {
-                    const int e = pk[u];
-                    const double *src = (e & 1) ? part_ + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
-                    v[u] = src[(e & 2) ? eb * 6 + ea : ea * 6 + eb];       // element (a, b) of the (possibly transposed) fine block
-                }
+            for (int u = 0; u < 8; ++u) { const int tt = min(t + u, t1 - 1); pk[u] = tent[tt]; ij[u] = tij[tt]; }
 #pragma unroll
-                for (int u = 0; u < kFly; ++u) {
-                    const bool in = t + u < t1;
-                    const double x = in ? ((pk[u] & 1) ? -v[u] : v[u]) : 0.0;
-                    const double pi = ((ij[u] >> 16) - cg) * ig, pj = ((ij[u] & 0xffff) - ch) * ih;
-                    s00 += x; s01 += pj * x; s10 += pi * x; s11 += pi * pj * x;
+            for (int u = 0; u < 8; ++u) {
+                const int e = pk[u];
+                const double *src = (e & 1) ? part_ + (size_t)(e >> 2) * kPartStride : blocks + (size_t)(e >> 2) * 36;
+                // row a of the (possibly transposed) fine block
+                const int o0 = (e & 2) ? a : a * 6, st = (e & 2) ? 6 : 1;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) v[u][m] = src[o0 + st * m];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = t + u < t1;
+                const double sgn = in ? ((pk[u] & 1) ? -1.0 : 1.0) : 0.0;
+                const double pi = ((ij[u] >> 16) - cg) * ig, pj = ((ij[u] & 0xffff) - ch) * ih;
+#pragma unroll
+                for (int m = 0; m < 6; ++m) {
+                    const double x = sgn * v[u][m];
+                    s00[m] += x; s01[m] += pj * x; s10[m] += pi * x; s11[m] += pi * pj * x;
                 }
             }
-            if (ln < 36) {
-                double *dst = Ac + (g * kPA + ea) * kNC + h * kPA + eb;
-                dst[0] = s00; dst[6] = s01; dst[6 * kNC] = s10; dst[6 * kNC + 6] = s11;
-            }
+        }
+        return Ac + (g * kPA + a) * kNC + h * kPA;
+    };
+    if (split) {
+        const bool active = tid < 2 * nw;
+        const int half = tid >= nw, wi = tid - half * nw;
+        double s00[6], s01[6], s10[6], s11[6];
+        double *dst = nullptr;
+        if (active) dst = walk(wi / 6, wi - (wi / 6) * 6, half, s00, s01, s10, s11);
+        if (active && !half) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
+        }
+        __syncthreads();
+        if (active && half) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { dst[m] += s00[m]; dst[6 + m] += s01[m]; dst[6 * kNC + m] += s10[m]; dst[6 * kNC + 6 + m] += s11[m]; }
+        }
+    } else {
+        for (int wi = tid; wi < nw; wi += kT) {
+            double s00[6], s01[6], s10[6], s11[6];
+            double *dst = walk(wi / 6, wi - (wi / 6) * 6, 0, s00, s01, s10, s11);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) { dst[m] = s00[m]; dst[6 + m] = s01[m]; dst[6 * kNC + m] = s10[m]; dst[6 * kNC + 6 + m] = s11[m]; }
         }
     }
     __syncthreads();
+    if (signal_read && tid == 0) hx_st_u32(w.xs + kXsCoarseRead, (unsigned)trial + 1u);    // (every load of the partials has returned: their values are in A_c)
     // dofs without support (an aggregate with no rows; the linear modes of an aggregate with a single row): identity
     // rows keep A_c invertible, their restricted residual is always zero
     if (tid < kNC) {

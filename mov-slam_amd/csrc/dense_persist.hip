@@ -41,7 +41,6 @@ namespace {
 
 constexpr int kPT = 256;                        // threads: 4 waves, one per SIMD
 constexpr int kTileLds = NB * LD;               // doubles of one LDS tile image
-constexpr unsigned long long kWaitTicks = 2000000ull;      // 20 ms of the 100 MHz clock
 constexpr int kTaskCache = 128;                 // tasks of the workgroup's list held in LDS at a time (32 bytes each)
 __host__ __device__ constexpr int kTaskOff(int nslots) { return (2 + nslots) * kTileLds + 672; }       // (doubles) behind the carve
 __host__ __device__ constexpr int kBadOff(int nslots) { return (2 + nslots) * kTileLds + 660; }     // LDS word of sweep_inverse's bad-pivot flag (in the carve's spare doubles)
@@ -66,11 +65,13 @@ struct Lds {
     double *rrow, *yv, *xv, *xs, *ps, *pivb, *rinvb, *red;
     lds_vint *prog;         // pivots published by the factorising wave
     int *abort;
+    unsigned long long wait_ticks;      // bound of every wait (DevWindow::wait_ticks: 20 ms; a test hook shortens it)
 };
 
-__device__ __forceinline__ Lds carve(double *sm, int nslots)
+__device__ __forceinline__ Lds carve(double *sm, int nslots, unsigned long long wait_ticks)
 {
     Lds l;
+    l.wait_ticks = wait_ticks;
     l.A = sm; l.B = sm + kTileLds; l.slots = sm + 2 * kTileLds;
     double *p = l.slots + (size_t)nslots * kTileLds;
     l.rrow = p; l.yv = p + 64; l.xv = p + 128; l.xs = p + 192; l.ps = p + 256; l.pivb = p + 512; l.rinvb = p + 576; l.red = p + 640;
@@ -150,7 +151,7 @@ __device__ __forceinline__ bool ld_tagged(const unsigned *rec_base, int nrec_byt
             q = __builtin_amdgcn_raw_buffer_load_b128(r, mine ? tid * 16 : 0, 0, 16);
             const bool ok = q.z == epoch && q.w == (epoch ^ q.x ^ q.y ^ kTagSalt);
             if (__all(ok || !mine)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) { good = false; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > l.wait_ticks) { good = false; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         v = __hiloint2double((int)q.y, (int)q.x);
@@ -183,7 +184,7 @@ __device__ __forceinline__ bool wg_wait(const unsigned *flags, unsigned epoch, i
             for (;;) {
                 const bool ok = ld_flag(f) == epoch;
                 if (__all(ok || !mine)) break;
-                if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) { good = false; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > l.wait_ticks) { good = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -205,7 +206,7 @@ __device__ __forceinline__ int wg_wait2(const unsigned *flags, unsigned epoch, i
         for (;;) {
             m = __ballot(ld_flag(f) == epoch);
             if (m & 1) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) { good = false; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > l.wait_ticks) { good = false; break; }
             __builtin_amdgcn_s_sleep(2);
         }
         if (tid == 0) { if (!good) *l.abort = 1; l.abort[1] = (int)(m & 3); }
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
     unsigned long long *const stamps = w.dense.stamps;
     const DenseTask *const gtasks = w.dense.tasks;
     AsmView av = { w.part, w.dense.prange, w.bp, w.nfree, w.dense.n, nullptr };
-    const Lds l = carve(sm, nslots);
+    const Lds l = carve(sm, nslots, w.wait_ticks);
     const double lambda = c->lambda;
     if (tid == 0) { *l.abort = 0; *l.prog = 0; }
     __syncthreads();

@@ -26,6 +26,17 @@ constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-ite
 constexpr int kEntPackSlots = 1 << 22, kEntPackPoints = 1 << 20;
 __host__ __device__ inline unsigned long long ent_pack(int si, int sj, int l) { return (unsigned long long)(unsigned)si | ((unsigned long long)(unsigned)sj << 22) | ((unsigned long long)(unsigned)l << 44); }
 
+// Hand-off words between the kernels of one LM trial that run on TWO streams (api.cpp, lm_loop): the reduced solve of trial t
+// (k_pcg_rows) is resident on its own stream before the schur pass of trial t has finished and takes the pass's partials item by
+// item; the back-substitution pass is resident while the solve still runs and starts from its result.  DevWindow::xs, zeroed by
+// k_init_pose; every word carries the trial's epoch (trial + 1), words of different roles on cache lines of their own:
+//   [kXsSkip]        schur pass of this epoch was a no-op (solve finished or parked): the solve of the epoch leaves at once
+//   [kXsPcgDone]     solve of this epoch has published its result: epoch | status << 24
+//   [kXsCoarseRead]  the coarse-level workgroup has read the epoch's partials (the next schur pass may overwrite them)
+//   [kXsItem0 + i]   schur work item i of this epoch has published its partial
+constexpr int kXsSkip = 0, kXsPcgDone = 32, kXsCoarseRead = 64, kXsItem0 = 96;
+constexpr unsigned kXsEpochMask = 0xffffffu, kXsOk = 0u, kXsParked = 1u, kXsFailed = 2u;
+
 constexpr int kPointGroup = 8;      // lanes cooperating on one map point
 #ifndef MOVBA_POINT_BLOCK
 #define MOVBA_POINT_BLOCK 256
@@ -62,6 +73,8 @@ struct Ctrl {
     int32_t pad_c[2];
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
     unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8], dbg_wseg[8][8];
+    unsigned long long dbg_xs[8];       // two-stream path, 10 ns ticks: [0] time of the schur pass's last item flag of the trial (atomic max), then sums over the
+                                        // trials of: [1] last flag -> partials in registers, [2] -> CG starts, [3] -> CG ends, [4] -> done word stored; [5] trials
 };
 
 // Written by k_decide into pinned host memory so the host can keep the queue fed
@@ -149,6 +162,11 @@ struct DevWindow {
     const double *pose0, *point0;   // uploaded initial state (for reset)
     // reduced system
     double *part;       // nitems x kPartStride: k_schur work-item partials
+    // what the schur pass leaves once more in the layout the on-chip PCG's setup reads (pcg_kernel.hip), beside `part`:
+    double *rec_d;      // per DIAGONAL work item (items [0, pair_item_start[nfree])) 6 rows x 8 doubles: row a of Hpp - sum B Dinv B^T (6), then
+                        // (sum B Dinv b_l)_a and (b_p)_a
+    double *img_b;      // 72 x kPcgRowsThreads: element q (oriented) of the block that PCG thread t holds in slot k at ((36 k + q) 512 + t), for
+                        // off-diagonal pairs that are one work item (SchedItem::dst_a / dst_b say where an item's block goes)
     double *blocks_ov;  // overflow windows only: oriented copies of the blocks of the gather-list tails (entry e at 36 e)
     double *blocks_c;   // npairs x 36: the coarse-level workgroup's own copy of S (coarse_level.h)
     double *aci;        // 2 x kCoarseDim x kCoarseDim: inverse coarse matrices (by trial parity)
@@ -158,6 +176,7 @@ struct DevWindow {
     double *bp;         // 6 nfree
     double *xp;         // 6 nfree
     double *scale_part; // n_pt_blocks + 1
+    unsigned *xs;       // kXsItem0 + nitems words: the hand-offs between the two streams of the LM loop (above)
     unsigned *dec_rec;  // 2 n_pt_blocks records of 16 bytes (handoff.h): every workgroup of the back-substitution pass hands its cost and scale
                         // partials to the pass's deciding workgroup as tagged records (tag = trial + 1)
     double *hmax_part;  // n_pt_blocks
@@ -171,6 +190,10 @@ struct DevWindow {
     // direct solver
     DenseSys dense;
     int32_t direct_only, lds_poses;     // no on-chip PCG for this window (size); keyframe poses fit the point kernels' LDS staging
+    // bound of every device-side wait of one workgroup for another, in ticks of the 100 MHz clock: 20 ms (a workgroup that gives up
+    // marks the solve - Ctrl::n_sync_timeouts - and the host runs it again on the paths that wait for nothing; MOVBA_TEST_WAIT_TICKS
+    // shortens the first attempt's bound so that tests can see that happen)
+    unsigned long long wait_ticks;
 };
 
 // Device view of the structure pass (struct_kernels.hip)

@@ -22,6 +22,8 @@ __device__ __forceinline__ void hx_st_f64(double *p, double v)
 {
     __hip_atomic_store((hx_g_i64 *)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ int hx_ld_i32(const int *p) { return (int)__hip_atomic_load((const hx_g_u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hx_st_i32(int *p, int v) { __hip_atomic_store((hx_g_u32 *)p, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned hx_ld_u32(const unsigned *p) { return __hip_atomic_load((const hx_g_u32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void hx_st_u32(unsigned *p, unsigned v) { __hip_atomic_store((hx_g_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // returning agent-scope add: the caller's later loads are ordered behind the returned value by its use
@@ -45,6 +47,15 @@ __device__ __forceinline__ void hx_st_f64x2(__amdgpu_buffer_rsrc_t r, unsigned b
     const hx_u32x4 v = { (unsigned)__double2loint(a), (unsigned)__double2hiint(a), (unsigned)__double2loint(b), (unsigned)__double2hiint(b) };
     __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16);
 }
+
+// 8-byte sc1 load through a descriptor (element index in doubles)
+__device__ __forceinline__ double hx_ld_f64(__amdgpu_buffer_rsrc_t r, unsigned idx)
+{
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)(idx * 8u), 0, 16);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+constexpr unsigned long long kHxWaitTicks = 2000000ull;      // bound of every device-side wait: 20 ms of the 100 MHz clock
 
 // ---- a double handed over as ONE self-announcing 16-byte record (value, tag, check word): one sc1 store of one lane, no
 // drain, no flag; the consumer's lane polls the record itself until tag and check word fit (MI355X_MICROARCH.md's

@@ -35,6 +35,7 @@ namespace movba {
 __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int nblk)
 {
     const int i = bid * blockDim.x + threadIdx.x;
+    for (int k = i; k < kXsItem0 + w.nitems; k += nblk * blockDim.x) w.xs[k] = 0u;      // hand-off words of the two streams: no epoch of an earlier run may fit
     for (int k = i; k < 8 * w.n_pt_blocks; k += nblk * blockDim.x) w.dec_rec[k] = 0u;  // the point pass's hand-off records: no tag of an earlier run may fit
     {
         const double2 *src = reinterpret_cast<const double2 *>(w.point0);
@@ -54,7 +55,7 @@ __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int 
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         w.ac_prev[kCoarseDim * kCoarseDim + 1] = -1.0;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
-        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; for (int q = 0; q < 8; ++q) c->dbg_wseg[k][q] = 0; }
+        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; c->dbg_xs[k] = 0; for (int q = 0; q < 8; ++q) c->dbg_wseg[k][q] = 0; }
     }
     if (i >= w.NP) return;
     double q[7];
@@ -88,6 +89,19 @@ __device__ __forceinline__ Cam cam_of_rt(const DevWindow &w, int ip) { return w.
 
 __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim.x); }
 
+// one lane waits for the reduced solve of epoch `epoch` (it runs on another stream): kXsOk, kXsParked or kXsFailed (also when
+// the wait itself gives up after 20 ms)
+__device__ __forceinline__ unsigned xs_wait_pcg(const DevWindow &w, unsigned epoch)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned v = hx_ld_u32(w.xs + kXsPcgDone);
+        if ((v & kXsEpochMask) == epoch) return v >> 24;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > w.wait_ticks) return kXsFailed;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
 // --------------------------------------------------------------------------------
 // decide_body: one wave - wave 0 of the extra workgroup of the back-substitution pass (block n_pt_blocks of point_body).
 // The accept / reject logic and lambda schedule of OptimizationAlgorithmLevenberg::solve plus the loop conditions of
@@ -97,10 +111,25 @@ __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim
 // and scale partials to this wave INSIDE the launch, as tagged 16-byte records (handoff.h) which its lanes poll: the
 // decision is taken ~1 us behind the last workgroup's partials, and the launch ends with it.)
 // --------------------------------------------------------------------------------
-__device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
+__device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigned wait_epoch)
 {
     Ctrl *c = w.ctrl;
     const int lane = threadIdx.x;
+    if (wait_epoch) {
+        // the trial's reduced solve runs on another stream (point_body): parked -> the host queues the direct solver and a
+        // pass of its own; gave up or never came -> the solve ends here (MOVBA_ERR_DEVICE_WAIT through n_sync_timeouts)
+        unsigned st = 0;
+        if (lane == 0) st = xs_wait_pcg(w, wait_epoch);
+        st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
+        if (st == kXsParked) return;
+        if (st != kXsOk) {
+            if (lane == 0) {
+                c->n_sync_timeouts += 1; c->done = 1;
+                __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
     // Lane-strided partial sums, records polled 10 blocks deep per lane (10 x 64 covers cfg3's 625 blocks in one round),
     // added in a fixed order once a round is complete.  A producer that never shows up (it cannot: none of them waits for
     // anything) ends the solve through the bounded wait instead of hanging the launch.
@@ -122,7 +151,7 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
                 ok &= hx_ld_tagged(rr, 2u * k + 1u, tag, sv[u]);
             }
             if (__all(ok)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t_start > 2000000ull) { good = false; break; }     // 20 ms of the 100 MHz clock
+            if (__builtin_amdgcn_s_memrealtime() - t_start > w.wait_ticks) { good = false; break; }      // (20 ms)
             __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
@@ -141,8 +170,10 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
     F1 = wave_sum(F1);
     scale = wave_sum(scale);
     if (lane != 0) return;
-    scale += w.scale_part[w.n_pt_blocks];
-    if (c->pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
+    // (what the solver left for this wave - the pose part of the scale, its failure flag, its iteration count - was written
+    //  through by a kernel that may have run beside this one: L1-bypassing loads)
+    scale += wait_epoch ? hx_ld_f64(w.scale_part + w.n_pt_blocks) : w.scale_part[w.n_pt_blocks];
+    if (wait_epoch ? hx_ld_i32(&c->pcg_fail) : c->pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
     scale += 1e-3;
     const double F0 = c->F0;
     const double rho = (F0 - F1) / scale;
@@ -150,7 +181,7 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
     const int tr = c->n_trace;
     if (tr < kMaxTrace) {
         c->tr_lambda[tr] = c->lambda; c->tr_f0[tr] = F0; c->tr_f1[tr] = F1; c->tr_rho[tr] = rho;
-        c->tr_pcg[tr] = c->pcg_last_iters;
+        c->tr_pcg[tr] = wait_epoch ? hx_ld_i32(&c->pcg_last_iters) : c->pcg_last_iters;
     }
     bool lambda_ok = true;
     int accepted = 0;
@@ -199,15 +230,18 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
 // --------------------------------------------------------------------------------
 // LDSP: the keyframe rotations (and, for BACKSUB, the pose increments and hessian indices) are staged in LDS; windows
 // with more keyframes than fit (~850) read them through L2 instead (same arithmetic, same results).
+// wait_epoch != 0 (back-substitution passes of a solve whose reduced solve runs on another stream, DevWindow::xs): the pass is
+// resident while the solve of its trial still runs; everything that does not depend on the solve (the points' own data, their
+// edges, the current state's rotations) is requested first, then the workgroup waits for the solve's word.
 template <bool BACKSUB, bool STEREO, bool LDSP, bool PERKF = false>
-__device__ __forceinline__ void point_body(const DevWindow &w, int bid)
+__device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned wait_epoch)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = w.ctrl;
     if (c->done) return;
     const int cur = c->cur;
     if (bid >= w.n_pt_blocks) {         // the pass's extra workgroup: its first wave takes the LM decision (back-substitution passes only)
-        if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur);
+        if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur, wait_epoch);
         return;
     }
     const int dst = BACKSUB ? (cur ^ 1) : cur;
@@ -260,13 +294,34 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         pur[k] = (STEREO && in) ? w.obs_r[g] : -1.0;
     }
 
-    if (LDSP) {
-        for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
-        if (BACKSUB) {
+    if (BACKSUB) {
+        if (LDSP) {
             for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[k];
-            for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
             for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
         }
+        // the trial's reduced solve (poses of the trial state, increments) may still be running on its own stream: one lane
+        // polls its word, the barrier releases the others.  A solve that parked itself or gave up: nothing to do here.
+        if (wait_epoch) {
+            int *stw = reinterpret_cast<int *>(red);
+            if (threadIdx.x == 0) *stw = (int)xs_wait_pcg(w, wait_epoch);
+            __syncthreads();
+            const int st = *stw;
+            __syncthreads();                                // (red is reused by the reductions at the end)
+            if (st != (int)kXsOk) return;
+            if (!LDSP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // poses / increments are read through L2 by plain loads: drop this CU's stale lines
+        }
+        if (LDSP) {
+            if (wait_epoch) {       // (write-through by the solve, L1-bypassing here: handoff.h)
+                for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = hx_ld_f64(S1.Rt + k);
+                for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = hx_ld_f64(w.xp + k);
+            } else {
+                for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+                for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
+            }
+            __syncthreads();
+        }
+    } else if (LDSP) {
+        for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
         __syncthreads();
     }
 
@@ -425,10 +480,10 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
 }
 
 template <bool BACKSUB, bool STEREO, bool LDSP>
-__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w) { point_body<BACKSUB, STEREO, LDSP>(w, blockIdx.x); }
+__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w, unsigned wait_epoch) { point_body<BACKSUB, STEREO, LDSP>(w, blockIdx.x, wait_epoch); }
 // intrinsics by keyframe (DevWindow::kcam): the variant that reads the keyframes' data through L2
 template <bool BACKSUB, bool STEREO>
-__global__ __launch_bounds__(kPointBlock) void k_point_kf(DevWindow w) { point_body<BACKSUB, STEREO, false, true>(w, blockIdx.x); }
+__global__ __launch_bounds__(kPointBlock) void k_point_kf(DevWindow w, unsigned wait_epoch) { point_body<BACKSUB, STEREO, false, true>(w, blockIdx.x, wait_epoch); }
 
 // Batched launches (movba_lba_run_batch): one grid over the concatenated windows; `pre` is the prefix of the windows'
 // block counts for this kernel.  Every window runs exactly the code of its solo launch, so results are bit-identical.
@@ -443,7 +498,7 @@ template <bool BACKSUB, bool STEREO, bool LDSP>
 __global__ __launch_bounds__(kPointBlock) void k_point_b(BatchDev b)
 {
     const int wi = batch_window(b.blk_point, b.n, blockIdx.x);
-    point_body<BACKSUB, STEREO, LDSP>(b.wins[wi], blockIdx.x - b.blk_point[wi]);
+    point_body<BACKSUB, STEREO, LDSP>(b.wins[wi], blockIdx.x - b.blk_point[wi], 0u);
 }
 
 __global__ void k_init_pose_b(BatchDev b)
@@ -621,8 +676,10 @@ constexpr int kSchurBatchDiag = MOVBA_SCHUR_BD;     // entries per lane whose ga
 constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
 
 // HPP_ONLY: diagonal pairs only, Hpp and b_p only (one launch per solve, seeds lambda)
+// trial >= 0: the pass belongs to LM trial `trial` of a solve whose reduced solve waits on another stream (DevWindow::xs):
+// every finished item raises its flag, a pass that finds the solve finished or parked says so
 template <int NR, bool HPP_ONLY, bool PERKF = false>
-__device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
+__device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int trial)
 {
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long wst[5];
@@ -639,7 +696,10 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
     const int wg = (bid & 7) * (w.sched_per_xcd / ipw) + (bid >> 3);
     const SchedItem it = w.sched[wg * ipw + wv / kSchurWPI];
     const Ctrl *c = w.ctrl;
-    if (c->done) return;
+    if (c->done) {
+        if (trial >= 0 && bid == 0 && threadIdx.x == 0) hx_st_u32(w.xs + kXsSkip, (unsigned)trial + 1u);
+        return;
+    }
     const int sub = wv % kSchurWPI;
     __shared__ __attribute__((aligned(16))) double strips[kSchurWaves][54 * 16];
     __shared__ double wsum[kSchurWaves][64];
@@ -747,13 +807,41 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
         double t = wsum[wv][lane];
 #pragma unroll
         for (int q = 1; q < kSchurWPI; ++q) t += wsum[wv + q][lane];
+        // (write-through stores: the item's partial may be taken by a solve that is already resident on another stream)
         if (is_diag) {
             if (lane < 54) {
-                out[kDiagMap[lane]] = t;
+                hx_st_f64(out + kDiagMap[lane], t);
                 // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
-                if (lane < 21 && kDiagMirror[lane] >= 0) out[kDiagMirror[lane]] = t;
+                if (lane < 21 && kDiagMirror[lane] >= 0) hx_st_f64(out + kDiagMirror[lane], t);
             }
-        } else if (lane < 36) out[lane] = t;
+            // ... and once more as the on-chip PCG's setup reads it (DevWindow::rec_d): per row a of the keyframe's block the six
+            // values of Hpp - sum B Dinv B^T, then (sum B Dinv b_l)_a and (b_p)_a.  The 54 sums sit one per lane ([0,21) upper
+            // B Dinv B^T, [21,27) B Dinv b_l, [27,48) upper Hpp, [48,54) b_p): exchanged through the wave's LDS strip.
+            wsum[wv][lane] = t;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < 48) {
+                double *rec = w.rec_d + (size_t)item * 48;
+                if (lane < 36) {
+                    const int a = lane / 6, q = lane - a * 6, u = a <= q ? ut6(a, q) : ut6(q, a);
+                    hx_st_f64(rec + a * 8 + q, wsum[wv][27 + u] - wsum[wv][u]);
+                } else if (lane < 42) hx_st_f64(rec + (lane - 36) * 8 + 6, wsum[wv][21 + (lane - 36)]);
+                else hx_st_f64(rec + (lane - 42) * 8 + 7, wsum[wv][48 + (lane - 42)]);
+            }
+        } else if (lane < 36) {
+            hx_st_f64(out + lane, t);
+            // ... and where the lanes of the on-chip PCG that hold the block read it (DevWindow::img_b), as stored and transposed
+            if (it.dst_a >= 0) hx_st_f64(w.img_b + it.dst_a + (size_t)lane * kPcgRowsThreads, t);
+            if (it.dst_b >= 0) hx_st_f64(w.img_b + it.dst_b + (size_t)((lane % 6) * 6 + lane / 6) * kPcgRowsThreads, t);
+        }
+        if (trial >= 0) {           // ONE wave stored the item: its drain, then its first lane raises the item's flag
+            hx_drain();
+            if (lane == 0) hx_st_u32(w.xs + kXsItem0 + item, (unsigned)trial + 1u);
+#ifdef MOVBA_CLOCK_STAMP
+            if (lane == 0) atomicMax(&w.ctrl->dbg_xs[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+#endif
+        }
     }
 #ifdef MOVBA_CLOCK_STAMP
     WSTAMP(4);
@@ -768,17 +856,17 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
 }
 
 template <int NR, bool HPP_ONLY>
-__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w) { schur_body<NR, HPP_ONLY>(w, blockIdx.x); }
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int trial) { schur_body<NR, HPP_ONLY>(w, blockIdx.x, trial); }
 
 // (a window with intrinsics by keyframe: solved on its own, never in a batch - api.cpp)
 template <int NR, bool HPP_ONLY>
-__global__ __launch_bounds__(kSchurWaves * 64) void k_schur_kf(DevWindow w) { schur_body<NR, HPP_ONLY, true>(w, blockIdx.x); }
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur_kf(DevWindow w, int trial) { schur_body<NR, HPP_ONLY, true>(w, blockIdx.x, trial); }
 
 template <int NR, bool HPP_ONLY>
 __global__ __launch_bounds__(kSchurWaves * 64) void k_schur_b(BatchDev b)
 {
     const int wi = batch_window(b.blk_schur, b.n, blockIdx.x);
-    schur_body<NR, HPP_ONLY>(b.wins[wi], blockIdx.x - b.blk_schur[wi]);
+    schur_body<NR, HPP_ONLY>(b.wins[wi], blockIdx.x - b.blk_schur[wi], -1);
 }
 
 // --------------------------------------------------------------------------------
@@ -944,34 +1032,34 @@ hipError_t launch_init(const DevWindow &w, hipStream_t s)
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 {
     if (w.kcam) {
-        if (w.stereo) hipLaunchKernelGGL((k_point_kf<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w);
-        else hipLaunchKernelGGL((k_point_kf<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w, 0u);
+        else hipLaunchKernelGGL((k_point_kf<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w, 0u);
     } else if (!w.lds_poses) {
-        if (w.stereo) hipLaunchKernelGGL((k_point<false, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
-        else hipLaunchKernelGGL((k_point<false, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
-    } else if (w.stereo) hipLaunchKernelGGL((k_point<false, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
-    else hipLaunchKernelGGL((k_point<false, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_point<false, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
+        else hipLaunchKernelGGL((k_point<false, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<false, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
+    else hipLaunchKernelGGL((k_point<false, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
     return hipGetLastError();
 }
 
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
     const int nblk = 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI));                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
-    (void)trial;
+    if (mode == 1) trial = -1;          // (the pass that seeds lambda hands nothing over)
     if (w.kcam) {
         if (mode == 1) {
-            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
-            else hipLaunchKernelGGL((k_schur_kf<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+            else hipLaunchKernelGGL((k_schur_kf<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
         } else {
-            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
-            else hipLaunchKernelGGL((k_schur_kf<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+            else hipLaunchKernelGGL((k_schur_kf<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
         }
     } else if (mode == 1) {
-        if (w.stereo) hipLaunchKernelGGL((k_schur<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
-        else hipLaunchKernelGGL((k_schur<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_schur<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+        else hipLaunchKernelGGL((k_schur<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
     } else {
-        if (w.stereo) hipLaunchKernelGGL((k_schur<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
-        else hipLaunchKernelGGL((k_schur<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_schur<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+        else hipLaunchKernelGGL((k_schur<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
     }
     return hipGetLastError();
 }
@@ -982,17 +1070,17 @@ hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
+hipError_t launch_backsub(const DevWindow &w, unsigned wait_epoch, hipStream_t s)
 {
     // (one workgroup more than the points need: its first wave takes the LM decision, decide_body)
     if (w.kcam) {
-        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
-        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w, wait_epoch);
+        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w, wait_epoch);
     } else if (!w.lds_poses) {
-        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
-    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
+        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
+    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
     return hipGetLastError();
 }
 

@@ -31,6 +31,7 @@
 #include "coarse_level.h"
 #include "device_math.h"
 #include "device_types.h"
+#include "handoff.h"
 #include "kernels.h"
 
 namespace movba {
@@ -64,53 +65,110 @@ __device__ __forceinline__ double sum_fixed(const double *red)
     return ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
 }
 
-// element (r,c) of the damped reduced-matrix block `pr` (upper-triangle pair id), summed from the
-// schur work-item partials in item order
-__device__ __forceinline__ double s_block_elem(const double *part, int pr, int i0, int i1, int r, int c, double lambda, int nf)
-{
-    double s = 0.0;
-    for (int itx = i0; itx < i1; ++itx) s += part[(size_t)itx * kPartStride + r * 6 + c];
-    double v = -s;
-    if (pr < nf) {
-        const int u = r <= c ? ut6(r, c) : ut6(c, r);
-        double hpp = 0.0;
-        for (int itx = i0; itx < i1; ++itx) hpp += part[(size_t)itx * kPartStride + 42 + u];
-        v += hpp + (r == c ? lambda : 0.0);
-    }
-    return v;
-}
-
 }  // namespace
 
 // OVERFLOW: some wave's gather list does not fit its 64 VGPR-resident pairs; the tail is multiplied from an L2 copy of S
 // (a separate instantiation: its extra live values must not cost the common case registers)
 // role 0: the solving workgroup, role 1: the coarse-level builder of the same launch
-template <bool OVERFLOW>
+// The workgroup waits until every work item of the trial's schur pass has raised its flag (the pass runs on another stream and
+// may still be at work when this launch becomes resident): 0 = all there, 1 = the pass was a no-op (the solve is finished or
+// parked: leave), 2 = gave up after 20 ms.  Workgroup-uniform; `scratch`: 8 ints of LDS.
+template <int kThreads>
+__device__ __forceinline__ int xs_wait_items(const DevWindow &w, unsigned epoch, int *scratch)
+{
+    const int tid = threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        bool ok = true;
+        for (int i = tid; i < w.nitems; i += kThreads) ok &= hx_ld_u32(w.xs + kXsItem0 + i) == epoch;
+        const bool skip = hx_ld_u32(w.xs + kXsSkip) >= epoch;        // (epochs only grow within a run: a later no-op pass may have overwritten this one's)
+        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > w.wait_ticks;
+        const int bits = (__any(!ok) ? 1 : 0) | (__any(skip) ? 2 : 0) | (__any(late) ? 4 : 0);
+        if ((tid & 63) == 0) scratch[tid >> 6] = bits;
+        __syncthreads();
+        int all = 0;
+#pragma unroll
+        for (int k = 0; k < kThreads / 64; ++k) all |= scratch[k];
+        __syncthreads();
+        if (all & 2) return 1;
+        if (!(all & 1)) return 0;
+        if (all & 4) return 2;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// one wave waits for the first sign of life of the trial's schur pass (the flag of work item 0: the pass found the solve
+// running, so the LM state this trial starts from is final) or for the pass's no-op word: 0 / 1 / 2 as xs_wait_items
+template <int kThreads>
+__device__ __forceinline__ int xs_wait_live(const DevWindow &w, unsigned epoch, int *scratch)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int st = 0;
+        for (;;) {
+            if (hx_ld_u32(w.xs + kXsItem0) == epoch) break;
+            if (hx_ld_u32(w.xs + kXsSkip) >= epoch) { st = 1; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > w.wait_ticks) { st = 2; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        scratch[0] = st;
+    }
+    __syncthreads();
+    const int st = scratch[0];
+    __syncthreads();
+    return st;
+}
+
+// XS: the launch sits on a stream of its own beside the schur pass of its trial (api.cpp, lm_loop).  Nothing the other stream's
+// kernels write is read before the pass's flags say so: the workgroup waits for the whole pass, makes ONE agent-scope acquire
+// (cdna_hip_programming.md Guideline 16's recipe) and reads what the pass left with plain loads.  Results leave
+// write-through, behind them the word the back-substitution pass waits for.  The arithmetic does not depend on XS.
+// (A solver that took the partials item by item, each lane as soon as its items were flagged, was measured 10 us per trial
+//  SLOWER than the one-stream launch: every look at a flag and every dependent load is a 1.5 - 2 us device-scope round trip,
+//  and a lane made six of them per turn of its polling loop - DESIGN.md, round 4.)
+template <bool OVERFLOW, bool XS>
 __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParams &pp, int trial, int role)
 {
+    static_assert(!(OVERFLOW && XS), "windows whose lists overflow the registers stay on one stream");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
-    if (c->done) return;
     const int tid = threadIdx.x, ln = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: row ranges and their predicates live in SGPRs
+    const unsigned epoch = (unsigned)trial + 1u;
+    // use_coarse == 2 (windows with at most one keyframe per wave: the coarse space is the whole space): the coarse level
+    // is built FIRST, by this workgroup, from THIS trial's matrix, and the solve below converges in a couple of iterations
+    const bool fresh = pp.use_coarse == 2;
+    // two streams: the solver proper first loads what does not depend on the pass (its plans, the coarse inverse), then waits
+    const bool late_wait = XS && role == 0 && !fresh;
+    if (!XS) { if (c->done) return; }
+    else if (!late_wait) {
+        const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(sm));
+        if (wt == 1) return;
+        if (wt == 2) {              // never seen: the back-substitution pass ends the solve and the host runs it again on one stream
+            if (role == 0 && tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24));
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     const int nf = w.nfree, n = 6 * nf;
-    const int cur = c->cur;
+    // the LM state of this trial (written by the previous trial's decision: on the two-stream path a kernel of the other stream,
+    // finished by the time the schur pass shows its flags)
+    int cur = 0;
+    double lambda = 0.0;
+    if (!late_wait) { cur = XS ? hx_ld_i32(&c->cur) : c->cur; lambda = XS ? hx_ld_f64(&c->lambda) : c->lambda; }
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long setup_last = stamp_c0;
 #endif
-    const double lambda = c->lambda;
-    // use_coarse == 2 (windows with at most one keyframe per wave: the coarse space is the whole space): the coarse level
-    // is built FIRST, by this workgroup, from THIS trial's matrix, and the solve below converges in a couple of iterations
-    const bool fresh = pp.use_coarse == 2;
+    const double *part = w.part;
     if (fresh) {
-        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false);
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false, false);
         __syncthreads();
     } else if (role == 1) {         // second workgroup: coarse level of THIS trial's matrix, for the next trial
-        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true);
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true, true);
         return;
     }
-    const double *part = w.part;
     const int npad = (n + 1) & ~1;
     const int nrowent_all = w.row_ptr[nf];
 
@@ -209,68 +267,96 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // ---- diagonal blocks and right-hand side, cooperatively: owner lane (bi, ba) sums ROW ba of S_ii = Hpp + lambda I -
     // sum B Dinv B^T, b_p and B Dinv b_l over the work items of pair (bi, bi), four items in flight: the cost does not
     // grow with the number of items a long diagonal pair is cut into ----
+    // ---- two streams: everything above came from this stream's own kernels and from the upload; from here on the schur pass ----
+    if (late_wait) {
+        const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(red0));       // (its barriers also order s_fail = 0 above)
+        if (wt == 1) return;
+        if (wt == 2) { if (tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24)); return; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        cur = hx_ld_i32(&c->cur); lambda = hx_ld_f64(&c->lambda);
+    }
+    // ---- diagonal blocks and right-hand side: owner lane (bi, ba) sums ROW ba of S_ii = Hpp - sum B Dinv B^T (+ lambda), of
+    // B Dinv b_l and of b_p over the work items of pair (bi, bi).  The schur pass leaves every diagonal item once more in the
+    // layout THIS loop reads (DevWindow::rec_d: per item and row 8 contiguous doubles = the row of Hpp - B Dinv B^T, then
+    // B Dinv b_l and b_p): four 16-byte loads per item and lane, the six rows of a keyframe on one 384-byte run - until round 4
+    // the lane gathered 14 scattered doubles per item from the 72-double partial (6 us per launch on the one CU's texture
+    // addresser).  Items in order, four in flight. ----
     double r_r = 0.0;
     if (owner) {
-        int hu[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) hu[q] = 42 + (ba <= q ? ut6(ba, q) : ut6(q, ba));
-        double s6[6] = { 0, 0, 0, 0, 0, 0 }, h6[6] = { 0, 0, 0, 0, 0, 0 }, cc = 0.0, bb = 0.0;
+        double d6[6] = { 0, 0, 0, 0, 0, 0 }, cc = 0.0, bb = 0.0;
         for (int i0 = oi0; i0 < oi1; i0 += 4) {
-            double sv[4][6], hv[4][6], cv[4], bv[4];
+            double2 v[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double *src = part + (size_t)min(i0 + u, oi1 - 1) * kPartStride;
+                const double2 *src = reinterpret_cast<const double2 *>(w.rec_d + (size_t)min(i0 + u, oi1 - 1) * 48 + ba * 8);
 #pragma unroll
-                for (int q = 0; q < 6; ++q) { sv[u][q] = src[ba * 6 + q]; hv[u][q] = src[hu[q]]; }
-                cv[u] = src[36 + ba]; bv[u] = src[63 + ba];
+                for (int q = 0; q < 4; ++q) v[u][q] = src[q];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool in = i0 + u < oi1;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) { s6[q] += in ? sv[u][q] : 0.0; h6[q] += in ? hv[u][q] : 0.0; }
-                cc += in ? cv[u] : 0.0; bb += in ? bv[u] : 0.0;
+                d6[0] += in ? v[u][0].x : 0.0; d6[1] += in ? v[u][0].y : 0.0; d6[2] += in ? v[u][1].x : 0.0;
+                d6[3] += in ? v[u][1].y : 0.0; d6[4] += in ? v[u][2].x : 0.0; d6[5] += in ? v[u][2].y : 0.0;
+                cc += in ? v[u][3].x : 0.0; bb += in ? v[u][3].y : 0.0;
             }
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) sdiag[bi * 36 + ba * 6 + q] = (h6[q] + (q == ba ? lambda : 0.0)) - s6[q];
+        for (int q = 0; q < 6; ++q) sdiag[bi * 36 + ba * 6 + q] = d6[q] + (q == ba ? lambda : 0.0);
         r_r = bb - cc;
         w.bp[row] = bb;
     }
     SETUP_STAMP(0);
     __syncthreads();
+#ifdef MOVBA_CLOCK_STAMP
+    const unsigned long long xs_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    // ---- this lane's pair of oriented blocks: off-diagonal ones straight from the partials, diagonal ones from LDS ----
+    // ---- this lane's pair of oriented blocks.  Off-diagonal ones: the schur pass leaves the block of a pair that is ONE work
+    // item (almost all are) in both orientations where this kernel's lanes read it - DevWindow::img_b, element q of the block
+    // of (thread, slot k) at ((36 k + q) 512 + thread): 72 coalesced 8-byte loads per lane instead of eighteen 16-byte gathers
+    // per block from the item's partial (each lane its own three cache lines: 4.5 us per launch).  Pairs cut into several items
+    // are still summed from the partials here; diagonal blocks come from LDS. ----
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         colo[k] = 0;
-        double raw[36];
+        const int4 pl = k ? pl1 : pl0;
+        const bool valid = pl.x >= 0, tr = valid && ((pl.y >> 30) & 1) != 0;
+        if (valid) colo[k] = pl.y & 0x3fffffff;
+        const bool diag = valid && pl.x < nf, from_img = !OVERFLOW && valid && pl.x >= nf && pl.w - pl.z == 1;
+        if (!OVERFLOW) {
+            // (every lane reads its image slot - the loads are coalesced whatever the lanes need; a slot nothing wrote is not used)
+            const double *src = w.img_b + (size_t)(36 * k) * kT + tid;
+            double v[36];
 #pragma unroll
-        for (int q = 0; q < 36; ++q) raw[q] = 0.0;
-        bool valid = false, tr = false;
-        {
-            const int4 pl = k ? pl1 : pl0;
-            if (pl.x >= 0) {
-                valid = true; tr = ((pl.y >> 30) & 1) != 0;
-                colo[k] = pl.y & 0x3fffffff;
-                if (pl.x < nf) {
-                    const double2 *src = reinterpret_cast<const double2 *>(sdiag + pl.x * 36);
+            for (int q = 0; q < 36; ++q) v[q] = src[(size_t)q * kT];
 #pragma unroll
-                    for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] = v.x; raw[2 * q + 1] = v.y; }
-                } else {
-                    // S_block = - sum over the pair's work items of the 6x6 partial (wide, independent loads)
-                    for (int itx = pl.z; itx < pl.w; ++itx) {
-                        const double2 *src = reinterpret_cast<const double2 *>(part + (size_t)itx * kPartStride);
+            for (int q = 0; q < 36; ++q) Bo[k][q] = from_img ? -v[q] : 0.0;
+        } else {
 #pragma unroll
-                        for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] -= v.x; raw[2 * q + 1] -= v.y; }
-                    }
-                }
-            }
+            for (int q = 0; q < 36; ++q) Bo[k][q] = 0.0;
         }
+        if (diag) {         // (symmetric: no orientation)
+            const double2 *src = reinterpret_cast<const double2 *>(sdiag + pl.x * 36);
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int q = 0; q < 18; ++q) { const double2 v = src[q]; Bo[k][2 * q] = v.x; Bo[k][2 * q + 1] = v.y; }
+        }
+        if (__any(valid && !diag && !from_img)) {
+            // pairs cut into several work items (and every off-diagonal block of a window whose lists overflow the registers):
+            // S_block = - sum over the pair's work items of the 6x6 partial (wide, independent loads), then oriented
+            double raw[36];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = valid ? (tr ? raw[q * 6 + a] : raw[a * 6 + q]) : 0.0;
+            for (int q = 0; q < 36; ++q) raw[q] = 0.0;
+            const bool mine = valid && !diag && !from_img;
+            for (int itx = mine ? pl.z : 0; itx < (mine ? pl.w : 0); ++itx) {
+                const double2 *src = reinterpret_cast<const double2 *>(part + (size_t)itx * kPartStride);
+#pragma unroll
+                for (int q = 0; q < 18; ++q) { const double2 v = src[q]; raw[2 * q] -= v.x; raw[2 * q + 1] -= v.y; }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Bo[k][a * 6 + q] = mine ? (tr ? raw[q * 6 + a] : raw[a * 6 + q]) : Bo[k][a * 6 + q];
+        }
     }
     SETUP_STAMP(1);
 
@@ -414,12 +500,17 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // of three and two.  The restricted residual P^T r follows r_c -= alpha P^T s with P^T s = P^T w + beta P^T s.
     double p_r = 0.0, s_r = 0.0;
     double inv_gamma = 1.0, inv_alpha = 0.0, alpha = 0.0, thresh = 0.0;
+    if (XS && s_fail == 2) {        // a wait for the schur pass's items was given up (never seen): the host runs the solve again on one stream
+        if (tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24));
+        return;
+    }
     bool fail = s_fail != 0;
     bool first = true;
     int iters = 0;
 
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, seg_last = __builtin_amdgcn_s_memtime();
+    const unsigned long long xs_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (!fail) {
         for (iters = 1; iters <= pp.max_iters; ++iters) {
@@ -537,25 +628,35 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     const bool capped = iters > pp.max_iters;
     if (capped) iters = pp.max_iters;
     __syncthreads();
+#ifdef MOVBA_CLOCK_STAMP
+    const unsigned long long xs_t3 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- no answer from the PCG (a diagonal block was not positive definite, the recurrence broke down, or the cap was
     // reached before the tolerance: a weakly constrained window, where an iterative solve departs from the exact step
     // anyway): park the solve (Ctrl::done = 2 turns every kernel queued behind into a no-op) and tell the host, which
     // queues the direct solver (dense_solve.hip) for this trial and for every later one.  fail / capped are workgroup-uniform.
     if (fail || capped) {
         if (tid == 0) {
-            c->pcg_last_iters = iters;
-            c->pcg_total_iters += iters;
-            c->solver_mode = 1; c->direct_from = c->n_solves;
-            c->n_pause += 1;
-            c->done = 2;
-            __hip_atomic_store(&w.hstat->pause_seq, c->n_pause, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // (write-through: the back-substitution pass of this trial may already be resident on the other stream, and the
+            //  passes queued behind it must find the solve parked)
+            const int np = c->n_pause + 1;
+            hx_st_i32(&c->pcg_last_iters, iters);
+            hx_st_i32(&c->pcg_total_iters, c->pcg_total_iters + iters);
+            hx_st_i32(&c->solver_mode, 1); hx_st_i32(&c->direct_from, XS ? hx_ld_i32(&c->n_solves) : c->n_solves);
+            hx_st_i32(&c->n_pause, np);
+            hx_st_i32(&c->done, 2);
+            if (XS) { hx_drain(); hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsParked << 24)); }
+            __hip_atomic_store(&w.hstat->pause_seq, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
 
     // ---- outputs: increment, pose part of computeScale(), trial poses (VertexSE3Expmap::oplusImpl) ----
+    // (two streams: everything the back-substitution pass reads leaves write-through, handoff.h: the pass may be resident already)
+    auto stq = [&](double *p, double v) { if (XS) hx_st_f64(p, v); else *p = v; };
+    auto sti = [&](int *p, int v) { if (XS) hx_st_i32(p, v); else *p = v; };
     const double xv = owner ? x_r : 0.0;
-    if (owner) { w.xp[row] = xv; p_lds[row] = xv; }
+    if (owner) { stq(w.xp + row, xv); p_lds[row] = xv; }
     {
         const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + w.bp[row]) : 0.0);
         if (ln == 0) red0[wv] = ps;
@@ -581,19 +682,19 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         double R[9];
         quat_to_R(Tn, R);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) S1.pose[7 * i + k] = Tn[k];
+        for (int k = 0; k < 7; ++k) stq(S1.pose + 7 * i + k, Tn[k]);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
-        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
+        for (int k = 0; k < 9; ++k) stq(S1.Rt + 12 * i + k, R[k]);
+        stq(S1.Rt + 12 * i + 9, Tn[4]); stq(S1.Rt + 12 * i + 10, Tn[5]); stq(S1.Rt + 12 * i + 11, Tn[6]);
     }
 #ifdef MOVBA_CLOCK_STAMP
     if (ln == 0) for (int k = 0; k < 8; ++k) c->dbg_wseg[wv][k] += seg[k];
 #endif
     if (tid == 0) {
-        w.scale_part[w.n_pt_blocks] = scs;
-        c->pcg_fail = 0;
-        c->pcg_last_iters = iters;
-        c->pcg_total_iters += iters;
+        stq(w.scale_part + w.n_pt_blocks, scs);
+        sti(&c->pcg_fail, 0);
+        sti(&c->pcg_last_iters, iters);
+        sti(&c->pcg_total_iters, c->pcg_total_iters + iters);
 #ifdef MOVBA_CLOCK_STAMP
         c->dbg_cycles += __builtin_amdgcn_s_memtime() - stamp_c0;
         c->dbg_ticks += __builtin_amdgcn_s_memrealtime() - stamp_t0;
@@ -601,10 +702,29 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         (void)setup_last;
 #endif
     }
+    // every storing wave drains, the workgroup meets, ONE lane raises the word the back-substitution pass waits for - once the
+    // coarse-level workgroup has read this trial's partials (long ago: the next schur pass, which overwrites them, starts
+    // behind that pass)
+    if (!XS) return;
+    hx_drain();
+    __syncthreads();
+    if (tid == 0) {
+        if (pp.use_coarse == 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (hx_ld_u32(w.xs + kXsCoarseRead) != epoch && __builtin_amdgcn_s_memrealtime() - t0 <= w.wait_ticks) __builtin_amdgcn_s_sleep(4);
+        }
+        hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsOk << 24));
+#ifdef MOVBA_CLOCK_STAMP
+        if (XS) {
+            const unsigned long long xs_t4 = __builtin_amdgcn_s_memrealtime(), last = hx_ld_u32(w.xs) * 0ull + __hip_atomic_load(&c->dbg_xs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c->dbg_xs[1] += xs_t1 - last; c->dbg_xs[2] += xs_t2 - last; c->dbg_xs[3] += xs_t3 - last; c->dbg_xs[4] += xs_t4 - last; c->dbg_xs[5] += 1;
+        }
+#endif
+    }
 }
 
-template <bool OVERFLOW>
-__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW>(w, pp, trial, blockIdx.x); }
+template <bool OVERFLOW, bool XS>
+__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW, XS>(w, pp, trial, blockIdx.x); }
 
 // batched: workgroups 2 i and 2 i + 1 are the solver and the coarse builder of window i (a window in fresh-coarse mode
 // has no builder: its second workgroup returns at once)
@@ -614,15 +734,20 @@ __global__ __launch_bounds__(kT) void k_pcg_rows_b(BatchDev b, int trial)
     const int wi = blockIdx.x >> 1, role = blockIdx.x & 1;
     const PcgParams &pp = b.pps[wi];
     if (role == 1 && pp.use_coarse != 1) return;
-    pcg_rows_body<OVERFLOW>(b.wins[wi], pp, trial, role);
+    pcg_rows_body<OVERFLOW, false>(b.wins[wi], pp, trial, role);
 }
 
 static_assert(kNW == kPcgPlanWaves && kNC == kCoarseDim && kOwnBatch == kPcgPlanOwnBatch, "pcg_plan.cpp sizes the LDS carve of this kernel");
 
-hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, bool xs, hipStream_t s)
 {
-    if (pp.overflow) hipLaunchKernelGGL(k_pcg_rows<true>, dim3(pp.use_coarse == 1 ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
-    else hipLaunchKernelGGL(k_pcg_rows<false>, dim3(pp.use_coarse == 1 ? 2 : 1), dim3(kT), pcg_rows_lds_bytes(w.nfree, nrowent), s, w, pp, trial);
+    const dim3 g(pp.use_coarse == 1 ? 2 : 1), t(kT);
+    const size_t lds = pcg_rows_lds_bytes(w.nfree, nrowent);
+    if (pp.overflow) {
+        if (xs) return hipErrorInvalidValue;        // (api.cpp keeps such windows on one stream)
+        hipLaunchKernelGGL((k_pcg_rows<true, false>), g, t, lds, s, w, pp, trial);
+    } else if (xs) hipLaunchKernelGGL((k_pcg_rows<false, true>), g, t, lds, s, w, pp, trial);
+    else hipLaunchKernelGGL((k_pcg_rows<false, false>), g, t, lds, s, w, pp, trial);
     return hipGetLastError();
 }
 
@@ -635,7 +760,8 @@ hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, size_t lds, i
 
 hipError_t configure_pcg_rows()
 {
-    const void *fs[4] = { reinterpret_cast<const void *>(k_pcg_rows<false>), reinterpret_cast<const void *>(k_pcg_rows<true>),
+    const void *fs[5] = { reinterpret_cast<const void *>(k_pcg_rows<false, false>), reinterpret_cast<const void *>(k_pcg_rows<true, false>),
+                          reinterpret_cast<const void *>(k_pcg_rows<false, true>),
                           reinterpret_cast<const void *>(k_pcg_rows_b<false>), reinterpret_cast<const void *>(k_pcg_rows_b<true>) };
     for (const void *f : fs) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);

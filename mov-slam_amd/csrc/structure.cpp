@@ -204,13 +204,13 @@ int finish_pairs(Structure& s, const int32_t* cnt)
             longest = std::max(longest, (size_t)(seg_begin[g + 1] - seg_begin[g]));
         }
         s.sched_per_xcd = (int)((longest + ipw - 1) / ipw) * ipw;
-        s.sched.assign((size_t)8 * s.sched_per_xcd, SchedItem{ 0, 0, -1, 0, 0, { 0, 0, 0 } });
+        s.sched.assign((size_t)8 * s.sched_per_xcd, SchedItem{ 0, 0, -1, 0, 0, -1, -1, 0 });
         for (int g = 0; g < 8; ++g)
             for (int n = seg_begin[g]; n < seg_begin[g + 1]; ++n) {
                 const int item = order[(uint32_t)key[n]];
                 const Item& it = s.items[item];
                 s.sched[(size_t)g * s.sched_per_xcd + (n - seg_begin[g])] = SchedItem{ it.begin, it.end, (item << 1) | (it.diag ? 1 : 0),
-                                                                                      s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], { 0, 0, 0 } };
+                                                                                      s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], -1, -1, 0 };
             }
     }
 

@@ -20,7 +20,12 @@ struct Int2 { int32_t x, y; };
 struct Int4 { int32_t x, y, z, w; };
 struct Item { int32_t pair, begin, end, diag; };   // entries [begin,end) of one pair
 // one slot of the k_schur launch schedule: everything a workgroup needs to start, in one 32-byte scalar load
-struct SchedItem { int32_t begin, end, tag /* (item << 1) | diagonal, -1 = padding */, pose_i, pose_j /* pose indices of the pair */, pad[3]; };
+struct SchedItem {
+    int32_t begin, end, tag /* (item << 1) | diagonal, -1 = padding */, pose_i, pose_j /* pose indices of the pair */;
+    // off-diagonal items of single-item pairs, windows with an on-chip PCG: where the item's 6 x 6 block goes in DevWindow::img_b,
+    // as stored (dst_a) and transposed (dst_b): 36 k 512 + thread of the PCG lane slot that holds it, or -1
+    int32_t dst_a, dst_b, pad;
+};
 struct RowEnt { int32_t block, col, transposed, pad; };
 
 struct Structure {

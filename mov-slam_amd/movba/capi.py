@@ -54,7 +54,7 @@ class LbaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
-                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32), ("reorder", C.c_int32), ("pad_o", C.c_int32)]
+                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32), ("reorder", C.c_int32), ("two_streams", C.c_int32)]
 
 
 class Profile(C.Structure):

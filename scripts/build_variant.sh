@@ -11,6 +11,7 @@ done
 for f in api.cpp structure.cpp dense_plan.cpp pcg_plan.cpp; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -I$ROOT/include -I. -Wno-unused-function --offload-arch=gfx950 -ffp-contract=on "$@" -x hip -c $f -o $B/${f%.cpp}.o &
 done
-wait
+FAIL=0; for j in $(jobs -p); do wait $j || FAIL=1; done
+[ $FAIL = 0 ] || { echo "build_variant: a compile failed" >&2; exit 1; }
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/libmovba_$TAG.so $B/*.o
 echo built $ROOT/build/libmovba_$TAG.so

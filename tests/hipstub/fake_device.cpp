@@ -8,6 +8,7 @@
 
 #include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "device_types.h"
@@ -147,6 +148,14 @@ hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t
 
 // ---- the LM controller's protocol ----
 namespace {
+// (Ctrl::done is the one word both streams of a two-stream solve may touch at the same moment - the solve parks itself while
+//  the back-substitution pass of its trial is starting - as on the device, where the pass then learns it from the solve's word)
+int rd_done(const Ctrl *c) { return __atomic_load_n(&c->done, __ATOMIC_ACQUIRE); }
+void wr_done(Ctrl *c, int v) { __atomic_store_n(&c->done, v, __ATOMIC_RELEASE); }
+// the hand-off words of the two streams (DevWindow::xs), as the kernels use them
+unsigned xs_rd(const DevWindow &w, int k) { return __atomic_load_n(w.xs + k, __ATOMIC_ACQUIRE); }
+void xs_wr(const DevWindow &w, int k, unsigned v) { __atomic_store_n(w.xs + k, v, __ATOMIC_RELEASE); }
+
 void fake_init(const DevWindow &w)
 {
     // reads everything the upload sent (the caller's arrays crossed on the copy stream: the solve waits for their event)
@@ -158,55 +167,89 @@ void fake_init(const DevWindow &w)
     std::memcpy(w.st[0].pose, w.pose0, 56 * (size_t)w.NP);
     std::memcpy(w.st[0].point, w.point0, 24 * (size_t)w.P);
     std::memset(w.dec_rec, 0, sizeof(unsigned) * 8 * (size_t)w.n_pt_blocks);
+    for (int k = 0; k < kXsItem0 + w.nitems; ++k) xs_wr(w, k, 0u);
     Ctrl *c = w.ctrl;
     std::memset(c, 0, sizeof(Ctrl));
-    c->nu = 2.0; c->done = (w.max_iters <= 0) ? 1 : 0; c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
+    c->nu = 2.0; wr_done(c, (w.max_iters <= 0) ? 1 : 0); c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
 }
 void fake_decide(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
-    if (c->done) return;
+    if (__atomic_load_n(&c->done, __ATOMIC_ACQUIRE)) return;
     const int stall = g_stall_after.load();
     if (stall >= 0 && c->n_solves >= stall) return;              // a hung device: no progress, no completion
     c->n_solves += 1; c->it += 1; c->iters_done = c->it;
     if (c->n_trace < kMaxTrace) { c->tr_accept[c->n_trace] = 1; c->tr_pcg[c->n_trace] = c->pcg_last_iters; c->n_trace += 1; }
-    if (c->it >= w.max_iters || __atomic_load_n(&w.hstat->stop, __ATOMIC_ACQUIRE)) c->done = 1;
-    __atomic_store_n(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, c->done == 1), __ATOMIC_RELEASE);
+    const bool fin = c->it >= w.max_iters || __atomic_load_n(&w.hstat->stop, __ATOMIC_ACQUIRE);
+    if (fin) __atomic_store_n(&c->done, 1, __ATOMIC_RELEASE);
+    __atomic_store_n(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, fin), __ATOMIC_RELEASE);
 }
-void fake_pcg(const DevWindow &w)
+void fake_schur(const DevWindow &w, int trial)
+{
+    g_sink += (w.ent64 ? (long)w.ent64[0] : (long)w.ent_i[0]) + w.slot_point[0];
+    if (rd_done(w.ctrl)) { if (trial >= 0) xs_wr(w, kXsSkip, (unsigned)trial + 1u); return; }
+    if (trial >= 0) for (int i = 0; i < w.nitems; ++i) xs_wr(w, kXsItem0 + i, (unsigned)trial + 1u);
+}
+
+void fake_pcg(const DevWindow &w, int trial, bool xs)
 {
     Ctrl *c = w.ctrl;
-    if (c->done) return;
+    const unsigned epoch = (unsigned)trial + 1u;
+    if (!xs) { if (rd_done(c)) return; }
+    else {
+        for (;;) {              // every item of the trial's schur pass, or the pass's no-op word
+            if (xs_rd(w, kXsSkip) >= epoch) return;
+            bool ok = true;
+            for (int i = 0; i < w.nitems && ok; ++i) ok = xs_rd(w, kXsItem0 + i) == epoch;
+            if (ok) break;
+            std::this_thread::yield();
+        }
+    }
     if (g_park_trial.load() >= 0 && c->n_solves >= g_park_trial.load() && c->solver_mode == 0) {
-        c->solver_mode = 1; c->direct_from = c->n_solves; c->n_pause += 1; c->done = 2;
+        c->solver_mode = 1; c->direct_from = c->n_solves; c->n_pause += 1; wr_done(c, 2);
+        xs_wr(w, kXsPcgDone, epoch | (kXsParked << 24));
         __atomic_store_n(&w.hstat->pause_seq, c->n_pause, __ATOMIC_RELEASE);
         return;
     }
     c->pcg_last_iters = 7; c->pcg_total_iters += 7;
+    xs_wr(w, kXsPcgDone, epoch | (kXsOk << 24));
+}
+
+// the back-substitution pass and, in its last workgroup, the LM decision; wait_epoch: the solve of that epoch runs on another stream
+void fake_backsub(const DevWindow &w, unsigned wait_epoch)
+{
+    if (rd_done(w.ctrl)) return;
+    g_sink += w.dec_rec[0];
+    if (wait_epoch) {
+        unsigned v;
+        while (((v = xs_rd(w, kXsPcgDone)) & kXsEpochMask) != wait_epoch) std::this_thread::yield();
+        if ((v >> 24) != kXsOk) return;
+    }
+    fake_decide(w);
 }
 void fake_direct(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
-    if (c->done == 1) return;
+    if (rd_done(c) == 1) return;
     if (w.dense.G > 0) g_sink += sum_bytes(w.dense.flags, 16);
     c->pcg_last_iters = -1; c->n_direct += 1;
-    if (c->done == 2) c->done = 0;
+    if (rd_done(c) == 2) wr_done(c, 0);
 }
 void fake_finalize(const DevWindow &w)
 {
     for (int e = 0; e < w.E; ++e) { w.out_chi2[e] = 1.0; w.out_outlier[e] = 0; }
     if (w.pose_export) std::memcpy(w.pose_export, w.st[0].pose, 56 * (size_t)w.NP);
     std::memcpy(w.ctrl_out, w.ctrl, sizeof(Ctrl));
-    if (w.ctrl->done == 1) __atomic_store_n(&w.hstat->progress, HostStatus::pack(w.ctrl->n_solves, w.ctrl->it, 1), __ATOMIC_RELEASE);
+    if (__atomic_load_n(&w.ctrl->done, __ATOMIC_ACQUIRE) == 1) __atomic_store_n(&w.hstat->progress, HostStatus::pack(w.ctrl->n_solves, w.ctrl->it, 1), __ATOMIC_RELEASE);
 }
 }  // namespace
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_init(w); }); return hipSuccess; }
-hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done; }); return hipSuccess; }
-hipError_t launch_schur(const DevWindow &w, int, int, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + (w.ent64 ? (long)w.ent64[0] : (long)w.ent_i[0]) + w.slot_point[0]; }); return hipSuccess; }
+hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += rd_done(w.ctrl); }); return hipSuccess; }
+hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s) { fake_enqueue(s, [w, mode, trial] { fake_schur(w, mode == 1 ? -1 : trial); }); return hipSuccess; }
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->lambda = 1e-3; }); return hipSuccess; }
 // (the back-substitution pass takes the LM decision in its last workgroup: one launch)
-hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += w.ctrl->done + w.dec_rec[0]; fake_decide(w); }); return hipSuccess; }
+hipError_t launch_backsub(const DevWindow &w, unsigned wait_epoch, hipStream_t s) { fake_enqueue(s, [w, wait_epoch] { fake_backsub(w, wait_epoch); }); return hipSuccess; }
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_finalize(w); }); return hipSuccess; }
 hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
 {
@@ -218,7 +261,7 @@ hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
     });
     return hipSuccess;
 }
-hipError_t launch_pcg_rows(const DevWindow &w, int, const PcgParams &, int, hipStream_t s) { fake_enqueue(s, [w] { fake_pcg(w); }); return hipSuccess; }
+hipError_t launch_pcg_rows(const DevWindow &w, int, const PcgParams &, int trial, bool xs, hipStream_t s) { fake_enqueue(s, [w, trial, xs] { fake_pcg(w, trial, xs); }); return hipSuccess; }
 hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_direct(w); }); return hipSuccess; }
 hipError_t launch_dense_persist(const DevWindow &w, unsigned, hipStream_t s) { fake_enqueue(s, [w] { fake_direct(w); }); return hipSuccess; }
 
@@ -226,13 +269,13 @@ hipError_t launch_dense_persist(const DevWindow &w, unsigned, hipStream_t s) { f
 hipError_t launch_init_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_init(b.wins[i]); }); return hipSuccess; }
 hipError_t launch_point_batch(const BatchDev &b, int, bool backsub, bool, bool, size_t, hipStream_t s)
 {
-    fake_enqueue(s, [b, backsub] { for (int i = 0; i < b.n; ++i) { g_sink += b.wins[i].ctrl->done + b.blk_point[i]; if (backsub) fake_decide(b.wins[i]); } });
+    fake_enqueue(s, [b, backsub] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_point[i]; if (backsub) fake_backsub(b.wins[i], 0u); } });
     return hipSuccess;
 }
-hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) g_sink += b.wins[i].ctrl->done + b.blk_schur[i]; }); return hipSuccess; }
+hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_schur[i]; fake_schur(b.wins[i], -1); } }); return hipSuccess; }
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) b.wins[i].ctrl->lambda = 1e-3; }); return hipSuccess; }
 hipError_t launch_finalize_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_finalize(b.wins[i]); }); return hipSuccess; }
-hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i]); } }); return hipSuccess; }
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i], 0, false); } }); return hipSuccess; }
 
 // ---- pose-only optimisation: echoes the start pose, every match an inlier ----
 hipError_t launch_pose_hyp(const PoseDev &p, hipStream_t s) { fake_enqueue(s, [p] { g_sink += sum_bytes(p.Xw, 24 * (size_t)p.n) + sum_bytes(p.samples, 12 * (size_t)p.n_hyp); }); return hipSuccess; }
