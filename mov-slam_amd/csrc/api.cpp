@@ -615,6 +615,7 @@ struct Upload {
     size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_tick = 0, o_xs = 0, o_recd = 0, o_imgb = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
     size_t o_dtiles = 0, o_ddiag = 0, o_dfail = 0, o_dx = 0, o_dflags = 0, o_dcontrib = 0, o_dstamps = 0;
     std::vector<int32_t> lane_plan;
+    int rec_slots = 1;
     size_t ncb = 0;
     int ntile = 0;
     bool dense_one = false, dense_stamps = false;
@@ -1119,27 +1120,43 @@ int Upload::lay_out_rest()
     lane_plan.clear();
     if (h->rows_kernel) {
         // which two oriented blocks every lane of k_pcg_rows holds, and where their partial items are
-        lane_plan.assign((size_t)kPcgRowsThreads * 8, -1);
+        lane_plan.assign((size_t)kPcgRowsThreads * 12, -1);
         for (int wv = 0; wv < kPcgRowsThreads / 64; ++wv) {
-            const int P0 = s().row_ptr[h->pp.wave_row0[wv]] >> 1, P1 = s().row_ptr[h->pp.wave_row0[wv + 1]] >> 1;
+            const int r0 = h->pp.wave_row0[wv], r1 = h->pp.wave_row0[wv + 1];
+            const int P0 = s().row_ptr[r0] >> 1, P1 = s().row_ptr[r1] >> 1;
             for (int ln = 0; ln < 64 && P0 + ln < P1; ++ln)
                 for (int k = 0; k < 2; ++k) {
                     const RowEnt &re = s().row_ent[2 * (P0 + ln) + k];
-                    int32_t *pl = &lane_plan[((size_t)(wv * 64 + ln) * 2 + k) * 4];
+                    int32_t *pl = &lane_plan[((size_t)(wv * 64 + ln) * 3 + k) * 4];
                     if (re.block < 0) continue;
                     pl[0] = re.block; pl[1] = (re.col * 6) | (re.transposed ? (1 << 30) : 0);
                     pl[2] = s().pair_item_start[re.block]; pl[3] = s().pair_item_start[re.block + 1];
                 }
+            for (int ln = 0; ln < 64; ++ln) {               // owner lanes: what they need of their keyframe
+                int32_t *pl = &lane_plan[((size_t)(wv * 64 + ln) * 3 + 2) * 4];
+                pl[0] = pl[1] = pl[2] = pl[3] = 0;
+                if (ln >= 6 * (r1 - r0)) continue;
+                const int bi = r0 + ln / 6;
+                pl[0] = s().pair_item_start[bi]; pl[1] = s().pair_item_start[bi + 1]; pl[2] = s().row_ptr[bi]; pl[3] = s().row_ptr[bi + 1];
+            }
         }
+        for (int wv = 0; wv <= kPcgRowsThreads / 64; ++wv) h->pp.wave_ent0[wv] = s().row_ptr[h->pp.wave_row0[wv]];
+        h->pp.nrowent = s().row_ptr[nf];
     }
+    // the diagonal items' records (DevWindow::rec_d): by keyframe and place in the pair
+    rec_slots = 1;
+    for (int hh = 0; hh < nf; ++hh) rec_slots = std::max(rec_slots, (int)(s().pair_item_start[hh + 1] - s().pair_item_start[hh]));
     // where the schur pass leaves the block of every single-item off-diagonal pair for those lanes (DevWindow::img_b)
-    for (SchedItem &si : h->st.sched) { si.dst_a = -1; si.dst_b = -1; }
+    for (SchedItem &si : h->st.sched) {
+        si.dst_a = -1; si.dst_b = -1;
+        if (si.tag >= 0 && (si.tag & 1)) { const Item &it = s().items[(size_t)(si.tag >> 1)]; si.dst_a = it.pair * rec_slots + ((si.tag >> 1) - s().pair_item_start[it.pair]); }
+    }
     if (h->rows_kernel && !h->pp.overflow) {
         std::vector<int32_t> slot_of_item((size_t)s().nitems, -1);
         for (size_t q = 0; q < s().sched.size(); ++q) if (s().sched[q].tag >= 0) slot_of_item[(size_t)(s().sched[q].tag >> 1)] = (int32_t)q;
         for (int t = 0; t < kPcgRowsThreads; ++t)
             for (int k = 0; k < 2; ++k) {
-                const int32_t *pl = &lane_plan[((size_t)t * 2 + k) * 4];
+                const int32_t *pl = &lane_plan[((size_t)t * 3 + k) * 4];
                 if (pl[0] < nf || pl[3] - pl[2] != 1) continue;         // no block, a diagonal one, or a pair cut into several items
                 SchedItem &si = h->st.sched[(size_t)slot_of_item[(size_t)pl[2]]];
                 const int32_t dst = 36 * k * kPcgRowsThreads + t;
@@ -1173,7 +1190,7 @@ int Upload::lay_out_rest()
     o_obspm = c.take<double>(2 * (size_t)s().E_free + 2); o_obsrpm = c.take<double>(stereo ? (size_t)s().E_free + 1 : 1);
     const size_t part_stride = ((size_t)s().nitems * kPartStride + 31) / 32 * 32;
     o_part = c.take<double>(part_stride + 1); o_blocks = c.take<double>((size_t)s().npairs * 36 + 1);
-    o_recd = c.take<double>((size_t)s().pair_item_start[nf] * 48 + 2); o_imgb = c.take<double>((size_t)72 * kPcgRowsThreads);
+    o_recd = c.take<double>((size_t)nf * rec_slots * 48 + 2); o_imgb = c.take<double>((size_t)72 * kPcgRowsThreads);
     o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s().row_ent.size() * 36 + 2 : 2);
     o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
     o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
@@ -1309,7 +1326,7 @@ void Upload::device_view()
         S.Fpart = reinterpret_cast<double *>(a + o_st[b][8]);
     }
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
-    w.rec_d = reinterpret_cast<double *>(a + o_recd); w.img_b = reinterpret_cast<double *>(a + o_imgb);
+    w.rec_d = reinterpret_cast<double *>(a + o_recd); w.img_b = reinterpret_cast<double *>(a + o_imgb); w.rec_slots = rec_slots;
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c); w.blocks_ov = reinterpret_cast<double *>(a + o_blocks_ov);
     w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);

@@ -151,7 +151,8 @@ struct DevWindow {
     const int32_t *pair_i, *pair_j, *pair_item_start, *row_ptr;
     const RowEnt *row_ent;
     // k_pcg_rows: per (wave, lane, slot) plan {pair id or -1, transposed, col*6, first item, end item} (host-built)
-    const int32_t *lane_plan;   // kPcgRowsThreads x 2 x 4 int32
+    const int32_t *lane_plan;   // kPcgRowsThreads x 3 x 4 int32: the thread's two blocks {pair id or -1, col * 6 | transposed << 30, first item, end item},
+                                // then, for the owner lane of a scalar row, {first item, end item of its keyframe's diagonal pair, row_ptr of its block row, of the next}
     // coarse level of the PCG preconditioner
     int32_t n_agg, n_cblk;
     const int32_t *cblk_g, *cblk_h, *cblk_ptr, *cblk_ent, *cblk_ij;
@@ -163,8 +164,9 @@ struct DevWindow {
     // reduced system
     double *part;       // nitems x kPartStride: k_schur work-item partials
     // what the schur pass leaves once more in the layout the on-chip PCG's setup reads (pcg_kernel.hip), beside `part`:
-    double *rec_d;      // per DIAGONAL work item (items [0, pair_item_start[nfree])) 6 rows x 8 doubles: row a of Hpp - sum B Dinv B^T (6), then
-                        // (sum B Dinv b_l)_a and (b_p)_a
+    double *rec_d;      // per free keyframe h and work item s of its diagonal pair, at (h rec_slots + s) 48: 6 rows x 8 doubles: row a of
+                        // Hpp - sum B Dinv B^T (6), then (sum B Dinv b_l)_a and (b_p)_a
+    int32_t rec_slots, pad7;    // most work items a diagonal pair of this window is cut into
     double *img_b;      // 72 x kPcgRowsThreads: element q (oriented) of the block that PCG thread t holds in slot k at ((36 k + q) 512 + t), for
                         // off-diagonal pairs that are one work item (SchedItem::dst_a / dst_b say where an item's block goes)
     double *blocks_ov;  // overflow windows only: oriented copies of the blocks of the gather-list tails (entry e at 36 e)
@@ -216,6 +218,8 @@ struct PcgParams {
     int32_t wave_row0[17];      // k_pcg_rows: wave wv owns block rows [wave_row0[wv], wave_row0[wv+1])
     int32_t overflow;           // k_pcg_rows: some wave has more gather entries than fit in VGPRs
     int32_t use_coarse;         // k_pcg_rows: add the aggregate coarse-level correction to block-Jacobi (1: lagged, 2: fresh)
+    int32_t wave_ent0[17];      // row_ptr[wave_row0[wv]]: first gather-list entry of the wave's rows (so that the kernel's setup needs no
+    int32_t nrowent;            // load for them), and row_ptr[nfree]
 };
 
 // Batched launches over n resident windows (movba_lba_run_batch): device arrays of the windows' views and PCG plans, and

@@ -822,7 +822,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lane < 48) {
-                double *rec = w.rec_d + (size_t)item * 48;
+                double *rec = w.rec_d + (size_t)it.dst_a * 48;        // (diagonal items: dst_a = keyframe * rec_slots + the item's place in its pair)
                 if (lane < 36) {
                     const int a = lane / 6, q = lane - a * 6, u = a <= q ? ut6(a, q) : ut6(q, a);
                     hx_st_f64(rec + a * 8 + q, wsum[wv][27 + u] - wsum[wv][u]);

@@ -141,36 +141,77 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     const bool fresh = pp.use_coarse == 2;
     // two streams: the solver proper first loads what does not depend on the pass (its plans, the coarse inverse), then waits
     const bool late_wait = XS && role == 0 && !fresh;
-    if (!XS) { if (c->done) return; }
-    else if (!late_wait) {
-        const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(sm));
-        if (wt == 1) return;
-        if (wt == 2) {              // never seen: the back-substitution pass ends the solve and the host runs it again on one stream
-            if (role == 0 && tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24));
-            return;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    // ---- the solver proper: everything whose address follows from the kernel's arguments alone is REQUESTED first - its plans,
+    // the rows of the gather lists, the previous trial's coarse inverse, on one stream also the blocks the schur pass left for
+    // this thread - before anything is waited for: the setup used to be a chain of five dependent round trips behind the
+    // launch boundary (Ctrl -> plans -> item ranges -> partials), ~1 us each from a cold L2 ----
+    const bool solver = role == 0 && !fresh;
     const int nf = w.nfree, n = 6 * nf;
-    // the LM state of this trial (written by the previous trial's decision: on the two-stream path a kernel of the other stream,
-    // finished by the time the schur pass shows its flags)
+    const int b0 = pp.wave_row0[wv], b1 = pp.wave_row0[wv + 1];      // wave wv owns block rows [b0, b1); lane ln < 6 (b1 - b0) owns scalar row 6 b0 + ln
+    const int row = b0 * 6 + ln;
+    const bool owner = ln < 6 * (b1 - b0);
+    const int bi = owner ? row / 6 : 0, ba = owner ? row - bi * 6 : 0;
+    const int ctrial = fresh ? trial : trial - 1;         // the trial whose coarse matrix preconditions this solve
     int cur = 0;
     double lambda = 0.0;
-    if (!late_wait) { cur = XS ? hx_ld_i32(&c->cur) : c->cur; lambda = XS ? hx_ld_f64(&c->lambda) : c->lambda; }
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long setup_last = stamp_c0;
 #endif
     const double *part = w.part;
-    if (fresh) {
+    if (!solver) {
+        // the coarse-level workgroup, and a solver that builds its coarse level first, read every partial of the schur pass
+        if (!XS) { if (c->done) return; }
+        else {
+            const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(sm));
+            if (wt == 1) return;
+            if (wt == 2) {              // never seen: the back-substitution pass ends the solve and the host runs it again on one stream
+                if (role == 0 && tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24));
+                return;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        // (the LM state of this trial was written by the previous trial's decision: on the two-stream path a kernel of the other
+        //  stream, finished by the time the schur pass shows its flags)
+        cur = XS ? hx_ld_i32(&c->cur) : c->cur; lambda = XS ? hx_ld_f64(&c->lambda) : c->lambda;
+        if (role == 1) {            // second workgroup: coarse level of THIS trial's matrix, for the next trial
+            coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true, true);
+            return;
+        }
         coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false, false);
         __syncthreads();
-    } else if (role == 1) {         // second workgroup: coarse level of THIS trial's matrix, for the next trial
-        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true, true);
-        return;
     }
+    // ---- the requests, in the order their answers are needed (vector loads return in order).  One plan load per thread says
+    // everything it needs of the window's structure (api.cpp, lay_out_rest); the rest follows from the kernel's arguments. ----
+    int done_w = 0;
+    if (solver && !XS) { done_w = c->done; cur = c->cur; lambda = c->lambda; }
+    const int4 *plan = reinterpret_cast<const int4 *>(w.lane_plan) + (size_t)tid * 3;
+    const int4 pl0 = plan[0], pl1 = plan[1], plo = plan[2];
+    const int oi0 = plo.x, oi1 = plo.y;                   // owner lanes: items of the diagonal pair (bi, bi): they carry b_p and B Dinv b_l
+    const int rp_b0 = pp.wave_ent0[wv], rp_b1 = pp.wave_ent0[wv + 1], rp_nf = pp.nrowent, rp_bi = plo.z, rp_bi1 = plo.w;
+    // the keyframe's first four diagonal records (DevWindow::rec_d: place s of keyframe bi at (bi rec_slots + s) 48; row ba = 8 doubles)
+    constexpr int kRecFly = 4;
+    double2 rv[kRecFly][4];
+    const double2 *rec0 = reinterpret_cast<const double2 *>(w.rec_d + (size_t)bi * w.rec_slots * 48 + ba * 8);
+    if (!late_wait) {
+#pragma unroll
+        for (int u = 0; u < kRecFly; ++u) {
+            const double2 *src = rec0 + (size_t)min(u, w.rec_slots - 1) * 24;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rv[u][q] = src[q];
+        }
+    }
+    double Bo[2][36];
+    if (!OVERFLOW && !late_wait) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < 36; ++q) Bo[k][q] = w.img_b[(size_t)(36 * k + q) * kT + tid];
+    }
+    if (solver && !XS && done_w) return;
+    SETUP_STAMP(6);
     const int npad = (n + 1) & ~1;
-    const int nrowent_all = w.row_ptr[nf];
+    const int nrowent_all = rp_nf;
 
     // LDS carve (16-byte aligned pieces, no static LDS in front of it)
     double *p_lds = sm;                                   // n
@@ -178,31 +219,15 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     double *minv = r_lds + npad;                          // nf x 36
     double *red0 = minv + 36 * nf;                        // kNW
     double *red1 = red0 + kNW;                            // kNW
-    int &s_fail = *reinterpret_cast<int *>(red1 + kNW);
     float *Acf = reinterpret_cast<float *>(red1 + kNW + 2); // kNC x kNC floats: inverse coarse matrix of the previous trial
     double *rcg = red1 + kNW + 2 + kNC * kNC / 2;         // kNC: restricted vector of every aggregate
     double *zstrip = rcg + kNC + 32 * wv;                 // 16 per wave: the wave's coarse correction z_c = A_c^-1 P^T r (kPA used)
     double *ustrip = zstrip + 16;                         // 16 per wave: A_c^-1 P^T s of the wave's aggregate
     double *ypart = rcg + kNC + 32 * kNW;                 // 6 doubles per gather-list PAIR (+ one dummy strip)
     double *sdiag = ypart + 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);     // nf x 36: the damped diagonal blocks S_ii
-    if (tid == 0) s_fail = 0;
-    // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial)
-    const int ctrial = fresh ? trial : trial - 1;         // the trial whose coarse matrix preconditions this solve
-    const bool coarse = pp.use_coarse && ctrial >= 0 && w.aci_tag[ctrial & 1] == ctrial;
-    if (coarse) {
-        const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)(ctrial & 1) * kNC * kNC);
-        float2 *dst = reinterpret_cast<float2 *>(Acf);
-        for (int idx = tid; idx < kNC * kNC / 2; idx += kT) { const double2 v = src[idx]; dst[idx] = make_float2((float)v.x, (float)v.y); }
-    }
-
-    // ---- ownership: wave wv owns block rows [b0, b1); lane ln < 6*(b1-b0) owns scalar row b0*6 + ln ----
-    const int b0 = pp.wave_row0[wv], b1 = pp.wave_row0[wv + 1];
-    const int row = b0 * 6 + ln;
-    const bool owner = ln < 6 * (b1 - b0);
-    const int bi = owner ? row / 6 : 0, ba = owner ? row - bi * 6 : 0;
     const int nrowent = nrowent_all;
-    const int P0 = w.row_ptr[b0] >> 1, P1 = w.row_ptr[b1] >> 1;      // the wave's entry pairs
-    const int own_p0 = owner ? (w.row_ptr[bi] >> 1) : 0, own_p1 = owner ? (w.row_ptr[bi + 1] >> 1) : 0;
+    const int P0 = rp_b0 >> 1, P1 = rp_b1 >> 1;          // the wave's entry pairs
+    const int own_p0 = rp_bi >> 1, own_p1 = rp_bi1 >> 1;
     const int own_cnt = own_p1 - own_p0;                  // pair sums of this lane's row (0 for non-owners)
     const int nb = b1 - b0;                               // block rows of this wave (wave-uniform)
 
@@ -254,26 +279,27 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
 
     // ---- this lane's pair of oriented blocks, assembled straight from the partials into VGPRs ----
     // (the host-built lane plan says which blocks and which partial items: one dependent load level)
-    double Bo[2][36];
     int colo[2];
     const int my_pair = P0 + ln;
     const bool have_pair = my_pair < P1;
     const int yslot = (have_pair ? my_pair : (nrowent >> 1)) * 6;     // lanes without a pair write the dummy strip
     const double *yown = ypart + own_p0 * 6 + ba;         // first pair sum of this lane's row
-    const int4 *plan = reinterpret_cast<const int4 *>(w.lane_plan) + (size_t)tid * 2;
-    const int4 pl0 = plan[0], pl1 = plan[1];
-    // owner lanes: items of the diagonal pair (bi, bi) carry b_p and B Dinv b_l
-    const int oi0 = owner ? w.pair_item_start[bi] : 0, oi1 = owner ? w.pair_item_start[bi + 1] : 0;
     // ---- diagonal blocks and right-hand side, cooperatively: owner lane (bi, ba) sums ROW ba of S_ii = Hpp + lambda I -
     // sum B Dinv B^T, b_p and B Dinv b_l over the work items of pair (bi, bi), four items in flight: the cost does not
     // grow with the number of items a long diagonal pair is cut into ----
     // ---- two streams: everything above came from this stream's own kernels and from the upload; from here on the schur pass ----
     if (late_wait) {
-        const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(red0));       // (its barriers also order s_fail = 0 above)
+        const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(red0));
         if (wt == 1) return;
         if (wt == 2) { if (tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24)); return; }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         cur = hx_ld_i32(&c->cur); lambda = hx_ld_f64(&c->lambda);
+#pragma unroll
+        for (int u = 0; u < kRecFly; ++u) {
+            const double2 *src = rec0 + (size_t)min(u, w.rec_slots - 1) * 24;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rv[u][q] = src[q];
+        }
     }
     // ---- diagonal blocks and right-hand side: owner lane (bi, ba) sums ROW ba of S_ii = Hpp - sum B Dinv B^T (+ lambda), of
     // B Dinv b_l and of b_p over the work items of pair (bi, bi).  The schur pass leaves every diagonal item once more in the
@@ -282,31 +308,113 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // the lane gathered 14 scattered doubles per item from the 72-double partial (6 us per launch on the one CU's texture
     // addresser).  Items in order, four in flight. ----
     double r_r = 0.0;
+    double mi[6] = { 1, 1, 1, 1, 1, 1 };                 // this lane's row of S_ii, then of its inverse
+    auto wave_lds_sync0 = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     if (owner) {
         double d6[6] = { 0, 0, 0, 0, 0, 0 }, cc = 0.0, bb = 0.0;
-        for (int i0 = oi0; i0 < oi1; i0 += 4) {
-            double2 v[4][4];
+        const int ni = oi1 - oi0;
+        auto add = [&](const double2 (&v)[4], bool in) {
+            d6[0] += in ? v[0].x : 0.0; d6[1] += in ? v[0].y : 0.0; d6[2] += in ? v[1].x : 0.0;
+            d6[3] += in ? v[1].y : 0.0; d6[4] += in ? v[2].x : 0.0; d6[5] += in ? v[2].y : 0.0;
+            cc += in ? v[3].x : 0.0; bb += in ? v[3].y : 0.0;
+        };
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double2 *src = reinterpret_cast<const double2 *>(w.rec_d + (size_t)min(i0 + u, oi1 - 1) * 48 + ba * 8);
+        for (int u = 0; u < kRecFly; ++u) add(rv[u], u < ni);
+        for (int i0 = kRecFly; i0 < ni; i0 += kRecFly) {        // (keyframes with more than 2 048 edges)
+            double2 v[kRecFly][4];
+#pragma unroll
+            for (int u = 0; u < kRecFly; ++u) {
+                const double2 *src = rec0 + (size_t)min(i0 + u, ni - 1) * 24;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[u][q] = src[q];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = i0 + u < oi1;
-                d6[0] += in ? v[u][0].x : 0.0; d6[1] += in ? v[u][0].y : 0.0; d6[2] += in ? v[u][1].x : 0.0;
-                d6[3] += in ? v[u][1].y : 0.0; d6[4] += in ? v[u][2].x : 0.0; d6[5] += in ? v[u][2].y : 0.0;
-                cc += in ? v[u][3].x : 0.0; bb += in ? v[u][3].y : 0.0;
-            }
+            for (int u = 0; u < kRecFly; ++u) add(v[u], i0 + u < ni);
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) sdiag[bi * 36 + ba * 6 + q] = d6[q] + (q == ba ? lambda : 0.0);
+        for (int q = 0; q < 6; ++q) d6[q] += q == ba ? lambda : 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) sdiag[bi * 36 + ba * 6 + q] = d6[q];
         r_r = bb - cc;
         w.bp[row] = bb;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) mi[q] = d6[q];
+    }
+    SETUP_STAMP(7);
+    // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial).  Requested here: its
+    // round trip runs beside the block inverses below.
+    int aci_tag = -1;
+    double2 av[kNC * kNC / 2 / kT];
+    if (pp.use_coarse) {
+        aci_tag = w.aci_tag[max(ctrial, 0) & 1];
+        const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)(max(ctrial, 0) & 1) * kNC * kNC);
+#pragma unroll
+        for (int u = 0; u < kNC * kNC / 2 / kT; ++u) av[u] = src[tid + u * kT];
+    }
+    // ---- block-Jacobi preconditioner: S_ii^-1 by the block's six owner lanes, each holding a row: in-place Gauss-Jordan, the
+    // scaled pivot row handed round through a wave-private LDS strip (alternating between two: no wait before the next
+    // pivot's write), then symmetrised.  (Until round 4 ONE thread per keyframe factored its block on its own - a 600-flop
+    // dependent chain with 50 of 512 threads at work, ~2.5 us in front of every solve.)  A pivot that is not positive fails the
+    // solve like a failed factorisation. ----
+    {
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double *strip = ((k & 1) ? p_lds : r_lds) + (owner ? bi * 6 : 0);
+            if (owner && ba == k) {
+                const double p = mi[k];
+                if (!(p > 0.0)) bad = true;
+                double pinv = __builtin_amdgcn_rcp(p);
+                pinv = pinv * (2.0 - p * pinv);
+                pinv = pinv * (2.0 - p * pinv);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { mi[q] = q == k ? pinv : mi[q] * pinv; strip[q] = mi[q]; }
+            }
+            wave_lds_sync0();
+            if (owner && ba != k) {
+                const double2 *sr = reinterpret_cast<const double2 *>(strip);
+                const double2 s0 = sr[0], s1 = sr[1], s2 = sr[2];
+                const double srow[6] = { s0.x, s0.y, s1.x, s1.y, s2.x, s2.y };
+                const double f = mi[k];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) mi[q] = q == k ? -f * srow[k] : mi[q] - f * srow[q];
+            }
+        }
+        // symmetrise: rows out, columns in
+        if (owner) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) minv[bi * 36 + ba * 6 + q] = mi[q];
+        }
+        wave_lds_sync0();
+        if (owner) {
+            double col[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) col[q] = minv[bi * 36 + q * 6 + ba];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) mi[q] = 0.5 * (mi[q] + col[q]);
+        }
+        wave_lds_sync0();
+        if (owner) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) minv[bi * 36 + ba * 6 + q] = mi[q];
+        }
+        // (a wave's verdict in a slot of its own: read by everyone behind the workgroup barrier in front of the solve)
+        const int wbad = __any(bad) ? 1 : 0;
+        if (ln == 0) reinterpret_cast<int *>(red1)[wv] = wbad;
+    }
+    const bool coarse = pp.use_coarse && ctrial >= 0 && aci_tag == ctrial;
+    if (coarse) {
+        float2 *dst = reinterpret_cast<float2 *>(Acf);
+#pragma unroll
+        for (int u = 0; u < kNC * kNC / 2 / kT; ++u) dst[tid + u * kT] = make_float2((float)av[u].x, (float)av[u].y);
     }
     SETUP_STAMP(0);
-    __syncthreads();
+    // (a keyframe's diagonal block is read by a lane of the wave that owns its rows: no workgroup barrier between the two)
+    wave_lds_sync0();
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long xs_t1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -324,13 +432,15 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         if (valid) colo[k] = pl.y & 0x3fffffff;
         const bool diag = valid && pl.x < nf, from_img = !OVERFLOW && valid && pl.x >= nf && pl.w - pl.z == 1;
         if (!OVERFLOW) {
-            // (every lane reads its image slot - the loads are coalesced whatever the lanes need; a slot nothing wrote is not used)
-            const double *src = w.img_b + (size_t)(36 * k) * kT + tid;
-            double v[36];
+            // (every lane reads its image slot - the loads are coalesced whatever the lanes need; a slot nothing wrote is not used;
+            //  on one stream they were requested at the top of the kernel)
+            if (late_wait) {
+                const double *src = w.img_b + (size_t)(36 * k) * kT + tid;
 #pragma unroll
-            for (int q = 0; q < 36; ++q) v[q] = src[(size_t)q * kT];
+                for (int q = 0; q < 36; ++q) Bo[k][q] = src[(size_t)q * kT];
+            }
 #pragma unroll
-            for (int q = 0; q < 36; ++q) Bo[k][q] = from_img ? -v[q] : 0.0;
+            for (int q = 0; q < 36; ++q) Bo[k][q] = from_img ? -Bo[k][q] : 0.0;
         } else {
 #pragma unroll
             for (int q = 0; q < 36; ++q) Bo[k][q] = 0.0;
@@ -359,57 +469,6 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         }
     }
     SETUP_STAMP(1);
-
-    // ---- block-Jacobi preconditioner: invert each 6x6 diagonal block in place (Cholesky) ----
-    for (int i = tid; i < nf; i += kT) {
-        double L[36], Li[36], rinv[6];
-#pragma unroll
-        for (int k = 0; k < 36; ++k) L[k] = sdiag[i * 36 + k];
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double d = L[j * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
-            if (!(d > 0.0)) ok = false;
-            // 1 / sqrt(d) by v_rsq_f64 and two Newton steps, the only "division" of the column (this is a preconditioner:
-            // the chain of 6 square roots and 36 divisions was ~2 us in front of every solve with one wave at work)
-            double ri = __builtin_amdgcn_rsq(d);
-            ri = ri * (1.5 - 0.5 * d * ri * ri);
-            ri = ri * (1.5 - 0.5 * d * ri * ri);
-            rinv[j] = ri;
-            L[j * 6 + j] = d * ri;
-#pragma unroll
-            for (int q = j + 1; q < 6; ++q) {
-                double s = L[q * 6 + j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) s -= L[q * 6 + k] * L[j * 6 + k];
-                L[q * 6 + j] = s * ri;
-            }
-        }
-#pragma unroll
-        for (int col = 0; col < 6; ++col) {
-#pragma unroll
-            for (int rw = 0; rw < 6; ++rw) {
-                if (rw < col) { Li[rw * 6 + col] = 0.0; continue; }
-                double s = (rw == col) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = col; k < rw; ++k) s -= L[rw * 6 + k] * Li[k * 6 + col];
-                Li[rw * 6 + col] = s * rinv[rw];
-            }
-        }
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                double s = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) s += (k >= a && k >= b) ? Li[k * 6 + a] * Li[k * 6 + b] : 0.0;
-                minv[i * 36 + a * 6 + b] = s;
-            }
-        if (!ok) s_fail = 1;
-    }
-    __syncthreads();
 
     double x_r = 0.0, z_r = 0.0;
     // z = Minv r: a block's six rows sit in one wave, so its residuals are exchanged through LDS
@@ -481,7 +540,10 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         const double t = coarse_rows();
         if (cq == 0 && ln < 4 * kPA) zstrip[ln >> 2] = t;
         __syncthreads();                                      // rcg is rewritten inside the loop
-    }
+    } else __syncthreads();                                   // (the waves' block-inverse verdicts are in)
+    int anybad = 0;
+#pragma unroll
+    for (int k = 0; k < kNW; ++k) anybad |= reinterpret_cast<const int *>(red1)[k];
     auto precond = [&](double rv) {
         if (owner) r_lds[row] = rv;
         wave_lds_sync();
@@ -500,11 +562,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // of three and two.  The restricted residual P^T r follows r_c -= alpha P^T s with P^T s = P^T w + beta P^T s.
     double p_r = 0.0, s_r = 0.0;
     double inv_gamma = 1.0, inv_alpha = 0.0, alpha = 0.0, thresh = 0.0;
-    if (XS && s_fail == 2) {        // a wait for the schur pass's items was given up (never seen): the host runs the solve again on one stream
-        if (tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24));
-        return;
-    }
-    bool fail = s_fail != 0;
+    bool fail = anybad != 0;
     bool first = true;
     int iters = 0;
 

@@ -23,7 +23,8 @@ struct Item { int32_t pair, begin, end, diag; };   // entries [begin,end) of one
 struct SchedItem {
     int32_t begin, end, tag /* (item << 1) | diagonal, -1 = padding */, pose_i, pose_j /* pose indices of the pair */;
     // off-diagonal items of single-item pairs, windows with an on-chip PCG: where the item's 6 x 6 block goes in DevWindow::img_b,
-    // as stored (dst_a) and transposed (dst_b): 36 k 512 + thread of the PCG lane slot that holds it, or -1
+    // as stored (dst_a) and transposed (dst_b): 36 k 512 + thread of the PCG lane slot that holds it, or -1.
+    // Diagonal items: dst_a = the item's record in DevWindow::rec_d (keyframe * rec_slots + place in the pair)
     int32_t dst_a, dst_b, pad;
 };
 struct RowEnt { int32_t block, col, transposed, pad; };
