@@ -1607,7 +1607,7 @@ int movba_lba_run(movba_handle *h)
     // uploaded state on the paths that wait for nothing - one stream, the direct solver one launch per block column
     // (dense_solve.hip) - instead of handing the caller an error: the reference never skips a solve for such a reason
     // (src/Optimizer.cc:535).  movba_lba_result::n_sync_timeouts reports that it happened.
-    static const unsigned long long test_ticks = [] { const char *e = std::getenv("MOVBA_TEST_WAIT_TICKS"); return e ? std::strtoull(e, nullptr, 10) : ~0ull; }();
+    const unsigned long long test_ticks = [] { const char *e = std::getenv("MOVBA_TEST_WAIT_TICKS"); return e ? std::strtoull(e, nullptr, 10) : ~0ull; }();
     h->sync_retries = 0;
     const int32_t dense_G = h->win.dense.G;
     for (int attempt = 0;; ++attempt) {

@@ -240,10 +240,10 @@ class Solver:
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
                  pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0,
-                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True):
+                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True, two_streams: bool = False):
         self._h = C.c_void_p()
         self._pinned_blocks = []
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, 1 if direct else 0, 0 if reorder else -1, 0)
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, 1 if direct else 0, 0 if reorder else -1, 1 if two_streams else 0)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()

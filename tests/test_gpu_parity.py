@@ -1018,3 +1018,55 @@ def test_two_handles_on_the_one_launch_direct_solver_at_once(built_lib):
         assert max(times["a"]) < 0.150 and max(times["b"]) < 0.150, (max(times["a"]), max(times["b"]))
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "revisit"])
+def test_two_stream_lm_loop_gives_the_bits_of_the_one_stream_loop(built_lib, solver, oracle_mod, name):
+    """movba_options::two_streams: the PCG launches of a solve on a stream of the handle's own, resident beside the schur pass of
+    their trial, the passes handing over through flags in device memory (DevWindow::xs).  Same kernels' arithmetic, so the same
+    bits as the one-stream loop, run after run; held to the oracle like every other path."""
+    if name == "stereo":
+        w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5)
+    else:
+        w = synth.cfg(name) if name != "revisit" else synth.pattern_cfg(name)
+    two = built_lib.Solver(two_streams=True)
+    try:
+        r1 = solver.solve(w)
+        r2 = two.solve(w)
+        assert r2["status"] == 0 and r2["n_sync_timeouts"] == 0 and r2["n_direct"] == r1["n_direct"]
+        for k in ("poses", "points", "chi2", "outlier"):
+            assert np.array_equal(r1[k], r2[k]), k
+        assert np.array_equal(r1["trace"]["pcg"], r2["trace"]["pcg"])
+        r3 = two.solve(w)
+        assert np.array_equal(r2["poses"], r3["poses"]) and np.array_equal(r2["chi2"], r3["chi2"])
+        check_against(r2, oracle_mod.solve(w), w, noise_guard=True)
+    finally:
+        two.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["two_streams", "direct"])
+def test_a_given_up_wait_inside_a_launch_reruns_the_solve_on_the_paths_without_waits(built_lib, solver, oracle_mod, mode, monkeypatch):
+    """Kernels that wait for other workgroups inside a launch (the two-stream loop's passes, the one-launch direct solver) bound
+    every wait; a solve in which one was given up is run again from the uploaded state on one stream, the direct solver launch
+    by launch, and the caller gets the result with movba_lba_result::n_sync_timeouts saying that it happened - not an error and
+    no skipped local BA (the reference never skips a solve for such a reason, src/Optimizer.cc:535).  MOVBA_TEST_WAIT_TICKS=0
+    makes the first attempt's waits give up at their first unsuccessful look."""
+    w = synth.cfg("cfg2")
+    s = built_lib.Solver(two_streams=True) if mode == "two_streams" else built_lib.Solver(direct=True)
+    try:
+        ref = s.solve(w)
+        assert ref["status"] == 0 and ref["n_sync_timeouts"] == 0
+        monkeypatch.setenv("MOVBA_TEST_WAIT_TICKS", "0")
+        r = s.solve(w)
+        monkeypatch.delenv("MOVBA_TEST_WAIT_TICKS")
+        assert r["status"] == 0 and r["n_sync_timeouts"] > 0
+        o = oracle_mod.solve(w)
+        check_against(r, o, w, noise_guard=True)
+        if mode == "direct":
+            assert r["n_direct"] == r["n_solves"]
+        again = s.solve(w)
+        assert again["n_sync_timeouts"] == 0 and np.array_equal(again["poses"], ref["poses"])
+    finally:
+        s.close()
