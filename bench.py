@@ -92,12 +92,17 @@ def main():
     # MOVBA_BENCH_REHEARSAL=1: the N > 1 code path on a box with ONE GPU (every rank on device 0, gloo instead of RCCL,
     # which refuses two ranks on one device): exercises launch, sharding, timing and the JSON line, not the interconnect
     rehearsal = os.environ.get("MOVBA_BENCH_REHEARSAL") == "1"
+    # MOVBA_BENCH_RCCL_WORLD1=1: a ONE-rank run that still initialises the `nccl` (= RCCL) process group and sends the poses
+    # through all_gather_into_tensor inside the timed region: a real ncclCommInitRank and a real RCCL kernel behind the solve,
+    # on a box with one GPU (the N > 1 branch below is otherwise never taken there)
+    rccl_world1 = os.environ.get("MOVBA_BENCH_RCCL_WORLD1") == "1" and world == 1
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or rccl_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -122,6 +127,8 @@ def main():
         solver.solve_prepared(pack=False)
         if world > 1:
             return shard.gather_poses(pose_buf.cpu()) if rehearsal else shard.gather_poses(pose_buf)
+        if rccl_world1:
+            return shard.gather_poses(pose_buf, force_collective=True)
         return pose_buf
 
     def barrier():
@@ -193,7 +200,8 @@ def main():
                                    f"10 LM iterations ({args.config}, seed {seed}); one window per GPU",
                        "lm_iterations_per_step": res["n_solves"], "pcg_iterations_per_step": res["pcg_iters"],
                        "window_solves_per_s": world * args.steps / dt_max,
-                       "parallelism": (f"{world} independent window(s), " + ("gloo pose all-gather, all ranks on ONE GPU (rehearsal)" if rehearsal else "RCCL pose all-gather")) if world > 1 else "1 window"},
+                       "parallelism": (f"{world} independent window(s), " + ("gloo pose all-gather, all ranks on ONE GPU (rehearsal)" if rehearsal else "RCCL pose all-gather")) if world > 1
+                                      else ("1 window, RCCL pose all-gather over a one-rank nccl group (MOVBA_BENCH_RCCL_WORLD1)" if rccl_world1 else "1 window")},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": ab[dominant], "avg_launch_us": avg_s * 1e6,
@@ -298,6 +306,73 @@ def main():
             except Exception as exc:                        # context only
                 out["config"]["covisibility_patterns"] = {"error": str(exc)}
         if extras:
+            # for information only (never `value`): the other BASELINE configurations in the same run - cfg2 (LocalBundleAdjustment
+            # 10 KF x 2k MapPoints) through the whole movba_lba_solve call, cfg1 (PoseOptimization on one Frame of 500 matches) through
+            # movba_pose_opt with and without the hypothesis stage - each beside the single-threaded oracle on this box's host
+            try:
+                from oracle import oracle as _orc            # (CPU legs of the extras: the oracle as the timed "port", as below)
+                oc = {}
+                w2 = synth.cfg("cfg2")
+                s2 = capi.Solver(device=local_rank, stream=stream.cuda_stream)
+                s2.prepare(w2, pinned=True)
+                for _ in range(3):
+                    s2.solve_prepared(pack=False)
+                t1 = time.perf_counter()
+                for _ in range(20):
+                    s2.solve_prepared(pack=False)
+                t2 = (time.perf_counter() - t1) / 20
+                r2 = s2.solve_prepared()
+                s2.close()
+                c2 = {"ms_per_window_solve": 1e3 * t2, "lm_iterations_per_s": r2["n_solves"] / t2, "lm_iterations_per_step": r2["n_solves"], "E": w2.n_edges}
+                if not args.no_cpu_baseline:
+                    _orc.build()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        o2 = _orc.solve(w2)
+                    tc = (time.perf_counter() - t1) / 5
+                    c2["cpu_1thread_ms_per_window_solve"] = 1e3 * tc
+                    c2["pose_max_abs_vs_oracle"] = float(np.abs(r2["poses"] - o2["poses"]).max())
+                oc["cfg2_local_ba_10kf_2k"] = c2
+                f1 = synth.make_frame(n=500)
+                hub, gate = float(np.float32(np.sqrt(5.991))), 5.991
+                s1 = capi.Solver(device=local_rank, stream=stream.cuda_stream)
+                def tpose(**kw):
+                    for _ in range(5):
+                        rr = s1.pose_opt(f1["Xw"], f1["obs"], f1["pose0"], f1["cam"], hub, gate, **kw)
+                    ts = []
+                    for _ in range(40):
+                        t1 = time.perf_counter(); rr = s1.pose_opt(f1["Xw"], f1["obs"], f1["pose0"], f1["cam"], hub, gate, **kw); ts.append(time.perf_counter() - t1)
+                    ts.sort()
+                    return 1e3 * ts[len(ts) // 2], rr
+                m_lm, r_lm = tpose()
+                m_hyp, r_hyp = tpose(ransac_iters=50, ransac_seed=7)
+                s1.close()
+                c1 = {"ms_motion_only_lm": m_lm, "ms_with_50_hypotheses": m_hyp, "inliers": int(r_hyp["n_inliers"]), "matches": 500}
+                if not args.no_cpu_baseline:
+                    t1 = time.perf_counter()
+                    for _ in range(20):
+                        _orc.pose_opt(f1["Xw"], f1["obs"], f1["pose0"], f1["cam"], hub, gate)
+                    c1["cpu_1thread_ms_motion_only_lm"] = 1e3 * (time.perf_counter() - t1) / 20
+                oc["cfg1_pose_optimization_500"] = c1
+                if args.config == "cfg3":
+                    st = capi.Solver(device=local_rank, stream=stream.cuda_stream, two_streams=True)
+                    st.prepare(w, pinned=True)
+                    for _ in range(3):
+                        st.solve_prepared(pack=False)
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        st.solve_prepared(pack=False)
+                    tts = (time.perf_counter() - t1) / 10
+                    rts = st.solve_prepared()
+                    st.close()
+                    oc["cfg3_two_stream_lm_loop"] = {"ms_per_window_solve": 1e3 * tts, "lm_iterations_per_s": rts["n_solves"] / tts,
+                                                     "bits_equal_one_stream": bool(np.array_equal(rts["poses"], res["poses"])),
+                                                     "note": "movba_options::two_streams = 1 (opt-in): PCG launches resident beside the schur pass on a stream of their own"}
+                oc["note"] = "whole-call wall times through the C-ABI, pinned result arrays, same timed region as `value` for cfg2"
+                out["config"]["other_baseline_configs"] = oc
+            except Exception as exc:                        # context only
+                out["config"]["other_baseline_configs"] = {"error": str(exc)}
+        if extras:
             # for information only: host-side cost of the Optimizer.h adapter around the solve on this window (mock map classes,
             # mov-slam_amd/host/adapter_test): window selection + flattening, and the write-back under the map mutex
             try:
@@ -379,7 +454,7 @@ def main():
                 "outlier_mismatches": int((res["outlier"] != o["outlier"]).sum())}
         print(json.dumps(out), flush=True)
     solver.close()
-    if world > 1:
+    if world > 1 or rccl_world1:
         dist.barrier()
         dist.destroy_process_group()
 

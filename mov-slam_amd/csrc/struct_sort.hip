@@ -6,14 +6,16 @@
 //           result does not depend on their order) and the point's number of couples;
 //   emit    after an exclusive scan over the points, every point writes its couples (key = pair bin, value = the packed
 //           entry) at its own offset: the emission order is point order;
-//   sort    a STABLE radix sort by pair bin (rocPRIM through hipCUB): entries of a bin keep the emission order, i.e. point
+//   sort    a STABLE radix sort by pair bin (rocPRIM's radix_sort_pairs, called directly): entries of a bin keep the emission order, i.e. point
 //           order, and the bins come out in row-major order - the sorted values ARE the entry lists, written straight
 //           into the arena.  Nothing depends on scheduling: bit-identical to the host builder (structure.cpp) whatever the run.
 // What it replaces in the reference is the block-pattern part of g2o's BlockSolver::buildStructure (called from
 // optimizer.initializeOptimization(), /root/reference/src/Optimizer.cc:754); on the host it cost 3.9 ms of a 9 ms call at
 // 150 free keyframes x 60 000 points.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "device_types.h"
 #include "kernels.h"
@@ -113,9 +115,9 @@ hipError_t launch_couple_count(const StructDev &sd, int32_t *cnt_pt, hipStream_t
 size_t sorted_fill_temp_bytes(int P, long long noff, int nfree)
 {
     size_t a = 0, b = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const int32_t *)nullptr, (int32_t *)nullptr, P, (hipStream_t)nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned long long *)nullptr,
-                                             (unsigned long long *)nullptr, (int)noff, 0, key_bits(nfree), (hipStream_t)nullptr);
+    (void)rocprim::exclusive_scan(nullptr, a, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)P, rocprim::plus<int32_t>(), (hipStream_t)nullptr);
+    (void)rocprim::radix_sort_pairs(nullptr, b, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned long long *)nullptr,
+                                    (unsigned long long *)nullptr, (size_t)noff, 0u, (unsigned)key_bits(nfree), (hipStream_t)nullptr);
     return (a > b ? a : b) + 256;
 }
 
@@ -125,13 +127,13 @@ hipError_t launch_sorted_fill(const StructDev &sd, const int32_t *cnt_pt, int32_
 {
     if (noff <= 0) return hipSuccess;
     size_t tb = tmp_bytes;
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tb, cnt_pt, off, sd.P, s);
+    hipError_t e = rocprim::exclusive_scan(tmp, tb, cnt_pt, off, (int32_t)0, (size_t)sd.P, rocprim::plus<int32_t>(), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_couple_emit, dim3((sd.P + kCoupleBlock - 1) / kCoupleBlock), dim3(kCoupleBlock), 0, s, sd, off, keys_in, vals_in);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     tb = tmp_bytes;
-    return hipcub::DeviceRadixSort::SortPairs(tmp, tb, keys_in, keys_out, vals_in, sd.ent64, (int)noff, 0, key_bits(sd.nfree), s);
+    return rocprim::radix_sort_pairs(tmp, tb, keys_in, keys_out, vals_in, sd.ent64, (size_t)noff, 0u, (unsigned)key_bits(sd.nfree), s);
 }
 
 }  // namespace movba

@@ -21,10 +21,11 @@ def window_seed(window_id: int, base_seed: int = 2000) -> int:
     return base_seed + window_id
 
 
-def gather_poses(local: torch.Tensor, group=None) -> torch.Tensor:
-    """local: (n_local, NP, 7) f64 on this rank's device -> (world, n_local, NP, 7) on every rank."""
+def gather_poses(local: torch.Tensor, group=None, force_collective: bool = False) -> torch.Tensor:
+    """local: (n_local, NP, 7) f64 on this rank's device -> (world, n_local, NP, 7) on every rank.
+    force_collective: run the all-gather even in a one-rank group (a real RCCL call on a box with one GPU)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         return local.unsqueeze(0).clone()
     flat = local.contiguous().view(-1)
     out = torch.empty(world * flat.numel(), dtype=local.dtype, device=local.device)

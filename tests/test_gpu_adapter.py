@@ -102,8 +102,9 @@ def _local_subwindow(w):
     return sub, used_pose, local_pt, keep_e
 
 
-@pytest.mark.parametrize("name", ["small", "cfg2", "stereo", "cameras", "stereo-cameras"])
+@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "cameras", "stereo-cameras"])
 def test_local_bundle_adjustment_through_the_adapter(adapter_bin, oracle_mod, tmp_path, name):
+    # "cfg3": the window the headline is quoted on (50 + 10 keyframes x 20 000 map points), map content checked like the small ones
     # "stereo": a window whose keyframes hold stereo observations (mvuRight >= 0, Optimizer.cc:673-705)
     # "cameras": every keyframe with a GeometricCamera (and mbf) of its own, three different ones in the window
     # (e->pCamera = pKFi->mpCamera, Optimizer.cc:664; e->bf = pKFi->mbf, :695)

@@ -45,3 +45,28 @@ def test_bench_with_two_ranks_gathers_the_poses_of_both_windows(built_lib, tmp_p
         sv.close()
     # whole-job value = the LM iterations of ALL ranks' steps / the max-over-ranks time of the timed region
     assert abs(out["value"] - solves * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+
+
+def test_bench_sends_the_poses_through_rccl_in_a_one_rank_group(built_lib, tmp_path):
+    """The `nccl` branch of bench.py on the hardware there is: MOVBA_BENCH_RCCL_WORLD1=1 initialises the RCCL process group at
+    world size 1 (ncclCommInitRank) and gathers the poses with all_gather_into_tensor (an RCCL kernel on the stream behind the
+    solve), inside the timed region, in a fresh child process.  What it cannot show is the interconnect: the 2/4/8-GPU curve
+    stays the driver's to measure."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dump = str(tmp_path / "poses1.npy")
+    env = dict(os.environ, MOVBA_BENCH_RCCL_WORLD1="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               MOVBA_BENCH_DUMP_POSES=dump)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and "RCCL" in out["config"]["parallelism"] and out["value"] > 0
+    g = np.load(dump)
+    sv = built_lib.Solver()
+    try:
+        r = sv.solve(synth.make_window(50, 10, 20000, 1003, run_lo=2, run_hi=10))
+    finally:
+        sv.close()
+    assert g.shape[0] == 1 and np.array_equal(g[0].reshape(-1, 7), r["poses"])
