@@ -306,12 +306,42 @@ __device__ void hyp_solve(const PoseDev &p, const double *Xw, const double *obs,
     }
 }
 
-// one wave scores candidate cidx on all matches: inliers at the caller's threshold, truncated cost (score[2 cidx], [2 cidx + 1])
+// sigma-consensus++ (MAGSAC++: Barath, Noskova, Ivashechkin, Matas, CVPR 2020), what flag 38 = cv::USAC_MAGSAC of the reference's
+// call scores models with (src/Optimizer.cc:437, Examples/Monocular/TartanAir.yaml:51): a residual is not classified at ONE
+// threshold, its noise scale is marginalised over (0, sigma_max], sigma_max = tau / k, tau^2 = chi2_gate (the caller's
+// reprojectionError), k^2 = 9.21034 (0.99 quantile of chi^2 with the residual's 2 degrees of freedom).  With x = r^2 / (2
+// sigma_max^2), x_k = k^2 / 2 the paper's incomplete gamma functions are elementary for n = 2:
+//     weight  w(r)   = sqrt(pi) (erfc(sqrt x) - erfc(sqrt x_k))                                             r <= tau, else 0
+//     loss    rho(r) = sigma_max^2 / 2 (sqrt(pi) / 2 erf(sqrt x) - sqrt x exp(-x)) + r^2 / 4 w(r)           r <= tau, rho(tau) beyond
+// (common factors dropped).  loss: rho / rho(tau) in [0, 1], 1 = outlier or behind the camera; weight: w / w(0).
+struct Magsac {
+    double s2, g_k, inv_rho_max, inv_w0;
+    __device__ explicit Magsac(double gate)
+    {
+        const double sq_pi = 1.7724538509055160273, k2 = 9.210340371976184, xk = 0.5 * k2;
+        s2 = gate / k2;
+        g_k = sq_pi * erfc(sqrt(xk));
+        inv_rho_max = 1.0 / (0.5 * s2 * (0.5 * sq_pi * erf(sqrt(xk)) - sqrt(xk) * exp(-xk)));
+        inv_w0 = 1.0 / (sq_pi * (1.0 - erfc(sqrt(xk))));
+    }
+    __device__ void terms(double chi2, bool in_front, double gate, double &loss, double &weight) const
+    {
+        const double sq_pi = 1.7724538509055160273;
+        if (!in_front || !(chi2 <= gate)) { loss = 1.0; weight = 0.0; return; }
+        const double x = chi2 / (2.0 * s2), sx = sqrt(x);
+        const double w = sq_pi * erfc(sx) - g_k;
+        loss = (0.5 * s2 * (0.5 * sq_pi * erf(sx) - sx * exp(-x)) + 0.25 * chi2 * w) * inv_rho_max;
+        weight = w > 0.0 ? w * inv_w0 : 0.0;
+    }
+};
+
+// one wave scores candidate cidx on all matches: matches inside the caller's threshold, sigma-consensus++ loss (score[2 cidx], [2 cidx + 1])
 __device__ void hyp_score(const PoseDev &p, const double *Xw, const double *obs, const double *isig, int cidx, const double *cand,
                           const int *nsol, double *score, int lane)
 {
     double cnt = 0.0, cst = 0.0;
     if ((cidx & 3) < nsol[cidx >> 2]) {
+        const Magsac ms(p.chi2_gate);
         const double *R = cand + (size_t)cidx * 12;
         for (int i = lane; i < p.n; i += 64) {
             const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
@@ -322,7 +352,9 @@ __device__ void hyp_score(const PoseDev &p, const double *Xw, const double *obs,
             const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
             const double chi2 = e0 * (om * e0) + e1 * (om * e1);
             const bool in = (z > 0.0) && (chi2 <= p.chi2_gate);
-            cnt += in ? 1.0 : 0.0; cst += in ? chi2 : p.chi2_gate;
+            double ls, wt;
+            ms.terms(chi2, z > 0.0, p.chi2_gate, ls, wt);
+            cnt += in ? 1.0 : 0.0; cst += ls;
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); cst += __shfl_xor(cst, o, 64); }
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         for (int i = tid; i < 2 * p.n; i += kT) so[i] = p.obs[i];
         for (int i = tid; i < p.n; i += kT) si[i] = p.isig[i];
         Xw = sX; obs = so; isig = si;
-        level1 = reinterpret_cast<uint8_t *>(si + p.n);
+        level1 = reinterpret_cast<uint8_t *>(si + 2 * p.n);     // (behind the n IRLS weights of the local-optimisation step)
     }
     const double dsqr = p.huber_delta * p.huber_delta;
     double pose0[7];
@@ -391,7 +423,8 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             for (int cidx = wv; cidx < 4 * p.n_hyp; cidx += kW) hyp_score(p, Xw, obs, isig, cidx, cand, nsol, score, lane);
         }
         __syncthreads();
-        // best candidate: most inliers, then lowest truncated cost, then lowest index; every thread scans the same table.
+        // best candidate: lowest sigma-consensus++ loss among those with at least 4 matches inside the threshold, then lowest
+        // index; every thread scans the same table.
         // The samples are walked in the order a sequential RANSAC would draw them, with its stopping rule (cv::solvePnPRansac's
         // `confidence`, Optimizer.cc:437): after sample h, N = log(1 - confidence) / log(1 - w^3) with w the inlier ratio of the best
         // pose so far; the walk ends once h + 1 >= N — hypotheses behind that point were scored (all at once, on the grid) but are
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         for (int h = 0; h < p.n_hyp; ++h) {
             for (int cidx = 4 * h; cidx < 4 * h + 4; ++cidx) {
                 const double cnt = score[2 * cidx], cst = score[2 * cidx + 1];
-                if (cnt > bc || (cnt == bc && best >= 0 && cst < bs)) { best = cidx; bc = cnt; bs = cst; }
+                if (cnt > 3.5 && cst < bs) { best = cidx; bc = cnt; bs = cst; }
             }
             if (stop_rule && best >= 0) {
                 const double wr = bc / (double)p.n, w3 = wr * wr * wr;
@@ -430,6 +463,8 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 #pragma unroll
     for (int k = 0; k < 7; ++k) pose[k] = pose0[k];
 
+    double *wls = STAGED ? dyn + 6 * (size_t)p.n : p.chi2;       // (not staged: the chi2 output array, rewritten by every round below)
+    const double *wuse = nullptr;                               // weights of the LM passes (the local-optimisation step), or none
     // robust cost of the active matches at a pose
     auto cost = [&](const double T[7], bool robust) {
         double R[12];
@@ -441,7 +476,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
             const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
             const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-            const double om = isig[i];
+            const double om = wuse ? isig[i] * wuse[i] : isig[i];
             const double iz = fast_rcp(z);
             const double e0 = obs[2 * i] - (p.fx * x * iz + p.cx), e1 = obs[2 * i + 1] - (p.fy * y * iz + p.cy);
             const double chi2 = e0 * (om * e0) + e1 * (om * e1);
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
                 const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
                 const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
                 const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-                const double om = isig[i];
+                const double om = wuse ? isig[i] * wuse[i] : isig[i];
                 // (one reciprocal per match and pass instead of six divisions)
                 const double iz = fast_rcp(z), uu = p.fx * x * iz, vv = p.fy * y * iz;
                 const double e0 = obs[2 * i] - (uu + p.cx), e1 = obs[2 * i + 1] - (vv + p.cy);
@@ -538,8 +573,10 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             if (qmax == 10 || rho == 0.0 || !isfinite(lambda)) ok = false;
         }
     };
-    // inliers of a pose at the hypothesis threshold: count and truncated cost (the scores of the hypothesis stage)
+    // a pose at the hypothesis threshold: matches inside it and sigma-consensus++ loss (the scores of the hypothesis stage); mark:
+    // also the matches outside (level1) and the IRLS weights of those inside (wls)
     auto score_pose = [&](const double T[7], double &cnt_o, double &cst_o, bool mark) {
+        const Magsac ms(p.chi2_gate);
         double R[12];
         q2R(T, R);
         double sc[2] = { 0.0, 0.0 };
@@ -552,23 +589,27 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             const double e0 = obs[2 * i] - (p.fx * x / z + p.cx), e1 = obs[2 * i + 1] - (p.fy * y / z + p.cy);
             const double chi2 = e0 * (om * e0) + e1 * (om * e1);
             const bool in = (z > 0.0) && (chi2 <= p.chi2_gate);
-            sc[0] += in ? 1.0 : 0.0; sc[1] += in ? chi2 : p.chi2_gate;
-            if (mark) level1[i] = in ? 0 : 1;
+            double ls, wt;
+            ms.terms(chi2, z > 0.0, p.chi2_gate, ls, wt);
+            sc[0] += in ? 1.0 : 0.0; sc[1] += ls;
+            if (mark) { level1[i] = in ? 0 : 1; wls[i] = wt; }
         }
         reduce_all<2>(sc, lds);
         cnt_o = sc[0]; cst_o = sc[1];
     };
-    // ---- local optimisation of the winning hypothesis (USAC's LO step; cv::solvePnPRansac refits on the inliers too): LM on its
-    // inliers without robust kernel, kept when the refit pose has more inliers at the same threshold (ties: lower truncated
-    // cost).  The four rounds below then start from that pose, over all matches. ----
+    // ---- local optimisation of the winning hypothesis (USAC's LO step; MAGSAC++'s model polishing is iteratively reweighted least
+    // squares): LM on the matches inside the threshold, each weighted by its sigma-consensus weight at the winner, no robust
+    // kernel; kept when the refit pose has a lower loss.  The four rounds below then start from that pose, over all matches. ----
     if (have_hyp && p.lo_its > 0) {
         double c0, s0, c1, s1;
         __syncthreads();
         score_pose(pose0, c0, s0, true);
         __syncthreads();
+        wuse = wls;
         lm_round(false, p.lo_its);
+        wuse = nullptr;
         score_pose(pose, c1, s1, false);
-        const bool keep = c1 > c0 || (c1 == c0 && s1 < s0);
+        const bool keep = c1 > 3.5 && s1 < s0;
         if (keep) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) pose0[k] = pose[k];
@@ -622,7 +663,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 }
 
 size_t pose_ransac_bytes(int n_hyp) { return n_hyp > 0 ? (size_t)n_hyp * (48 + 8) * sizeof(double) + (size_t)n_hyp * sizeof(int) + 16 : 0; }
-size_t pose_opt_staged_lds_bytes(int n, int n_hyp) { return (size_t)n * 6 * sizeof(double) + (((size_t)n + 15) & ~(size_t)15) + pose_ransac_bytes(n_hyp); }
+size_t pose_opt_staged_lds_bytes(int n, int n_hyp) { return (size_t)n * 7 * sizeof(double) + (((size_t)n + 15) & ~(size_t)15) + pose_ransac_bytes(n_hyp); }
 
 hipError_t configure_pose_kernels()
 {

@@ -870,7 +870,8 @@ int lba_oracle_pose_opt(const lba_oracle_pose_problem *pb, double pose_out[7],
  * cv::solvePnPRansac, which the reference calls with useExtrinsicGuess = false at src/Optimizer.cc:437;
  * OpenCV's own arithmetic is not in the reference tree).  Plain restatement of the same algorithm the
  * kernel runs: Grunert's three-point solution (Haralick et al. 1994: quartic in v = s3 / s1), every
- * candidate scored on all matches by its inlier count at chi2_gate, ties by truncated cost, then index.
+ * candidate scored on all matches by its sigma-consensus++ loss (below), among those with at least 4 matches inside
+ * the threshold; ties by index.
  * --------------------------------------------------------------------------------------------- */
 typedef struct { double re, im; } cplx_t;
 static cplx_t c_mul(cplx_t a, cplx_t b) { cplx_t r = { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; return r; }
@@ -986,9 +987,38 @@ static int p3p_grunert(double X[3][3], double j[3][3], double Rs[4][9], double t
     return ns;
 }
 
-/* Best pose over n_hyp minimal samples (n_hyp x 3 match indices).  pose_out = pb->pose0 (normalised) when no candidate
- * reaches 4 inliers.  Returns the inlier count of the pose returned (0 in that case). */
-static void pose_score(const lba_oracle_pose_problem *pb, const double pose[7], double *cnt_o, double *cst_o, uint8_t *mark)
+/* ---------------------------------------------------------------------------------------------
+ * sigma-consensus++ (MAGSAC++; D. Barath, J. Noskova, M. Ivashechkin, J. Matas, "MAGSAC++, a fast, reliable and accurate
+ * robust estimator", CVPR 2020), what flag 38 = cv::USAC_MAGSAC of the reference's call (src/Optimizer.cc:437,
+ * Examples/Monocular/TartanAir.yaml:51) scores models with; restated from the paper, OpenCV's source is not in the tree.
+ * A residual r (here r^2 = the edge's chi2, 2 degrees of freedom) is not classified at one threshold: its noise scale sigma
+ * is marginalised over (0, sigma_max], sigma_max = tau / k with tau the caller's threshold (reprojectionError, tau^2 =
+ * chi2_gate) and k^2 = 9.21034 the 0.99 quantile of chi^2 with 2 degrees of freedom.  With x = r^2 / (2 sigma_max^2),
+ * x_k = k^2 / 2 and n = 2 the paper's incomplete gamma functions are elementary:
+ *     Gamma(1/2, x) = sqrt(pi) erfc(sqrt x),      gamma(3/2, x) = sqrt(pi) / 2 erf(sqrt x) - sqrt x exp(-x)
+ *   weight (eq. 6; the IRLS weight of the local optimisation)   w(r)   = Gamma(1/2, x) - Gamma(1/2, x_k)         r <= tau, else 0
+ *   loss   (eq. 9-10; the model quality is minus its sum)       rho(r) = sigma_max^2 / 2 gamma(3/2, x) + r^2 / 4 w(r)   r <= tau,
+ *                                                                rho(tau) beyond (and for a point behind the camera)
+ * both up to the common factor C(n) 2^((n+1)/2) / sigma_max, which cancels in every comparison; the loss is reported
+ * divided by rho(tau): in [0, 1] per match, 1 = outlier.
+ * --------------------------------------------------------------------------------------------- */
+#define MAGSAC_K2 9.210340371976184          /* -2 ln(0.01) */
+static void magsac_terms(double chi2, int in_front, double gate, double *loss, double *weight)
+{
+    const double sq_pi = 1.7724538509055160273, xk = 0.5 * MAGSAC_K2;
+    const double s2 = gate / MAGSAC_K2;                      /* sigma_max^2 */
+    const double g_k = sq_pi * erfc(sqrt(xk));
+    const double rho_max = 0.5 * s2 * (0.5 * sq_pi * erf(sqrt(xk)) - sqrt(xk) * exp(-xk));
+    if (!in_front || !(chi2 <= gate)) { *loss = 1.0; *weight = 0.0; return; }
+    const double x = chi2 / (2.0 * s2), sx = sqrt(x);
+    const double w = sq_pi * erfc(sx) - g_k;
+    const double rho = 0.5 * s2 * (0.5 * sq_pi * erf(sx) - sx * exp(-x)) + 0.25 * chi2 * w;
+    *loss = rho / rho_max; *weight = w > 0.0 ? w : 0.0;
+}
+
+/* tentative inliers of a pose at the threshold (count) and its MAGSAC++ loss; mark / wgt (optional): matches outside the
+ * threshold, IRLS weights of those inside (largest = 1) */
+static void pose_score(const lba_oracle_pose_problem *pb, const double pose[7], double *cnt_o, double *cst_o, uint8_t *mark, double *wgt)
 {
     const double cam[4] = { pb->fx, pb->fy, pb->cx, pb->cy };
     double cnt = 0.0, cst = 0.0;
@@ -999,8 +1029,11 @@ static void pose_score(const lba_oracle_pose_problem *pb, const double pose[7], 
         const double om = pb->inv_sigma2 ? pb->inv_sigma2[i] : 1.0;
         const double chi2 = om * (e[0] * e[0] + e[1] * e[1]);
         const int in = (Xc[2] > 0.0) && (chi2 <= pb->chi2_gate);
-        cnt += in ? 1.0 : 0.0; cst += in ? chi2 : pb->chi2_gate;
+        double ls, wt;
+        magsac_terms(chi2, Xc[2] > 0.0, pb->chi2_gate, &ls, &wt);
+        cnt += in ? 1.0 : 0.0; cst += ls;
         if (mark) mark[i] = in ? 0 : 1;
+        if (wgt) wgt[i] = wt / (1.7724538509055160273 * (1.0 - erfc(sqrt(0.5 * MAGSAC_K2))));      /* w(0) = sqrt(pi) (1 - erfc(sqrt x_k)) */
     }
     *cnt_o = cnt; *cst_o = cst;
 }
@@ -1009,8 +1042,9 @@ static void pose_score(const lba_oracle_pose_problem *pb, const double pose[7], 
  * flag 38 = USAC_MAGSAC, whose pipeline refits the best model on its inliers):
  *   confidence in (0, 1): the samples are walked in order; after sample h, N = log(1 - confidence) / log(1 - w^3) with w the
  *     inlier ratio of the best pose so far, and the walk ends once h + 1 >= N (info[0] = samples admitted);
- *   lo_its > 0: LM refit of the winner on its inliers at chi2_gate, no robust kernel, lo_its iterations; kept when it has
- *     more inliers, or as many at a lower truncated cost (info[1] = kept, info[2] = inliers of the pose returned). */
+ *   lo_its > 0: LM refit of the winner on the matches inside the threshold, each weighted by its sigma-consensus weight at
+ *     the winner (one IRLS step of MAGSAC++'s model polishing), no robust kernel, lo_its iterations; kept when its loss is
+ *     lower (info[1] = kept, info[2] = matches inside the threshold at the pose returned). */
 int lba_oracle_pose_ransac_lo(const lba_oracle_pose_problem *pb, int n_hyp, const int32_t *samples, double confidence, int lo_its,
                               double pose_out[7], int32_t info[3])
 {
@@ -1042,9 +1076,12 @@ int lba_oracle_pose_ransac_lo(const lba_oracle_pose_problem *pb, int n_hyp, cons
                 const double e0 = pb->obs[2 * i] - (pb->fx * x / z + pb->cx), e1 = pb->obs[2 * i + 1] - (pb->fy * y / z + pb->cy);
                 const double chi2 = e0 * (om * e0) + e1 * (om * e1);
                 const int in = (z > 0.0) && (chi2 <= pb->chi2_gate);
-                cnt += in ? 1.0 : 0.0; cst += in ? chi2 : pb->chi2_gate;
+                double ls, wt;
+                magsac_terms(chi2, z > 0.0, pb->chi2_gate, &ls, &wt);
+                cnt += in ? 1.0 : 0.0; cst += ls;
             }
-            if (cnt > best_cnt || (cnt == best_cnt && have && cst < best_cost)) {
+            /* the model of lowest sigma-consensus loss among those with at least 4 matches inside the threshold */
+            if (cnt > 3.5 && cst < best_cost) {
                 best_cnt = cnt; best_cost = cst; have = 1;
                 memcpy(bestR, R, sizeof bestR); memcpy(bestt, t, sizeof bestt);
             }
@@ -1066,11 +1103,17 @@ int lba_oracle_pose_ransac_lo(const lba_oracle_pose_problem *pb, int n_hyp, cons
         uint8_t *mark = (uint8_t *)calloc((size_t)n + 1, 1);
         double *err = (double *)calloc(2 * (size_t)n + 2, sizeof(double));
         double c0, s0, c1, s1, refit[7];
-        pose_score(pb, pose_out, &c0, &s0, mark);
+        /* one iteratively-reweighted step: the matches inside the threshold, each with its sigma-consensus weight at the winner */
+        double *wls = (double *)calloc((size_t)n + 1, sizeof(double));
+        pose_score(pb, pose_out, &c0, &s0, mark, wls);
+        for (int i = 0; i < n; ++i) wls[i] *= pb->inv_sigma2 ? pb->inv_sigma2[i] : 1.0;
+        lba_oracle_pose_problem pw = *pb;
+        pw.inv_sigma2 = wls;
         memcpy(refit, pose_out, sizeof refit);
-        pose_lm_round(pb, refit, mark, 0, lo_its, err);
-        pose_score(pb, refit, &c1, &s1, NULL);
-        const int keep = c1 > c0 || (c1 == c0 && s1 < s0);
+        pose_lm_round(&pw, refit, mark, 0, lo_its, err);
+        pose_score(pb, refit, &c1, &s1, NULL, NULL);
+        free(wls);
+        const int keep = c1 > 3.5 && s1 < s0;
         if (keep) memcpy(pose_out, refit, sizeof refit);
         if (info) { info[1] = keep; info[2] = (int32_t)(keep ? c1 : c0); }
         free(mark); free(err);
