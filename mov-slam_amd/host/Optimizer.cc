@@ -774,9 +774,10 @@ namespace MOV_SLAM
     {
         // `confidence` is cv::solvePnPRansac's stopping rule: the hypothesis stage scores all iterationCount minimal samples at
         // once, and only those a sequential RANSAC over the same samples would have drawn before stopping are eligible.
-        // `algorithm` picks OpenCV's sampler / scorer (38 = USAC_MAGSAC, sigma-consensus scoring): the stage here scores by inlier
-        // count at the reprojection threshold (ties by truncated cost), followed — like the USAC pipeline — by one local
-        // optimisation of the winner on its inliers and the final refit (the four LM rounds); the flag itself is not interpreted.
+        // `algorithm` picks OpenCV's sampler / scorer; the reference's configurations pass 38 = cv::USAC_MAGSAC (TartanAir.yaml:51):
+        // the stage scores every hypothesis by its sigma-consensus++ loss (MAGSAC++, restated from the paper: pose_kernels.hip),
+        // followed - like the USAC pipeline - by one sigma-consensus-weighted local optimisation of the winner and the final refit
+        // (the four LM rounds).  Other flag values run the same pipeline: the flag itself is not interpreted.
         (void)algorithm;
         // ---- gather 3D-2D matches (Optimizer.cc:404-413) ----
         std::vector<double> Xw, obs;
