@@ -322,6 +322,7 @@ def main():
                     s2.solve_prepared(pack=False)
                 t2 = (time.perf_counter() - t1) / 20
                 r2 = s2.solve_prepared()
+                r2 = {"n_solves": int(r2["n_solves"]), "poses": np.array(r2["poses"])}      # (copies: the arrays are views of the handle's pinned memory)
                 s2.close()
                 c2 = {"ms_per_window_solve": 1e3 * t2, "lm_iterations_per_s": r2["n_solves"] / t2, "lm_iterations_per_step": r2["n_solves"], "E": w2.n_edges}
                 if not args.no_cpu_baseline:
@@ -364,9 +365,10 @@ def main():
                         st.solve_prepared(pack=False)
                     tts = (time.perf_counter() - t1) / 10
                     rts = st.solve_prepared()
+                    ts_info = (int(rts["n_solves"]), bool(np.array_equal(rts["poses"], res["poses"])), int(rts["n_sync_timeouts"]))   # (before close(): the arrays are views of the handle's pinned memory)
                     st.close()
-                    oc["cfg3_two_stream_lm_loop"] = {"ms_per_window_solve": 1e3 * tts, "lm_iterations_per_s": rts["n_solves"] / tts,
-                                                     "bits_equal_one_stream": bool(np.array_equal(rts["poses"], res["poses"])),
+                    oc["cfg3_two_stream_lm_loop"] = {"ms_per_window_solve": 1e3 * tts, "lm_iterations_per_s": ts_info[0] / tts,
+                                                     "bits_equal_one_stream": ts_info[1], "given_up_waits_in_the_last_solve": ts_info[2],
                                                      "note": "movba_options::two_streams = 1 (opt-in): PCG launches resident beside the schur pass on a stream of their own"}
                 oc["note"] = "whole-call wall times through the C-ABI, pinned result arrays, same timed region as `value` for cfg2"
                 out["config"]["other_baseline_configs"] = oc

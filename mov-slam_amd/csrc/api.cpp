@@ -486,15 +486,24 @@ int movba_structure_probe(const movba_lba_desc *desc, movba_structure_info *info
     }
     {   // launch schedule and pose-major slots: self-checks reported to the caller (CPU tests)
         info->n_sched_slots = (int32_t)s.sched.size(); info->sched_items = 0; info->sched_max_permille = 0; info->slots_ok = 1;
+        // (every item once: the wave slots that share it lie side by side in ONE workgroup, their places 0 .. n - 1 in order, and
+        //  their entry ranges cut the item's range without gap or overlap)
         std::vector<uint8_t> seen(s.nitems > 0 ? s.nitems : 1, 0);
         int64_t segw[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tot = 0;
         for (size_t k = 0; k < s.sched.size(); ++k) {
             const SchedItem &it = s.sched[k];
-            if (it.tag < 0) continue;
-            const int item = it.tag >> 1;
-            if (item >= s.nitems || seen[item] || s.items[item].begin != it.begin || s.items[item].end != it.end) { info->sched_items = -1; break; }
+            if (it.tag < 0 || (it.sub & 0xff) != 0) continue;
+            const int item = it.tag >> 1, nw = it.sub >> 8;
+            bool ok = item < s.nitems && !seen[item] && nw >= 1 && nw <= 4 && (k & 3) + (size_t)nw <= 4 && s.items[item].begin == it.begin;
+            int32_t at = it.begin;
+            for (int q = 0; ok && q < nw; ++q) {
+                const SchedItem &w = s.sched[k + q];
+                ok = w.tag == it.tag && w.sub == (q | (nw << 8)) && w.begin == at && w.end >= w.begin;
+                at = w.end;
+            }
+            if (!ok || at != s.items[item].end) { info->sched_items = -1; break; }
             seen[item] = 1; info->sched_items++;
-            const int64_t wgt = (int64_t)(it.end - it.begin) * ((it.tag & 1) ? 3 : 2) + 128;
+            const int64_t wgt = (int64_t)(s.items[item].end - s.items[item].begin) * ((it.tag & 1) ? 3 : 2) + 128;
             if (s.sched_per_xcd > 0) segw[k / s.sched_per_xcd] += wgt;
             tot += wgt;
         }
@@ -1153,7 +1162,8 @@ int Upload::lay_out_rest()
     }
     if (h->rows_kernel && !h->pp.overflow) {
         std::vector<int32_t> slot_of_item((size_t)s().nitems, -1);
-        for (size_t q = 0; q < s().sched.size(); ++q) if (s().sched[q].tag >= 0) slot_of_item[(size_t)(s().sched[q].tag >> 1)] = (int32_t)q;
+        for (size_t q = 0; q < s().sched.size(); ++q)      // (the slot of the wave that stores the item: place 0 among the item's waves)
+            if (s().sched[q].tag >= 0 && (s().sched[q].sub & 0xff) == 0) slot_of_item[(size_t)(s().sched[q].tag >> 1)] = (int32_t)q;
         for (int t = 0; t < kPcgRowsThreads; ++t)
             for (int k = 0; k < 2; ++k) {
                 const int32_t *pl = &lane_plan[((size_t)t * 3 + k) * 4];
@@ -1629,6 +1639,14 @@ int movba_lba_run(movba_handle *h)
         if (!h->pcg_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&h->pcg_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&h->xs_event, hipEventDisableTiming));
+            // (the stream's hardware queue is set up by its first launch: not in front of a solve the back-substitution pass of
+            //  its trial - resident on every CU by then - is waiting for)
+            HIP_TRY(launch_stream_warmup(h->pcg_stream));
+            // ... and the two-stream PCG kernel's first launch (its scratch allocation) neither: a launch of trial -1 finds its
+            // schur pass's no-op word (any value >= 0) and leaves at once
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(launch_pcg_rows(w, (int)h->st.row_ent.size(), run_pcg_params(h), -1, true, h->pcg_stream));
+            HIP_TRY(hipStreamSynchronize(h->pcg_stream));
         }
         // (k_init_pose has zeroed the hand-off words: no PCG launch of this run may look at them before that)
         HIP_TRY(hipEventRecord(h->xs_event, s));

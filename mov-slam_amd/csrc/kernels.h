@@ -27,6 +27,7 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
 // xs: the launch is on a stream of its own beside the schur pass of its trial and waits for the pass's items (DevWindow::xs)
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, bool xs, hipStream_t s);
 
+hipError_t launch_stream_warmup(hipStream_t s);
 hipError_t launch_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s);
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s);

@@ -692,15 +692,15 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // wave-uniform: item, poses and rotations live in SGPRs
     // XCD-aware launch schedule (structure.cpp): workgroups b, b+8, ... share an XCD (and its L2) and take the slots of
     // that XCD's segment in order.  The slot is fetched together with the LM state (one scalar round trip).
-    constexpr int ipw = kSchurWaves / kSchurWPI;            // kSchurWPI waves share one work item
-    const int wg = (bid & 7) * (w.sched_per_xcd / ipw) + (bid >> 3);
-    const SchedItem it = w.sched[wg * ipw + wv / kSchurWPI];
+    static_assert(kSchurWaves == 4, "the schedule deals wave slots in workgroups of four (structure.cpp)");
+    const int wg = (bid & 7) * (w.sched_per_xcd / kSchurWaves) + (bid >> 3);
+    const SchedItem it = w.sched[wg * kSchurWaves + wv];    // this wave's slot: its share of an item one, two or four waves take
     const Ctrl *c = w.ctrl;
     if (c->done) {
         if (trial >= 0 && bid == 0 && threadIdx.x == 0) hx_st_u32(w.xs + kXsSkip, (unsigned)trial + 1u);
         return;
     }
-    const int sub = wv % kSchurWPI;
+    const int sub = it.sub & 0xff, nsub = it.sub >> 8;
     __shared__ __attribute__((aligned(16))) double strips[kSchurWaves][54 * 16];
     __shared__ double wsum[kSchurWaves][64];
     double *strip = strips[wv];
@@ -708,8 +708,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
     const int item = active ? (it.tag >> 1) : 0;
     const bool is_diag = active && (it.tag & 1);
     if (HPP_ONLY && !is_diag) active = false;
-    const int epw = (it.end - it.begin + kSchurWPI - 1) / kSchurWPI;          // entries per wave: the item split evenly
-    const int wbeg = it.begin + sub * epw, wend = active ? min(it.end, wbeg + epw) : wbeg;
+    const int wbeg = it.begin, wend = active ? it.end : it.begin;
     const int cur = c->cur;
     const double lambda = c->lambda;
     const DevState &S0 = w.st[cur];
@@ -802,11 +801,10 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
         wsum[wv][lane] = wave_reduce<36>(acc, strip, lane);
     }
     WSTAMP(3);
-    if (kSchurWPI > 1) __syncthreads();
+    __syncthreads();
     if (active && sub == 0) {
         double t = wsum[wv][lane];
-#pragma unroll
-        for (int q = 1; q < kSchurWPI; ++q) t += wsum[wv + q][lane];
+        for (int q = 1; q < nsub; ++q) t += wsum[wv + q][lane];
         // (write-through stores: the item's partial may be taken by a solve that is already resident on another stream)
         if (is_diag) {
             if (lane < 54) {
@@ -1020,6 +1018,14 @@ size_t point_lds_need(int NP, int nfree)
     return (24 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
+// (first launch on a new stream: its hardware queue is set up here, not in front of a kernel other kernels wait for)
+__global__ void k_stream_warmup() {}
+hipError_t launch_stream_warmup(hipStream_t s)
+{
+    hipLaunchKernelGGL(k_stream_warmup, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 hipError_t launch_init(const DevWindow &w, hipStream_t s)
 {
     const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;
@@ -1044,7 +1050,7 @@ hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
 {
-    const int nblk = 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI));                       // one item per workgroup; multiple of 8: a contiguous run of items per XCD
+    const int nblk = 8 * (w.sched_per_xcd / kSchurWaves);     // four wave slots per workgroup; multiple of 8: a contiguous run of slots per XCD
     if (mode == 1) trial = -1;          // (the pass that seeds lambda hands nothing over)
     if (w.kcam) {
         if (mode == 1) {
@@ -1127,7 +1133,7 @@ size_t point_lds_bytes_for(const DevWindow &w, bool backsub, bool ldsp)
     return point_lds_bytes(v, backsub);
 }
 
-int schur_blocks(const DevWindow &w) { return 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI)); }
+int schur_blocks(const DevWindow &w) { return 8 * (w.sched_per_xcd / kSchurWaves); }
 
 hipError_t launch_schur_batch(const BatchDev &b, int nblk, int mode, bool stereo, hipStream_t s)
 {

@@ -650,14 +650,26 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             {
                 double g = owner ? r_r * z_r : 0.0, d = owner ? w_r * z_r : 0.0;
                 wave_sum_dpp2(g, d);
-                if (ln == 0) { red0[wv] = g; red1[wv] = d; }
+                if (ln == 0) *reinterpret_cast<double2 *>(red0 + 2 * wv) = make_double2(g, d);      // (red0 / red1: one run of 2 kNW doubles)
             }
             SEG_STAMP(4);
             __syncthreads();                                  // (B) r.z, w.z and P^T w visible; all reads of z done
             SEG_STAMP(5);
-            // the dense coarse product of this iteration, issued before the scalar recurrences (independent of them)
+            // the eight waves' (r.z, w.z): lane k < 8 reads wave k's pair, three DPP steps add them in the fixed tree
+            // ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)) - ONE 16-byte LDS read per lane and six adds where every lane used to read
+            // all sixteen values and add them up itself; requested ahead of the coarse product's reads (LDS answers in order: the
+            // scalar recurrences below start while those are still in flight)
+            double g, delta;
+            {
+                const double2 gd = *reinterpret_cast<const double2 *>(red0 + 2 * (ln & 7));
+                double a = gd.x, b = gd.y;
+                a += dpp_mov0<0xb1>(a); b += dpp_mov0<0xb1>(b);
+                a += dpp_mov0<0x4e>(a); b += dpp_mov0<0x4e>(b);
+                a += dpp_mov0<0x141>(a); b += dpp_mov0<0x141>(b);       // row_half_mirror: lanes 0 - 3 meet lanes 7 - 4
+                g = uniform_f64(a); delta = uniform_f64(b);
+            }
+            // the dense coarse product of this iteration (independent of the scalar recurrences)
             const double yc = coarse ? coarse_rows() : 0.0;
-            const double g = uniform_f64(sum_fixed(red0)), delta = uniform_f64(sum_fixed(red1));
             if (!isfinite(g) || !isfinite(delta)) { fail = true; break; }
             if (first) {
                 thresh = uniform_f64(pp.rel_tol * pp.rel_tol * g);

@@ -198,20 +198,43 @@ int finish_pairs(Structure& s, const int32_t* cnt)
             }
             while (x < 8) seg_begin[++x] = s.nitems;
         }
+        // Waves per item: a wave takes 128 entries per turn of its loop (64 lanes x 2 in flight), so an item of up to 128 entries
+        // is ONE wave's single turn, up to 256 two waves', beyond that four waves share it (diagonal items always: they are cut
+        // at 512 entries and cost 1.5x per entry).  Workgroups of four waves are filled in schedule order - four small items, two
+        // medium ones, or one large - so that a 50-keyframe window's ~630 items need ~400 workgroups: ONE round on the 512 the
+        // chip holds at 232 registers per lane, where every item its own workgroup left 120 tiny items to a second round that
+        // started 7 - 9 us in and ended the pass at 14.5 us.
+        auto waves_of = [&](int k) { const Item& it = s.items[k]; const int n = it.end - it.begin; return it.diag ? 4 : (n > 256 ? 4 : (n > 128 ? 2 : 1)); };
         size_t longest = 1;
         for (int g = 0; g < 8; ++g) {
             std::sort(key.begin() + seg_begin[g], key.begin() + seg_begin[g + 1]);
-            longest = std::max(longest, (size_t)(seg_begin[g + 1] - seg_begin[g]));
+            size_t slots = 0;
+            for (int n = seg_begin[g]; n < seg_begin[g + 1]; ++n) {
+                const size_t nw = (size_t)waves_of(order[(uint32_t)key[n]]);
+                if ((slots & 3) + nw > 4) slots = (slots + 3) & ~(size_t)3;     // does not fit the open workgroup: the next one
+                slots += nw;
+            }
+            longest = std::max(longest, (slots + 3) & ~(size_t)3);
         }
-        s.sched_per_xcd = (int)((longest + ipw - 1) / ipw) * ipw;
+        (void)ipw;
+        s.sched_per_xcd = (int)longest;                     // wave slots per XCD (a multiple of 4)
         s.sched.assign((size_t)8 * s.sched_per_xcd, SchedItem{ 0, 0, -1, 0, 0, -1, -1, 0 });
-        for (int g = 0; g < 8; ++g)
+        for (int g = 0; g < 8; ++g) {
+            size_t slots = 0;
             for (int n = seg_begin[g]; n < seg_begin[g + 1]; ++n) {
                 const int item = order[(uint32_t)key[n]];
                 const Item& it = s.items[item];
-                s.sched[(size_t)g * s.sched_per_xcd + (n - seg_begin[g])] = SchedItem{ it.begin, it.end, (item << 1) | (it.diag ? 1 : 0),
-                                                                                      s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], -1, -1, 0 };
+                const int nw = waves_of(item);
+                if ((slots & 3) + (size_t)nw > 4) slots = (slots + 3) & ~(size_t)3;
+                const int len = it.end - it.begin, epw = (len + nw - 1) / nw;          // the item's entries split evenly over its waves
+                for (int sub = 0; sub < nw; ++sub) {
+                    const int wb = std::min(it.begin + sub * epw, it.end), we = std::min(wb + epw, it.end);
+                    s.sched[(size_t)g * s.sched_per_xcd + slots + sub] = SchedItem{ wb, we, (item << 1) | (it.diag ? 1 : 0),
+                                                                                   s.free_pose[s.pair_i[it.pair]], s.free_pose[s.pair_j[it.pair]], -1, -1, sub | (nw << 8) };
+                }
+                slots += (size_t)nw;
             }
+        }
     }
 
     // ---- block-row gather lists for y = S x with S given by its upper blocks: row i lists, by ascending column, the

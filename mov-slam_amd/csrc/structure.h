@@ -20,12 +20,14 @@ struct Int2 { int32_t x, y; };
 struct Int4 { int32_t x, y, z, w; };
 struct Item { int32_t pair, begin, end, diag; };   // entries [begin,end) of one pair
 // one slot of the k_schur launch schedule: everything a workgroup needs to start, in one 32-byte scalar load
+// ONE WAVE SLOT of the k_schur launch (four per workgroup): the entries [begin, end) of work item tag >> 1 this wave takes
 struct SchedItem {
     int32_t begin, end, tag /* (item << 1) | diagonal, -1 = padding */, pose_i, pose_j /* pose indices of the pair */;
     // off-diagonal items of single-item pairs, windows with an on-chip PCG: where the item's 6 x 6 block goes in DevWindow::img_b,
     // as stored (dst_a) and transposed (dst_b): 36 k 512 + thread of the PCG lane slot that holds it, or -1.
     // Diagonal items: dst_a = the item's record in DevWindow::rec_d (keyframe * rec_slots + place in the pair)
-    int32_t dst_a, dst_b, pad;
+    int32_t dst_a, dst_b;
+    int32_t sub;        // this wave's place among the waves that share the item | their number << 8 (place 0 adds the waves' sums up and stores)
 };
 struct RowEnt { int32_t block, col, transposed, pad; };
 
@@ -56,7 +58,7 @@ struct Structure {
     std::vector<int32_t> ent_i, ent_j, ent_l;
     int E_free = 0;                     // edges of free poses = entries of the diagonal pairs
     std::vector<Item> items;            // nitems
-    // k_schur launch schedule: 8 segments (one per XCD) of sched_per_xcd slots
+    // k_schur launch schedule: 8 segments (one per XCD) of sched_per_xcd wave slots (four per workgroup)
     std::vector<SchedItem> sched;
     int sched_per_xcd = 0;
     std::vector<int32_t> row_ptr;       // nfree+1

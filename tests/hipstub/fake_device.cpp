@@ -7,6 +7,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -45,7 +48,7 @@ hipError_t configure_pose_kernels() { return hipSuccess; }
 bool struct_lds_fits(int, int) { return true; }
 size_t point_lds_need(int NP, int) { return (size_t)NP * 96; }
 size_t point_lds_bytes_for(const DevWindow &w, bool, bool) { return (size_t)w.NP * 96; }
-int schur_blocks(const DevWindow &w) { return 8 * (w.sched_per_xcd / (kSchurWaves / kSchurWPI)); }
+int schur_blocks(const DevWindow &w) { return 8 * (w.sched_per_xcd / kSchurWaves); }
 size_t dense_tiles_doubles(int nfree) { const size_t nt = ((size_t)6 * nfree + kDenseNB - 1) / kDenseNB; return (nt + 1) * (nt + 2) / 2 * (size_t)(kDenseNB * kDenseNB); }
 int dense_ntile(int nfree) { return (6 * nfree + kDenseNB - 1) / kDenseNB; }
 bool dense_persist_supported(const DensePlan &p) { return p.ok; }
@@ -227,11 +230,60 @@ void fake_backsub(const DevWindow &w, unsigned wait_epoch)
     }
     fake_decide(w);
 }
+// What the one-launch direct solver (dense_persist.hip) indexes with values the HOST built - the item-range table prange read
+// by assemble_tile, the work items' partials behind it, every task's tile / operand tiles / flags, the tagged-record area - walked
+// here with the same index arithmetic, every index checked against the size the upload carved and the last element of every
+// range touched (AddressSanitizer sees the rest).  An assembly variant of round 3 faulted on the GPU and its cause was never
+// found: whatever such a variant gets wrong on the device, a table that points outside its arrays is caught here on the CPU.
+long walk_direct_tables(const DevWindow &w)
+{
+    long sink = 0;
+    const int nf = w.nfree, nt = w.dense.ntile, NB = kDenseNB;
+    auto need = [](bool ok, const char *what) { if (!ok) { std::fprintf(stderr, "fake device: direct-solver table out of range: %s\n", what); std::abort(); } };
+    need(nt == (6 * nf + NB - 1) / NB && w.dense.n == 6 * nf, "tile count");
+    for (int lo = 0; lo < nf; ++lo)
+        for (int hi = lo; hi < nf; ++hi) {
+            const int32_t i0 = w.dense.prange[2 * ((size_t)lo * nf + hi)], i1 = w.dense.prange[2 * ((size_t)lo * nf + hi) + 1];
+            need(0 <= i0 && i0 <= i1 && i1 <= w.nitems, "prange");
+            need(lo != hi || i1 > i0, "a diagonal pair without work items");
+            if (i1 > i0) sink += (long)w.part[(size_t)(i1 - 1) * kPartStride + kPartStride - 1];
+        }
+    // the staging pass of a diagonal tile reads the records of its eight diagonal pairs as ONE run: they must be contiguous
+    for (int K = 0; K < nt; ++K) {
+        const int b0 = K * (NB / 6), b1 = std::min(b0 + NB / 6, nf);
+        for (int b = b0; b + 1 < b1; ++b)
+            need(w.dense.prange[2 * ((size_t)b * nf + b) + 1] == w.dense.prange[2 * ((size_t)(b + 1) * nf + b + 1)], "diagonal pairs' items not contiguous");
+    }
+    const size_t tile_doubles = (size_t)NB * NB, ntiles = (size_t)(nt + 1) * (nt + 2) / 2;
+    const int nflag = dense_flag_count(nt);
+    auto tile_last = [&](int I, int K) { need(0 <= K && K <= I && I <= nt, "tile index"); const size_t t = (size_t)I * (I + 1) / 2 + K; need(t < ntiles, "tile offset"); return (long)w.dense.tiles[t * tile_doubles + tile_doubles - 1]; };
+    need(w.dense.task_ptr[0] == 0, "task list start");
+    for (int g = 0; g < w.dense.G; ++g) {
+        need(w.dense.task_ptr[g] <= w.dense.task_ptr[g + 1], "task list order");
+        for (int t = w.dense.task_ptr[g]; t < w.dense.task_ptr[g + 1]; ++t) {
+            const DenseTask &tk = w.dense.tasks[t];
+            need(tk.op >= DT_ASM && tk.op <= DT_COL, "task op");
+            need(tk.slot >= -1 && tk.slot < w.dense.slots, "task slot");
+            if (tk.op == DT_EPI) continue;
+            need(tk.I >= 0 && tk.I < nt && tk.K >= 0 && tk.K <= tk.I, "task tile");
+            sink += tile_last(tk.I, tk.K);
+            if (tk.op == DT_UPD || tk.op == DT_UPD2 || tk.op == DT_RUP) {
+                need(tk.k >= 0 && tk.k < tk.K + (tk.op == DT_RUP ? 1 : 0), "task block column");
+                sink += tile_last(tk.I, tk.k) + tile_last(tk.K, tk.k);
+                need(dense_flag_F(nt, tk.I, tk.k) < nflag && dense_flag_F(nt, tk.K, tk.k) < nflag, "flag index");
+            }
+            need(dense_flag_FC(nt, tk.I, tk.K) < nflag && dense_flag_PD(nt, tk.K) < nflag && dense_flag_FX(nt, tk.I) < nflag, "flag index");
+        }
+    }
+    sink += (long)w.dense.flags[dense_flag_words(nt) - 1] + (long)w.dense.contrib[(size_t)nt * nt * NB - 1] + (long)w.dense.failw[1];
+    return sink;
+}
+
 void fake_direct(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
     if (rd_done(c) == 1) return;
-    if (w.dense.G > 0) g_sink += sum_bytes(w.dense.flags, 16);
+    if (w.dense.G > 0) g_sink += sum_bytes(w.dense.flags, 16) + walk_direct_tables(w);
     c->pcg_last_iters = -1; c->n_direct += 1;
     if (rd_done(c) == 2) wr_done(c, 0);
 }
@@ -244,6 +296,7 @@ void fake_finalize(const DevWindow &w)
 }
 }  // namespace
 
+hipError_t launch_stream_warmup(hipStream_t) { return hipSuccess; }
 hipError_t launch_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_init(w); }); return hipSuccess; }
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += rd_done(w.ctrl); }); return hipSuccess; }
 hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s) { fake_enqueue(s, [w, mode, trial] { fake_schur(w, mode == 1 ? -1 : trial); }); return hipSuccess; }
