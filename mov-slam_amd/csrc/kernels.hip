@@ -668,9 +668,14 @@ __device__ __forceinline__ void schur_offdiag_entry(const Cam &cmi, const Cam &c
     }
 }
 
+// (one entry per lane in flight, diagonal and off-diagonal items alike: 196 registers per lane instead of 232 and, with the
+//  small items sharing workgroups - structure.cpp - a shorter pass than two in flight: 14.0 against 15.1 us at cfg3, batched
+//  2.09 against 2.17 ms per eight windows; round 4, builds with -DMOVBA_SCHUR_BD / _BO)
 #ifndef MOVBA_SCHUR_BD
-#define MOVBA_SCHUR_BD 2
-#define MOVBA_SCHUR_BO 2
+#define MOVBA_SCHUR_BD 1
+#endif
+#ifndef MOVBA_SCHUR_BO
+#define MOVBA_SCHUR_BO 1
 #endif
 constexpr int kSchurBatchDiag = MOVBA_SCHUR_BD;     // entries per lane whose gathers are in flight together (diagonal items)
 constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
@@ -853,8 +858,11 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
 #endif
 }
 
+#ifndef MOVBA_SCHUR_MINWAVES
+#define MOVBA_SCHUR_MINWAVES 1
+#endif
 template <int NR, bool HPP_ONLY>
-__global__ __launch_bounds__(kSchurWaves * 64) void k_schur(DevWindow w, int trial) { schur_body<NR, HPP_ONLY>(w, blockIdx.x, trial); }
+__global__ __launch_bounds__(kSchurWaves * 64, MOVBA_SCHUR_MINWAVES) void k_schur(DevWindow w, int trial) { schur_body<NR, HPP_ONLY>(w, blockIdx.x, trial); }
 
 // (a window with intrinsics by keyframe: solved on its own, never in a batch - api.cpp)
 template <int NR, bool HPP_ONLY>

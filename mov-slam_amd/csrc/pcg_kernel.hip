@@ -697,6 +697,15 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     }
     const bool capped = iters > pp.max_iters;
     if (capped) iters = pp.max_iters;
+    // (the current pose of this thread's keyframe, for the update at the very end: requested here, a cold round trip that runs
+    //  beside the barriers and the reduction below instead of behind them)
+    double T0[7] = { 0, 0, 0, 1, 0, 0, 0 };
+    int h0 = -1;
+    if (tid < w.NP) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) T0[k] = w.st[cur].pose[7 * tid + k];
+        h0 = w.hidx[tid];
+    }
     __syncthreads();
 #ifdef MOVBA_CLOCK_STAMP
     const unsigned long long xs_t3 = __builtin_amdgcn_s_memrealtime();
@@ -738,8 +747,8 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     for (int i = tid; i < w.NP; i += kT) {
         double T[7], Tn[7];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) T[k] = S0.pose[7 * i + k];
-        const int h = w.hidx[i];
+        for (int k = 0; k < 7; ++k) T[k] = i == tid ? T0[k] : S0.pose[7 * i + k];
+        const int h = i == tid ? h0 : w.hidx[i];
         if (h >= 0) {
             double u[6];
 #pragma unroll

@@ -204,7 +204,11 @@ int finish_pairs(Structure& s, const int32_t* cnt)
         // medium ones, or one large - so that a 50-keyframe window's ~630 items need ~400 workgroups: ONE round on the 512 the
         // chip holds at 232 registers per lane, where every item its own workgroup left 120 tiny items to a second round that
         // started 7 - 9 us in and ended the pass at 14.5 us.
-        auto waves_of = [&](int k) { const Item& it = s.items[k]; const int n = it.end - it.begin; return it.diag ? 4 : (n > 256 ? 4 : (n > 128 ? 2 : 1)); };
+#ifndef MOVBA_SCHUR_T1
+#define MOVBA_SCHUR_T1 128
+#define MOVBA_SCHUR_T2 256
+#endif
+        auto waves_of = [&](int k) { const Item& it = s.items[k]; const int n = it.end - it.begin; return it.diag ? 4 : (n > MOVBA_SCHUR_T2 ? 4 : (n > MOVBA_SCHUR_T1 ? 2 : 1)); };
         size_t longest = 1;
         for (int g = 0; g < 8; ++g) {
             std::sort(key.begin() + seg_begin[g], key.begin() + seg_begin[g + 1]);
