@@ -135,6 +135,17 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigne
     // anything) ends the solve through the bounded wait instead of hanging the launch.
     constexpr int kDeep = 10;
     const unsigned tag = (unsigned)c->n_solves + 1u;
+    // What the decision reads besides the partials is requested HERE, ahead of the wait: the caller's stop flag sits in host
+    // memory (one PCIe round trip, ~1.5 us) and the controller's words are cold lines of L2 - behind the wait each of them was a
+    // dependent round trip on the path of every trial.
+    const int stop = __hip_atomic_load(&w.hstat->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double F0 = c->F0, lambda0 = c->lambda, nu0 = c->nu;
+    const int tr = c->n_trace, qmax0 = c->qmax, it0 = c->it, nsolves0 = c->n_solves;
+    // (what the solver left for this wave - the pose part of the scale, its failure flag, its iteration count: final before
+    //  this launch started when the solve ran ahead of it on the same stream)
+    double scale_pose = 0.0;
+    int pcg_fail = 0, pcg_iters = 0;
+    if (!wait_epoch) { scale_pose = w.scale_part[w.n_pt_blocks]; pcg_fail = c->pcg_fail; pcg_iters = c->pcg_last_iters; }
     const __amdgpu_buffer_rsrc_t rr = hx_rsrc(w.dec_rec, 32u * (unsigned)w.n_pt_blocks);
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     double F1 = 0.0, scale = 0.0;
@@ -170,55 +181,56 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigne
     F1 = wave_sum(F1);
     scale = wave_sum(scale);
     if (lane != 0) return;
-    // (what the solver left for this wave - the pose part of the scale, its failure flag, its iteration count - was written
-    //  through by a kernel that may have run beside this one: L1-bypassing loads)
-    scale += wait_epoch ? hx_ld_f64(w.scale_part + w.n_pt_blocks) : w.scale_part[w.n_pt_blocks];
-    if (wait_epoch ? hx_ld_i32(&c->pcg_fail) : c->pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
+    // (two streams: written through by a kernel that ran beside this one - L1-bypassing loads, behind the wait)
+    if (wait_epoch) { scale_pose = hx_ld_f64(w.scale_part + w.n_pt_blocks); pcg_fail = hx_ld_i32(&c->pcg_fail); pcg_iters = hx_ld_i32(&c->pcg_last_iters); }
+    scale += scale_pose;
+    if (pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
     scale += 1e-3;
-    const double F0 = c->F0;
     const double rho = (F0 - F1) / scale;
-    const int stop = __hip_atomic_load(&w.hstat->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const int tr = c->n_trace;
     if (tr < kMaxTrace) {
-        c->tr_lambda[tr] = c->lambda; c->tr_f0[tr] = F0; c->tr_f1[tr] = F1; c->tr_rho[tr] = rho;
-        c->tr_pcg[tr] = wait_epoch ? hx_ld_i32(&c->pcg_last_iters) : c->pcg_last_iters;
+        c->tr_lambda[tr] = lambda0; c->tr_f0[tr] = F0; c->tr_f1[tr] = F1; c->tr_rho[tr] = rho;
+        c->tr_pcg[tr] = pcg_iters;
     }
     bool lambda_ok = true;
     int accepted = 0;
     if (rho > 0.0 && isfinite(F1)) {
-        const double tr = 2.0 * rho - 1.0;
-        double alpha = 1.0 - tr * tr * tr;             // (pow(tmp, 3) in g2o: a library call of ~100 instructions here)
+        const double t = 2.0 * rho - 1.0;
+        double alpha = 1.0 - t * t * t;                // (pow(tmp, 3) in g2o: a library call of ~100 instructions here)
         alpha = fmin(alpha, 2.0 / 3.0);
-        c->lambda *= fmax(1.0 / 3.0, alpha);
+        c->lambda = lambda0 * fmax(1.0 / 3.0, alpha);
         c->nu = 2.0;
         c->F0 = F1;
         c->cur = cur ^ 1;                    // discardTop(): the trial state becomes current
         c->last_rejected = 0;
         accepted = 1;
     } else {
-        c->lambda *= c->nu;
-        c->nu *= 2.0;
+        const double lam = lambda0 * nu0;
+        c->lambda = lam;
+        c->nu = nu0 * 2.0;
         c->last_rejected = 1;                // pop(): keep the current state
-        lambda_ok = isfinite(c->lambda);
+        lambda_ok = isfinite(lam);
     }
     if (tr < kMaxTrace) { c->tr_accept[tr] = accepted; c->n_trace = tr + 1; }
-    c->n_solves += 1;
-    c->qmax += 1;
-    const bool more_trials = lambda_ok && (rho < 0.0) && (c->qmax < w.max_trials) && !stop;
+    const int nsolves = nsolves0 + 1, qmax = qmax0 + 1;
+    int it = it0, qnext = qmax;
+    c->n_solves = nsolves;
+    const bool more_trials = lambda_ok && (rho < 0.0) && (qmax < w.max_trials) && !stop;
     int done = 0;
     if (!more_trials) {
-        c->iters_done = c->it + 1;
-        if (c->qmax == w.max_trials || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
+        c->iters_done = it0 + 1;
+        if (qmax == w.max_trials || rho == 0.0 || !lambda_ok) done = 1;       // Terminate
         else {
-            c->it += 1;
-            c->qmax = 0;
-            if (c->it >= w.max_iters || stop) done = 1;
+            it = it0 + 1;
+            c->it = it;
+            qnext = 0;
+            if (it >= w.max_iters || stop) done = 1;
         }
     }
+    c->qmax = qnext;
     c->done = done;
     // one word, one store: the host sees a consistent (trials_done, it, done), and the launch ends behind ONE write
     // acknowledgement from host memory instead of a chain of them
-    __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&w.hstat->progress, HostStatus::pack(nsolves, it, done), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // --------------------------------------------------------------------------------
