@@ -250,6 +250,13 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = w.ctrl;
+    // (the map point's edge range does not depend on the LM state: requested together with the controller's words, one cold
+    //  round trip instead of two in a row)
+    const int sub = threadIdx.x & (kPointGroup - 1);
+    const int l = bid * kPointsPerBlock + (threadIdx.x / kPointGroup);
+    const bool valid = l < w.P && bid < w.n_pt_blocks;
+    int begin = 0, end = 0;
+    if (valid) { begin = w.pt_start[l]; end = w.pt_start[l + 1]; }
     if (c->done) return;
     const int cur = c->cur;
     if (bid >= w.n_pt_blocks) {         // the pass's extra workgroup: its first wave takes the LM decision (back-substitution passes only)
@@ -274,11 +281,6 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
 
     // ---- everything this lane needs from HBM is requested before the LDS staging barrier, so that the
     //      point / edge gathers and the pose staging overlap instead of queueing behind each other ----
-    const int sub = threadIdx.x & (kPointGroup - 1);
-    const int l = bid * kPointsPerBlock + (threadIdx.x / kPointGroup);
-    const bool valid = l < w.P;
-    int begin = 0, end = 0;
-    if (valid) { begin = w.pt_start[l]; end = w.pt_start[l + 1]; }
     double X[3] = { 0, 0, 0 };
     double Hc[6] = { 1, 0, 0, 1, 0, 1 }, bc[3] = { 0, 0, 0 };
     if (valid) {

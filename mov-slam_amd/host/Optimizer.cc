@@ -68,6 +68,10 @@ namespace MOV_SLAM
             std::vector<KeyFrame *> key;
             std::vector<int32_t> val;
             std::vector<uint8_t> usable;        // per vertex: !isBad() && same map (see build)
+            // per vertex, read once per window instead of once per observation: where the keyframe's (immutable) keypoint
+            // arrays start, its camera's four parameters (GeometricCamera::getParameter is a virtual call) and its baseline
+            struct PerKf { const cv::KeyPoint *keys; const float *uright; const float *inv_sigma2; double cam[4]; double bf; };
+            std::vector<PerKf> kf;
             size_t mask = 0;
             static size_t hash(const KeyFrame *p) { return (size_t)((reinterpret_cast<uintptr_t>(p) >> 4) * 0x9E3779B97F4A7C15ull >> 20); }
             // `pCurrentMap` non-null: a keyframe of another map yields no edges (Optimizer.cc:646).  The edge loop asks
@@ -77,6 +81,14 @@ namespace MOV_SLAM
             {
                 usable.resize(kfs.size());
                 for (size_t i = 0; i < kfs.size(); ++i) usable[i] = (!kfs[i]->isBad() && (!pCurrentMap || kfs[i]->GetMap() == pCurrentMap)) ? 1 : 0;
+                kf.resize(kfs.size());
+                for (size_t i = 0; i < kfs.size(); ++i)
+                {
+                    const KeyFrame *k = kfs[i];
+                    kf[i].keys = k->mvKeysUn.data(); kf[i].uright = k->mvuRight.data(); kf[i].inv_sigma2 = k->mvInvLevelSigma2.data();
+                    for (int q = 0; q < 4; ++q) kf[i].cam[q] = k->mpCamera ? (double)k->mpCamera->getParameter(q) : 0.0;
+                    kf[i].bf = k->mbf;
+                }
                 size_t cap = 16;
                 while (cap < 2 * kfs.size() + 2) cap <<= 1;
                 key.assign(cap, nullptr); val.assign(cap, -1); mask = cap - 1;
@@ -179,15 +191,30 @@ namespace MOV_SLAM
         // The edges of one MapPoint vertex (Optimizer.cc:623-705 / :142-190) from the point's observation list, written to
         // edge slots e0, e0 + 1, ... of `f` (sized by the caller: at most one edge per observation) as edges of problem point
         // `pid`.  Returns the number of edges written.
+        // The vertices of a run of observations, looked up ahead of emit_point (resolved = true there), and the two cache lines
+        // each edge will read - its keypoint and its right-image coordinate, at random places of the keyframes' arrays -
+        // requested while the edges of the points before are written (LocalBundleAdjustment: two points ahead).
+        void resolve_ahead(ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex)
+        {
+            for (; ob != ob_end; ++ob)
+            {
+                const int32_t vertex = kfIndex.find(ob->kf);
+                ob->vertex = vertex;
+                if (vertex < 0 || ob->left < 0) continue;
+                __builtin_prefetch(kfIndex.kf[vertex].keys + ob->left);
+                __builtin_prefetch(kfIndex.kf[vertex].uright + ob->left);
+            }
+        }
+
         int emit_point(Flat &f, CamState &cs, size_t e0, MapPoint *pMP, int32_t pid, ObsRef *ob, ObsRef *ob_end, const KfIndex &kfIndex,
-                       Map *pCurrentMap, bool requireSameMap)
+                       Map *pCurrentMap, bool requireSameMap, bool resolved = false)
         {
             (void)pCurrentMap; (void)requireSameMap;             // (folded into kfIndex.usable by its build)
             size_t e = e0;
             for (; ob != ob_end; ++ob)
             {
                 KeyFrame *pKFi = ob->kf;
-                const int32_t vertex = kfIndex.find(pKFi);
+                const int32_t vertex = resolved ? ob->vertex : kfIndex.find(pKFi);
                 ob->vertex = vertex;
                 if (vertex < 0)
                     continue;                                   // observer without a vertex
@@ -196,14 +223,15 @@ namespace MOV_SLAM
                 const int leftIndex = ob->left;
                 if (leftIndex == -1)
                     continue;
-                const cv::KeyPoint &kpUn = pKFi->mvKeysUn[leftIndex];
+                const KfIndex::PerKf &pk = kfIndex.kf[vertex];
+                const cv::KeyPoint &kpUn = pk.keys[leftIndex];   // pKFi->mvKeysUn[leftIndex]
                 // stereo observation (Optimizer.cc:673-705): third measurement kp_ur = mvuRight[idx], e->bf = pKFi->mbf
-                const float kp_ur = pKFi->mvuRight[leftIndex];
+                const float kp_ur = pk.uright[leftIndex];
                 if (kp_ur >= 0)
                 {
-                    if (cs.any_stereo && cs.bf != (double)pKFi->mbf) cs.cam_mixed = true;
+                    if (cs.any_stereo && cs.bf != pk.bf) cs.cam_mixed = true;
                     cs.any_stereo = true;
-                    cs.bf = pKFi->mbf;
+                    cs.bf = pk.bf;
                 }
                 f.obs_right[e] = kp_ur >= 0 ? (double)kp_ur : -1.0;
                 // e->pCamera = pKFi->mpCamera per edge (Optimizer.cc:664): ONE pinhole for the window is what every MoV-SLAM
@@ -211,16 +239,15 @@ namespace MOV_SLAM
                 // a window whose keyframes disagree goes over with movba_lba_desc::cam_kf / bf_kf (solve() below)
                 if (!cs.cam_set)
                 {
-                    for (int k = 0; k < 4; ++k) cs.cam[k] = pKFi->mpCamera->getParameter(k);
+                    for (int k = 0; k < 4; ++k) cs.cam[k] = pk.cam[k];
                     cs.cam_set = true;
                 }
-                else
-                    for (int k = 0; k < 4; ++k)
-                        if (cs.cam[k] != (double)pKFi->mpCamera->getParameter(k)) cs.cam_mixed = true;
+                else if ((cs.cam[0] != pk.cam[0]) | (cs.cam[1] != pk.cam[1]) | (cs.cam[2] != pk.cam[2]) | (cs.cam[3] != pk.cam[3]))
+                    cs.cam_mixed = true;
                 f.edge_pose[e] = vertex;
                 f.edge_point[e] = pid;
                 f.obs[2 * e] = kpUn.pt.x; f.obs[2 * e + 1] = kpUn.pt.y;
-                f.inv_sigma2[e] = pKFi->mvInvLevelSigma2[kpUn.octave];
+                f.inv_sigma2[e] = pk.inv_sigma2[kpUn.octave];
                 f.edge_kf[e] = pKFi;
                 f.edge_mp[e] = pMP;
                 ++e;
@@ -501,8 +528,11 @@ namespace MOV_SLAM
             if (pKFi->mnId == pMap->GetInitKFid())
                 num_fixedKF = 1;
             const std::vector<MapPoint *> vpMPs = pKFi->GetMapPointMatches();
-            for (MapPoint *pMP : vpMPs)
+            const size_t nMatches = vpMPs.size();
+            for (size_t im = 0; im < nMatches; ++im)
             {
+                MapPoint *pMP = vpMPs[im];
+                if (im + 8 < nMatches && vpMPs[im + 8]) __builtin_prefetch(&vpMPs[im + 8]->mnBALocalForKF);      // (the points sit all over the heap)
                 // (the reference's conjunction, Optimizer.cc:489-499, with the plain member test first: a point seen by five
                 //  local keyframes is met five times, and MapPoint::isBad() / GetMap() take three mutexes between them)
                 if (pMP && pMP->mnBALocalForKF != pKF->mnId && !pMP->isBad() && pMP->GetMap() == pCurrentMap)
@@ -584,12 +614,19 @@ namespace MOV_SLAM
         const size_t nObsAll = f.obs_all.size();
         f.resize_edges(nObsAll);
         f.mps.assign(nLocal, nullptr); f.points.resize(3 * nLocal); nedge.resize(nLocal);
+        constexpr size_t kAhead = 2;                              // points whose observations are resolved and prefetched ahead
+        resolve_ahead(f.obs_all.data(), f.obs_all.data() + f.obs_start[std::min(kAhead, nLocal)], kfIndex);
         for (size_t lp = 0; lp < nLocal; ++lp)
         {
             MapPoint *pMP = lLocalMapPoints[lp];
+            if (lp + kAhead < nLocal)
+            {
+                resolve_ahead(f.obs_all.data() + f.obs_start[lp + kAhead], f.obs_all.data() + f.obs_start[lp + kAhead + 1], kfIndex);
+                __builtin_prefetch(lLocalMapPoints[lp + kAhead]);
+            }
             const Eigen::Vector3f wp = pMP->GetWorldPos();
             nedge[lp] = emit_point(f, f, f.obs_start[lp], pMP, (int32_t)lp, f.obs_all.data() + f.obs_start[lp],
-                                   f.obs_all.data() + f.obs_start[lp + 1], kfIndex, pCurrentMap, true);
+                                   f.obs_all.data() + f.obs_start[lp + 1], kfIndex, pCurrentMap, true, true);
             f.mps[lp] = pMP;
             f.points[3 * lp] = wp(0); f.points[3 * lp + 1] = wp(1); f.points[3 * lp + 2] = wp(2);
         }
@@ -695,6 +732,11 @@ namespace MOV_SLAM
         for (size_t k = 0; k < f.mps.size(); ++k)
         {
             MapPoint *pMP = f.mps[k];
+            if (k + 4 < f.mps.size())                           // (the points sit all over the heap)
+            {
+                const char *nx = reinterpret_cast<const char *>(f.mps[k + 4]);
+                __builtin_prefetch(nx); __builtin_prefetch(nx + 64); __builtin_prefetch(nx + 128);
+            }
             const Eigen::Vector3f Pos((float)s.points[3 * k], (float)s.points[3 * k + 1], (float)s.points[3 * k + 2]);
             pMP->SetWorldPos(Pos);
 #ifdef MOVBA_MAPPOINT_HAS_SET_DISTANCES
@@ -715,16 +757,20 @@ namespace MOV_SLAM
                 {
                     // the observation became edge e iff its keyframe is the edge's (edges follow the observation order)
                     bool erased = false;
+                    int32_t eo = -1;
                     if (e < e_end && f.edge_kf[e] == ob->kf)
                     {
+                        eo = e;
                         erased = s.outlier[e] != 0;
                         ++e;
                     }
                     if (erased)
                         continue;                               // EraseObservation removed it before the update
                     any = true;
-                    // (what MapPoint::AddObservation counted for this observation, MapPoint.cc:162-165: stereo twice)
-                    nobs_expected += (ob->left != -1 && ob->kf->mvuRight[ob->left] >= 0) ? 2 : 1;
+                    // (what MapPoint::AddObservation counted for this observation, MapPoint.cc:162-165: stereo twice; an edge's
+                    //  mvuRight[left] was read when the edge was written)
+                    const bool stereo_obs = eo >= 0 ? f.obs_right[eo] >= 0.0 : (ob->left != -1 && ob->kf->mvuRight[ob->left] >= 0);
+                    nobs_expected += stereo_obs ? 2 : 1;
                     if (ob->vertex < 0 || ob->right != -1) { fallback = true; break; }
                     if (ob->left != -1)
                     {
