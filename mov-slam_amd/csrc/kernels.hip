@@ -250,6 +250,13 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = w.ctrl;
+#ifdef MOVBA_CLOCK_STAMP
+    unsigned long long pst[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    pst[0] = __builtin_amdgcn_s_memrealtime();
+#define PSTAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); pst[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
     // (the map point's edge range does not depend on the LM state: requested together with the controller's words, one cold
     //  round trip instead of two in a row)
     const int sub = threadIdx.x & (kPointGroup - 1);
@@ -260,9 +267,19 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
     if (c->done) return;
     const int cur = c->cur;
     if (bid >= w.n_pt_blocks) {         // the pass's extra workgroup: its first wave takes the LM decision (back-substitution passes only)
+#ifdef MOVBA_CLOCK_STAMP
+        const int ns0 = c->n_solves;
+#endif
         if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur, wait_epoch);
+#ifdef MOVBA_CLOCK_STAMP
+        if (BACKSUB && threadIdx.x == 0 && ns0 == 3) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 20000 + 8 * (size_t)bid;
+            dbg[0] = pst[0]; dbg[1] = __builtin_amdgcn_s_memrealtime(); dbg[7] = 2;
+        }
+#endif
         return;
     }
+    PSTAMP(1);
     const int dst = BACKSUB ? (cur ^ 1) : cur;
     const double lambda = c->lambda;
     const DevState &S0 = w.st[cur];
@@ -271,8 +288,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
     double *sRt = sm;                               // NP x 12 at dst
     double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 12 at cur  (BACKSUB)
     double *sxp = sR0 + ((BACKSUB && LDSP) ? 12 * w.NP : 0);  // nfree x 6       (BACKSUB)
-    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 4
-    int *shidx = reinterpret_cast<int *>(red + 4);  // NP              (BACKSUB)
+    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 8
+    int *shidx = reinterpret_cast<int *>(red + 8);  // NP              (BACKSUB)
     // where the pose data is read from: the LDS images, or the state buffers themselves
     const double *pRt = LDSP ? sRt : S1.Rt;
     const double *pR0 = LDSP ? sR0 : S0.Rt;
@@ -286,8 +303,9 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
     if (valid) {
         X[0] = S0.point[3 * l]; X[1] = S0.point[3 * l + 1]; X[2] = S0.point[3 * l + 2];
         if (BACKSUB) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) Hc[k] = S0.Hll[6 * l + k];
+            const double2 *hp = reinterpret_cast<const double2 *>(S0.Hll + 6 * (size_t)l);      // 48-byte records: 16-byte aligned
+            const double2 q0 = hp[0], q1 = hp[1], q2 = hp[2];
+            Hc[0] = q0.x; Hc[1] = q0.y; Hc[2] = q1.x; Hc[3] = q1.y; Hc[4] = q2.x; Hc[5] = q2.y;
             bc[0] = S0.bl[3 * l]; bc[1] = S0.bl[3 * l + 1]; bc[2] = S0.bl[3 * l + 2];
         }
     }
@@ -308,7 +326,32 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
         pur[k] = (STEREO && in) ? w.obs_r[g] : -1.0;
     }
 
-    if (BACKSUB) {
+    // Staging of the keyframes' data, the usual window (up to 85 keyframes): every thread requests its pieces of ALL the
+    // images - 16 bytes each, two per image - before it stores the first one.  (Loop after loop, as below for larger windows,
+    // the passes were nine dependent L2 round trips per thread: 3 us of a 12 us pass at cfg3.)
+    const bool stage_at_once = LDSP && BACKSUB && !wait_epoch && 12 * w.NP <= 4 * kPointBlock && 6 * w.nfree <= 4 * kPointBlock;
+    if (stage_at_once) {
+        const int n2 = 6 * w.NP, x2 = 3 * w.nfree;            // 16-byte pieces of a rotation image / of the increments
+        const double2 *g0 = reinterpret_cast<const double2 *>(S0.Rt), *g1 = reinterpret_cast<const double2 *>(S1.Rt), *gx = reinterpret_cast<const double2 *>(w.xp);
+        double2 a[2], b[2], x[2];
+        int hh = -1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = threadIdx.x + kPointBlock * u;
+            a[u] = k < n2 ? g0[k] : make_double2(0.0, 0.0);
+            b[u] = k < n2 ? g1[k] : make_double2(0.0, 0.0);
+            x[u] = k < x2 ? gx[k] : make_double2(0.0, 0.0);
+        }
+        if ((int)threadIdx.x < w.NP) hh = w.hidx[threadIdx.x];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = threadIdx.x + kPointBlock * u;
+            if (k < n2) { reinterpret_cast<double2 *>(sR0)[k] = a[u]; reinterpret_cast<double2 *>(sRt)[k] = b[u]; }
+            if (k < x2) reinterpret_cast<double2 *>(sxp)[k] = x[u];
+        }
+        if ((int)threadIdx.x < w.NP) shidx[threadIdx.x] = hh;
+        __syncthreads();
+    } else if (BACKSUB) {
         if (LDSP) {
             for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[k];
             for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
@@ -339,6 +382,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
         __syncthreads();
     }
 
+    PSTAMP(2);
     double scale = 0.0;
     if (BACKSUB) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -408,6 +452,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
         }
     }
 
+    PSTAMP(3);
     // ---- evaluate at the destination state ----
     double h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0, h5 = 0, v0 = 0, v1 = 0, v2 = 0, F = 0.0;
     const double dsqr = w.huber_delta * w.huber_delta;
@@ -477,17 +522,35 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
         if (BACKSUB) { S1.point[3 * l] = X[0]; S1.point[3 * l + 1] = X[1]; S1.point[3 * l + 2] = X[2]; }
         if (end > begin) hmax = fmax(fabs(h0), fmax(fabs(h3), fabs(h5)));
     }
-    const double Fsum = block_reduce<kPointBlock / 64, false>(F, red);
+    PSTAMP(4);
     if (BACKSUB) {
-        const double ssum = block_reduce<kPointBlock / 64, false>(scale, red);
+        // cost and scale partials of the workgroup behind ONE barrier (the sums in block_reduce's order)
+        constexpr int NWV = kPointBlock / 64;
+        static_assert(2 * NWV <= 8, "red holds eight doubles (point_lds_bytes)");
+        F = wave_sum(F); scale = wave_sum(scale);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = F; red[NWV + (threadIdx.x >> 6)] = scale; }
+        __syncthreads();
         // the LM decision needs every workgroup's partials: handed to the pass's deciding wave (decide_body) as two tagged
         // records, one 16-byte write-through store each, nothing to wait for
         if (threadIdx.x == 0) {
+            double Fsum = red[0], ssum = red[NWV];
+#pragma unroll
+            for (int k = 1; k < NWV; ++k) { Fsum += red[k]; ssum += red[NWV + k]; }
             const unsigned tag = (unsigned)c->n_solves + 1u;
             const __amdgpu_buffer_rsrc_t rr = hx_rsrc(w.dec_rec, 32u * (unsigned)w.n_pt_blocks);
             hx_st_tagged(rr, 2u * (unsigned)bid, Fsum, tag); hx_st_tagged(rr, 2u * (unsigned)bid + 1u, ssum, tag);
+#ifdef MOVBA_CLOCK_STAMP
+            if (c->n_solves == 3) {
+                PSTAMP(5);
+                unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 20000 + 8 * (size_t)bid;
+                for (int k = 0; k < 6; ++k) dbg[k] = pst[k];
+                dbg[6] = ((unsigned long long)__builtin_amdgcn_s_getreg(63492)) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+                dbg[7] = 1;
+            }
+#endif
         }
     } else {
+        const double Fsum = block_reduce<kPointBlock / 64, false>(F, red);
         const double m = block_reduce<kPointBlock / 64, true>(hmax, red);
         if (threadIdx.x == 0) { w.hmax_part[bid] = m; S1.Fpart[bid] = Fsum; }
     }
@@ -1029,15 +1092,15 @@ __global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
 // --------------------------------------------------------------------------------
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
-    if (!w.lds_poses) return 4 * sizeof(double) + 16;
-    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 4;
+    if (!w.lds_poses) return 8 * sizeof(double) + 16;
+    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 8;
     return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
 // the largest LDS image the point kernels would stage for this window (decides DevWindow::lds_poses)
 size_t point_lds_need(int NP, int nfree)
 {
-    return (24 * (size_t)NP + 6 * (size_t)nfree + 4) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
+    return (24 * (size_t)NP + 6 * (size_t)nfree + 8) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
 // (first launch on a new stream: its hardware queue is set up here, not in front of a kernel other kernels wait for)
