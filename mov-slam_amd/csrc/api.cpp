@@ -1338,7 +1338,7 @@ void Upload::device_view()
     w.part = reinterpret_cast<double *>(a + o_part); w.blocks = reinterpret_cast<double *>(a + o_blocks);
     w.rec_d = reinterpret_cast<double *>(a + o_recd); w.img_b = reinterpret_cast<double *>(a + o_imgb); w.rec_slots = rec_slots;
     w.blocks_c = reinterpret_cast<double *>(a + o_blocks_c); w.blocks_ov = reinterpret_cast<double *>(a + o_blocks_ov);
-    w.aci = reinterpret_cast<double *>(a + o_aci); w.ac_prev = w.aci + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
+    w.aci = reinterpret_cast<float *>(a + o_aci); w.ac_prev = reinterpret_cast<double *>(a + o_aci) + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
     w.dec_rec = reinterpret_cast<unsigned *>(a + o_tick); w.xs = reinterpret_cast<unsigned *>(a + o_xs);

@@ -340,11 +340,11 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
     __syncthreads();
     COARSE_STAMP(4);
     // ---- publish: A_c^-1 = D (D A_c D)^-1 D for trial+1 and its validity tag ----
-    double *dst = w.aci + (size_t)(trial & 1) * kNC * kNC;
+    float *dst = w.aci + (size_t)(trial & 1) * kNC * kNC;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) dst[(3 * rg + r) * kNC + 6 * cg + q] = t[r][q] * dsc[3 * rg + r] * dsc[6 * cg + q];
+        for (int q = 0; q < 6; ++q) dst[(3 * rg + r) * kNC + 6 * cg + q] = (float)(t[r][q] * dsc[3 * rg + r] * dsc[6 * cg + q]);
     __syncthreads();
     if (tid == 0) w.aci_tag[trial & 1] = s_bad ? -1 : trial;
     COARSE_STAMP(5);

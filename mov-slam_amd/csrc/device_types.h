@@ -171,7 +171,8 @@ struct DevWindow {
                         // off-diagonal pairs that are one work item (SchedItem::dst_a / dst_b say where an item's block goes)
     double *blocks_ov;  // overflow windows only: oriented copies of the blocks of the gather-list tails (entry e at 36 e)
     double *blocks_c;   // npairs x 36: the coarse-level workgroup's own copy of S (coarse_level.h)
-    double *aci;        // 2 x kCoarseDim x kCoarseDim: inverse coarse matrices (by trial parity)
+    float *aci;         // 2 x kCoarseDim x kCoarseDim: inverse coarse matrices (by trial parity), rounded to fp32 by the workgroup that
+                        // builds them: the solver keeps them in LDS in that precision (pcg_kernel.hip) and takes in half the bytes
     int32_t *aci_tag;   // 2: trial that produced aci[parity], -1 = unusable
     double *ac_prev;    // kCoarseDim^2 + 2: coarse matrix of the previous build, then its lambda and its trial (coarse_level.h)
     double *blocks;     // npairs x 36 upper blocks of S (damped), diagonal pairs first

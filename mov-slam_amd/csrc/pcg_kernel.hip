@@ -345,13 +345,13 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         for (int q = 0; q < 6; ++q) mi[q] = d6[q];
     }
     SETUP_STAMP(7);
-    // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial).  Requested here: its
-    // round trip runs beside the block inverses below.
+    // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial).  Requested here (36 KB, rounded to
+    // fp32 by its builder): its round trip runs beside the block inverses below.
     int aci_tag = -1;
-    double2 av[kNC * kNC / 2 / kT];
+    float2 av[kNC * kNC / 2 / kT];
     if (pp.use_coarse) {
         aci_tag = w.aci_tag[max(ctrial, 0) & 1];
-        const double2 *src = reinterpret_cast<const double2 *>(w.aci + (size_t)(max(ctrial, 0) & 1) * kNC * kNC);
+        const float2 *src = reinterpret_cast<const float2 *>(w.aci + (size_t)(max(ctrial, 0) & 1) * kNC * kNC);
 #pragma unroll
         for (int u = 0; u < kNC * kNC / 2 / kT; ++u) av[u] = src[tid + u * kT];
     }
@@ -410,7 +410,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     if (coarse) {
         float2 *dst = reinterpret_cast<float2 *>(Acf);
 #pragma unroll
-        for (int u = 0; u < kNC * kNC / 2 / kT; ++u) dst[tid + u * kT] = make_float2((float)av[u].x, (float)av[u].y);
+        for (int u = 0; u < kNC * kNC / 2 / kT; ++u) dst[tid + u * kT] = av[u];
     }
     SETUP_STAMP(0);
     // (a keyframe's diagonal block is read by a lane of the wave that owns its rows: no workgroup barrier between the two)
