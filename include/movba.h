@@ -40,8 +40,10 @@ extern "C" {
 #define MOVBA_ERR_ARG        -1
 #define MOVBA_ERR_HIP        -2   /* HIP runtime failure (no device, OOM, launch error)       */
 #define MOVBA_ERR_STATE      -3   /* call order violated (run before upload, ...)             */
-#define MOVBA_ERR_DEVICE_WAIT -4  /* one-launch direct solver: a workgroup gave up waiting for another (20 ms); the results
-                                     of the solve are not trustworthy and are not returned as MOVBA_OK               */
+#define MOVBA_ERR_DEVICE_WAIT -4  /* a workgroup gave up a bounded wait inside a launch (20 ms) in the FIRST attempt of a run
+                                     AND in its repeat on the paths that do not wait inside launches: never seen.  The usual
+                                     outcome of a given-up wait is MOVBA_OK with n_sync_timeouts > 0 (movba_lba_run solves the
+                                     window again, see movba_lba_result); results are never handed out from a failed attempt */
 #define MOVBA_ERR_TOO_LARGE  -5   /* the window's reduced system exceeds what the direct solver can hold             */
 /* Free keyframes per window: <= 80 the on-chip PCG (where the reduced matrix fits its registers), <= 432 the one-launch
  * direct solver, beyond that one launch per block column; the solution vector of the latter's back substitution lives in
@@ -113,7 +115,10 @@ typedef struct {
     int32_t direct_from;        /* n_solves at the switch to the direct solver (0: whole solve), -1: never     */
     int32_t n_chol_fail;        /* trials whose factorisation met a non-positive pivot: rejected, as g2o does  */
     int32_t n_pcg_giveups;      /* 0 or 1: the PCG gave up once, the solve went on with the direct solver      */
-    int32_t n_sync_timeouts;    /* direct solves in which a workgroup gave up waiting (status is then MOVBA_ERR_DEVICE_WAIT) */
+    int32_t n_sync_timeouts;    /* waits inside a launch that a workgroup gave up (one-launch direct solver without all its
+                                   workgroups resident; two-stream loop): > 0 with status MOVBA_OK = the run was repeated on one
+                                   stream with the multi-launch direct solver and THIS is its result (the reference never skips
+                                   a solve, src/Optimizer.cc:535, 754)                                                          */
     int32_t pad_r;
 } movba_lba_result;
 
