@@ -1102,6 +1102,9 @@ void Upload::choose_solver()
 {
     h->pp = PcgParams{};
     h->rows_kernel = pcg_rows_supported(s().nfree, s().row_ptr.data(), &h->pp);
+    // (test switch: the packed layout of the mat-vec's pair sums where the padded one would do - same bits, tests/test_gpu_parity.py)
+    static const bool packed_only = std::getenv("MOVBA_PCG_PACKED") != nullptr;
+    if (packed_only) h->pp.padded = 0;
     // A reduced matrix beyond the PCG workgroup's registers (dense covisibility: every keyframe pair shares points, as in the
     // reference's own windows, KeyFrame.cc:227-231; or simply more keyframes) is not iterated over from L2: the one-launch
     // direct solver takes the window from the first trial, whatever its pattern.  Measured (profiles/r03zd_solver_switch.log,
@@ -1718,13 +1721,13 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
     }
     const int na = (int)act.size();
     if (na > 0) {
-        bool stereo = act[0]->win.stereo != 0, ldsp = true, overflow = false;
+        bool stereo = act[0]->win.stereo != 0, ldsp = true, overflow = false, padded = true;
         for (movba_handle *h : act) {
             if ((h->win.stereo != 0) != stereo) {
                 std::fprintf(stderr, "libmovba: a batch holds either stereo or monocular windows, not both\n");
                 return MOVBA_ERR_ARG;
             }
-            ldsp &= h->win.lds_poses != 0; overflow |= h->pp.overflow != 0;
+            ldsp &= h->win.lds_poses != 0; overflow |= h->pp.overflow != 0; padded &= h->pp.padded != 0 && !h->pp.overflow;
         }
         // Groups of windows on streams of their own, out of phase: a group's PCG launch keeps 2 CUs per window busy for most
         // of a trial while its point / schur launches fill the chip for the rest, so the PCG of one group runs beside the
@@ -1795,7 +1798,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 int nb = (work + 255) / 256; nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
                 bi[i + 1] = bi[i] + nb;
                 G.lds_lin = std::max(G.lds_lin, point_lds_bytes_for(w, false, ldsp)); G.lds_back = std::max(G.lds_back, point_lds_bytes_for(w, true, ldsp));
-                G.lds_pcg = std::max(G.lds_pcg, pcg_rows_lds_bytes(w.nfree, (int)h->st.row_ent.size()));
+                G.lds_pcg = std::max(G.lds_pcg, pcg_rows_lds_bytes(w.nfree, (int)h->st.row_ent.size(), padded && !overflow));
                 G.max_trials = std::max(G.max_trials, (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials);
                 G.max_iters = std::max(G.max_iters, w.max_iters);
             }
@@ -1855,7 +1858,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 if (g > 0 && grp[g - 1].t > G.t) HIP_TRY(hipStreamWaitEvent(G.s, h0->batch_phase_ev[g - 1][G.t % kPhaseEvents], 0));
                 if (G.nb_schur > 0) HIP_TRY(launch_schur_batch(G.b, G.nb_schur, 0, stereo, G.s));
                 if (g + 1 < ngroups) HIP_TRY(hipEventRecord(h0->batch_phase_ev[g][G.t % kPhaseEvents], G.s));
-                HIP_TRY(launch_pcg_rows_batch(G.b, overflow, G.lds_pcg, G.t, G.s));
+                HIP_TRY(launch_pcg_rows_batch(G.b, overflow, padded && !overflow, G.lds_pcg, G.t, G.s));
                 HIP_TRY(launch_point_batch(G.b, G.nb_point, true, stereo, ldsp, G.lds_back, G.s));
                 G.t += 1;
                 t_progress = now_ms();

@@ -221,6 +221,9 @@ struct PcgParams {
     int32_t use_coarse;         // k_pcg_rows: add the aggregate coarse-level correction to block-Jacobi (1: lagged, 2: fresh)
     int32_t wave_ent0[17];      // row_ptr[wave_row0[wv]]: first gather-list entry of the wave's rows (so that the kernel's setup needs no
     int32_t nrowent;            // load for them), and row_ptr[nfree]
+    int32_t padded;             // k_pcg_rows: no block row has more than kPcgPlanOwnBatch entry pairs and nothing overflows: the pair
+                                // sums of the mat-vec sit in zero-padded slots by row (pcg_kernel.hip, PADDED), no masks in the loop
+    int32_t pad_pp;
 };
 
 // Batched launches over n resident windows (movba_lba_run_batch): device arrays of the windows' views and PCG plans, and

@@ -47,8 +47,8 @@ int schur_blocks(const DevWindow &w);
 hipError_t launch_schur_batch(const BatchDev &b, int nblk, int mode, bool stereo, hipStream_t s);
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s);
 hipError_t launch_finalize_batch(const BatchDev &b, int nblk, hipStream_t s);
-hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, size_t lds, int trial, hipStream_t s);
-size_t pcg_rows_lds_bytes(int nfree, int nrowent);
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, bool padded, size_t lds, int trial, hipStream_t s);
+size_t pcg_rows_lds_bytes(int nfree, int nrowent, bool padded);
 
 // direct solver (dense_solve.hip): assemble + one launch per block column + back substitution / pose update
 hipError_t configure_dense_kernels();

@@ -127,10 +127,16 @@ __device__ __forceinline__ int xs_wait_live(const DevWindow &w, unsigned epoch, 
 // (A solver that took the partials item by item, each lane as soon as its items were flagged, was measured 10 us per trial
 //  SLOWER than the one-stream launch: every look at a flag and every dependent load is a 1.5 - 2 us device-scope round trip,
 //  and a lane made six of them per turn of its polling loop - DESIGN.md, round 4.)
-template <bool OVERFLOW, bool XS>
+// PADDED (PcgParams::padded: no block row with more than kOwnBatch entry pairs, nothing overflows - cfg3 and everything smaller):
+// the pair sums of the mat-vec are parked by ROW, each row with kOwnBatch slots of which the unused ones hold zeros for the
+// whole solve, and the residual exchange of a wave goes through a strip of its own whose unowned places hold zeros: the owner
+// sums and the restriction read their ten values without the forty v_cndmask per iteration that masked the over-read of the
+// packed layout.  Same values added in the same order: the two layouts give the same bits (batched runs may mix them).
+template <bool OVERFLOW, bool XS, bool PADDED>
 __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParams &pp, int trial, int role)
 {
     static_assert(!(OVERFLOW && XS), "windows whose lists overflow the registers stay on one stream");
+    static_assert(!(OVERFLOW && PADDED), "the padded layout holds the register-resident pairs only");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
     const int tid = threadIdx.x, ln = tid & 63;
@@ -223,8 +229,14 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     double *rcg = red1 + kNW + 2 + kNC * kNC / 2;         // kNC: restricted vector of every aggregate
     double *zstrip = rcg + kNC + 32 * wv;                 // 16 per wave: the wave's coarse correction z_c = A_c^-1 P^T r (kPA used)
     double *ustrip = zstrip + 16;                         // 16 per wave: A_c^-1 P^T s of the wave's aggregate
-    double *ypart = rcg + kNC + 32 * kNW;                 // 6 doubles per gather-list PAIR (+ one dummy strip)
-    double *sdiag = ypart + 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);     // nf x 36: the damped diagonal blocks S_ii
+    double *ypart = rcg + kNC + 32 * kNW;                 // 6 doubles per gather-list PAIR (+ one dummy strip); PADDED: kOwnBatch per row
+    constexpr int kYDummy = 5 * kOwnBatch + 6;            // PADDED: where the lanes without a pair write (stride kOwnBatch like the others)
+    const int ypart_len = PADDED ? n * kOwnBatch + kYDummy + kOwnBatch : 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);
+    double *sdiag = ypart + ypart_len;                    // nf x 36: the damped diagonal blocks S_ii
+    double *rsw = sdiag + 36 * nf + 64 * wv;              // 64 per wave: the wave's residual exchange (PADDED: zeros at unowned places)
+    if (PADDED) {                                         // (ordered before the loop's first writes by the barriers in front of it)
+        for (int k = tid; k < ypart_len; k += kT) ypart[k] = 0.0;
+    }
     const int nrowent = nrowent_all;
     const int P0 = rp_b0 >> 1, P1 = rp_b1 >> 1;          // the wave's entry pairs
     const int own_p0 = rp_bi >> 1, own_p1 = rp_bi1 >> 1;
@@ -282,8 +294,18 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     int colo[2];
     const int my_pair = P0 + ln;
     const bool have_pair = my_pair < P1;
-    const int yslot = (have_pair ? my_pair : (nrowent >> 1)) * 6;     // lanes without a pair write the dummy strip
+    int yslot = (have_pair ? my_pair : (nrowent >> 1)) * 6;     // lanes without a pair write the dummy strip
     const double *yown = ypart + own_p0 * 6 + ba;         // first pair sum of this lane's row
+    if (PADDED) {
+        // the pair's row and its place in the row: the wave's rows' list ranges sit in their owner lanes (lane 6 u: row b0 + u)
+        yslot = n * kOwnBatch;                            // (no pair: the dummy strip)
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int q0 = __builtin_amdgcn_readlane(rp_bi, 6 * u) >> 1, q1 = __builtin_amdgcn_readlane(rp_bi1, 6 * u) >> 1;
+            if (u < nb && have_pair && my_pair >= q0 && my_pair < q1) yslot = (b0 + u) * 6 * kOwnBatch + (my_pair - q0);
+        }
+        yown = ypart + (owner ? row : 0) * kOwnBatch;
+    }
     // ---- diagonal blocks and right-hand side, cooperatively: owner lane (bi, ba) sums ROW ba of S_ii = Hpp + lambda I -
     // sum B Dinv B^T, b_p and B Dinv b_l over the work items of pair (bi, bi), four items in flight: the cost does not
     // grow with the number of items a long diagonal pair is cut into ----
@@ -474,7 +496,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // z = Minv r: a block's six rows sit in one wave, so its residuals are exchanged through LDS
     // without a workgroup barrier (LDS operations of one wave execute in order)
     const double2 *mrow = reinterpret_cast<const double2 *>(minv + (owner ? bi * 36 + ba * 6 : 0));
-    const double2 *rblk = reinterpret_cast<const double2 *>(r_lds + (owner ? bi * 6 : 0));
+    const double2 *rblk = reinterpret_cast<const double2 *>(PADDED ? rsw + (owner ? (bi - b0) * 6 : 0) : r_lds + (owner ? bi * 6 : 0));
     auto wave_lds_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -493,18 +515,21 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     const int crow = min(ln >> 2, kPA - 1), cq = ln & 3;                // coarse product: 4 lanes per coarse row, 24 columns each
     // restriction of a vector held one value per owner lane: P^T v of this wave's aggregate -> rcg[wv * kPA ..]
     auto restrict_own = [&](double v_r) {
-        if (owner) r_lds[row] = v_r;
+        if (PADDED) rsw[ln] = owner ? v_r : 0.0;
+        else if (owner) r_lds[row] = v_r;
         wave_lds_sync();
         if (ln < kPA) {
             // rows b0 .. b0+9 at fixed offsets; the ones past the wave's last row are masked by a wave-uniform
-            // predicate; lanes 0-5 sum them (constant modes), lanes 6-11 weight them by the linear mode
+            // predicate (PADDED: they hold zeros); lanes 0-5 sum them (constant modes), lanes 6-11 weight them by the linear mode
             const int a = ln < 6 ? ln : ln - 6;
-            const double *rb = r_lds + b0 * 6 + a;
+            const double *rb = PADDED ? rsw + a : r_lds + b0 * 6 + a;
             double v[10];
 #pragma unroll
             for (int u = 0; u < 10; ++u) v[u] = rb[6 * u];
+            if (!PADDED) {
 #pragma unroll
-            for (int u = 0; u < 10; ++u) v[u] = (u < nb) ? v[u] : 0.0;
+                for (int u = 0; u < 10; ++u) v[u] = (u < nb) ? v[u] : 0.0;
+            }
             const double tc = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (v[8] + v[9]);
             // sum_u (u - cc) v_u / h = (sum_u u v_u - cc sum_u v_u) / h, with the row offsets u as constants
             const double ti = (((v[1] + 2.0 * v[2]) + (3.0 * v[3] + 4.0 * v[4])) + ((5.0 * v[5] + 6.0 * v[6]) + (7.0 * v[7] + 8.0 * v[8]))) + 9.0 * v[9];
@@ -545,7 +570,8 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
 #pragma unroll
     for (int k = 0; k < kNW; ++k) anybad |= reinterpret_cast<const int *>(red1)[k];
     auto precond = [&](double rv) {
-        if (owner) r_lds[row] = rv;
+        if (PADDED) rsw[ln] = owner ? rv : 0.0;
+        else if (owner) r_lds[row] = rv;
         wave_lds_sync();
         const double2 m0 = mrow[0], m1 = mrow[1], m2 = mrow[2];
         const double2 r0 = rblk[0], r1 = rblk[1], r2 = rblk[2];
@@ -606,8 +632,14 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
                            Bo[0][a * 6 + 4] * a2.x + Bo[0][a * 6 + 5] * a2.y +
                            Bo[1][a * 6] * c0.x + Bo[1][a * 6 + 1] * c0.y + Bo[1][a * 6 + 2] * c1.x + Bo[1][a * 6 + 3] * c1.y +
                            Bo[1][a * 6 + 4] * c2.x + Bo[1][a * 6 + 5] * c2.y;
-                double2 *yo = reinterpret_cast<double2 *>(ypart + yslot);
-                yo[0] = make_double2(y[0], y[1]); yo[1] = make_double2(y[2], y[3]); yo[2] = make_double2(y[4], y[5]);
+                if (PADDED) {
+                    double *yo = ypart + yslot;           // the pair's slot in each of its row's six runs
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) yo[a * kOwnBatch] = y[a];
+                } else {
+                    double2 *yo = reinterpret_cast<double2 *>(ypart + yslot);
+                    yo[0] = make_double2(y[0], y[1]); yo[1] = make_double2(y[2], y[3]); yo[2] = make_double2(y[4], y[5]);
+                }
             }
             if (OVERFLOW) for (int pq = P0 + ln + 64; pq < P1; pq += 64) {          // overflow pairs: oriented blocks from the L2 copy
                 const int c0 = w.row_ent[2 * pq].col * 6, c1 = w.row_ent[2 * pq + 1].col * 6;
@@ -630,7 +662,14 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             wave_lds_sync();
             // owner: add up its row's pair sums in list order; loads issued together, adds in order
             double w_r = 0.0;
-            {
+            if (PADDED) {
+                // the row's ten slots (zeros behind its last pair), five 16-byte loads, the same tree
+                const double2 *yb = reinterpret_cast<const double2 *>(yown);
+                const double2 v0 = yb[0], v1 = yb[1], v2 = yb[2], v3 = yb[3], v4 = yb[4];
+                static_assert(kOwnBatch == 10, "tree written for 10");
+                w_r += (((v0.x + v0.y) + (v1.x + v1.y)) + ((v2.x + v2.y) + (v3.x + v3.y))) + (v4.x + v4.y);
+                w_r = owner ? w_r : 0.0;
+            } else {
                 // loads at fixed offsets from the row's first pair sum (no per-load address arithmetic); the slots past the
                 // row's end hold other rows' sums (or the padding behind ypart) and are masked out
                 const double *yb = yown;
@@ -802,18 +841,18 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     }
 }
 
-template <bool OVERFLOW, bool XS>
-__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW, XS>(w, pp, trial, blockIdx.x); }
+template <bool OVERFLOW, bool XS, bool PADDED>
+__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW, XS, PADDED>(w, pp, trial, blockIdx.x); }
 
 // batched: workgroups 2 i and 2 i + 1 are the solver and the coarse builder of window i (a window in fresh-coarse mode
 // has no builder: its second workgroup returns at once)
-template <bool OVERFLOW>
+template <bool OVERFLOW, bool PADDED>
 __global__ __launch_bounds__(kT) void k_pcg_rows_b(BatchDev b, int trial)
 {
     const int wi = blockIdx.x >> 1, role = blockIdx.x & 1;
     const PcgParams &pp = b.pps[wi];
     if (role == 1 && pp.use_coarse != 1) return;
-    pcg_rows_body<OVERFLOW, false>(b.wins[wi], pp, trial, role);
+    pcg_rows_body<OVERFLOW, false, PADDED>(b.wins[wi], pp, trial, role);
 }
 
 static_assert(kNW == kPcgPlanWaves && kNC == kCoarseDim && kOwnBatch == kPcgPlanOwnBatch, "pcg_plan.cpp sizes the LDS carve of this kernel");
@@ -821,27 +860,35 @@ static_assert(kNW == kPcgPlanWaves && kNC == kCoarseDim && kOwnBatch == kPcgPlan
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, bool xs, hipStream_t s)
 {
     const dim3 g(pp.use_coarse == 1 ? 2 : 1), t(kT);
-    const size_t lds = pcg_rows_lds_bytes(w.nfree, nrowent);
+    const bool padded = pp.padded && !pp.overflow;
+    const size_t lds = pcg_rows_lds_bytes(w.nfree, nrowent, padded);
     if (pp.overflow) {
         if (xs) return hipErrorInvalidValue;        // (api.cpp keeps such windows on one stream)
-        hipLaunchKernelGGL((k_pcg_rows<true, false>), g, t, lds, s, w, pp, trial);
-    } else if (xs) hipLaunchKernelGGL((k_pcg_rows<false, true>), g, t, lds, s, w, pp, trial);
-    else hipLaunchKernelGGL((k_pcg_rows<false, false>), g, t, lds, s, w, pp, trial);
+        hipLaunchKernelGGL((k_pcg_rows<true, false, false>), g, t, lds, s, w, pp, trial);
+    } else if (xs) {
+        if (padded) hipLaunchKernelGGL((k_pcg_rows<false, true, true>), g, t, lds, s, w, pp, trial);
+        else hipLaunchKernelGGL((k_pcg_rows<false, true, false>), g, t, lds, s, w, pp, trial);
+    } else if (padded) hipLaunchKernelGGL((k_pcg_rows<false, false, true>), g, t, lds, s, w, pp, trial);
+    else hipLaunchKernelGGL((k_pcg_rows<false, false, false>), g, t, lds, s, w, pp, trial);
     return hipGetLastError();
 }
 
-hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, size_t lds, int trial, hipStream_t s)
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, bool padded, size_t lds, int trial, hipStream_t s)
 {
-    if (overflow) hipLaunchKernelGGL(k_pcg_rows_b<true>, dim3(2 * b.n), dim3(kT), lds, s, b, trial);
-    else hipLaunchKernelGGL(k_pcg_rows_b<false>, dim3(2 * b.n), dim3(kT), lds, s, b, trial);
+    // (padded: EVERY window of the batch has the padded layout's plan; the two layouts give the same bits)
+    if (overflow) hipLaunchKernelGGL((k_pcg_rows_b<true, false>), dim3(2 * b.n), dim3(kT), lds, s, b, trial);
+    else if (padded) hipLaunchKernelGGL((k_pcg_rows_b<false, true>), dim3(2 * b.n), dim3(kT), lds, s, b, trial);
+    else hipLaunchKernelGGL((k_pcg_rows_b<false, false>), dim3(2 * b.n), dim3(kT), lds, s, b, trial);
     return hipGetLastError();
 }
 
 hipError_t configure_pcg_rows()
 {
-    const void *fs[5] = { reinterpret_cast<const void *>(k_pcg_rows<false, false>), reinterpret_cast<const void *>(k_pcg_rows<true, false>),
-                          reinterpret_cast<const void *>(k_pcg_rows<false, true>),
-                          reinterpret_cast<const void *>(k_pcg_rows_b<false>), reinterpret_cast<const void *>(k_pcg_rows_b<true>) };
+    const void *fs[8] = { reinterpret_cast<const void *>(k_pcg_rows<false, false, false>), reinterpret_cast<const void *>(k_pcg_rows<false, false, true>),
+                          reinterpret_cast<const void *>(k_pcg_rows<true, false, false>),
+                          reinterpret_cast<const void *>(k_pcg_rows<false, true, false>), reinterpret_cast<const void *>(k_pcg_rows<false, true, true>),
+                          reinterpret_cast<const void *>(k_pcg_rows_b<false, false>), reinterpret_cast<const void *>(k_pcg_rows_b<false, true>),
+                          reinterpret_cast<const void *>(k_pcg_rows_b<true, false>) };
     for (const void *f : fs) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;

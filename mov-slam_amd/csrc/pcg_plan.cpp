@@ -8,10 +8,12 @@ namespace {
 constexpr int kNW = kPcgPlanWaves, kNC = kCoarseDim, kOwnBatch = kPcgPlanOwnBatch;
 }
 
-size_t pcg_rows_lds_bytes(int nfree, int nrowent)
+// `padded`: the mat-vec's pair sums by row in kOwnBatch zero-padded slots (+ a strip for the lanes without a pair and ten zeros)
+size_t pcg_rows_lds_bytes(int nfree, int nrowent, bool padded)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
-    const size_t solve = (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC / 2 + kNC + 32 * kNW + 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch) + 36 * (size_t)nfree) * sizeof(double);
+    const size_t ypart = padded ? n * kOwnBatch + 5 * kOwnBatch + 6 + kOwnBatch : 6 * ((size_t)nrowent / 2 + 1 + kOwnBatch);
+    const size_t solve = (2 * npad + 36 * (size_t)nfree + 2 * kNW + 2 + kNC * kNC / 2 + kNC + 32 * kNW + ypart + 36 * (size_t)nfree + 64 * kNW) * sizeof(double);
     const size_t coarse = ((size_t)kNC * kNC + 9 * kNC + 8) * sizeof(double) + 2 * sizeof(int32_t) * ((size_t)nrowent + 2);   // the second workgroup (coarse_level.h)
     return solve > coarse ? solve : coarse;
 }
@@ -23,7 +25,11 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
 {
     if (nfree <= 0 || nfree > 10 * kNW) return false;
     const int nrowent = row_ptr[nfree];
-    if (pcg_rows_lds_bytes(nfree, nrowent) > 159 * 1024) return false;
+    int maxrow = 0;
+    for (int b = 0; b < nfree; ++b) maxrow = row_ptr[b + 1] - row_ptr[b] > maxrow ? row_ptr[b + 1] - row_ptr[b] : maxrow;
+    pp->padded = 0;
+    if (pcg_rows_lds_bytes(nfree, nrowent, false) > 159 * 1024) return false;
+    const bool pad_fits = maxrow <= 2 * kOwnBatch && pcg_rows_lds_bytes(nfree, nrowent, true) <= 159 * 1024;
     // smallest per-wave entry budget for which a greedy fill (<= 10 rows per wave) needs <= kNW waves
     auto fill = [&](int cap, int32_t *out) {
         int b = 0, wv = 0;
@@ -40,6 +46,7 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
         // one keyframe per wave: the aggregates are single keyframes and the coarse level is the exact inverse (fresh mode)
         for (int wv = 0; wv <= kNW; ++wv) pp->wave_row0[wv] = wv < nfree ? wv : nfree;
         pp->overflow = 0;
+        pp->padded = pad_fits ? 1 : 0;
         return true;
     }
     int lo = 1, hi = nrowent > 1 ? nrowent : 1;
@@ -52,6 +59,7 @@ bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp)
     pp->overflow = 0;
     for (int wv = 0; wv < kNW; ++wv)
         if (row_ptr[pp->wave_row0[wv + 1]] - row_ptr[pp->wave_row0[wv]] > 128) pp->overflow = 1;
+    pp->padded = (pad_fits && !pp->overflow) ? 1 : 0;
     return true;
 }
 

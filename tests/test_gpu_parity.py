@@ -1021,6 +1021,35 @@ def test_two_handles_on_the_one_launch_direct_solver_at_once(built_lib):
 
 
 @pytest.mark.gpu
+def test_padded_and_packed_pair_sums_of_the_pcg_give_the_same_bits(built_lib, solver, tmp_path):
+    """k_pcg_rows keeps the mat-vec's pair sums by row in zero-padded slots when no block row has more than ten entry pairs
+    (PcgParams::padded: cfg3 and everything smaller), packed pair by pair otherwise; a batch runs the packed layout unless all
+    its windows are padded.  Same values, same order of additions: the bits must not depend on the layout.  The packed layout
+    is forced in a child process (MOVBA_PCG_PACKED is read once per process)."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from movba import capi, synth\n"
+        "s = capi.Solver()\n"
+        "out = {}\n"
+        "for name in ('small', 'cfg2', 'cfg3'):\n"
+        "    r = s.solve(synth.cfg(name))\n"
+        "    out[name + '_poses'] = r['poses']; out[name + '_points'] = r['points']; out[name + '_chi2'] = r['chi2']; out[name + '_pcg'] = r['trace']['pcg']\n"
+        "np.savez(sys.argv[1], **out)\n" % os.path.join(ROOT, "mov-slam_amd"))
+    dump = str(tmp_path / "packed.npz")
+    p = subprocess.run([sys.executable, "-c", code, dump], env=dict(os.environ, MOVBA_PCG_PACKED="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    packed = np.load(dump)
+    for name in ("small", "cfg2", "cfg3"):
+        r = solver.solve(synth.cfg(name))
+        assert r["n_direct"] == 0
+        for k in ("poses", "points", "chi2"):
+            assert np.array_equal(r[k], packed[name + "_" + k]), (name, k)
+        assert np.array_equal(r["trace"]["pcg"], packed[name + "_pcg"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "revisit"])
 def test_two_stream_lm_loop_gives_the_bits_of_the_one_stream_loop(built_lib, solver, oracle_mod, name):
     """movba_options::two_streams: the PCG launches of a solve on a stream of the handle's own, resident beside the schur pass of
