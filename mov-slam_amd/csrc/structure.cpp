@@ -208,7 +208,10 @@ int finish_pairs(Structure& s, const int32_t* cnt)
 #define MOVBA_SCHUR_T1 128
 #define MOVBA_SCHUR_T2 256
 #endif
-        auto waves_of = [&](int k) { const Item& it = s.items[k]; const int n = it.end - it.begin; return it.diag ? 4 : (n > MOVBA_SCHUR_T2 ? 4 : (n > MOVBA_SCHUR_T1 ? 2 : 1)); };
+#ifndef MOVBA_SCHUR_DW
+#define MOVBA_SCHUR_DW 4
+#endif
+        auto waves_of = [&](int k) { const Item& it = s.items[k]; const int n = it.end - it.begin; return it.diag ? MOVBA_SCHUR_DW : (n > MOVBA_SCHUR_T2 ? 4 : (n > MOVBA_SCHUR_T1 ? 2 : 1)); };
         size_t longest = 1;
         for (int g = 0; g < 8; ++g) {
             std::sort(key.begin() + seg_begin[g], key.begin() + seg_begin[g + 1]);
