@@ -378,7 +378,17 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
             __syncthreads();
         }
     } else if (LDSP) {
-        for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+        if (12 * w.NP <= 4 * kPointBlock) {                   // (both pieces of the image in flight at once, as above)
+            const int n2 = 6 * w.NP;
+            const double2 *g1 = reinterpret_cast<const double2 *>(S1.Rt);
+            double2 b[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int k = threadIdx.x + kPointBlock * u; b[u] = k < n2 ? g1[k] : make_double2(0.0, 0.0); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const int k = threadIdx.x + kPointBlock * u; if (k < n2) reinterpret_cast<double2 *>(sRt)[k] = b[u]; }
+        } else {
+            for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+        }
         __syncthreads();
     }
 
@@ -976,12 +986,31 @@ __device__ __forceinline__ void lambda_init_body(const DevWindow &w)
             F += in ? fv[u] : 0.0; m = fmax(m, in ? mv[u] : 0.0);
         }
     }
-    for (int i = lane; i < w.nfree; i += 64) {
-        for (int a = 0; a < 6; ++a) {
+    // diagonal of Hpp: element (a, a) of keyframe i = the sum over the keyframe's diagonal work items, in item order, of what
+    // the Hpp-only schur pass left in DevWindow::rec_d (row a, place a: Hpp - 0).  One (keyframe, a) per lane and round, five
+    // rounds and four items each in flight at once (until round 4: a lane per keyframe walking items and elements one dependent
+    // load at a time, ~7 us of the solve's setup).
+    constexpr int kRounds = 5, kItemsFly = 4;
+    for (int t0 = lane; t0 < 6 * w.nfree; t0 += 64 * kRounds) {
+        int ni[kRounds];
+        double v[kRounds][kItemsFly];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int t = min(t0 + 64 * r, 6 * w.nfree - 1), i = t / 6, a = t - 6 * i;
+            ni[r] = w.pair_item_start[i + 1] - w.pair_item_start[i];
+            const double *rec = w.rec_d + (size_t)i * w.rec_slots * 48 + a * 9;
+#pragma unroll
+            for (int u = 0; u < kItemsFly; ++u) v[r][u] = rec[(size_t)min(u, w.rec_slots - 1) * 48];
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const int t = min(t0 + 64 * r, 6 * w.nfree - 1), i = t / 6, a = t - 6 * i;
             double s = 0.0;
-            for (int itx = w.pair_item_start[i]; itx < w.pair_item_start[i + 1]; ++itx)
-                s += w.part[(size_t)itx * kPartStride + 42 + ut6(a, a)];
-            m = fmax(m, fabs(s));
+#pragma unroll
+            for (int u = 0; u < kItemsFly; ++u) s += u < ni[r] ? v[r][u] : 0.0;
+            const double *rec = w.rec_d + (size_t)i * w.rec_slots * 48 + a * 9;
+            for (int u = kItemsFly; u < ni[r]; ++u) s += rec[(size_t)u * 48];       // (keyframes with more than 8 192 edges)
+            m = fmax(m, t0 + 64 * r < 6 * w.nfree ? fabs(s) : 0.0);
         }
     }
     m = wave_max(m);
