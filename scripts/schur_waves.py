@@ -6,7 +6,7 @@ import numpy as np
 from movba import synth, capi
 w = synth.cfg("cfg3")
 s = capi.Solver(); s.upload(w); s.run(); s.run(); r = s.download()
-st = r["chi2"][:32768].view(np.uint64).reshape(-1, 8).astype(np.int64)
+st = r["chi2"][:20000].view(np.uint64).reshape(-1, 8).astype(np.int64)
 st = st[st[:, 7] == 1]
 t0 = st[:, 0].min()
 T = (st[:, :5] - t0) * 0.01
