@@ -108,6 +108,7 @@ struct Worker {
 
 struct movba_handle {
     int device = 0;
+    int device_cus = 256;               // compute units of the device (or of this process's partition of it): bounds the one-launch direct solver's workgroups
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t copy_stream = nullptr;  // H2D of the caller's arrays, issued by the helper thread of movba_lba_upload (shared by the
@@ -410,6 +411,8 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     if (h->opt.host_wait == 1) h->packer.spin_ms = 0;      // (a caller that asks for yielding waits does not want a spinning helper either)
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
     if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->device_cus = cus; }
+    if (const char *e = std::getenv("MOVBA_TEST_DEVICE_CUS")) { const int v = std::atoi(e); if (v > 0 && v < h->device_cus) h->device_cus = v; }    // (tests: plan for a smaller device)
     if (stream) { h->stream = static_cast<hipStream_t>(stream); }
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
@@ -1184,8 +1187,12 @@ int Upload::lay_out_rest()
     // one-launch direct solver: the static schedule depends on the number of block columns only (rebuilt when that changes)
     ntile = dense_ntile(nf);
     static const bool dense_multi = std::getenv("MOVBA_DENSE_MULTILAUNCH") != nullptr;
-    if (h->dplan_nt != ntile) { build_dense_plan(ntile, h->dplan); h->dplan_nt = ntile; }
-    dense_one = !dense_multi && dense_persist_supported(h->dplan);
+    // every workgroup of the one-launch solver must be resident while it runs: no more of them than the device (a partition
+    // of an MI355X in CPX mode shows 32 compute units) has to give, a thirty-second held back as on the whole chip (248 of
+    // 256); a plan that then needs more tiles per workgroup than fit LDS falls to the multi-launch solver
+    const int dense_groups = std::min(kDenseMaxGroups, h->device_cus - std::max(1, h->device_cus / 32));
+    if (h->dplan_nt != ntile) { build_dense_plan(ntile, h->dplan, std::max(dense_groups, 1)); h->dplan_nt = ntile; }
+    dense_one = !dense_multi && dense_groups >= 8 && dense_persist_supported(h->dplan);
     o_dtp = c.take<int32_t>(dense_one ? h->dplan.task_ptr.size() : 1); o_dtk = c.take<DenseTask>(dense_one ? h->dplan.tasks.size() : 1);
     o_prange = c.take<int32_t>(dense_one ? 2 * (size_t)nf * nf : 1);
     if (!dev_structure) o_ent = c.take<int32_t>(ent_words());       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region

@@ -55,6 +55,7 @@ void fake_enqueue(hipStream_t s, std::function<void()> f)
 }
 
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int *value, hipDeviceAttribute_t, int) { *value = 256; return hipSuccess; }
 hipError_t hipSetDevice(int) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }

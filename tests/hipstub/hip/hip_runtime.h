@@ -20,6 +20,8 @@ enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemc
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostMallocMapped = 2 };
 
 hipError_t hipGetDeviceCount(int *n);
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+hipError_t hipDeviceGetAttribute(int *value, hipDeviceAttribute_t attr, int device);
 hipError_t hipSetDevice(int d);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();

@@ -1021,6 +1021,39 @@ def test_two_handles_on_the_one_launch_direct_solver_at_once(built_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cus", [64, 20, 4])
+def test_one_launch_direct_solver_planned_for_a_device_with_fewer_compute_units(built_lib, oracle_mod, tmp_path, cus):
+    """Every workgroup of the one-launch direct solver must be resident while it runs, so its schedule is built for the
+    compute units the device reports (a CPX partition of an MI355X shows 32): MOVBA_TEST_DEVICE_CUS makes a handle plan for
+    fewer than the box has.  Where the tiles of a window still fit the fewer workgroups' LDS slots (cfg3's 28 tiles on 62 or 19
+    workgroups) the solve stays one launch; where they do not (a 150-keyframe window's 190 tiles on 19 workgroups) or the device
+    is too small (4 compute units) the library goes launch by launch (dense_solve.hip).  Either way the oracle's result.
+    Child process: the variable is read when a handle is made."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from movba import capi, synth\n"
+        "s = capi.Solver(direct=True)\n"
+        "out = {}\n"
+        "for name, w in (('cfg3', synth.cfg('cfg3')), ('kf150', synth.make_window(150, 6, 3000, 77, run_lo=2, run_hi=9))):\n"
+        "    r = s.solve(w)\n"
+        "    out[name + '_poses'] = r['poses']; out[name + '_points'] = r['points']; out[name + '_nd'] = np.array([r['n_direct'], r['n_sync_timeouts'], r['status']])\n"
+        "np.savez(sys.argv[1], **out)\n" % os.path.join(ROOT, "mov-slam_amd"))
+    dump = str(tmp_path / "fewcus.npz")
+    p = subprocess.run([sys.executable, "-c", code, dump], env=dict(os.environ, MOVBA_TEST_DEVICE_CUS=str(cus)), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = np.load(dump)
+    for name, w in (("cfg3", synth.cfg("cfg3")), ("kf150", synth.make_window(150, 6, 3000, 77, run_lo=2, run_hi=9))):
+        o = oracle_mod.solve(w)
+        nd = got[name + "_nd"]
+        assert nd[0] > 0 and nd[1] == 0 and nd[2] == 0, nd
+        assert quat_angle(got[name + "_poses"][:, :4], o["poses"][:, :4]).max() < 1e-8
+        assert np.abs(got[name + "_poses"][:, 4:] - o["poses"][:, 4:]).max() < 1e-8
+        assert np.abs(got[name + "_points"] - o["points"]).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_padded_and_packed_pair_sums_of_the_pcg_give_the_same_bits(built_lib, solver, tmp_path):
     """k_pcg_rows keeps the mat-vec's pair sums by row in zero-padded slots when no block row has more than ten entry pairs
     (PcgParams::padded: cfg3 and everything smaller), packed pair by pair otherwise; a batch runs the packed layout unless all
