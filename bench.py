@@ -146,9 +146,10 @@ def main():
     dominant = max(KERNEL_CLASSES[:3], key=lambda k: prof_all[k]["ms"])
     solver.set_profile_mask(1 << KERNEL_CLASSES.index(dominant)); solver.reset_profile()
 
-    # HIP events bracket the dominant kernel's launches during the first quarter of the timed steps only: an event pair per
-    # launch costs the solve ~2.5 us of GPU-side serialisation each (20 launches per step: 4 % of the step)
-    n_evt = max(1, (args.steps + 3) // 4)
+    # HIP events bracket the dominant kernel's launches during the first tenth of the timed steps only (20 launches at the
+    # default 20 steps): an event pair per launch costs the solve ~2.5 us of GPU-side serialisation each - 5 % of a step that
+    # carries them (scripts/event_cost.py: 1.174 / 1.186 / 1.235 ms per step with events on 0 / 5 / 20 of 20 steps)
+    n_evt = max(1, args.steps // 10)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
