@@ -119,7 +119,7 @@ typedef struct {
                                    workgroups resident; two-stream loop): > 0 with status MOVBA_OK = the run was repeated on one
                                    stream with the multi-launch direct solver and THIS is its result (the reference never skips
                                    a solve, src/Optimizer.cc:535, 754)                                                          */
-    int32_t pad_r;
+    int32_t n_band;             /* trials solved by the single-workgroup banded factorisation (exact, one launch)  */
 } movba_lba_result;
 
 /* Solver options (all have defaults; pass NULL to movba_create for defaults). */
@@ -138,7 +138,9 @@ typedef struct {
     int32_t pcg_spill;          /* 1 = keep the PCG for windows whose reduced matrix does not fit the PCG workgroup's registers
                                  * (list tails read from an L2 copy every iteration); 0 = default: such windows take the
                                  * one-launch direct solver from the first trial                                        */
-    int32_t solver;             /* 0 = default (PCG where it fits, direct solver elsewhere), 1 = direct solver for every window */
+    int32_t solver;             /* 0 = default, 1 = the dense direct solver for every window, 2 = the banded factorisation in one workgroup
+                                   where the window's band fits LDS (else as 0), 3 = never the banded factorisation (PCG where it fits,
+                                   dense direct solver elsewhere)                                                                    */
     int32_t reorder;            /* 0 = default: free keyframes are renumbered by covisibility (reverse Cuthill-McKee on the pair
                                  * graph) when that shrinks the reduced matrix's envelope by a fifth or more; -1 = keep the
                                  * caller's order (KeyFrame::mnId order, as the reference numbers its vertices)             */

@@ -155,6 +155,8 @@ struct movba_handle {
     int run_status = MOVBA_OK;          // decided per run (MOVBA_STOPPED when the flag was up before the solve)
     PcgParams pp{};
     bool rows_kernel = false;
+    bool band = false;                  // this window's reduced system is solved by the single-workgroup banded factorisation (band_kernel.hip)
+    int band_bw = 0;                    // its half bandwidth in blocks
     DensePlan dplan;                    // static schedule of the one-launch direct solver (kept across uploads of the same size)
     int dplan_nt = -1;
     bool dense_flags_clean = false;     // the window's hand-off flags have been zeroed since its upload (done before the first direct launch)
@@ -403,7 +405,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         if (opt->pcg_coarse < 0) h->opt.pcg_coarse = 0;
         h->opt.host_wait = opt->host_wait == 1 ? 1 : 0;
         h->opt.pcg_spill = opt->pcg_spill == 1 ? 1 : 0;
-        h->opt.solver = opt->solver == 1 ? 1 : 0;
+        h->opt.solver = (opt->solver >= 1 && opt->solver <= 3) ? opt->solver : 0;
         h->opt.reorder = opt->reorder == -1 ? -1 : 0;
         h->opt.two_streams = opt->two_streams == 1 ? 1 : 0;
     }
@@ -425,7 +427,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->ctrl_host_dev), h->ctrl_host, 0) != hipSuccess ||
-        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_struct_kernels() != hipSuccess ||
+        configure_kernels(0) != hipSuccess || configure_pcg_rows() != hipSuccess || configure_band() != hipSuccess || configure_struct_kernels() != hipSuccess ||
         configure_dense_kernels() != hipSuccess || configure_dense_persist() != hipSuccess ||
         configure_pose_kernels() != hipSuccess) {
         movba_destroy(h);
@@ -1120,7 +1122,25 @@ void Upload::choose_solver()
         const bool over = h->rows_kernel && h->pp.overflow;
         if (h->rows_kernel && ((over && !h->opt.pcg_spill) || h->opt.solver == 1)) h->rows_kernel = false;
     }
-    if (h->rows_kernel) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
+    // The banded factorisation in one workgroup (band_kernel.hip): every window whose band - in the numbering the upload has
+    // settled on - fits one CU's LDS, the PCG's windows and the dense small ones of the direct solver alike.
+    {
+        int bw = 0;
+        for (int p = nf; p < s().npairs; ++p) bw = std::max(bw, (int)(s().pair_j[p] - s().pair_i[p]));
+        h->band_bw = bw;
+        // ... where it is the faster of the two: its cost is its 6 nfree pivots in a row and the trailing blocks behind each of
+        // them - measured per step ~2 500 cycles + 19 per trailing block element group (tests/dev/band_scan.py: 8 to 28 keyframes
+        // at a band of 9: 0.45 - 0.80 ms per window solve against the PCG's 0.77 - 0.85; from 32 on the PCG wins) - against the
+        // PCG's ~135 000 cycles whatever the size.  MOVBA_BAND=0 / 1 (or movba_options::solver = 3 / 2) switch the choice off / force it.
+        static const int band_env = [] { const char *e = std::getenv("MOVBA_BAND"); return e ? std::atoi(e) : -1; }();
+        const int64_t est = (int64_t)nf * (2500 + 19 * bw * (bw + 1) + 54 * (bw + 1) + 350);
+        // (the environment variable speaks for handles made with solver = 0 only)
+        const bool forced = h->opt.solver == 2 || (h->opt.solver == 0 && band_env == 1);
+        const bool off = h->opt.solver == 3 || h->opt.solver == 1 || (h->opt.solver == 0 && band_env == 0);
+        const bool want = forced || (h->rows_kernel && est <= 135000);
+        h->band = want && !off && !h->opt.two_streams && band_supported(nf, bw);
+    }
+    if (h->rows_kernel && !h->band) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     lap("pcg plan + coarse lists");
 }
 
@@ -1495,6 +1515,7 @@ int lm_loop(movba_handle *h, bool parked)
     const int nrowent = (int)h->st.row_ent.size();
     // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
     bool direct = !h->rows_kernel;
+    const bool band = h->band;                      // (an exact solve in one launch: nothing parks, nothing waits)
     // Two streams (h->xs_run): the PCG launch of trial t goes to h->pcg_stream and is resident while the schur pass of its trial
     // still runs on `s` (it takes the pass's partials item by item behind their flags: what used to be 11 us of assembly
     // behind a launch boundary); the back-substitution pass of trial t follows the schur pass on `s`, is resident while the
@@ -1526,7 +1547,8 @@ int lm_loop(movba_handle *h, bool parked)
         return MOVBA_OK;
     };
     auto queue_solve = [&]() -> int {
-        if (direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(queue_direct(h)); }
+        if (band) { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_band(w, h->band_bw, s)); }
+        else if (direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(queue_direct(h)); }
         else { ScopedEvents ev(h, KC_PCG, sp); HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, xs, sp)); }
         return MOVBA_OK;
     };
@@ -1755,7 +1777,8 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             hipStream_t s = nullptr;
             BatchDev b{};
             int nb_point = 0, nb_schur = 0, nb_final = 0, nb_init = 0, max_trials = 0, max_iters = 0;
-            size_t lds_lin = 0, lds_back = 0, lds_pcg = 0;
+            size_t lds_lin = 0, lds_back = 0, lds_pcg = 0, lds_band = 0;
+            bool any_band = false, any_pcg = false;     // windows solved by k_band_b / by k_pcg_rows_b (each window as in its solo run)
             int t = 0, final_after = -1;
             bool finished = false;
         } grp[kMaxGroups];
@@ -1764,11 +1787,12 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
         for (int g = 1; g < ngroups; ++g) grp[g].s = g == 1 ? h0->copy_stream : h0->batch_streams[g];
         // ---- device views, PCG plans and block prefixes of both groups in one buffer ----
         Carver c;
-        size_t o_win[kMaxGroups], o_pp[kMaxGroups], o_bp[kMaxGroups], o_bs[kMaxGroups], o_bf[kMaxGroups], o_bi[kMaxGroups];
+        size_t o_win[kMaxGroups], o_pp[kMaxGroups], o_bp[kMaxGroups], o_bs[kMaxGroups], o_bf[kMaxGroups], o_bi[kMaxGroups], o_bw[kMaxGroups];
         for (int g = 0; g < ngroups; ++g) {
             const size_t m = grp[g].hs.size();
             o_win[g] = c.take<DevWindow>(m); o_pp[g] = c.take<PcgParams>(m);
             o_bp[g] = c.take<int32_t>(m + 1); o_bs[g] = c.take<int32_t>(m + 1); o_bf[g] = c.take<int32_t>(m + 1); o_bi[g] = c.take<int32_t>(m + 1);
+            o_bw[g] = c.take<int32_t>(m + 1);
         }
         if (c.off > h0->batch_cap) {
             HIP_TRY(hipStreamSynchronize(s));
@@ -1790,6 +1814,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             PcgParams *pps = reinterpret_cast<PcgParams *>(bh + o_pp[g]);
             int32_t *bp = reinterpret_cast<int32_t *>(bh + o_bp[g]), *bs = reinterpret_cast<int32_t *>(bh + o_bs[g]);
             int32_t *bf = reinterpret_cast<int32_t *>(bh + o_bf[g]), *bi = reinterpret_cast<int32_t *>(bh + o_bi[g]);
+            int32_t *bwv = reinterpret_cast<int32_t *>(bh + o_bw[g]);
             bp[0] = bs[0] = bf[0] = bi[0] = 0;
             for (int i = 0; i < m; ++i) {
                 movba_handle *h = G.hs[i];
@@ -1797,6 +1822,8 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0); __atomic_store_n(&h->hstat->pause_seq, 0, __ATOMIC_RELAXED);
                 wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
                 pps[i] = run_pcg_params(h);
+                bwv[i] = h->band ? h->band_bw : -1;
+                if (h->band) { G.any_band = true; G.lds_band = std::max(G.lds_band, band_lds_bytes(h->win.nfree, h->band_bw)); } else G.any_pcg = true;
                 const DevWindow &w = h->win;
                 bp[i + 1] = bp[i] + w.n_pt_blocks + 1;          // (+ the deciding workgroup of the window's back-substitution pass)
                 bs[i + 1] = bs[i] + (w.nitems > 0 ? schur_blocks(w) : 0);
@@ -1813,6 +1840,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
             G.b.wins = reinterpret_cast<const DevWindow *>(bd + o_win[g]); G.b.pps = reinterpret_cast<const PcgParams *>(bd + o_pp[g]);
             G.b.blk_point = reinterpret_cast<const int32_t *>(bd + o_bp[g]); G.b.blk_schur = reinterpret_cast<const int32_t *>(bd + o_bs[g]);
             G.b.blk_final = reinterpret_cast<const int32_t *>(bd + o_bf[g]); G.b.blk_init = reinterpret_cast<const int32_t *>(bd + o_bi[g]);
+            G.b.band_bw = reinterpret_cast<const int32_t *>(bd + o_bw[g]);
             G.b.n = m;
         }
         HIP_TRY(hipMemcpyAsync(bd, bh, c.off, hipMemcpyHostToDevice, s));
@@ -1865,7 +1893,8 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 if (g > 0 && grp[g - 1].t > G.t) HIP_TRY(hipStreamWaitEvent(G.s, h0->batch_phase_ev[g - 1][G.t % kPhaseEvents], 0));
                 if (G.nb_schur > 0) HIP_TRY(launch_schur_batch(G.b, G.nb_schur, 0, stereo, G.s));
                 if (g + 1 < ngroups) HIP_TRY(hipEventRecord(h0->batch_phase_ev[g][G.t % kPhaseEvents], G.s));
-                HIP_TRY(launch_pcg_rows_batch(G.b, overflow, padded && !overflow, G.lds_pcg, G.t, G.s));
+                if (G.any_pcg) HIP_TRY(launch_pcg_rows_batch(G.b, overflow, padded && !overflow, G.lds_pcg, G.t, G.s));
+                if (G.any_band) HIP_TRY(launch_band_batch(G.b, G.lds_band, G.s));
                 HIP_TRY(launch_point_batch(G.b, G.nb_point, true, stereo, ldsp, G.lds_back, G.s));
                 G.t += 1;
                 t_progress = now_ms();
@@ -1907,7 +1936,7 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     res->status = pre;
     res->iters_done = 0; res->n_solves = 0; res->n_outliers = 0; res->pcg_iters = 0; res->last_rejected = 0;
     res->lambda = 0; res->cost0 = 0; res->cost = 0; res->n_trace = 0;
-    res->n_direct = 0; res->direct_from = -1; res->n_chol_fail = 0; res->n_pcg_giveups = 0; res->n_sync_timeouts = 0; res->pad_r = 0;
+    res->n_direct = 0; res->direct_from = -1; res->n_chol_fail = 0; res->n_pcg_giveups = 0; res->n_sync_timeouts = 0; res->n_band = 0;
     if (pre != MOVBA_OK) return pre;
     const double t0 = now_ms();
     const DevWindow &w = h->win;
@@ -1950,6 +1979,7 @@ int movba_lba_download(movba_handle *h, movba_lba_result *res)
     res->iters_done = c.iters_done; res->n_solves = c.n_solves; res->n_outliers = n_out;
     res->pcg_iters = c.pcg_total_iters; res->last_rejected = c.last_rejected;
     res->n_direct = c.n_direct; res->direct_from = c.direct_from; res->n_chol_fail = c.n_chol_fail; res->n_pcg_giveups = c.n_pause;
+    res->n_band = c.n_band;
     res->lambda = c.lambda; res->cost0 = c.cost0; res->cost = c.F0;
     res->n_trace = c.n_trace;
     for (int k = 0; k < c.n_trace && k < MOVBA_MAX_TRACE; ++k) {

@@ -70,7 +70,8 @@ struct Ctrl {
     int32_t solver_mode, n_pause, n_direct, n_chol_fail;
     int32_t direct_from;                // n_solves at the switch to the direct solver (-1: never)
     int32_t n_sync_timeouts;            // one-launch direct solver: solves in which a workgroup gave up waiting for another (dense_persist.hip)
-    int32_t pad_c[2];
+    int32_t n_band;                     // trials solved by the single-workgroup banded factorisation (band_kernel.hip)
+    int32_t pad_c[1];
     // diagnostic build only (-DMOVBA_CLOCK_STAMP): shader cycles / 100 MHz ticks spent in k_pcg_rows
     unsigned long long dbg_cycles, dbg_ticks, dbg_seg[8], dbg_seg2[8], dbg_wseg[8][8];
     unsigned long long dbg_xs[8];       // two-stream path, 10 ns ticks: [0] time of the schur pass's last item flag of the trial (atomic max), then sums over the
@@ -232,6 +233,7 @@ struct BatchDev {
     const DevWindow *wins;
     const PcgParams *pps;
     const int32_t *blk_point, *blk_schur, *blk_final, *blk_init;
+    const int32_t *band_bw;     // per window: half bandwidth of its reduced matrix in blocks (batches solved by k_band_b), or null
     int32_t n, pad;
 };
 

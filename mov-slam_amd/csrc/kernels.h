@@ -6,6 +6,7 @@
 
 namespace movba {
 
+constexpr int kBandThreads = 512;       // k_band: one workgroup of 8 waves
 constexpr int kPcgRowsThreads = 512;    // 8 waves: 2 per SIMD, 256 VGPRs per lane
 constexpr int kPcgPlanWaves = kPcgRowsThreads / 64, kPcgPlanOwnBatch = 10;     // (pcg_plan.cpp / pcg_kernel.hip)
 
@@ -49,6 +50,13 @@ hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s);
 hipError_t launch_finalize_batch(const BatchDev &b, int nblk, hipStream_t s);
 hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, bool padded, size_t lds, int trial, hipStream_t s);
 size_t pcg_rows_lds_bytes(int nfree, int nrowent, bool padded);
+// single-workgroup banded factorisation (band_kernel.hip): LDS of a window of nfree keyframes whose reduced matrix has half
+// bandwidth bw (in blocks); band_supported: the band fits one workgroup's LDS
+size_t band_lds_bytes(int nfree, int bw);
+bool band_supported(int nfree, int bw);
+hipError_t launch_band(const DevWindow &w, int bw, hipStream_t s);
+hipError_t launch_band_batch(const BatchDev &b, size_t lds, hipStream_t s);
+hipError_t configure_band();
 
 // direct solver (dense_solve.hip): assemble + one launch per block column + back substitution / pose update
 hipError_t configure_dense_kernels();

@@ -50,7 +50,7 @@ __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int 
         c->it = 0; c->qmax = 0; c->cur = 0; c->done = (w.max_iters <= 0) ? 1 : 0;
         c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
-        c->solver_mode = w.direct_only ? 1 : 0; c->n_pause = 0; c->n_direct = 0; c->n_chol_fail = 0;
+        c->solver_mode = w.direct_only ? 1 : 0; c->n_pause = 0; c->n_direct = 0; c->n_chol_fail = 0; c->n_band = 0;
         c->direct_from = w.direct_only ? 0 : -1; c->n_sync_timeouts = 0;
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         w.ac_prev[kCoarseDim * kCoarseDim + 1] = -1.0;

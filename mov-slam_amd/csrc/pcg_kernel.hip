@@ -851,6 +851,7 @@ __global__ __launch_bounds__(kT) void k_pcg_rows_b(BatchDev b, int trial)
 {
     const int wi = blockIdx.x >> 1, role = blockIdx.x & 1;
     const PcgParams &pp = b.pps[wi];
+    if (b.band_bw && b.band_bw[wi] >= 0) return;           // (this window's reduced solve is k_band_b's)
     if (role == 1 && pp.use_coarse != 1) return;
     pcg_rows_body<OVERFLOW, false, PADDED>(b.wins[wi], pp, trial, role);
 }

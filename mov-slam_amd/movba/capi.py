@@ -49,7 +49,7 @@ class LbaResult(C.Structure):
                 ("tr_f1", C.c_double * MAX_TRACE), ("tr_rho", C.c_double * MAX_TRACE),
                 ("tr_accept", C.c_int32 * MAX_TRACE), ("tr_pcg_iters", C.c_int32 * MAX_TRACE),
                 ("n_direct", C.c_int32), ("direct_from", C.c_int32), ("n_chol_fail", C.c_int32), ("n_pcg_giveups", C.c_int32),
-                ("n_sync_timeouts", C.c_int32), ("pad_r", C.c_int32)]
+                ("n_sync_timeouts", C.c_int32), ("n_band", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -240,10 +240,10 @@ class Solver:
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
                  pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0,
-                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True, two_streams: bool = False):
+                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True, two_streams: bool = False, solver: int | None = None):
         self._h = C.c_void_p()
         self._pinned_blocks = []
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, 1 if direct else 0, 0 if reorder else -1, 1 if two_streams else 0)
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, (int(solver) if solver is not None else (1 if direct else 0)), 0 if reorder else -1, 1 if two_streams else 0)
         rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()
@@ -295,7 +295,7 @@ class Solver:
         out.update(status=rc, iters_done=r.iters_done, n_solves=r.n_solves, n_outliers=r.n_outliers,
                    pcg_iters=r.pcg_iters, last_rejected=r.last_rejected, lam=r.lambda_, cost0=r.cost0, cost=r.cost,
                    n_direct=r.n_direct, direct_from=r.direct_from, n_chol_fail=r.n_chol_fail, n_pcg_giveups=r.n_pcg_giveups,
-                   n_sync_timeouts=r.n_sync_timeouts,
+                   n_sync_timeouts=r.n_sync_timeouts, n_band=r.n_band,
                    trace=dict(lam=np.array(r.tr_lambda[:n]), f0=np.array(r.tr_f0[:n]), f1=np.array(r.tr_f1[:n]),
                               rho=np.array(r.tr_rho[:n]), accept=np.array(r.tr_accept[:n]),
                               pcg=np.array(r.tr_pcg_iters[:n])))

@@ -16,7 +16,7 @@ W = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16, "ubyte": 1, "sbyte"
 pat = re.compile(r"^\s*(global_load|buffer_load|flat_load)_(\w+?)\s")
 out = {}
 with tempfile.TemporaryDirectory() as tmp:
-    for f in ("kernels.hip", "pcg_kernel.hip", "dense_solve.hip", "dense_persist.hip", "struct_kernels.hip", "pose_kernels.hip"):
+    for f in ("kernels.hip", "pcg_kernel.hip", "band_kernel.hip", "dense_solve.hip", "dense_persist.hip", "struct_kernels.hip", "pose_kernels.hip"):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include", f"-I{CS}", "--offload-arch=gfx950", "-munsafe-fp-atomics",
                                "-ffp-contract=on", "-Wno-unused-function", "-save-temps", "-c", os.path.join(CS, f), "-o", os.path.join(tmp, "x.o")], cwd=tmp,
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

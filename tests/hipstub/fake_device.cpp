@@ -328,7 +328,12 @@ hipError_t launch_point_batch(const BatchDev &b, int, bool backsub, bool, bool, 
 hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_schur[i]; fake_schur(b.wins[i], -1); } }); return hipSuccess; }
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) b.wins[i].ctrl->lambda = 1e-3; }); return hipSuccess; }
 hipError_t launch_finalize_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_finalize(b.wins[i]); }); return hipSuccess; }
-hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i], 0, false); } }); return hipSuccess; }
+// the banded factorisation: an exact solve in one launch - nothing parks, nothing waits
+static void fake_band(const DevWindow &w) { Ctrl *c = w.ctrl; if (rd_done(c)) return; c->pcg_last_iters = -2; c->n_band += 1; }
+hipError_t launch_band(const DevWindow &w, int, hipStream_t s) { fake_enqueue(s, [w] { fake_band(w); }); return hipSuccess; }
+hipError_t launch_band_batch(const BatchDev &b, size_t, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) if (b.band_bw[i] >= 0) fake_band(b.wins[i]); }); return hipSuccess; }
+hipError_t configure_band() { return hipSuccess; }
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { if (b.band_bw && b.band_bw[i] >= 0) continue; g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i], 0, false); } }); return hipSuccess; }
 
 // ---- pose-only optimisation: echoes the start pose, every match an inlier ----
 hipError_t launch_pose_hyp(const PoseDev &p, hipStream_t s) { fake_enqueue(s, [p] { g_sink += sum_bytes(p.Xw, 24 * (size_t)p.n) + sum_bytes(p.samples, 12 * (size_t)p.n_hyp); }); return hipSuccess; }

@@ -125,8 +125,10 @@ int main()
     // ---- 3. the PCG parks the solve in trial 2: the host queues the direct solver for that trial and stays with it ----
     {
         fake_set_mode(2, -1);
+        movba_options opt{};
+        opt.solver = 3;                         // (never the banded factorisation: a 12-keyframe window would not reach the PCG)
         movba_handle *h = nullptr;
-        EXPECT(movba_create(&h, 0, nullptr, nullptr) == MOVBA_OK);
+        EXPECT(movba_create(&h, 0, nullptr, &opt) == MOVBA_OK);
         Win w; make(w, 12, 2, 800, 7, false, false);
         check_solved(w, movba_lba_solve(h, &w.d, &w.r));
         EXPECT(w.r.n_pcg_giveups == 1 && w.r.direct_from == 2 && w.r.n_direct == 8);
@@ -218,6 +220,37 @@ int main()
         check_solved(w, movba_lba_solve(h, &w.d, &w.r));
         EXPECT(w.r.n_pcg_giveups == 0 && w.r.n_direct == 0);
         movba_destroy(h);
+    }
+    // ---- 8. the banded factorisation in one workgroup (small windows by default, any window whose band fits on request): one
+    //         solve launch per trial, nothing parks; alone, and as part of a batch beside windows of the PCG ----
+    {
+        movba_options opt{};
+        opt.solver = 2;
+        movba_handle *h = nullptr;
+        EXPECT(movba_create(&h, 0, nullptr, &opt) == MOVBA_OK);
+        Win w;
+        for (int it = 0; it < 4; ++it) {
+            make(w, 8 + 9 * it, 2, 400 + 500 * it, 800 + it, false, it % 2 == 1);
+            check_solved(w, movba_lba_solve(h, &w.d, &w.r));
+            EXPECT(w.r.n_band == w.r.n_solves && w.r.n_direct == 0 && w.r.n_pcg_giveups == 0);
+        }
+        movba_destroy(h);
+        movba_handle *hs[3] = { nullptr, nullptr, nullptr };
+        Win ws[3];
+        hipStream_t st = nullptr;
+        EXPECT(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
+        for (int i = 0; i < 3; ++i) {
+            EXPECT(movba_create(&hs[i], 0, st, nullptr) == MOVBA_OK);
+            make(ws[i], i == 1 ? 40 : 9 + i, 2, i == 1 ? 3000 : 500, 900 + i, false, false);       // (default choice: band, PCG, band)
+            EXPECT(movba_lba_upload(hs[i], &ws[i].d) == MOVBA_OK);
+        }
+        EXPECT(movba_lba_run_batch(hs, 3) == MOVBA_OK);
+        for (int i = 0; i < 3; ++i) {
+            check_solved(ws[i], movba_lba_download(hs[i], &ws[i].r));
+            EXPECT((ws[i].r.n_band > 0) == (i != 1));
+            movba_destroy(hs[i]);
+        }
+        (void)hipStreamDestroy(st);
     }
     if (fails) { std::fprintf(stderr, "HOST-TSAN FAILED: %d expectation(s)\n", fails); return 1; }
     std::printf("HOST-TSAN OK\n");

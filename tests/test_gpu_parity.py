@@ -165,7 +165,7 @@ def test_direct_solver_from_the_first_trial_on_ordinary_windows(built_lib, oracl
         w, _ = load_golden("lba_hard")
     else:
         w = synth.cfg(name)
-    s = built_lib.Solver(pcg_max_iters=1)
+    s = built_lib.Solver(pcg_max_iters=1, solver=3)        # (3: never the banded factorisation - small windows would not reach the PCG)
     try:
         r = s.solve(w)
         r2 = s.solve(w)
@@ -426,7 +426,7 @@ def test_pcg_tolerance_is_what_bounds_the_pose_error(built_lib, oracle_mod):
     """A loose PCG tolerance moves the result measurably; the default 1e-10 does not."""
     w = synth.cfg("cfg2")
     o = oracle_mod.solve(w)
-    tight = built_lib.Solver(pcg_rel_tol=1e-12); loose = built_lib.Solver(pcg_rel_tol=1e-3)
+    tight = built_lib.Solver(pcg_rel_tol=1e-12, solver=3); loose = built_lib.Solver(pcg_rel_tol=1e-3, solver=3)      # (the PCG, not the banded factorisation cfg2 gets by default)
     rt, rl = tight.solve(w), loose.solve(w)
     tight.close(); loose.close()
     assert np.abs(rt["poses"] - o["poses"]).max() < 1e-9
@@ -561,6 +561,8 @@ def test_batched_run_is_bit_identical_to_solo_runs(built_lib, oracle_mod):
     st, solvers = _shared_stream_solvers(built_lib, len(ws))
     try:
         solo = [s.solve(w) for s, w in zip(solvers, ws)]
+        # (the batch mixes windows of the banded factorisation - k_band_b - with windows of the PCG - k_pcg_rows_b)
+        assert sum(a["n_band"] > 0 for a in solo) >= 3 and sum(a["n_band"] == 0 for a in solo) >= 2
         for s, w in zip(solvers, ws):
             s.upload(w)
         assert built_lib.run_batch(solvers) == 0
@@ -1054,6 +1056,36 @@ def test_one_launch_direct_solver_planned_for_a_device_with_fewer_compute_units(
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "cfg2", "stereo", "dense16", "cfg3-forced", "hard"])
+def test_banded_factorisation_in_one_workgroup(built_lib, solver, oracle_mod, name):
+    """k_band (band_kernel.hip): the reduced system of a window whose band fits one CU's LDS is factored exactly - block LDL^T
+    with 6 x 6 pivot blocks, the lower band in LDS - by ONE workgroup in ONE launch per trial; the default for the windows it
+    solves faster than the PCG (up to ~28 keyframes at cfg3's band), on request (movba_options::solver = 2) wherever the band
+    fits.  The reference's own solve is exact too (LinearSolverCSparse, src/Optimizer.cc:535): same tolerances as every other
+    path, every trial marked -2 in the trace, bit-reproducible, a batch of such windows bit-identical to their solo runs."""
+    forced = name == "cfg3-forced"
+    if name == "stereo":
+        w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5)
+    elif name == "dense16":
+        w = synth.make_window(16, 3, 6400, seed=916, run_lo=2, run_hi=16)
+    elif name == "hard":
+        w, _ = load_golden("lba_hard")
+    else:
+        w = synth.cfg("cfg3" if forced else name)
+    s = built_lib.Solver(solver=2) if forced else solver
+    try:
+        r = s.solve(w)
+        o = oracle_mod.solve(w)
+        check_against(r, o, w, noise_guard=True)
+        assert r["status"] == 0 and r["n_band"] == r["n_solves"] and r["n_direct"] == 0 and (r["trace"]["pcg"] == -2).all()
+        r2 = s.solve(w)
+        for k in ("poses", "points", "chi2", "outlier"):
+            assert np.array_equal(r[k], r2[k]), k
+    finally:
+        if forced: s.close()
+
+
+@pytest.mark.gpu
 def test_padded_and_packed_pair_sums_of_the_pcg_give_the_same_bits(built_lib, solver, tmp_path):
     """k_pcg_rows keeps the mat-vec's pair sums by row in zero-padded slots when no block row has more than ten entry pairs
     (PcgParams::padded: cfg3 and everything smaller), packed pair by pair otherwise; a batch runs the packed layout unless all
@@ -1071,15 +1103,17 @@ def test_padded_and_packed_pair_sums_of_the_pcg_give_the_same_bits(built_lib, so
         "    out[name + '_poses'] = r['poses']; out[name + '_points'] = r['points']; out[name + '_chi2'] = r['chi2']; out[name + '_pcg'] = r['trace']['pcg']\n"
         "np.savez(sys.argv[1], **out)\n" % os.path.join(ROOT, "mov-slam_amd"))
     dump = str(tmp_path / "packed.npz")
-    p = subprocess.run([sys.executable, "-c", code, dump], env=dict(os.environ, MOVBA_PCG_PACKED="1"), capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, "-c", code, dump], env=dict(os.environ, MOVBA_PCG_PACKED="1", MOVBA_BAND="0"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     packed = np.load(dump)
+    pcg = built_lib.Solver(solver=3)
     for name in ("small", "cfg2", "cfg3"):
-        r = solver.solve(synth.cfg(name))
-        assert r["n_direct"] == 0
+        r = pcg.solve(synth.cfg(name))
+        assert r["n_direct"] == 0 and r["n_band"] == 0
         for k in ("poses", "points", "chi2"):
             assert np.array_equal(r[k], packed[name + "_" + k]), (name, k)
         assert np.array_equal(r["trace"]["pcg"], packed[name + "_pcg"])
+    pcg.close()
 
 
 @pytest.mark.gpu
@@ -1093,8 +1127,9 @@ def test_two_stream_lm_loop_gives_the_bits_of_the_one_stream_loop(built_lib, sol
     else:
         w = synth.cfg(name) if name != "revisit" else synth.pattern_cfg(name)
     two = built_lib.Solver(two_streams=True)
+    one = built_lib.Solver(solver=3)                 # (the one-stream loop on the same reduced solver: the PCG)
     try:
-        r1 = solver.solve(w)
+        r1 = one.solve(w)
         r2 = two.solve(w)
         assert r2["status"] == 0 and r2["n_sync_timeouts"] == 0 and r2["n_direct"] == r1["n_direct"]
         for k in ("poses", "points", "chi2", "outlier"):
@@ -1104,7 +1139,7 @@ def test_two_stream_lm_loop_gives_the_bits_of_the_one_stream_loop(built_lib, sol
         assert np.array_equal(r2["poses"], r3["poses"]) and np.array_equal(r2["chi2"], r3["chi2"])
         check_against(r2, oracle_mod.solve(w), w, noise_guard=True)
     finally:
-        two.close()
+        two.close(); one.close()
 
 
 @pytest.mark.gpu
