@@ -2,7 +2,7 @@
 
 The C++ adapter (mov-slam_amd/host/Optimizer.cc) writes every flattened LocalBundleAdjustment window it
 solves to $MOVBA_DUMP_DIR/lba_<n>.mbw when that variable is set, so that windows recorded inside a real
-MoV-SLAM run can be replayed on a GPU box (scripts/replay_windows.py) without the reference's stack.
+MoV-SLAM run can be replayed on a GPU box (tests/dev/replay_windows.py) without the reference's stack.
 Layout (little endian): magic 'MOVBAWIN', u32 version=1, i32 NP, P, E, max_iters, u32 flags,
 f64 cam[4], huber_delta, chi2_gate, then pose_fixed u8[NP] (padded to 8), poses f64[NP*7],
 points f64[P*3], edge_pose i32[E], edge_point i32[E], obs f64[E*2], inv_sigma2 f64[E]; when the top bit of

@@ -1,6 +1,6 @@
 """Time per window solve of the direct (dense Cholesky) path beside the on-chip PCG and the oracle (run on a GPU box)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 from movba import capi, synth

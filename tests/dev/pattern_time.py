@@ -1,7 +1,7 @@
 """Window solves of the covisibility patterns (hub / revisit / shuffled ids) beside cfg3: which reduced solver ran, CG
 iterations, time per resident solve and per movba_lba_solve call, parity against the oracle (run on a GPU box)."""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 import numpy as np
 from movba import capi, synth
@@ -11,7 +11,7 @@ names = [a for a in sys.argv[1:] if not a.startswith("--")] or ["cfg3", "shuffle
 out = {}
 s = capi.Solver(profile=True, direct="--direct" in sys.argv, pcg_spill="--spill" in sys.argv)
 for name in names:
-    w = synth.cfg("cfg3") if name == "cfg3" else synth.pattern_cfg(name)
+    w = synth.cfg(name) if name in ("cfg3", "cfg2", "small") else synth.pattern_cfg(name)
     plan = capi.structure_probe(w)
     o = oracle.solve(w)
     s.prepare(w, pinned=True)

@@ -1,7 +1,7 @@
 """Wall time of movba_pose_opt calls (cfg1: one Frame, 500 matches) against the single-threaded oracle."""
 import sys, time, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd")); sys.path.insert(0, ROOT)
 from movba import synth, capi
 s = capi.Solver()

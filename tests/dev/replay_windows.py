@@ -6,7 +6,7 @@
 (tests/dev/replay_check.py additionally compares every window with the CPU oracle.)
 """
 import glob, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
 from movba import capi, capture
 
