@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -1128,16 +1129,22 @@ void Upload::choose_solver()
         int bw = 0;
         for (int p = nf; p < s().npairs; ++p) bw = std::max(bw, (int)(s().pair_j[p] - s().pair_i[p]));
         h->band_bw = bw;
-        // ... where it is the faster of the two: its cost is its 6 nfree pivots in a row and the trailing blocks behind each of
-        // them - measured per step ~2 500 cycles + 19 per trailing block element group (tests/dev/band_scan.py: 8 to 28 keyframes
-        // at a band of 9: 0.45 - 0.80 ms per window solve against the PCG's 0.77 - 0.85; from 32 on the PCG wins) - against the
-        // PCG's ~135 000 cycles whatever the size.  MOVBA_BAND=0 / 1 (or movba_options::solver = 3 / 2) switch the choice off / force it.
+        // ... where it is the faster of the two.  Its cost (tests/dev/band_scan.py, profiles/r04_band_scan.log; cycles from the
+        // stamp build): per block step ~1 970 for the pivot block, ~780 per round of the panel, ~420 per round of 512 trailing
+        // elements - with the AVERAGE number of blocks below a pivot, min(bw, nfree - 1 - k) over the steps -, plus assembly,
+        // sweeps and epilogue; against the PCG's ~130 000 cycles whatever the size.  At a band of 9: 8 keyframes 0.49 ms per
+        // resident window solve against 0.78, 16: 0.63 / 0.78, 24: 0.78 / 0.80, from 28 on the PCG wins (0.88 / 0.87; 40: 1.12 / 0.88).
+        // MOVBA_BAND=0 / 1 (or movba_options::solver = 3 / 2) switch the choice off / force it.
         static const int band_env = [] { const char *e = std::getenv("MOVBA_BAND"); return e ? std::atoi(e) : -1; }();
-        const int64_t est = (int64_t)nf * (2500 + 19 * bw * (bw + 1) + 54 * (bw + 1) + 350);
+        double m_sum = 0.0;
+        for (int k = 0; k < nf; ++k) m_sum += std::min(bw, nf - 1 - k);
+        const double m_avg = nf > 0 ? m_sum / nf : 0.0;
+        const double rt = std::ceil((m_avg * (m_avg + 1.0) * 18.0 + 6.0 * m_avg) / 512.0), rp = std::max(1.0, std::ceil(m_avg * 36.0 / 512.0));
+        const double est = nf * (1970.0 + 780.0 * rp + 420.0 * rt) + 54.0 * nf * (bw + 1) + 360.0 * nf + 5000.0;
         // (the environment variable speaks for handles made with solver = 0 only)
         const bool forced = h->opt.solver == 2 || (h->opt.solver == 0 && band_env == 1);
         const bool off = h->opt.solver == 3 || h->opt.solver == 1 || (h->opt.solver == 0 && band_env == 0);
-        const bool want = forced || (h->rows_kernel && est <= 135000);
+        const bool want = forced || (h->rows_kernel && est <= 130000.0);
         h->band = want && !off && !h->opt.two_streams && band_supported(nf, bw);
     }
     if (h->rows_kernel && !h->band) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
@@ -1514,8 +1521,8 @@ int lm_loop(movba_handle *h, bool parked)
     PcgParams pp = run_pcg_params(h);
     const int nrowent = (int)h->st.row_ent.size();
     // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
-    bool direct = !h->rows_kernel;
-    const bool band = h->band;                      // (an exact solve in one launch: nothing parks, nothing waits)
+    const bool band = h->band;                      // (an exact solve in one launch; it parks the solve only when a pivot has lost too many digits)
+    bool direct = !h->rows_kernel && !band;
     // Two streams (h->xs_run): the PCG launch of trial t goes to h->pcg_stream and is resident while the schur pass of its trial
     // still runs on `s` (it takes the pass's partials item by item behind their flags: what used to be 11 us of assembly
     // behind a launch boundary); the back-substitution pass of trial t follows the schur pass on `s`, is resident while the
@@ -1547,7 +1554,7 @@ int lm_loop(movba_handle *h, bool parked)
         return MOVBA_OK;
     };
     auto queue_solve = [&]() -> int {
-        if (band) { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_band(w, h->band_bw, s)); }
+        if (band && !direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_band(w, h->band_bw, s)); }      // (direct: the factorisation parked the solve)
         else if (direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(queue_direct(h)); }
         else { ScopedEvents ev(h, KC_PCG, sp); HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, xs, sp)); }
         return MOVBA_OK;

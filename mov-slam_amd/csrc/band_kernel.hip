@@ -12,7 +12,10 @@
 // the right-hand side carried along as one more column, then z_k = Dk^-1 y_k and the backward sweep x_j -= L_kj^T x_k by one
 // wave.  Every sum runs in a fixed order: bit-reproducible run to run, solo or batched.
 // A pivot block that is not positive definite fails the trial as a failed Cholesky factorisation does in g2o (the trial is
-// rejected: Ctrl::pcg_fail, n_chol_fail).
+// rejected: Ctrl::pcg_fail, n_chol_fail).  The pivot blocks are inverted explicitly, which is only as accurate as they are
+// well conditioned: a pivot that has lost more than five digits against its diagonal element of S (keyframes held by a
+// handful of observations: the reduced matrix is singular but for the LM damping) PARKS the solve like a PCG that gives up -
+// the host queues the dense direct solver (backward stable) for this trial and stays with it.
 #include <hip/hip_runtime.h>
 
 #include "device_math.h"
@@ -25,6 +28,7 @@ namespace {
 
 constexpr int kBT = kBandThreads;       // 512
 constexpr int kBW = kBT / 64;
+constexpr double kBandPivotTol = 1e-5;  // a pivot below this share of its diagonal element of S: the window goes to the dense direct solver
 
 __device__ __forceinline__ int band_off(int i, int j, int bw) { return (i * (bw + 1) + (j - i + bw)) * 36; }
 
@@ -61,10 +65,11 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
     double *Lb = sm;                                  // nf x (bw + 1) x 36: block (i, j), i - bw <= j <= i, at band_off(i, j)
     double *rhs = Lb + (size_t)nf * B1 * 36;          // n
     double *aux = rhs + npad;                         // n
-    double *T = aux + npad;                           // bw x 36
+    double *dg = aux + npad;                          // n: the diagonal of S as assembled (what the pivots are measured against)
+    double *T = dg + npad;                            // bw x 36
     double *gs = T + bw * 36;                         // 12
     int *tri = reinterpret_cast<int *>(gs + 12);      // bw (bw + 1) / 2 pairs (irel << 8 | jrel)
-    int *failw = tri + ((bw * (bw + 1) / 2 + 1) & ~1);
+    int *failw = tri + ((bw * (bw + 1) / 2 + 1) & ~1);     // [0] a pivot was not positive, [1] a pivot lost too many digits
 
     // ---- assembly ----
     for (int k = tid; k < nf * B1 * 18; k += kBT) reinterpret_cast<double2 *>(Lb)[k] = make_double2(0.0, 0.0);
@@ -73,7 +78,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
         while ((irel + 1) * (irel + 2) / 2 <= pr) ++irel;
         tri[pr] = (irel << 8) | (pr - irel * (irel + 1) / 2);
     }
-    if (tid == 0) *failw = 0;
+    if (tid == 0) { failw[0] = 0; failw[1] = 0; }
     __syncthreads();
     // off-diagonal pairs (i < j): the lower block (j, i) = - (sum over the pair's work items of the 6 x 6 partial)^T, items in order
     // (sixteen elements per thread in flight through the two dependent load levels - pair -> its items' partials -: walked one
@@ -126,7 +131,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
             for (int t = 0; t < kItemsFly; ++t) s += t < ni[u] ? v[u][t] : 0.0;
             const double *rec = w.rec_d + (size_t)h * w.rec_slots * 48 + r;
             for (int t = kItemsFly; t < ni[u]; ++t) s += rec[(size_t)t * 48];
-            if (q < 6) Lb[band_off(h, h, bw) + a * 6 + q] = s + (q == a ? lambda : 0.0);
+            if (q < 6) { Lb[band_off(h, h, bw) + a * 6 + q] = s + (q == a ? lambda : 0.0); if (q == a) dg[6 * h + a] = s + lambda; }
             else if (q == 6) aux[6 * h + a] = s;
             else rhs[6 * h + a] = s;
         }
@@ -143,9 +148,9 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
     // (irel >= m) just drops out - or, behind them, component a of the right-hand side of block irel.
     const int step_stride = B1 * 36;
     const int p_irel = tid / 36;
-    int p_A, p_D;
+    int p_A, p_D, p_Dc;
     { const int q = tid - p_irel * 36, a = q / 6, b = q - a * 6;
-      p_A = ((1 + p_irel) * B1 + (bw - 1 - p_irel)) * 36 + a * 6; p_D = bw * 36 + b * 6; }
+      p_A = ((1 + p_irel) * B1 + (bw - 1 - p_irel)) * 36 + a * 6; p_D = bw * 36 + b * 6; p_Dc = bw * 36 + b; }
     constexpr int kTr = 4;
     const int ntr_full = bw * (bw + 1) / 2 * 36;
     const bool fast_tr = ntr_full + bw * 6 <= kTr * kBT;
@@ -177,7 +182,9 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
             const int lr = min(ln, 5);
 #pragma unroll
             for (int q = 0; q < 6; ++q) mi[q] = D[lr * 6 + q];
+            const double dref = dg[6 * k + lr] * kBandPivotTol;       // this lane's row: its pivot must keep that much of S's diagonal
             bool bad = false;
+            double p_own = 1.0;                                       // this lane's own pivot (lanes 0 - 5), compared once behind the elimination
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) {
                 double r[6];
@@ -185,6 +192,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
                 for (int q = 0; q < 6; ++q) r[q] = readlane_f64(mi[q], kk);
                 const double p = r[kk];
                 if (!(p > 0.0) || !isfinite(p)) bad = true;
+                p_own = ln == kk ? p : p_own;
                 double pinv = __builtin_amdgcn_rcp(p);
                 pinv = pinv * (2.0 - p * pinv);
                 pinv = pinv * (2.0 - p * pinv);
@@ -199,7 +207,8 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) D[ln * 6 + q] = mi[q];
             }
-            if (bad && ln == 0) *failw = 1;
+            if (bad && ln == 0) failw[0] = 1;
+            if (__any(ln < 6 && p_own < dref) && ln == 0) failw[1] = 1;
         } else if (k > 0) {
             // the other waves meanwhile store the previous step's panel as the factor's blocks L(i, k - 1) (nobody reads column
             // k - 1 of the band any more until the backward sweep; the panel is rewritten behind the barrier below)
@@ -216,14 +225,23 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
             if (p_irel < m) {
                 const double2 *A = reinterpret_cast<const double2 *>(Lk + p_A);
                 const double2 *Dr = reinterpret_cast<const double2 *>(Lk + p_D);
-                const double2 a0 = A[0], a1 = A[1], a2 = A[2], d0 = Dr[0], d1 = Dr[1], d2 = Dr[2];
+                const double *Dc = Lk + p_Dc;
+                const double2 a0 = A[0], a1 = A[1], a2 = A[2], r0 = Dr[0], r1 = Dr[1], r2 = Dr[2];
+                // (the elimination leaves Dk^-1 symmetric but for rounding; everything downstream uses ITS SYMMETRIC PART, row b and
+                //  column b averaged where they are read: taken as it came, row b for column b here and rows in the sweep, a chain of 40
+                //  keyframes held by tracks of three ended 4e-8 m from the oracle's poses instead of 2e-11)
+                const double2 d0 = make_double2(0.5 * (r0.x + Dc[0]), 0.5 * (r0.y + Dc[6])), d1 = make_double2(0.5 * (r1.x + Dc[12]), 0.5 * (r1.y + Dc[18])),
+                              d2 = make_double2(0.5 * (r2.x + Dc[24]), 0.5 * (r2.y + Dc[30]));
                 T[tid] = ((a0.x * d0.x + a0.y * d0.y) + (a1.x * d1.x + a1.y * d1.y)) + (a2.x * d2.x + a2.y * d2.y);
             }
         } else for (int idx = tid; idx < m * 36; idx += kBT) {
             const int irel = idx / 36, q = idx - irel * 36, a = q / 6, b = q - a * 6;
             const double2 *A = reinterpret_cast<const double2 *>(Lb + band_off(k + 1 + irel, k, bw) + a * 6);
             const double2 *Dr = reinterpret_cast<const double2 *>(D + b * 6);
-            const double2 a0 = A[0], a1 = A[1], a2 = A[2], d0 = Dr[0], d1 = Dr[1], d2 = Dr[2];
+            const double *Dc = D + b;
+            const double2 a0 = A[0], a1 = A[1], a2 = A[2], r0 = Dr[0], r1 = Dr[1], r2 = Dr[2];
+            const double2 d0 = make_double2(0.5 * (r0.x + Dc[0]), 0.5 * (r0.y + Dc[6])), d1 = make_double2(0.5 * (r1.x + Dc[12]), 0.5 * (r1.y + Dc[18])),
+                          d2 = make_double2(0.5 * (r2.x + Dc[24]), 0.5 * (r2.y + Dc[30]));
             T[idx] = ((a0.x * d0.x + a0.y * d0.y) + (a1.x * d1.x + a1.y * d1.y)) + (a2.x * d2.x + a2.y * d2.y);
         }
         __syncthreads();
@@ -282,16 +300,29 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
         __syncthreads();
         BAND_STAMP(3);
     }
-    const bool fail = *failw != 0;
+    const bool fail = failw[0] != 0;
+    if (failw[1] != 0 && !fail) {
+        // ill conditioned beyond what explicit pivot-block inverses carry: park the solve (Ctrl::done = 2 turns every kernel queued
+        // behind into a no-op) and tell the host, which queues the dense direct solver for this trial and every later one
+        if (tid == 0) {
+            const int np = c->n_pause + 1;
+            c->pcg_last_iters = 0;
+            c->solver_mode = 1; c->direct_from = c->n_solves;
+            c->n_pause = np;
+            c->done = 2;
+            __hip_atomic_store(&w.hstat->pause_seq, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     // (the last step has no panel: nothing left to store)
     // ---- z_k = Dk^-1 y_k, then the backward sweep by one wave: x_k final, z_j -= L_kj^T x_k for the band above ----
     for (int r = tid; r < n; r += kBT) {
         const int k = r / 6, a = r - k * 6;
-        const double *D = Lb + band_off(k, k, bw) + a * 6;
+        const double *D = Lb + band_off(k, k, bw) + a * 6, *Dc = Lb + band_off(k, k, bw) + a;
         const double *y = rhs + 6 * k;
-        double s = D[0] * y[0];
+        double s = (0.5 * (D[0] + Dc[0])) * y[0];
 #pragma unroll
-        for (int cc = 1; cc < 6; ++cc) s += D[cc] * y[cc];
+        for (int cc = 1; cc < 6; ++cc) s += (0.5 * (D[cc] + Dc[6 * cc])) * y[cc];
         aux[r] = s;
     }
     __syncthreads();

@@ -23,7 +23,7 @@ size_t band_lds_bytes(int nfree, int bw)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
     const size_t ntri = ((size_t)bw * (bw + 1) / 2 + 1) & ~(size_t)1;
-    return ((size_t)nfree * (bw + 1) * 36 + 2 * npad + (size_t)bw * 36 + 12) * sizeof(double) + (ntri + 4) * sizeof(int32_t);
+    return ((size_t)nfree * (bw + 1) * 36 + 3 * npad + (size_t)bw * 36 + 12) * sizeof(double) + (ntri + 4) * sizeof(int32_t);
 }
 
 bool band_supported(int nfree, int bw) { return nfree >= 1 && bw >= 0 && bw < 256 && band_lds_bytes(nfree, bw) <= 159 * 1024; }
