@@ -6,16 +6,18 @@
 // cfg3's 50 free keyframes couple over at most 9 neighbours either side, 50 x 10 blocks of 6 x 6 = 144 KB of the CU's 160 KB
 // of LDS.  A banded factorisation fills the band and nothing else, so the solve needs no global memory between its first load
 // and its last store, no second workgroup, no hand-off between workgroups (what makes the one-launch dense solver
-// 109 us at this size) and no stopping rule: block LDL^T with 6 x 6 pivot blocks,
-//     for k:  Dk^-1 (in place, Gauss-Jordan by six lanes of one wave);  T_i = A_ik Dk^-1 (i in the band below k);
-//             A_ij -= T_i A_jk^T (i >= j in the band);  b_i -= T_i b_k;  A_ik <- T_i (= L_ik),
-// the right-hand side carried along as one more column, then z_k = Dk^-1 y_k and the backward sweep x_j -= L_kj^T x_k by one
-// wave.  Every sum runs in a fixed order: bit-reproducible run to run, solo or batched.
-// A pivot block that is not positive definite fails the trial as a failed Cholesky factorisation does in g2o (the trial is
-// rejected: Ctrl::pcg_fail, n_chol_fail).  The pivot blocks are inverted explicitly, which is only as accurate as they are
-// well conditioned: a pivot that has lost more than five digits against its diagonal element of S (keyframes held by a
-// handful of observations: the reduced matrix is singular but for the LM damping) PARKS the solve like a PCG that gives up -
-// the host queues the dense direct solver (backward stable) for this trial and stays with it.
+// 109 us at this size) and no stopping rule: Cholesky S = L L^T in 6 x 6 blocks,
+//     for k:  one sweep over the stacked rows [ D_k ; A_ik (i in the band below k) ; b_k^T ], a row per lane:
+//                 L_kk L_kk^T = D_k,  L_ik = A_ik L_kk^-T,  y_k = L_kk^-1 b_k   (triangular solves, nothing is inverted);
+//             A_ij -= L_ik L_jk^T (i >= j in the band);  b_i -= L_ik y_k,
+// then the backward sweep L^T x = y by one wave, a triangular solve with L_kk^T per block.  Every sum runs in a fixed order:
+// bit-reproducible run to run, solo or batched.  Round 4's version inverted the pivot blocks explicitly (block LDL^T), which is
+// only as accurate as the blocks are conditioned, and needed a tuned threshold to hand weak windows to the dense solver;
+// the Cholesky sweep is backward stable whatever the conditioning, as the reference's factorisation is.
+// The only thing that can go wrong is a pivot that is not positive: NaN / inf in the normal equations fails the trial as a
+// failed Cholesky factorisation does in g2o (the trial is rejected: Ctrl::pcg_fail, n_chol_fail); a finite non-positive pivot
+// (S is positive definite in exact arithmetic: rounding in a window that is singular but for the LM damping) PARKS the solve
+// like a PCG that gives up - the host queues the dense direct solver for this trial and stays with it.
 #include <hip/hip_runtime.h>
 
 #include "device_math.h"
@@ -28,7 +30,7 @@ namespace {
 
 constexpr int kBT = kBandThreads;       // 512
 constexpr int kBW = kBT / 64;
-constexpr double kBandPivotTol = 1e-5;  // a pivot below this share of its diagonal element of S: the window goes to the dense direct solver
+constexpr int kSweepRows = 58;          // rows below the pivot block a wave takes in the factorisation's sweep (lanes 6 - 63)
 
 __device__ __forceinline__ int band_off(int i, int j, int bw) { return (i * (bw + 1) + (j - i + bw)) * 36; }
 
@@ -60,16 +62,15 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-    // LDS carve: the band, the right-hand side (then y), a second vector (b_p's partner, then z and x), the panel, two strips
-    // for the pivot block's elimination, the enumeration of the trailing blocks, a failure word
+    // LDS carve (pcg_plan.cpp: band_lds_bytes): the band, the right-hand side (then y), a second vector (b_p's partner, then x),
+    // the reciprocals of the factor's diagonal, a strip for the reductions, the enumeration of the trailing blocks, two failure words
     double *Lb = sm;                                  // nf x (bw + 1) x 36: block (i, j), i - bw <= j <= i, at band_off(i, j)
     double *rhs = Lb + (size_t)nf * B1 * 36;          // n
     double *aux = rhs + npad;                         // n
-    double *dg = aux + npad;                          // n: the diagonal of S as assembled (what the pivots are measured against)
-    double *T = dg + npad;                            // bw x 36
-    double *gs = T + bw * 36;                         // 12
+    double *idg = aux + npad;                         // n: 1 / L_aa of every pivot block (what the backward sweep divides by)
+    double *gs = idg + npad;                          // 12
     int *tri = reinterpret_cast<int *>(gs + 12);      // bw (bw + 1) / 2 pairs (irel << 8 | jrel)
-    int *failw = tri + ((bw * (bw + 1) / 2 + 1) & ~1);     // [0] a pivot was not positive, [1] a pivot lost too many digits
+    int *failw = tri + ((bw * (bw + 1) / 2 + 1) & ~1);     // [0] a pivot was NaN / inf, [1] a pivot was not positive
 
     // ---- assembly ----
     for (int k = tid; k < nf * B1 * 18; k += kBT) reinterpret_cast<double2 *>(Lb)[k] = make_double2(0.0, 0.0);
@@ -131,7 +132,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
             for (int t = 0; t < kItemsFly; ++t) s += t < ni[u] ? v[u][t] : 0.0;
             const double *rec = w.rec_d + (size_t)h * w.rec_slots * 48 + r;
             for (int t = kItemsFly; t < ni[u]; ++t) s += rec[(size_t)t * 48];
-            if (q < 6) { Lb[band_off(h, h, bw) + a * 6 + q] = s + (q == a ? lambda : 0.0); if (q == a) dg[6 * h + a] = s + lambda; }
+            if (q < 6) Lb[band_off(h, h, bw) + a * 6 + q] = s + (q == a ? lambda : 0.0);
             else if (q == 6) aux[6 * h + a] = s;
             else rhs[6 * h + a] = s;
         }
@@ -141,16 +142,27 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
     __syncthreads();
 
     BAND_STAMP(0);
-    // ---- factorisation, the right-hand side carried along ----
+    // ---- factorisation S = L L^T, the right-hand side carried along as one more row (y = L^-1 b) ----
+    // Step k is ONE sweep over the stacked rows [ D_k ; A_(k+1)k ; ... ; A_(k+m)k ; b_k^T ], one row of six per lane: column by
+    // column, pivot p = the diagonal element as updated so far, every row's entry scaled by 1 / sqrt(p) and taken out of the
+    // row's later entries with the pivot block's own scaled entries (broadcast from lanes 0 - 5 through v_readlane).  Lanes
+    // 0 - 5 come out holding L_kk, every other lane its row of L_ik = A_ik L_kk^-T - a triangular solve - or y_k: in place,
+    // no inverse of a pivot block anywhere (backward stable like the reference's own Cholesky, src/Optimizer.cc:535).
     // What a thread touches in a step does not depend on the step but for a common offset (k (bw + 1) 36 doubles into the band,
-    // 6 k into the right-hand side): decoded once.  Panel: element (a, b) of panel block `p_irel`.  Trailing phase: up to four
-    // elements per thread - (a, b) of block (irel, jrel) below the pivot, enumerated by irel so that a short last band
-    // (irel >= m) just drops out - or, behind them, component a of the right-hand side of block irel.
+    // 6 k into the right-hand side): decoded once.
     const int step_stride = B1 * 36;
-    const int p_irel = tid / 36;
-    int p_A, p_D, p_Dc;
-    { const int q = tid - p_irel * 36, a = q / 6, b = q - a * 6;
-      p_A = ((1 + p_irel) * B1 + (bw - 1 - p_irel)) * 36 + a * 6; p_D = bw * 36 + b * 6; p_Dc = bw * 36 + b; }
+    // the sweep: lanes 0 - 5 of every sweeping wave hold D_k's rows (identical arithmetic in every wave), lane 6 of wave 0 the
+    // right-hand side, the other lanes the rows below, 58 per wave
+    int s_off, s_irel;                                 // s_irel: -1 = row of D_k, -2 = right-hand side, >= 0: panel block
+    if (ln < 6) { s_off = bw * 36 + ln * 6; s_irel = -1; }
+    else {
+        const int rr = kSweepRows * wv + ln - 6;
+        if (rr == 0) { s_off = 0; s_irel = -2; }
+        else { const int irel = (rr - 1) / 6, a = (rr - 1) - irel * 6; s_irel = irel; s_off = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6; }
+    }
+    const int sw_first_irel = wv == 0 ? -1 : (kSweepRows * wv - 1) / 6;      // the first panel block a wave beyond the first has rows of
+    // Trailing phase: up to four elements per thread - (a, b) of block (irel, jrel) below the pivot, enumerated by irel so that
+    // a short last band (irel >= m) just drops out - or, behind them, component a of the right-hand side of block irel.
     constexpr int kTr = 4;
     const int ntr_full = bw * (bw + 1) / 2 * 36;
     const bool fast_tr = ntr_full + bw * 6 <= kTr * kBT;
@@ -162,91 +174,60 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
         if (idx < ntr_full) {
             const int pr = idx / 36, q = idx - pr * 36, a = q / 6, b = q - a * 6;
             const int ij = tri[pr], irel = ij >> 8, jrel = ij & 0xff;
-            t_irel[u] = irel; t_T[u] = irel * 36 + a * 6;
+            t_irel[u] = irel; t_T[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6;
             t_A[u] = ((1 + jrel) * B1 + (bw - 1 - jrel)) * 36 + b * 6;
             t_dst[u] = ((1 + irel) * B1 + (jrel - irel + bw)) * 36 + q;
         } else if (idx < ntr_full + bw * 6) {
             const int r = idx - ntr_full, irel = r / 6, a = r - irel * 6;
-            t_irel[u] = irel; t_T[u] = irel * 36 + a * 6; t_A[u] = -1; t_dst[u] = -1 - (6 * (1 + irel) + a);
+            t_irel[u] = irel; t_T[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6; t_A[u] = -1; t_dst[u] = -1 - (6 * (1 + irel) + a);
         }
     }
     for (int k = 0; k < nf; ++k) {
         const int m = min(bw, nf - 1 - k);
-        double *D = Lb + band_off(k, k, bw);
         double *Lk = Lb + (size_t)k * step_stride;        // what the decoded offsets are relative to
-        if (wv == 0) {
-            // Dk^-1 in place: Gauss-Jordan with the block's rows in lanes 0 - 5 and the pivot row broadcast through v_readlane
-            // (scalar operands of the other lanes' multiply-adds): no LDS round trip inside the elimination - through LDS strips,
-            // as the PCG's block-Jacobi setup does it, a block took 2 960 cycles of this kernel's critical path, 50 times
-            double mi[6] = { 1, 0, 0, 0, 0, 0 };
-            const int lr = min(ln, 5);
-#pragma unroll
-            for (int q = 0; q < 6; ++q) mi[q] = D[lr * 6 + q];
-            const double dref = dg[6 * k + lr] * kBandPivotTol;       // this lane's row: its pivot must keep that much of S's diagonal
-            bool bad = false;
-            double p_own = 1.0;                                       // this lane's own pivot (lanes 0 - 5), compared once behind the elimination
+        double v[6];
+        if (sw_first_irel < m) {
+            const bool act = s_irel < m;
+            double *row = s_irel == -2 ? rhs + 6 * k : Lk + s_off;
+            if (!act) row = gs;                             // (a place nobody writes here)
+            { const double2 *rp = reinterpret_cast<const double2 *>(row);
+              const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+              v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y; v[4] = r2.x; v[5] = r2.y; }
+            bool nonfinite = false, nonpos = false;
+            double ri_own = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) {
-                double r[6];
+                const double p = readlane_f64(v[kk], kk);
+                if (!isfinite(p)) nonfinite = true;
+                if (!(p > 0.0)) nonpos = true;
+                // 1 / sqrt(p): v_rsq_f64 and two Newton steps y <- y (1.5 - (p / 2) y^2)
+                const double hp = 0.5 * p;
+                double y = __builtin_amdgcn_rsq(p);
+                y = y * (1.5 - (hp * y) * y);
+                y = y * (1.5 - (hp * y) * y);
+                ri_own = ln == kk ? y : ri_own;
+                v[kk] *= y;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) r[q] = readlane_f64(mi[q], kk);
-                const double p = r[kk];
-                if (!(p > 0.0) || !isfinite(p)) bad = true;
-                p_own = ln == kk ? p : p_own;
-                double pinv = __builtin_amdgcn_rcp(p);
-                pinv = pinv * (2.0 - p * pinv);
-                pinv = pinv * (2.0 - p * pinv);
-                // row kk becomes the scaled pivot row (pivot -> 1 / p), every other row i: a_iq -= a_ik r_q / p (column kk -> - a_ik / p):
-                // one form for all lanes, new = keep * old + coef * (r_q / p), with keep = 0, coef = 1 on the pivot's own lane
-                const bool own = ln == kk;
-                const double keep = own ? 0.0 : 1.0, coef = own ? 1.0 : -mi[kk];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) mi[q] = q == kk ? coef * pinv : keep * mi[q] + coef * (r[q] * pinv);
+                for (int q = kk + 1; q < 6; ++q) v[q] -= v[kk] * readlane_f64(v[kk], q);
             }
-            if (ln < 6) {
-#pragma unroll
-                for (int q = 0; q < 6; ++q) D[ln * 6 + q] = mi[q];
+            if (act && ln >= 6) {
+                double2 *wp = reinterpret_cast<double2 *>(row);
+                wp[0] = make_double2(v[0], v[1]); wp[1] = make_double2(v[2], v[3]); wp[2] = make_double2(v[4], v[5]);
             }
-            if (bad && ln == 0) failw[0] = 1;
-            if (__any(ln < 6 && p_own < dref) && ln == 0) failw[1] = 1;
-        } else if (k > 0) {
-            // the other waves meanwhile store the previous step's panel as the factor's blocks L(i, k - 1) (nobody reads column
-            // k - 1 of the band any more until the backward sweep; the panel is rewritten behind the barrier below)
-            const int mp = min(bw, nf - k);
-            for (int idx = tid - 64; idx < mp * 36; idx += kBT - 64) {
-                const int irel = idx / 36, q = idx - irel * 36;
-                Lb[band_off(k + irel, k - 1, bw) + q] = T[idx];
+            if (wv == 0) {
+                if (ln < 6) idg[6 * k + ln] = ri_own;
+                if (ln == 0) { if (nonfinite) failw[0] = 1; if (nonpos) failw[1] = 1; }
             }
         }
-        __syncthreads();
+        // L_kk goes over D_k only when every sweeping wave has read D_k (the trailing phase does not touch block (k, k))
+        if (m > 0) __syncthreads();
+        if (wv == 0 && ln < 6) {
+            double2 *wp = reinterpret_cast<double2 *>(Lk + s_off);
+            wp[0] = make_double2(v[0], v[1]); wp[1] = make_double2(v[2], v[3]); wp[2] = make_double2(v[4], v[5]);
+        }
+        if (m == 0) break;                                  // (the last step has nothing below it)
         BAND_STAMP(1);
-        // panel: T_i = A_ik Dk^-1 (row b of the inverse stands for its column b: the block is symmetric)
-        if (bw * 36 <= kBT) {
-            if (p_irel < m) {
-                const double2 *A = reinterpret_cast<const double2 *>(Lk + p_A);
-                const double2 *Dr = reinterpret_cast<const double2 *>(Lk + p_D);
-                const double *Dc = Lk + p_Dc;
-                const double2 a0 = A[0], a1 = A[1], a2 = A[2], r0 = Dr[0], r1 = Dr[1], r2 = Dr[2];
-                // (the elimination leaves Dk^-1 symmetric but for rounding; everything downstream uses ITS SYMMETRIC PART, row b and
-                //  column b averaged where they are read: taken as it came, row b for column b here and rows in the sweep, a chain of 40
-                //  keyframes held by tracks of three ended 4e-8 m from the oracle's poses instead of 2e-11)
-                const double2 d0 = make_double2(0.5 * (r0.x + Dc[0]), 0.5 * (r0.y + Dc[6])), d1 = make_double2(0.5 * (r1.x + Dc[12]), 0.5 * (r1.y + Dc[18])),
-                              d2 = make_double2(0.5 * (r2.x + Dc[24]), 0.5 * (r2.y + Dc[30]));
-                T[tid] = ((a0.x * d0.x + a0.y * d0.y) + (a1.x * d1.x + a1.y * d1.y)) + (a2.x * d2.x + a2.y * d2.y);
-            }
-        } else for (int idx = tid; idx < m * 36; idx += kBT) {
-            const int irel = idx / 36, q = idx - irel * 36, a = q / 6, b = q - a * 6;
-            const double2 *A = reinterpret_cast<const double2 *>(Lb + band_off(k + 1 + irel, k, bw) + a * 6);
-            const double2 *Dr = reinterpret_cast<const double2 *>(D + b * 6);
-            const double *Dc = D + b;
-            const double2 a0 = A[0], a1 = A[1], a2 = A[2], r0 = Dr[0], r1 = Dr[1], r2 = Dr[2];
-            const double2 d0 = make_double2(0.5 * (r0.x + Dc[0]), 0.5 * (r0.y + Dc[6])), d1 = make_double2(0.5 * (r1.x + Dc[12]), 0.5 * (r1.y + Dc[18])),
-                          d2 = make_double2(0.5 * (r2.x + Dc[24]), 0.5 * (r2.y + Dc[30]));
-            T[idx] = ((a0.x * d0.x + a0.y * d0.y) + (a1.x * d1.x + a1.y * d1.y)) + (a2.x * d2.x + a2.y * d2.y);
-        }
-        __syncthreads();
-        BAND_STAMP(2);
-        // trailing blocks A_ij -= T_i A_jk^T (i >= j below k in the band) and right-hand side b_i -= T_i b_k
+        // trailing blocks A_ij -= L_ik L_jk^T (i >= j below k in the band) and right-hand side b_i -= L_ik y_k
         const int ntr = m * (m + 1) / 2 * 36;
         if (fast_tr) {
             double2 t0[kTr], t1[kTr], t2[kTr], u0[kTr], u1[kTr], u2[kTr];
@@ -255,7 +236,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
 #pragma unroll
             for (int u = 0; u < kTr; ++u) {
                 const bool act = t_irel[u] < m;
-                const double2 *tp = reinterpret_cast<const double2 *>(T + (act ? t_T[u] : 0));
+                const double2 *tp = reinterpret_cast<const double2 *>(Lk + (act ? t_T[u] : 0));
                 const double2 *ap = reinterpret_cast<const double2 *>(t_A[u] < 0 ? rhs + 6 * k : Lk + (act ? t_A[u] : 0));
                 dst[u] = t_dst[u] < 0 ? rhs + 6 * k + (-1 - t_dst[u]) : Lk + t_dst[u];
                 if (!act) dst[u] = gs;                      // (a place nobody reads here)
@@ -278,12 +259,12 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
                 if (idx < ntr) {
                     const int pr = idx / 36, q = idx - pr * 36, a = q / 6, b = q - a * 6;
                     const int ij = tri[pr], irel = ij >> 8, jrel = ij & 0xff;
-                    Ti = T + irel * 36 + a * 6;
+                    Ti = Lb + band_off(k + 1 + irel, k, bw) + a * 6;
                     Aj = Lb + band_off(k + 1 + jrel, k, bw) + b * 6;
                     dst[u] = Lb + band_off(k + 1 + irel, k + 1 + jrel, bw) + q;
                 } else {
                     const int r = idx - ntr, irel = r / 6, a = r - irel * 6;
-                    Ti = T + irel * 36 + a * 6;
+                    Ti = Lb + band_off(k + 1 + irel, k, bw) + a * 6;
                     Aj = rhs + 6 * k;
                     dst[u] = rhs + 6 * (k + 1 + irel) + a;
                 }
@@ -298,12 +279,15 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
             }
         }
         __syncthreads();
-        BAND_STAMP(3);
+        BAND_STAMP(2);
     }
+    __syncthreads();
     const bool fail = failw[0] != 0;
     if (failw[1] != 0 && !fail) {
-        // ill conditioned beyond what explicit pivot-block inverses carry: park the solve (Ctrl::done = 2 turns every kernel queued
-        // behind into a no-op) and tell the host, which queues the dense direct solver for this trial and every later one
+        // A pivot that is not positive where every input is finite: S is positive definite in exact arithmetic (Hpp + lambda I
+        // minus a Schur complement), so the window is ill conditioned beyond what this ordering carries in fp64.  Park the solve
+        // (Ctrl::done = 2 turns every kernel queued behind into a no-op) and tell the host, which queues the dense direct solver
+        // for this trial and every later one: that factorisation decides whether the trial fails as a failed Cholesky does in g2o.
         if (tid == 0) {
             const int np = c->n_pause + 1;
             c->pcg_last_iters = 0;
@@ -314,29 +298,49 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw)
         }
         return;
     }
-    // (the last step has no panel: nothing left to store)
-    // ---- z_k = Dk^-1 y_k, then the backward sweep by one wave: x_k final, z_j -= L_kj^T x_k for the band above ----
-    for (int r = tid; r < n; r += kBT) {
-        const int k = r / 6, a = r - k * 6;
-        const double *D = Lb + band_off(k, k, bw) + a * 6, *Dc = Lb + band_off(k, k, bw) + a;
-        const double *y = rhs + 6 * k;
-        double s = (0.5 * (D[0] + Dc[0])) * y[0];
-#pragma unroll
-        for (int cc = 1; cc < 6; ++cc) s += (0.5 * (D[cc] + Dc[6 * cc])) * y[cc];
-        aux[r] = s;
-    }
-    __syncthreads();
+    // ---- backward sweep L^T x = y by one wave: x_k = L_kk^-T s_k by a triangular solve in lanes 0 - 5 (the partial sums of
+    //      the later unknowns broadcast through v_readlane), then s_j -= L_kj^T x_k for the band above ----
     if (wv == 0) {
-        for (int k = nf - 1; k > 0; --k) {
+        const int a6 = min(ln, 5);
+        for (int k = nf - 1; k >= 0; --k) {
             const int mk = min(bw, k);
-            const double *xk = aux + 6 * k;
-            for (int l = ln; l < mk * 6; l += 64) {
+            const double *D = Lb + band_off(k, k, bw);
+            // (everything that does not depend on x_k is requested ahead of the chain)
+            double lc[6];
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) lc[cc] = D[cc * 6 + a6];                    // column a6 of L_kk
+            const double idv = idg[6 * k + a6];
+            double s = rhs[6 * k + a6];
+            const int jrel0 = ln / 6, a0 = ln - jrel0 * 6;
+            const bool up0 = ln < mk * 6;
+            const double *L0 = Lb + band_off(k, up0 ? k - 1 - jrel0 : k, bw) + a0;
+            double l0[6];
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) l0[cc] = L0[cc * 6];
+            double *y0 = rhs + 6 * (up0 ? k - 1 - jrel0 : k) + a0;
+            const double y0v = *y0;
+            double x[6], x_own = 0.0;
+#pragma unroll
+            for (int cc = 5; cc >= 0; --cc) {
+                const double t = s * idv;
+                x[cc] = readlane_f64(t, cc);
+                x_own = ln == cc ? x[cc] : x_own;
+                s -= lc[cc] * x[cc];
+            }
+            if (ln < 6) aux[6 * k + ln] = x_own;
+            if (up0) {
+                double acc = l0[0] * x[0];
+#pragma unroll
+                for (int cc = 1; cc < 6; ++cc) acc += l0[cc] * x[cc];
+                *y0 = y0v - acc;
+            }
+            for (int l = ln + 64; l < mk * 6; l += 64) {
                 const int jrel = l / 6, a = l - jrel * 6, j = k - 1 - jrel;
                 const double *L = Lb + band_off(k, j, bw) + a;
-                double s = L[0] * xk[0];
+                double acc = L[0] * x[0];
 #pragma unroll
-                for (int cc = 1; cc < 6; ++cc) s += L[cc * 6] * xk[cc];
-                aux[6 * j + a] -= s;
+                for (int cc = 1; cc < 6; ++cc) acc += L[cc * 6] * x[cc];
+                rhs[6 * j + a] -= acc;
             }
             band_wave_sync();
         }

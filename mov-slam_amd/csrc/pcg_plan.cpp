@@ -18,15 +18,16 @@ size_t pcg_rows_lds_bytes(int nfree, int nrowent, bool padded)
     return solve > coarse ? solve : coarse;
 }
 
-// k_band's LDS carve (band_kernel.hip): band, two vectors, panel, two strips, the enumeration of the trailing blocks, a word
+// k_band's LDS carve (band_kernel.hip): band, three vectors, a strip, the enumeration of the trailing blocks, two words
 size_t band_lds_bytes(int nfree, int bw)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
     const size_t ntri = ((size_t)bw * (bw + 1) / 2 + 1) & ~(size_t)1;
-    return ((size_t)nfree * (bw + 1) * 36 + 3 * npad + (size_t)bw * 36 + 12) * sizeof(double) + (ntri + 4) * sizeof(int32_t);
+    return ((size_t)nfree * (bw + 1) * 36 + 3 * npad + 12) * sizeof(double) + (ntri + 4) * sizeof(int32_t);
 }
 
-bool band_supported(int nfree, int bw) { return nfree >= 1 && bw >= 0 && bw < 256 && band_lds_bytes(nfree, bw) <= 159 * 1024; }
+// (8 waves x 58 rows of the sweep: 6 bw + 1 <= 464)
+bool band_supported(int nfree, int bw) { return nfree >= 1 && bw >= 0 && bw <= 77 && band_lds_bytes(nfree, bw) <= 159 * 1024; }
 
 // Deals block rows to the waves so that every wave gets about the same number of gather-list
 // entries (the mat-vec work) and at most 10 block rows (60 owner lanes).  A wave holds 64 entry

@@ -65,3 +65,25 @@ def quat_angle(q1, q2):
     (|q1 - q2| = 2 sin(theta/4); arccos of the dot product would floor at 3e-8)."""
     d = np.minimum(np.linalg.norm(q1 - q2, axis=-1), np.linalg.norm(q1 + q2, axis=-1))
     return 4 * np.arcsin(np.clip(d / 2, 0, 1))
+
+
+def oracle_order_noise(oracle_mod, w, n=3):
+    """How far the oracle's own result moves when ONLY the order of a map point's edges changes: the reference adds a point's
+    edges in the iteration order of a std::map keyed by KeyFrame POINTERS (MapPoint::GetObservations(), src/Optimizer.cc:629-700),
+    which differs from run to run, so every such order is the reference's arithmetic.  Well-conditioned windows move by 1e-13;
+    windows whose keyframes hang on a few short tracks move by 1e-8 ... 1e-6 m, and no solver can be held closer to ONE of those
+    orders than they are to each other.  -> (rotation [rad], translation [m], point [m]) maxima over n seeded permutations."""
+    import copy
+    o = oracle_mod.solve(w)
+    rot = trans = point = 0.0
+    for t in range(n):
+        pm = np.random.default_rng(7919 + t).permutation(w.n_edges)
+        pm = pm[np.argsort(w.edge_point[pm], kind="stable")]            # still grouped by point, shuffled inside a group
+        w2 = copy.copy(w)
+        w2.edge_pose, w2.edge_point, w2.obs, w2.inv_sigma2 = w.edge_pose[pm], w.edge_point[pm], w.obs[pm], w.inv_sigma2[pm]
+        if getattr(w, "obs_right", None) is not None: w2.obs_right = w.obs_right[pm]
+        o2 = oracle_mod.solve(w2)
+        rot = max(rot, float(quat_angle(o2["poses"][:, :4], o["poses"][:, :4]).max()))
+        trans = max(trans, float(np.abs(o2["poses"][:, 4:] - o["poses"][:, 4:]).max()))
+        point = max(point, float(np.abs(o2["points"] - o["points"]).max()) if w.n_points else 0.0)
+    return rot, trans, point

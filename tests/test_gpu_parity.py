@@ -7,7 +7,7 @@ Outlier flags must be identical except inside the guard band |chi2 - 5| <= 1e-6.
 import numpy as np
 import pytest
 
-from conftest import load_golden, quat_angle
+from conftest import load_golden, oracle_order_noise, quat_angle
 from movba import synth
 
 pytestmark = pytest.mark.gpu
@@ -1058,8 +1058,8 @@ def test_one_launch_direct_solver_planned_for_a_device_with_fewer_compute_units(
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["small", "cfg2", "stereo", "dense16", "cfg3-forced", "hard"])
 def test_banded_factorisation_in_one_workgroup(built_lib, solver, oracle_mod, name):
-    """k_band (band_kernel.hip): the reduced system of a window whose band fits one CU's LDS is factored exactly - block LDL^T
-    with 6 x 6 pivot blocks, the lower band in LDS - by ONE workgroup in ONE launch per trial; the default for the windows it
+    """k_band (band_kernel.hip): the reduced system of a window whose band fits one CU's LDS is factored exactly - Cholesky
+    in 6 x 6 blocks, the lower band in LDS - by ONE workgroup in ONE launch per trial; the default for the windows it
     solves faster than the PCG (up to ~28 keyframes at cfg3's band), on request (movba_options::solver = 2) wherever the band
     fits.  The reference's own solve is exact too (LinearSolverCSparse, src/Optimizer.cc:535): same tolerances as every other
     path, every trial marked -2 in the trace, bit-reproducible, a batch of such windows bit-identical to their solo runs."""
@@ -1085,22 +1085,48 @@ def test_banded_factorisation_in_one_workgroup(built_lib, solver, oracle_mod, na
         if forced: s.close()
 
 
+# windows of the randomised sweep (tests/dev/fuzz_parity.py) that round 4's block LDL^T with explicitly inverted pivot blocks
+# solved 1e-8 ... 1e-3 m away from the oracle: (K, F, P, run_lo, run_hi, stereo_frac, seed)
+BAND_SWEEP_WINDOWS = [(16, 5, 30, 2, 7, 0.0, 372277), (81, 4, 30, 2, 4, 1.0, 28338), (12, 3, 80, 2, 2, 0.0, 982937),
+                      (40, 1, 1500, 3, 3, 0.0, 166442), (50, 2, 600, 2, 3, 0.0, 398504), (50, 2, 600, 2, 4, 0.0, 563415)]
+
+
+def _sweep_tolerances(w, oracle_mod):
+    """The suite's usual tolerances by the sweep's classes (tests/dev/fuzz_parity.py: a free keyframe with fewer than twelve
+    observations makes the window weak - SURVEY 8(d)'s float32 tolerance -, one with fewer than three has no unique pose at all),
+    widened to three times the distance between the oracle's OWN results under the edge orders the reference itself produces
+    (conftest.oracle_order_noise) where that is larger: what the window's conditioning does to fp64, measured, not tuned."""
+    per_kf = np.bincount(w.edge_pose, minlength=w.n_poses)[w.pose_fixed == 0]
+    usual = dict(rot=1e-3, trans=1e-3, point=1e-2) if per_kf.min() < 3 else WEAK_TOL if per_kf.min() < 12 else dict(rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL)
+    nr, nt, npt = oracle_order_noise(oracle_mod, w, n=4)
+    return dict(rot=max(usual["rot"], 3 * nr), trans=max(usual["trans"], 3 * nt), point=max(usual["point"], 3 * npt)), usual, (nr, nt, npt)
+
+
 @pytest.mark.gpu
-def test_banded_factorisation_hands_an_ill_conditioned_window_to_the_dense_solver(solver, oracle_mod):
-    """Explicit inverses of the pivot blocks are only as accurate as the blocks are conditioned: twelve keyframes held together by
-    80 map points with two observers each (some keyframes by three observations) leave a pivot with less than 1e-5 of its diagonal
-    element of S in one of the later trials: k_band parks the solve there - as a PCG that gives up does - and the dense direct
-    solver finishes it.  Two exact solvers differ by cond(S) eps in the weak directions of such a window: SURVEY 8(d)'s float32
-    tolerance, as for every weakly constrained window."""
-    w = synth.make_window(12, 3, 80, seed=982937, run_lo=2, run_hi=2)
-    r = solver.solve(w)
-    o = oracle_mod.solve(w)
-    assert r["status"] == 0 and r["n_pcg_giveups"] == 1 and r["n_band"] > 0 and r["n_direct"] > 0 and r["n_band"] + r["n_direct"] == r["n_solves"]
-    assert r["direct_from"] == r["n_band"] and (r["trace"]["pcg"][: r["n_band"]] == -2).all() and (r["trace"]["pcg"][r["n_band"]:] == -1).all()
-    assert np.array_equal(r["trace"]["accept"], o["trace"]["accept"])
-    assert quat_angle(r["poses"][:, :4], o["poses"][:, :4]).max() < 1e-5 and np.abs(r["poses"][:, 4:] - o["poses"][:, 4:]).max() < 1e-5
-    r2 = solver.solve(w)
-    assert np.array_equal(r["poses"], r2["poses"]) and np.array_equal(r["points"], r2["points"])
+@pytest.mark.parametrize("which", ["default-solver", "banded", "dense-direct"])
+@pytest.mark.parametrize("K,F,P,lo,hi,stereo,seed", BAND_SWEEP_WINDOWS)
+def test_banded_factorisation_on_the_windows_the_sweep_found(built_lib, solver, oracle_mod, K, F, P, lo, hi, stereo, seed, which):
+    """The six windows on which the last kept sweep logs of round 4 show the banded factorisation away from the oracle (keyframes
+    held by a handful of observations, gauge-free chains of short tracks).  k_band is a Cholesky factorisation now - triangular
+    solves with the pivot blocks' factors, nothing inverted, no conditioning threshold - and never hands such a window over.
+    Held to the suite's usual tolerances, except where the oracle itself does not reproduce them: on four of the six the
+    oracle's poses move by MORE than the usual tolerance when a map point's edges are merely added in another order (seed
+    398504: 3e-8 ... 1.3e-7 m against 1e-8; seed 982937: 2e-7 ... 1.3e-6 m against 1e-6), and all three exact solvers of this
+    library - k_band, the one-launch dense Cholesky, the PCG with the dense solver behind it - sit inside that spread."""
+    w = synth.make_window(K, F, P, seed=seed, run_lo=lo, run_hi=max(lo, hi), stereo_frac=stereo)
+    s = solver if which == "default-solver" else built_lib.Solver(solver=2 if which == "banded" else 1)
+    try:
+        r, o = s.solve(w), oracle_mod.solve(w)
+        tol, usual, noise = _sweep_tolerances(w, oracle_mod)
+        check_against(r, o, w, noise_guard=True, **tol)
+        if which == "banded" and r["n_band"] > 0:
+            assert r["n_pcg_giveups"] == 0 and r["n_direct"] == 0 and r["n_band"] == r["n_solves"]
+        # a window the oracle reproduces to the usual tolerance is held to it
+        if noise[1] * 3 <= usual["trans"]: assert np.abs(r["poses"][:, 4:] - o["poses"][:, 4:]).max() < usual["trans"]
+        r2 = s.solve(w)
+        assert np.array_equal(r["poses"], r2["poses"]) and np.array_equal(r["points"], r2["points"])
+    finally:
+        if which != "default-solver": s.close()
 
 
 @pytest.mark.gpu
