@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOVBA_VERSION 4
+#define MOVBA_VERSION 5
 
 /* status codes */
 #define MOVBA_OK              0
@@ -107,18 +107,24 @@ typedef struct {
     double  tr_f1[MOVBA_MAX_TRACE];
     double  tr_rho[MOVBA_MAX_TRACE];
     int32_t tr_accept[MOVBA_MAX_TRACE];
-    int32_t tr_pcg_iters[MOVBA_MAX_TRACE];   /* PCG iterations of the trial; -1: solved by the direct solver */
-    /* Reduced solve (LinearSolverCSparse in the reference, Optimizer.cc:535): on-chip PCG for windows of up to 80 free
+    int32_t tr_pcg_iters[MOVBA_MAX_TRACE];   /* PCG iterations of the trial; -1: solved by the dense direct solver; -2: by the
+                                                banded factorisation                                                          */
+    /* Reduced solve (LinearSolverCSparse in the reference, Optimizer.cc:535): banded Cholesky in one workgroup for the
+     * windows it solves fastest (up to ~24 free keyframes at a band of 9), on-chip PCG for windows of up to 80 free
      * keyframes whose reduced matrix fits the PCG workgroup's registers, dense Cholesky otherwise (more keyframes, or
-     * denser covisibility) and from the first trial whose PCG gave up (breakdown or iteration cap). */
-    int32_t n_direct;           /* trials solved by the direct solver                                          */
-    int32_t direct_from;        /* n_solves at the switch to the direct solver (0: whole solve), -1: never     */
-    int32_t n_chol_fail;        /* trials whose factorisation met a non-positive pivot: rejected, as g2o does  */
-    int32_t n_pcg_giveups;      /* 0 or 1: the PCG gave up once, the solve went on with the direct solver      */
+     * denser covisibility) and from the first trial on which one of the other two handed the solve over. */
+    int32_t n_direct;           /* trials solved by the dense direct solver                                    */
+    int32_t direct_from;        /* n_solves at the switch to the dense direct solver (0: whole solve; > 0: the PCG gave up or
+                                   the banded factorisation met a non-positive pivot on that trial), -1: never */
+    int32_t n_chol_fail;        /* trials whose factorisation failed (dense solver: non-positive pivot; banded: NaN / inf in
+                                   the normal equations): rejected, as g2o rejects a trial whose Cholesky fails */
+    int32_t n_pcg_giveups;      /* 0 or 1: hand-overs of the solve to the dense direct solver - the PCG gave up (breakdown or
+                                   iteration cap), or the banded factorisation met a finite non-positive pivot (the name is
+                                   from when only the PCG could hand over)                                      */
     int32_t n_sync_timeouts;    /* waits inside a launch that a workgroup gave up (one-launch direct solver without all its
-                                   workgroups resident; two-stream loop): > 0 with status MOVBA_OK = the run was repeated on one
-                                   stream with the multi-launch direct solver and THIS is its result (the reference never skips
-                                   a solve, src/Optimizer.cc:535, 754)                                                          */
+                                   workgroups resident): > 0 with status MOVBA_OK = the run was repeated with the multi-launch
+                                   direct solver and THIS is its result (the reference never skips a solve,
+                                   src/Optimizer.cc:535, 754)                                                                   */
     int32_t n_band;             /* trials solved by the single-workgroup banded factorisation (exact, one launch)  */
 } movba_lba_result;
 
@@ -144,10 +150,8 @@ typedef struct {
     int32_t reorder;            /* 0 = default: free keyframes are renumbered by covisibility (reverse Cuthill-McKee on the pair
                                  * graph) when that shrinks the reduced matrix's envelope by a fifth or more; -1 = keep the
                                  * caller's order (KeyFrame::mnId order, as the reference numbers its vertices)             */
-    int32_t two_streams;        /* 0 = default: every kernel of a solve on the handle's stream, one after the other; 1 = the PCG launches of a
-                                 * solve go to a stream of the handle's own and run beside the schur and back-substitution passes of their
-                                 * trial, hand-offs through flags in device memory (also MOVBA_TWO_STREAMS=1).  Measured slower on MI355X
-                                 * (DESIGN.md, round 4): kept for boxes where launch boundaries cost more than device-scope round trips */
+    int32_t pad_o;              /* (keeps the struct a multiple of 8 bytes; until ABI 4 the opt-in two-stream LM loop, removed in
+                                 * round 5: measured 1 - 3 % slower on MI355X than the one-stream loop)                  */
 } movba_options;
 
 /* Per-kernel-class timing collected with HIP events on the handle's stream. */
@@ -261,15 +265,20 @@ typedef struct {
     /* Hypothesis stage in front of the LM, so that the result does not depend on pose0 (the reference calls
      * cv::solvePnPRansac with useExtrinsicGuess = false, Optimizer.cc:437): ransac_iters minimal P3P samples
      * (iterationCount of PoseOptimization, 50 by default), drawn from ransac_seed; every candidate pose is scored on
-     * all matches at chi2_gate and the best one starts the LM when it has at least 4 inliers.  0: LM from pose0. */
+     * all matches by MAGSAC++'s sigma-consensus loss (flag 38 = cv::USAC_MAGSAC, Optimizer.cc:437; sigma_max from
+     * chi2_gate: pose_kernels.hip) and the one of lowest loss among those with at least 4 matches inside chi2_gate starts
+     * the LM.  0: LM from pose0. */
     int32_t ransac_iters;       /* <= MOVBA_MAX_RANSAC_ITERS                                  */
     uint32_t ransac_seed;
     /* `confidence` of cv::solvePnPRansac (Optimizer.cc:437; 0.95 in TartanAir.yaml): the standard stopping rule
      * N = log(1 - confidence) / log(1 - w^3), w = inlier ratio of the best hypothesis so far.  The device scores all
      * ransac_iters samples at once; the rule decides which of them a sequential RANSAC over the same samples would have
      * drawn: only those are eligible (ransac_samples_used in the result).  <= 0 or >= 1: all samples are eligible.
-     * lo_iters > 0: one local-optimisation step on the winner (USAC's LO): LM refit on its inliers (no robust kernel,
-     * lo_iters iterations), kept when the refit pose scores more inliers (ties: lower truncated cost). */
+     * lo_iters > 0: one local-optimisation step on the winner (USAC's LO): an LM refit weighted by the sigma-consensus
+     * weights w(r) (lo_iters iterations), kept when its sigma-consensus loss is lower.
+     * rounds x its_per_round: the motion-only LM with re-classification behind the hypothesis stage is ORB-SLAM's
+     * PoseOptimization scheme (4 x 10); MoV-SLAM's own PoseOptimization (Optimizer.cc:397-459) takes solvePnPRansac's pose
+     * as it is - rounds = 0 gives exactly that. */
     double  confidence;
     int32_t lo_iters;
     int32_t pad_p;

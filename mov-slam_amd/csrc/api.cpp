@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "device_types.h"
@@ -107,6 +108,51 @@ struct Worker {
 
 }  // namespace
 
+// Diagnostic switches of the PROCESS, read from the environment once, at their first use (never on the path of a solve):
+//   MOVBA_WATCHDOG_MS        host gives up a device that makes no progress for that long (default 60 000)
+//   MOVBA_TIME_UPLOAD / MOVBA_TIME_SOLVE   print the phases of every upload / solve call to stderr
+//   MOVBA_DENSE_STAMPS       the one-launch direct solver records its tasks' clock stamps
+//   MOVBA_DENSE_MULTILAUNCH  the direct solver one launch per block column (dense_solve.hip) for every window
+//   MOVBA_BAND = 0 / 1       banded factorisation never / wherever its band fits (handles made with solver = 0)
+//   MOVBA_BATCH_GROUPS       number of stream groups of a batched run
+// Everything a TEST switches (structure pass on the host, entry formats, a late helper thread, short device-side waits, a
+// smaller device, a forced park of k_band) is a per-handle hook of the test build only: -DMOVBA_TEST_HOOKS, libmovba_hooks.so,
+// movba_test_hook().  The product library has neither the symbol nor the branches.
+struct ProcessSwitches {
+    double watchdog_ms = 60000.0;
+    bool time_upload = false, time_solve = false, dense_stamps = false, dense_multilaunch = false;
+    int band = -1, batch_groups = 0;
+};
+static const ProcessSwitches &process_switches()
+{
+    static const ProcessSwitches sw = [] {
+        ProcessSwitches v;
+        if (const char *e = std::getenv("MOVBA_WATCHDOG_MS")) { const double x = std::atof(e); if (x > 0.0) v.watchdog_ms = x; }
+        v.time_upload = std::getenv("MOVBA_TIME_UPLOAD") != nullptr; v.time_solve = std::getenv("MOVBA_TIME_SOLVE") != nullptr;
+        v.dense_stamps = std::getenv("MOVBA_DENSE_STAMPS") != nullptr; v.dense_multilaunch = std::getenv("MOVBA_DENSE_MULTILAUNCH") != nullptr;
+        if (const char *e = std::getenv("MOVBA_BAND")) v.band = std::atoi(e);
+        if (const char *e = std::getenv("MOVBA_BATCH_GROUPS")) v.batch_groups = std::atoi(e);
+        return v;
+    }();
+    return sw;
+}
+
+struct TestHooks {
+    int host_structure = 0;         // structure pass on the host even where the device would build it
+    int entries_unpacked = 0;       // 12-byte schur entries where the 8-byte packed form would do
+    int no_sorted_structure = 0;    // beyond the pair-bin masks: host structure pass instead of the sort-based device pass
+    int pcg_packed = 0;             // packed layout of the PCG's pair sums where the padded one would do
+    int helper_delay_us = 0;        // the upload's helper thread starts that much later
+    long long wait_ticks = -1;      // >= 0: bound of the in-launch waits of a run's FIRST attempt (10 ns ticks)
+    int band_park_trial = -1;       // >= 0: k_band treats that trial's factorisation as one that met a non-positive pivot
+};
+#ifdef MOVBA_TEST_HOOKS
+#define HOOK(h, field) ((h)->hooks.field)
+#else
+static constexpr TestHooks kNoHooks{};
+#define HOOK(h, field) (kNoHooks.field)
+#endif
+
 struct movba_handle {
     int device = 0;
     int device_cus = 256;               // compute units of the device (or of this process's partition of it): bounds the one-launch direct solver's workgroups
@@ -116,11 +162,9 @@ struct movba_handle {
                                         // handles of a device: every extra stream of the process competes for the few hardware queues,
                                         // and two streams of a batched run that land on one queue run in turns)
     hipEvent_t copy_event = nullptr;
-    // The reduced solves of a solo LM loop (k_pcg_rows) run on a stream of their own, resident beside the schur pass of their
-    // trial, fed and answered through flags in device memory (DevWindow::xs; lm_loop): created on first use
-    hipStream_t pcg_stream = nullptr;
-    hipEvent_t xs_event = nullptr;      // the run's setup launches have ended (stream -> pcg_stream, once per run)
-    bool xs_run = false;                // this run's PCG launches are on pcg_stream
+#ifdef MOVBA_TEST_HOOKS
+    TestHooks hooks;                    // (test build only: movba_test_hook)
+#endif
     int sync_retries = 0;               // > 0: this run's first attempt gave up that many in-launch waits and was repeated on the paths without any
     hipEvent_t edgeb_event = nullptr;   // the derived edge arrays sent early on the copy stream have arrived
     uint64_t count_seq = 0;             // uploads that went through the device structure pass (what the host polls for in the counts buffer)
@@ -238,11 +282,7 @@ inline int32_t rd_pause(const HostStatus *hs) { return __atomic_load_n(&hs->paus
 inline void wr_stop(HostStatus *hs, int32_t v) { __atomic_store_n(&hs->stop, v, __ATOMIC_RELEASE); }
 inline bool caller_stop(const volatile uint8_t *p) { return p && __atomic_load_n(p, __ATOMIC_RELAXED) != 0; }
 // how long the device may go without ANY progress (a changed progress word, or new work queued) before the host gives up
-inline double watchdog_ms()
-{
-    static const double v = [] { const char *e = std::getenv("MOVBA_WATCHDOG_MS"); const double x = e ? std::atof(e) : 0.0; return x > 0.0 ? x : 60000.0; }();
-    return v;
-}
+inline double watchdog_ms() { return process_switches().watchdog_ms; }
 
 struct Carver {
     size_t off = 0;
@@ -368,6 +408,26 @@ extern "C" {
 
 int movba_version(void) { return MOVBA_VERSION; }
 
+#ifdef MOVBA_TEST_HOOKS
+// Test build only (libmovba_hooks.so; declared by the tests themselves, not by include/movba.h): sets one hook of a handle.
+// "device_cus" plans the one-launch direct solver for a device with fewer compute units than this one has.
+int movba_test_hook(movba_handle *h, const char *name, long long value)
+{
+    if (!h || !name) return MOVBA_ERR_ARG;
+    const std::string n(name);
+    if (n == "host_structure") h->hooks.host_structure = (int)value;
+    else if (n == "entries_unpacked") h->hooks.entries_unpacked = (int)value;
+    else if (n == "no_sorted_structure") h->hooks.no_sorted_structure = (int)value;
+    else if (n == "pcg_packed") h->hooks.pcg_packed = (int)value;
+    else if (n == "helper_delay_us") h->hooks.helper_delay_us = (int)value;
+    else if (n == "wait_ticks") h->hooks.wait_ticks = value;
+    else if (n == "band_park_trial") h->hooks.band_park_trial = (int)value;
+    else if (n == "device_cus") { if (value > 0 && value < h->device_cus) h->device_cus = (int)value; }
+    else return MOVBA_ERR_ARG;
+    return MOVBA_OK;
+}
+#endif
+
 const char *movba_status_string(int s)
 {
     switch (s) {
@@ -397,7 +457,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     movba_handle *h = new (std::nothrow) movba_handle();
     if (!h) return MOVBA_ERR_HIP;
     h->device = device;
-    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0; h->opt.reorder = 0; h->opt.two_streams = 0;
+    h->opt.pcg_rel_tol = 1e-10; h->opt.pcg_max_iters = 0; h->opt.run_ahead = 2; h->opt.profile = 0; h->opt.pcg_coarse = 1; h->opt.host_wait = 0; h->opt.pcg_spill = 0; h->opt.solver = 0; h->opt.reorder = 0;
     if (opt) {
         if (opt->pcg_rel_tol > 0) h->opt.pcg_rel_tol = opt->pcg_rel_tol;
         if (opt->pcg_max_iters > 0) h->opt.pcg_max_iters = opt->pcg_max_iters;
@@ -408,14 +468,11 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
         h->opt.pcg_spill = opt->pcg_spill == 1 ? 1 : 0;
         h->opt.solver = (opt->solver >= 1 && opt->solver <= 3) ? opt->solver : 0;
         h->opt.reorder = opt->reorder == -1 ? -1 : 0;
-        h->opt.two_streams = opt->two_streams == 1 ? 1 : 0;
     }
-    if (std::getenv("MOVBA_TWO_STREAMS")) h->opt.two_streams = 1;
     if (h->opt.host_wait == 1) h->packer.spin_ms = 0;      // (a caller that asks for yielding waits does not want a spinning helper either)
     for (int k = 0; k < MOVBA_NKERNELS; ++k) h->prof.name[k] = kKernelNames[k];
     if (hipSetDevice(device) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->device_cus = cus; }
-    if (const char *e = std::getenv("MOVBA_TEST_DEVICE_CUS")) { const int v = std::atoi(e); if (v > 0 && v < h->device_cus) h->device_cus = v; }    // (tests: plan for a smaller device)
     if (stream) { h->stream = static_cast<hipStream_t>(stream); }
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return MOVBA_ERR_HIP; }
@@ -446,8 +503,6 @@ void movba_destroy(movba_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);        // shared: stays
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
-    if (h->pcg_stream) { (void)hipStreamSynchronize(h->pcg_stream); (void)hipStreamDestroy(h->pcg_stream); }
-    if (h->xs_event) (void)hipEventDestroy(h->xs_event);
     if (h->edgeb_event) (void)hipEventDestroy(h->edgeb_event);
     harvest_events(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -627,7 +682,7 @@ struct Upload {
     size_t o_cg = 0, o_ch = 0, o_cp = 0, o_ce = 0, o_cij = 0, o_multi = 0, o_pid = 0, o_prange = 0, o_dtp = 0, o_dtk = 0;
     size_t o_st[2][11] = {};
     size_t o_obspm = 0, o_obsrpm = 0, o_part = 0, o_blocks = 0, o_blocks_ov = 0, o_blocks_c = 0, o_aci = 0, o_acitag = 0;
-    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_tick = 0, o_xs = 0, o_recd = 0, o_imgb = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
+    size_t o_bp = 0, o_xp = 0, o_scale = 0, o_hmax = 0, o_tick = 0, o_recd = 0, o_imgb = 0, o_ctrl = 0, o_chi2 = 0, o_outl = 0;
     size_t o_dtiles = 0, o_ddiag = 0, o_dfail = 0, o_dx = 0, o_dflags = 0, o_dcontrib = 0, o_dstamps = 0;
     std::vector<int32_t> lane_plan;
     int rec_slots = 1;
@@ -690,8 +745,7 @@ int Upload::begin()
     HIP_TRY(hipSetDevice(h->device));
     h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK;
     t0 = lap_t = now_ms();
-    static const bool lap_env = std::getenv("MOVBA_TIME_UPLOAD") != nullptr;
-    lap_on = lap_env;
+    lap_on = process_switches().time_upload;
     // ---- edge region of the arena, laid out from the caller's counts alone so that the helper thread can start copying the
     // caller's big arrays (observations, information, initial estimates: 3/4 of the region) into the pinned staging buffer
     // while this thread runs the grouping / validation pass.  Its H2D copies are queued as soon as it is packed, so that
@@ -735,10 +789,9 @@ void Upload::post_helper()
 {
     ho.arena = h->arena;
     ho.arena_gen = h->arena_gen;
-    // (MOVBA_HELPER_DELAY_US: the helper starts that much later — for tests: whatever this thread takes from the helper
+    // (test hook helper_delay_us: the helper starts that much later: whatever this thread takes from the helper
     //  without waiting for it shows up as a wrong result instead of hiding behind the usual timing)
-    const char *delay_env = std::getenv("MOVBA_HELPER_DELAY_US");
-    const int helper_delay_us = delay_env ? std::atoi(delay_env) : 0;
+    const int helper_delay_us = HOOK(h, helper_delay_us);
     // (by value: the layout, the buffers and the handle's streams; by reference: the hand-off object alone)
     const EdgeLayout lay = L;
     char *const stage = sg;
@@ -1109,8 +1162,7 @@ void Upload::choose_solver()
     h->pp = PcgParams{};
     h->rows_kernel = pcg_rows_supported(s().nfree, s().row_ptr.data(), &h->pp);
     // (test switch: the packed layout of the mat-vec's pair sums where the padded one would do - same bits, tests/test_gpu_parity.py)
-    static const bool packed_only = std::getenv("MOVBA_PCG_PACKED") != nullptr;
-    if (packed_only) h->pp.padded = 0;
+    if (HOOK(h, pcg_packed)) h->pp.padded = 0;
     // A reduced matrix beyond the PCG workgroup's registers (dense covisibility: every keyframe pair shares points, as in the
     // reference's own windows, KeyFrame.cc:227-231; or simply more keyframes) is not iterated over from L2: the one-launch
     // direct solver takes the window from the first trial, whatever its pattern.  Measured (profiles/r03zd_solver_switch.log,
@@ -1135,7 +1187,7 @@ void Upload::choose_solver()
         // sweeps and epilogue; against the PCG's ~130 000 cycles whatever the size.  At a band of 9: 8 keyframes 0.49 ms per
         // resident window solve against 0.78, 16: 0.63 / 0.78, 24: 0.78 / 0.80, from 28 on the PCG wins (0.88 / 0.87; 40: 1.12 / 0.88).
         // MOVBA_BAND=0 / 1 (or movba_options::solver = 3 / 2) switch the choice off / force it.
-        static const int band_env = [] { const char *e = std::getenv("MOVBA_BAND"); return e ? std::atoi(e) : -1; }();
+        const int band_env = process_switches().band;
         double m_sum = 0.0;
         for (int k = 0; k < nf; ++k) m_sum += std::min(bw, nf - 1 - k);
         const double m_avg = nf > 0 ? m_sum / nf : 0.0;
@@ -1145,7 +1197,7 @@ void Upload::choose_solver()
         const bool forced = h->opt.solver == 2 || (h->opt.solver == 0 && band_env == 1);
         const bool off = h->opt.solver == 3 || h->opt.solver == 1 || (h->opt.solver == 0 && band_env == 0);
         const bool want = forced || (h->rows_kernel && est <= 130000.0);
-        h->band = want && !off && !h->opt.two_streams && band_supported(nf, bw);
+        h->band = want && !off && band_supported(nf, bw);
     }
     if (h->rows_kernel && !h->band) build_coarse(h->st, h->pp.wave_row0, kPcgRowsThreads / 64);
     lap("pcg plan + coarse lists");
@@ -1213,7 +1265,7 @@ int Upload::lay_out_rest()
     o_pid = c.take<int32_t>((size_t)nf * nf + 1);                                // block -> pair map of the direct solver's assembly
     // one-launch direct solver: the static schedule depends on the number of block columns only (rebuilt when that changes)
     ntile = dense_ntile(nf);
-    static const bool dense_multi = std::getenv("MOVBA_DENSE_MULTILAUNCH") != nullptr;
+    const bool dense_multi = process_switches().dense_multilaunch;
     // every workgroup of the one-launch solver must be resident while it runs: no more of them than the device (a partition
     // of an MI355X in CPX mode shows 32 compute units) has to give, a thirty-second held back as on the whole chip (248 of
     // 256); a plan that then needs more tiles per workgroup than fit LDS falls to the multi-launch solver
@@ -1242,15 +1294,13 @@ int Upload::lay_out_rest()
     o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
     o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
     o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(8 * (size_t)nb + 8);
-    o_xs = c.take<uint32_t>((size_t)kXsItem0 + (size_t)s().nitems + 8);
     o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
     o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
     o_dflags = c.take<uint32_t>(dense_one ? (size_t)dense_flag_words(ntile) : 8);
     o_dcontrib = c.take<double>(dense_one ? (size_t)ntile * ntile * kDenseNB : 1);
-    static const bool dense_stamps_env = std::getenv("MOVBA_DENSE_STAMPS") != nullptr;
-    dense_stamps = dense_stamps_env;
+    dense_stamps = process_switches().dense_stamps;
     o_dstamps = c.take<unsigned long long>(dense_one && dense_stamps ? 6 * h->dplan.tasks.size() : 1);
     total = c.off;
 
@@ -1378,7 +1428,7 @@ void Upload::device_view()
     w.aci = reinterpret_cast<float *>(a + o_aci); w.ac_prev = reinterpret_cast<double *>(a + o_aci) + 2 * kCoarseDim * kCoarseDim; w.aci_tag = reinterpret_cast<int32_t *>(a + o_acitag);
     w.bp = reinterpret_cast<double *>(a + o_bp); w.xp = reinterpret_cast<double *>(a + o_xp);
     w.scale_part = reinterpret_cast<double *>(a + o_scale); w.hmax_part = reinterpret_cast<double *>(a + o_hmax);
-    w.dec_rec = reinterpret_cast<unsigned *>(a + o_tick); w.xs = reinterpret_cast<unsigned *>(a + o_xs);
+    w.dec_rec = reinterpret_cast<unsigned *>(a + o_tick);
     w.ctrl = reinterpret_cast<Ctrl *>(a + o_ctrl); w.hstat = h->hstat_dev; w.ctrl_out = h->ctrl_host_dev;
     w.out_chi2 = reinterpret_cast<double *>(a + o_chi2); w.out_outlier = reinterpret_cast<uint8_t *>(a + o_outl);
     w.dense.tiles = reinterpret_cast<double *>(a + o_dtiles); w.dense.diagL = reinterpret_cast<double *>(a + o_ddiag);
@@ -1408,14 +1458,14 @@ int Upload::run()
     // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
     // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
     // (on the device: up to 80 free keyframes, and as many keyframes in all as the kernels' LDS image has room for)
-    const bool on_device = s().already_grouped && s().nfree > 0 && !std::getenv("MOVBA_HOST_STRUCTURE");
+    const bool on_device = s().already_grouped && s().nfree > 0 && !HOOK(h, host_structure);
     const bool masks_fit = s().nfree <= 80 && struct_lds_fits(s().nfree, NP);
     // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
     // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
-    // 8-byte packed entries when slots and point ids fit (any realistic window; MOVBA_ENTRIES_UNPACKED=1 keeps the 12-byte form, for tests)
-    ent_packed = s().E_free < kEntPackSlots && P < kEntPackPoints && !std::getenv("MOVBA_ENTRIES_UNPACKED");
+    // 8-byte packed entries when slots and point ids fit (any realistic window; the test hook entries_unpacked keeps the 12-byte form)
+    ent_packed = s().E_free < kEntPackSlots && P < kEntPackPoints && !HOOK(h, entries_unpacked);
     // (beyond the pair-bin masks: the sort-based pass, for packed entries and up to kSortedMaxPoses keyframes)
-    const bool sorted = on_device && !masks_fit && ent_packed && NP <= kSortedMaxPoses && !std::getenv("MOVBA_NO_SORTED_STRUCTURE");
+    const bool sorted = on_device && !masks_fit && ent_packed && NP <= kSortedMaxPoses && !HOOK(h, no_sorted_structure);
     dev_structure = on_device && (masks_fit || sorted);
     rc = !dev_structure ? structure_on_host() : (masks_fit ? structure_on_device() : structure_on_device_sorted()); if (rc) return rc;
     if (!edge_b_queued) { rc = queue_edge_b(); if (rc) return rc; }
@@ -1512,6 +1562,9 @@ hipError_t queue_direct(movba_handle *h)
     return el;
 }
 
+// k_band's second argument: the half bandwidth, and in the test build the trial whose factorisation is to park (+ 1, from bit 16)
+inline int band_arg(const movba_handle *h) { return h->band_bw | ((HOOK(h, band_park_trial) + 1) << 16); }
+
 // The LM trial loop of the handle's window on its own stream, from the state the device is in: a fresh window (after the
 // setup launches), or one that parked itself during a batched run (its pause is then the first thing answered).
 int lm_loop(movba_handle *h, bool parked)
@@ -1521,16 +1574,8 @@ int lm_loop(movba_handle *h, bool parked)
     PcgParams pp = run_pcg_params(h);
     const int nrowent = (int)h->st.row_ent.size();
     // the reduced solve of a trial: on-chip PCG, or (larger windows, and from the first PCG failure on) the direct solver
-    const bool band = h->band;                      // (an exact solve in one launch; it parks the solve only when a pivot has lost too many digits)
+    const bool band = h->band;                      // (an exact solve in one launch; it parks the solve only when a pivot comes out non-positive)
     bool direct = !h->rows_kernel && !band;
-    // Two streams (h->xs_run): the PCG launch of trial t goes to h->pcg_stream and is resident while the schur pass of its trial
-    // still runs on `s` (it takes the pass's partials item by item behind their flags: what used to be 11 us of assembly
-    // behind a launch boundary); the back-substitution pass of trial t follows the schur pass on `s`, is resident while the
-    // solve still runs, and starts from the solve's word (DevWindow::xs).  Whatever the hardware queues do with the two
-    // streams, every kernel's inputs come from kernels queued before it: a device that runs them one after the other in
-    // queueing order behaves like the one-stream loop.
-    const bool xs = h->xs_run;
-    hipStream_t sp = xs ? h->pcg_stream : s;
     int pauses_seen = 0;
     if (!parked) __atomic_store_n(&h->hstat->pause_seq, 0, __ATOMIC_RELAXED);
     const int max_trials = (w.max_iters > 0 ? w.max_iters : 0) * w.max_trials;
@@ -1554,15 +1599,14 @@ int lm_loop(movba_handle *h, bool parked)
         return MOVBA_OK;
     };
     auto queue_solve = [&]() -> int {
-        if (band && !direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_band(w, h->band_bw, s)); }      // (direct: the factorisation parked the solve)
+        if (band && !direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_band(w, band_arg(h), s)); }      // (direct: the factorisation parked the solve)
         else if (direct) { ScopedEvents ev(h, KC_PCG); HIP_TRY(queue_direct(h)); }
-        else { ScopedEvents ev(h, KC_PCG, sp); HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, xs, sp)); }
+        else { ScopedEvents ev(h, KC_PCG); HIP_TRY(launch_pcg_rows(w, nrowent, pp, t, s)); }
         return MOVBA_OK;
     };
     auto queue_tail = [&]() -> int {
-        // (the pass's extra workgroup takes the LM decision: no launch of its own; with the solve on the other stream the pass
-        //  waits for the solve's word of this trial inside the launch)
-        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, (xs && !direct) ? (unsigned)t + 1u : 0u, s)); }
+        // (the pass's extra workgroup takes the LM decision: no launch of its own)
+        { ScopedEvents ev(h, KC_BACKSUB); HIP_TRY(launch_backsub(w, s)); }
         return MOVBA_OK;
     };
     // The device parked the solve (k_pcg_rows gave up on trial `td`): every trial set queued behind has turned into no-ops.
@@ -1601,7 +1645,6 @@ int lm_loop(movba_handle *h, bool parked)
                     std::fprintf(stderr, "libmovba: device made no progress for %.0f ms, giving up\n", watchdog_ms());
                     wr_stop(h->hstat, 1); h->uploaded = false;
                     (void)hipStreamSynchronize(s);          // nothing of this solve is left queued when the caller gets the error
-                    if (xs) (void)hipStreamSynchronize(sp);
                     return MOVBA_ERR_HIP;
                 }
                 host_relax(h->opt.host_wait);
@@ -1610,14 +1653,12 @@ int lm_loop(movba_handle *h, bool parked)
             if (paused) { const int rq = answer_pause(); if (rq != MOVBA_OK) return rq; --t; continue; }
             if (caller_stop(h->stop)) wr_stop(h->hstat, 1);
             t_progress = now_ms();                          // (new work queued counts as progress)
-            if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, (xs && !direct) ? t : -1, s)); }
+            if (w.nitems > 0) { ScopedEvents ev(h, KC_SCHUR); HIP_TRY(launch_schur(w, 0, s)); }
             { const int rq = queue_solve(); if (rq != MOVBA_OK) return rq; }
             { const int rq = queue_tail(); if (rq != MOVBA_OK) return rq; }
         }
         if (final_after != t) { const int rq = queue_finalize(); if (rq != MOVBA_OK) return rq; }
         HIP_TRY(hipStreamSynchronize(s));
-        // (every PCG launch still queued on the other stream has left through its schur pass's no-op word: cheap to wait for)
-        if (xs) HIP_TRY(hipStreamSynchronize(sp));
         // a park that happened behind the last queued set is only seen now
         if (rd_pause(h->hstat) == pauses_seen) break;
         const int rq = answer_pause(); if (rq != MOVBA_OK) return rq;
@@ -1648,60 +1689,42 @@ int movba_lba_run(movba_handle *h)
     h->export_in_run = h->export_hint && export_layout(w).end <= h->stage_cap;
     if (!h->export_in_run) for (int k = 0; k < 3; ++k) { h->user_dst[k] = nullptr; h->user_host[k] = nullptr; }
 
-    // Two kinds of kernels wait for other workgroups INSIDE a launch: the two-stream LM loop (the back-substitution pass waits
-    // for the reduced solve, the solve for the schur pass: lm_loop) and the one-launch direct solver (dense_persist.hip).
-    // Every such wait is bounded (DevWindow::wait_ticks, 20 ms) and none can deadlock on an otherwise idle device, but none is
-    // GUARANTEED its workgroups' residency either: another process on the GPU, a CU-masked or partitioned device, any other
-    // kernel holding the CUs.  A solve in which a wait was given up (Ctrl::n_sync_timeouts) is therefore run AGAIN from the
-    // uploaded state on the paths that wait for nothing - one stream, the direct solver one launch per block column
-    // (dense_solve.hip) - instead of handing the caller an error: the reference never skips a solve for such a reason
-    // (src/Optimizer.cc:535).  movba_lba_result::n_sync_timeouts reports that it happened.
-    const unsigned long long test_ticks = [] { const char *e = std::getenv("MOVBA_TEST_WAIT_TICKS"); return e ? std::strtoull(e, nullptr, 10) : ~0ull; }();
+    // One kernel waits for other workgroups INSIDE a launch: the one-launch direct solver (dense_persist.hip).  Its waits are
+    // bounded (DevWindow::wait_ticks, 20 ms) and cannot deadlock on an otherwise idle device, but its workgroups are not
+    // GUARANTEED their residency either: another process on the GPU, a CU-masked or partitioned device, any other kernel
+    // holding the CUs.  A solve in which a wait was given up (Ctrl::n_sync_timeouts) is therefore run AGAIN from the uploaded
+    // state on the path that waits for nothing - the direct solver one launch per block column (dense_solve.hip) - instead
+    // of handing the caller an error: the reference never skips a solve for such a reason (src/Optimizer.cc:535).
+    // movba_lba_result::n_sync_timeouts reports that it happened.  (The deciding wave of the back-substitution pass waits
+    // too, for producers that wait for nothing themselves: that wait has the host watchdog's bound, kernels.hip.)
     h->sync_retries = 0;
-    const int32_t dense_G = h->win.dense.G;
+    // per-attempt values of the window descriptor, put back on every way out of the loop (an error return included)
+    struct Restore {
+        DevWindow &w; const int32_t G; const unsigned long long ticks;
+        ~Restore() { w.dense.G = G; w.wait_ticks = ticks; }
+    } restore{ h->win, h->win.dense.G, h->win.wait_ticks };
     for (int attempt = 0;; ++attempt) {
-    const bool careful = attempt > 0;
-    h->win.wait_ticks = (!careful && test_ticks != ~0ull) ? test_ticks : 2000000ull;
-    h->win.dense.G = careful ? 0 : dense_G;
-    __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0);
-
-    {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
-        ScopedEvents ev(h, KC_SETUP);
-        HIP_TRY(launch_init(w, s));
-        HIP_TRY(launch_linearize(w, s));
-        if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, 0, s));
-        HIP_TRY(launch_lambda_init(w, s));
-    }
-    // the PCG launches of this run on a stream of their own (lm_loop): windows with an on-chip PCG whose lists fit its registers
-    h->xs_run = h->rows_kernel && !h->pp.overflow && w.nitems > 0 && h->opt.two_streams && !careful;
-    if (h->xs_run) {
-        if (!h->pcg_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&h->pcg_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&h->xs_event, hipEventDisableTiming));
-            // (the stream's hardware queue is set up by its first launch: not in front of a solve the back-substitution pass of
-            //  its trial - resident on every CU by then - is waiting for)
-            HIP_TRY(launch_stream_warmup(h->pcg_stream));
-            // ... and the two-stream PCG kernel's first launch (its scratch allocation) neither: a launch of trial -1 finds its
-            // schur pass's no-op word (any value >= 0) and leaves at once
-            HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(launch_pcg_rows(w, (int)h->st.row_ent.size(), run_pcg_params(h), -1, true, h->pcg_stream));
-            HIP_TRY(hipStreamSynchronize(h->pcg_stream));
+        const bool careful = attempt > 0;
+        h->win.wait_ticks = (!careful && HOOK(h, wait_ticks) >= 0) ? (unsigned long long)HOOK(h, wait_ticks) : restore.ticks;
+        h->win.dense.G = careful ? 0 : restore.G;
+        __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0);
+        {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
+            ScopedEvents ev(h, KC_SETUP);
+            HIP_TRY(launch_init(w, s));
+            HIP_TRY(launch_linearize(w, s));
+            if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, s));
+            HIP_TRY(launch_lambda_init(w, s));
         }
-        // (k_init_pose has zeroed the hand-off words: no PCG launch of this run may look at them before that)
-        HIP_TRY(hipEventRecord(h->xs_event, s));
-        HIP_TRY(hipStreamWaitEvent(h->pcg_stream, h->xs_event, 0));
-    }
-    const int rl = lm_loop(h, false);
-    h->win.dense.G = dense_G;
-    if (rl != MOVBA_OK) return rl;
-    if (h->ctrl_host->n_sync_timeouts > 0 && !careful) {
-        std::fprintf(stderr, "libmovba: a workgroup gave up waiting for another in %d launch(es) of this solve: running it again on one stream, the direct solver launch by launch\n",
-                     h->ctrl_host->n_sync_timeouts);
-        h->sync_retries = h->ctrl_host->n_sync_timeouts;
-        h->dense_flags_clean = false;           // (hand-off flags of the abandoned launches: zeroed again before the next one-launch solve)
-        continue;
-    }
-    break;
+        const int rl = lm_loop(h, false);
+        if (rl != MOVBA_OK) return rl;
+        if (h->ctrl_host->n_sync_timeouts > 0 && !careful) {
+            std::fprintf(stderr, "libmovba: a workgroup gave up waiting for another in %d launch(es) of this solve: running it again, the direct solver launch by launch\n",
+                         h->ctrl_host->n_sync_timeouts);
+            h->sync_retries = h->ctrl_host->n_sync_timeouts;
+            h->dense_flags_clean = false;           // (hand-off flags of the abandoned launches: zeroed again before the next one-launch solve)
+            continue;
+        }
+        break;
     }
 #ifdef MOVBA_CLOCK_STAMP
     std::fprintf(stderr, "libmovba[stamp]: k_pcg_rows %llu shader cycles in %llu x 10 ns -> %.3f GHz\n", h->ctrl_host->dbg_cycles,
@@ -1711,11 +1734,6 @@ int movba_lba_run(movba_handle *h)
     for (int wv = 0; wv < 8; ++wv) {
         std::fprintf(stderr, "\nlibmovba[stamp]:   wave %d:", wv);
         for (int k = 0; k < 8; ++k) std::fprintf(stderr, " s%d=%.0f", k, (double)h->ctrl_host->dbg_wseg[wv][k] / (h->ctrl_host->pcg_total_iters ? h->ctrl_host->pcg_total_iters : 1));
-    }
-    if (h->ctrl_host->dbg_xs[5]) {
-        const double n = (double)h->ctrl_host->dbg_xs[5];
-        std::fprintf(stderr, "\nlibmovba[stamp]: two streams, us behind the schur pass's last item flag: partials in registers %.2f, CG starts %.2f, CG ends %.2f, done word %.2f",
-                     0.01 * h->ctrl_host->dbg_xs[1] / n, 0.01 * h->ctrl_host->dbg_xs[2] / n, 0.01 * h->ctrl_host->dbg_xs[3] / n, 0.01 * h->ctrl_host->dbg_xs[4] / n);
     }
     std::fprintf(stderr, "\nlibmovba[stamp]: setup phases per launch (cycles):");
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " p%d=%.0f", k, (double)h->ctrl_host->dbg_seg2[k] / (h->ctrl_host->n_solves ? h->ctrl_host->n_solves : 1));
@@ -1749,7 +1767,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
     std::vector<movba_handle *> act, solo;
     for (int i = 0; i < n; ++i) {
         movba_handle *h = hs[i];
-        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false; h->xs_run = false;
+        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false;
         if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
         if (caller_stop(h->stop)) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
         if (!h->rows_kernel || h->win.kcam) { solo.push_back(h); continue; }      // (direct-solver windows and windows with intrinsics by keyframe run on their own)
@@ -1770,7 +1788,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
         // streaming kernels of the others.  Each window's own kernels still run in its solo order on one stream.
         // (two by default: with more streams than hardware queues left to the process the groups fall back into lockstep)
         int ngroups = na >= 2 ? 2 : 1;
-        if (const char *eg = std::getenv("MOVBA_BATCH_GROUPS")) ngroups = std::max(1, std::min(std::min(kMaxGroups, na), std::atoi(eg)));
+        if (process_switches().batch_groups > 0) ngroups = std::max(1, std::min(std::min(kMaxGroups, na), process_switches().batch_groups));
         if (ngroups > 1 && !h0->batch_ev[0]) {
             for (hipEvent_t &e : h0->batch_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             for (auto &ring : h0->batch_phase_ev) for (hipEvent_t &e : ring) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1829,7 +1847,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
                 __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0); __atomic_store_n(&h->hstat->pause_seq, 0, __ATOMIC_RELAXED);
                 wins[i] = h->win; wins[i].lds_poses = ldsp ? 1 : 0;
                 pps[i] = run_pcg_params(h);
-                bwv[i] = h->band ? h->band_bw : -1;
+                bwv[i] = h->band ? band_arg(h) : -1;
                 if (h->band) { G.any_band = true; G.lds_band = std::max(G.lds_band, band_lds_bytes(h->win.nfree, h->band_bw)); } else G.any_pcg = true;
                 const DevWindow &w = h->win;
                 bp[i + 1] = bp[i] + w.n_pt_blocks + 1;          // (+ the deciding workgroup of the window's back-substitution pass)
@@ -2009,7 +2027,7 @@ int movba_lba_solve(movba_handle *h, const movba_lba_desc *desc, movba_lba_resul
 {
     if (!h || !desc || !res) return MOVBA_ERR_ARG;
     res->status = MOVBA_ERR_ARG;
-    static const bool lap_on = std::getenv("MOVBA_TIME_SOLVE") != nullptr;
+    const bool lap_on = process_switches().time_solve;
     const double t_s0 = lap_on ? now_ms() : 0.0;
     int rc = movba_lba_upload(h, desc);
     const double t_s1 = lap_on ? now_ms() : 0.0;

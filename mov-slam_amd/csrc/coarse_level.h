@@ -31,10 +31,8 @@ namespace movba {
 #endif
 
 // sm: >= kNC*kNC + 9*kNC + 8 doubles + 2 ints per coarse term (= gather-list entry) of LDS; 512 threads
-// signal_read: once the partials have been read for the last time, say so (DevWindow::xs: the solving workgroup holds the
-// word the next passes wait for until then)
 template <int kT, int kNC, int kPA>
-__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm, bool extrapolate, bool signal_read)
+__device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams &pp, int trial, double lambda, double *sm, bool extrapolate)
 {
     double *Ac = sm;
     double *gj = Ac + kNC * kNC;
@@ -184,7 +182,6 @@ __device__ __forceinline__ void coarse_build(const DevWindow &w, const PcgParams
         }
     }
     __syncthreads();
-    if (signal_read && tid == 0) hx_st_u32(w.xs + kXsCoarseRead, (unsigned)trial + 1u);    // (every load of the partials has returned: their values are in A_c)
     // dofs without support (an aggregate with no rows; the linear modes of an aggregate with a single row): identity
     // rows keep A_c invertible, their restricted residual is always zero
     if (tid < kNC) {

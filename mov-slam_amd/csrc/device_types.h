@@ -26,16 +26,8 @@ constexpr int kPartStride = MOVBA_PART_STRIDE;     // doubles per schur work-ite
 constexpr int kEntPackSlots = 1 << 22, kEntPackPoints = 1 << 20;
 __host__ __device__ inline unsigned long long ent_pack(int si, int sj, int l) { return (unsigned long long)(unsigned)si | ((unsigned long long)(unsigned)sj << 22) | ((unsigned long long)(unsigned)l << 44); }
 
-// Hand-off words between the kernels of one LM trial that run on TWO streams (api.cpp, lm_loop): the reduced solve of trial t
-// (k_pcg_rows) is resident on its own stream before the schur pass of trial t has finished and takes the pass's partials item by
-// item; the back-substitution pass is resident while the solve still runs and starts from its result.  DevWindow::xs, zeroed by
-// k_init_pose; every word carries the trial's epoch (trial + 1), words of different roles on cache lines of their own:
-//   [kXsSkip]        schur pass of this epoch was a no-op (solve finished or parked): the solve of the epoch leaves at once
-//   [kXsPcgDone]     solve of this epoch has published its result: epoch | status << 24
-//   [kXsCoarseRead]  the coarse-level workgroup has read the epoch's partials (the next schur pass may overwrite them)
-//   [kXsItem0 + i]   schur work item i of this epoch has published its partial
-constexpr int kXsSkip = 0, kXsPcgDone = 32, kXsCoarseRead = 64, kXsItem0 = 96;
-constexpr unsigned kXsEpochMask = 0xffffffu, kXsOk = 0u, kXsParked = 1u, kXsFailed = 2u;
+// bound of the deciding wave's wait for the back-substitution pass's records (10 ns ticks: 30 s, the host watchdog's order)
+constexpr unsigned long long kDecideWaitTicks = 3000000000ull;
 
 constexpr int kPointGroup = 8;      // lanes cooperating on one map point
 #ifndef MOVBA_POINT_BLOCK
@@ -180,7 +172,6 @@ struct DevWindow {
     double *bp;         // 6 nfree
     double *xp;         // 6 nfree
     double *scale_part; // n_pt_blocks + 1
-    unsigned *xs;       // kXsItem0 + nitems words: the hand-offs between the two streams of the LM loop (above)
     unsigned *dec_rec;  // 2 n_pt_blocks records of 16 bytes (handoff.h): every workgroup of the back-substitution pass hands its cost and scale
                         // partials to the pass's deciding workgroup as tagged records (tag = trial + 1)
     double *hmax_part;  // n_pt_blocks
@@ -197,7 +188,7 @@ struct DevWindow {
     // bound of every device-side wait of one workgroup for another, in ticks of the 100 MHz clock: 20 ms (a workgroup that gives up
     // marks the solve - Ctrl::n_sync_timeouts - and the host runs it again on the paths that wait for nothing; MOVBA_TEST_WAIT_TICKS
     // shortens the first attempt's bound so that tests can see that happen)
-    unsigned long long wait_ticks;
+    unsigned long long wait_ticks;      // bound of the waits inside the one-launch direct solver (10 ns ticks; 20 ms)
 };
 
 // Device view of the structure pass (struct_kernels.hip)

@@ -25,16 +25,13 @@ hipError_t launch_sorted_fill(const StructDev &sd, const int32_t *cnt_pt, int32_
                               unsigned long long *vals_in, void *tmp, size_t tmp_bytes, long long noff, hipStream_t s);
 hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
-// xs: the launch is on a stream of its own beside the schur pass of its trial and waits for the pass's items (DevWindow::xs)
-hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, bool xs, hipStream_t s);
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s);
 
-hipError_t launch_stream_warmup(hipStream_t s);
 hipError_t launch_init(const DevWindow &w, hipStream_t s);
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s);
-hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s);
+hipError_t launch_schur(const DevWindow &w, int mode, hipStream_t s);
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s);
-// wait_epoch != 0: the pass waits inside the launch for the reduced solve of that epoch (trial + 1), which runs on another stream
-hipError_t launch_backsub(const DevWindow &w, unsigned wait_epoch, hipStream_t s);
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s);
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s);
 // destinations of k_export in the host's pinned staging buffer (device view; null = not wanted), as 64-bit words
 struct ExportDst { unsigned long long *poses, *points, *chi2, *outlier; };

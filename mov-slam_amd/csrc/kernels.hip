@@ -35,7 +35,6 @@ namespace movba {
 __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int nblk)
 {
     const int i = bid * blockDim.x + threadIdx.x;
-    for (int k = i; k < kXsItem0 + w.nitems; k += nblk * blockDim.x) w.xs[k] = 0u;      // hand-off words of the two streams: no epoch of an earlier run may fit
     for (int k = i; k < 8 * w.n_pt_blocks; k += nblk * blockDim.x) w.dec_rec[k] = 0u;  // the point pass's hand-off records: no tag of an earlier run may fit
     {
         const double2 *src = reinterpret_cast<const double2 *>(w.point0);
@@ -55,7 +54,7 @@ __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int 
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         w.ac_prev[kCoarseDim * kCoarseDim + 1] = -1.0;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
-        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; c->dbg_xs[k] = 0; for (int q = 0; q < 8; ++q) c->dbg_wseg[k][q] = 0; }
+        for (int k = 0; k < 8; ++k) { c->dbg_seg[k] = 0; c->dbg_seg2[k] = 0; for (int q = 0; q < 8; ++q) c->dbg_wseg[k][q] = 0; }
     }
     if (i >= w.NP) return;
     double q[7];
@@ -89,19 +88,6 @@ __device__ __forceinline__ Cam cam_of_rt(const DevWindow &w, int ip) { return w.
 
 __global__ void k_init_pose(DevWindow w) { init_pose_body(w, blockIdx.x, gridDim.x); }
 
-// one lane waits for the reduced solve of epoch `epoch` (it runs on another stream): kXsOk, kXsParked or kXsFailed (also when
-// the wait itself gives up after 20 ms)
-__device__ __forceinline__ unsigned xs_wait_pcg(const DevWindow &w, unsigned epoch)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        const unsigned v = hx_ld_u32(w.xs + kXsPcgDone);
-        if ((v & kXsEpochMask) == epoch) return v >> 24;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > w.wait_ticks) return kXsFailed;
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-
 // --------------------------------------------------------------------------------
 // decide_body: one wave - wave 0 of the extra workgroup of the back-substitution pass (block n_pt_blocks of point_body).
 // The accept / reject logic and lambda schedule of OptimizationAlgorithmLevenberg::solve plus the loop conditions of
@@ -111,28 +97,15 @@ __device__ __forceinline__ unsigned xs_wait_pcg(const DevWindow &w, unsigned epo
 // and scale partials to this wave INSIDE the launch, as tagged 16-byte records (handoff.h) which its lanes poll: the
 // decision is taken ~1 us behind the last workgroup's partials, and the launch ends with it.)
 // --------------------------------------------------------------------------------
-__device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigned wait_epoch)
+__device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
 {
     Ctrl *c = w.ctrl;
     const int lane = threadIdx.x;
-    if (wait_epoch) {
-        // the trial's reduced solve runs on another stream (point_body): parked -> the host queues the direct solver and a
-        // pass of its own; gave up or never came -> the solve ends here (MOVBA_ERR_DEVICE_WAIT through n_sync_timeouts)
-        unsigned st = 0;
-        if (lane == 0) st = xs_wait_pcg(w, wait_epoch);
-        st = (unsigned)__builtin_amdgcn_readfirstlane((int)st);
-        if (st == kXsParked) return;
-        if (st != kXsOk) {
-            if (lane == 0) {
-                c->n_sync_timeouts += 1; c->done = 1;
-                __hip_atomic_store(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            return;
-        }
-    }
     // Lane-strided partial sums, records polled 10 blocks deep per lane (10 x 64 covers cfg3's 625 blocks in one round),
-    // added in a fixed order once a round is complete.  A producer that never shows up (it cannot: none of them waits for
-    // anything) ends the solve through the bounded wait instead of hanging the launch.
+    // added in a fixed order once a round is complete.  None of the producers waits for anything, and this wave's workgroup is
+    // the LAST of the grid (every producer was dispatched before it), so the wait cannot deadlock; it can only be slow - another
+    // process time-slicing the GPU, a preempted queue, a very long batched pass - and a slow pass must not cost the caller the
+    // solve: the bound is of the host watchdog's order (kDecideWaitTicks, 30 s), there for a device that has stopped altogether.
     constexpr int kDeep = 10;
     const unsigned tag = (unsigned)c->n_solves + 1u;
     // What the decision reads besides the partials is requested HERE, ahead of the wait: the caller's stop flag sits in host
@@ -142,10 +115,9 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigne
     const double F0 = c->F0, lambda0 = c->lambda, nu0 = c->nu;
     const int tr = c->n_trace, qmax0 = c->qmax, it0 = c->it, nsolves0 = c->n_solves;
     // (what the solver left for this wave - the pose part of the scale, its failure flag, its iteration count: final before
-    //  this launch started when the solve ran ahead of it on the same stream)
-    double scale_pose = 0.0;
-    int pcg_fail = 0, pcg_iters = 0;
-    if (!wait_epoch) { scale_pose = w.scale_part[w.n_pt_blocks]; pcg_fail = c->pcg_fail; pcg_iters = c->pcg_last_iters; }
+    //  this launch started: the solve ran ahead of it on the same stream)
+    const double scale_pose = w.scale_part[w.n_pt_blocks];
+    const int pcg_fail = c->pcg_fail, pcg_iters = c->pcg_last_iters;
     const __amdgpu_buffer_rsrc_t rr = hx_rsrc(w.dec_rec, 32u * (unsigned)w.n_pt_blocks);
     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
     double F1 = 0.0, scale = 0.0;
@@ -162,7 +134,7 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigne
                 ok &= hx_ld_tagged(rr, 2u * k + 1u, tag, sv[u]);
             }
             if (__all(ok)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t_start > w.wait_ticks) { good = false; break; }      // (20 ms)
+            if (__builtin_amdgcn_s_memrealtime() - t_start > kDecideWaitTicks) { good = false; break; }
             __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
@@ -181,8 +153,6 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigne
     F1 = wave_sum(F1);
     scale = wave_sum(scale);
     if (lane != 0) return;
-    // (two streams: written through by a kernel that ran beside this one - L1-bypassing loads, behind the wait)
-    if (wait_epoch) { scale_pose = hx_ld_f64(w.scale_part + w.n_pt_blocks); pcg_fail = hx_ld_i32(&c->pcg_fail); pcg_iters = hx_ld_i32(&c->pcg_last_iters); }
     scale += scale_pose;
     if (pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
     scale += 1e-3;
@@ -242,11 +212,8 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur, unsigne
 // --------------------------------------------------------------------------------
 // LDSP: the keyframe rotations (and, for BACKSUB, the pose increments and hessian indices) are staged in LDS; windows
 // with more keyframes than fit (~850) read them through L2 instead (same arithmetic, same results).
-// wait_epoch != 0 (back-substitution passes of a solve whose reduced solve runs on another stream, DevWindow::xs): the pass is
-// resident while the solve of its trial still runs; everything that does not depend on the solve (the points' own data, their
-// edges, the current state's rotations) is requested first, then the workgroup waits for the solve's word.
 template <bool BACKSUB, bool STEREO, bool LDSP, bool PERKF = false>
-__device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned wait_epoch)
+__device__ __forceinline__ void point_body(const DevWindow &w, int bid)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const Ctrl *c = w.ctrl;
@@ -270,7 +237,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
 #ifdef MOVBA_CLOCK_STAMP
         const int ns0 = c->n_solves;
 #endif
-        if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur, wait_epoch);
+        if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur);
 #ifdef MOVBA_CLOCK_STAMP
         if (BACKSUB && threadIdx.x == 0 && ns0 == 3) {
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 20000 + 8 * (size_t)bid;
@@ -329,7 +296,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
     // Staging of the keyframes' data, the usual window (up to 85 keyframes): every thread requests its pieces of ALL the
     // images - 16 bytes each, two per image - before it stores the first one.  (Loop after loop, as below for larger windows,
     // the passes were nine dependent L2 round trips per thread: 3 us of a 12 us pass at cfg3.)
-    const bool stage_at_once = LDSP && BACKSUB && !wait_epoch && 12 * w.NP <= 4 * kPointBlock && 6 * w.nfree <= 4 * kPointBlock;
+    const bool stage_at_once = LDSP && BACKSUB && 12 * w.NP <= 4 * kPointBlock && 6 * w.nfree <= 4 * kPointBlock;
     if (stage_at_once) {
         const int n2 = 6 * w.NP, x2 = 3 * w.nfree;            // 16-byte pieces of a rotation image / of the increments
         const double2 *g0 = reinterpret_cast<const double2 *>(S0.Rt), *g1 = reinterpret_cast<const double2 *>(S1.Rt), *gx = reinterpret_cast<const double2 *>(w.xp);
@@ -356,25 +323,9 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
             for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sR0[k] = S0.Rt[k];
             for (int k = threadIdx.x; k < w.NP; k += kPointBlock) shidx[k] = w.hidx[k];
         }
-        // the trial's reduced solve (poses of the trial state, increments) may still be running on its own stream: one lane
-        // polls its word, the barrier releases the others.  A solve that parked itself or gave up: nothing to do here.
-        if (wait_epoch) {
-            int *stw = reinterpret_cast<int *>(red);
-            if (threadIdx.x == 0) *stw = (int)xs_wait_pcg(w, wait_epoch);
-            __syncthreads();
-            const int st = *stw;
-            __syncthreads();                                // (red is reused by the reductions at the end)
-            if (st != (int)kXsOk) return;
-            if (!LDSP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // poses / increments are read through L2 by plain loads: drop this CU's stale lines
-        }
         if (LDSP) {
-            if (wait_epoch) {       // (write-through by the solve, L1-bypassing here: handoff.h)
-                for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = hx_ld_f64(S1.Rt + k);
-                for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = hx_ld_f64(w.xp + k);
-            } else {
-                for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
-                for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
-            }
+            for (int k = threadIdx.x; k < 12 * w.NP; k += kPointBlock) sRt[k] = S1.Rt[k];
+            for (int k = threadIdx.x; k < 6 * w.nfree; k += kPointBlock) sxp[k] = w.xp[k];
             __syncthreads();
         }
     } else if (LDSP) {
@@ -567,10 +518,10 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid, unsigned
 }
 
 template <bool BACKSUB, bool STEREO, bool LDSP>
-__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w, unsigned wait_epoch) { point_body<BACKSUB, STEREO, LDSP>(w, blockIdx.x, wait_epoch); }
+__global__ __launch_bounds__(kPointBlock) void k_point(DevWindow w) { point_body<BACKSUB, STEREO, LDSP>(w, blockIdx.x); }
 // intrinsics by keyframe (DevWindow::kcam): the variant that reads the keyframes' data through L2
 template <bool BACKSUB, bool STEREO>
-__global__ __launch_bounds__(kPointBlock) void k_point_kf(DevWindow w, unsigned wait_epoch) { point_body<BACKSUB, STEREO, false, true>(w, blockIdx.x, wait_epoch); }
+__global__ __launch_bounds__(kPointBlock) void k_point_kf(DevWindow w) { point_body<BACKSUB, STEREO, false, true>(w, blockIdx.x); }
 
 // Batched launches (movba_lba_run_batch): one grid over the concatenated windows; `pre` is the prefix of the windows'
 // block counts for this kernel.  Every window runs exactly the code of its solo launch, so results are bit-identical.
@@ -585,7 +536,7 @@ template <bool BACKSUB, bool STEREO, bool LDSP>
 __global__ __launch_bounds__(kPointBlock) void k_point_b(BatchDev b)
 {
     const int wi = batch_window(b.blk_point, b.n, blockIdx.x);
-    point_body<BACKSUB, STEREO, LDSP>(b.wins[wi], blockIdx.x - b.blk_point[wi], 0u);
+    point_body<BACKSUB, STEREO, LDSP>(b.wins[wi], blockIdx.x - b.blk_point[wi]);
 }
 
 __global__ void k_init_pose_b(BatchDev b)
@@ -768,10 +719,8 @@ constexpr int kSchurBatchDiag = MOVBA_SCHUR_BD;     // entries per lane whose ga
 constexpr int kSchurBatchOff = MOVBA_SCHUR_BO;      // same, off-diagonal items
 
 // HPP_ONLY: diagonal pairs only, Hpp and b_p only (one launch per solve, seeds lambda)
-// trial >= 0: the pass belongs to LM trial `trial` of a solve whose reduced solve waits on another stream (DevWindow::xs):
-// every finished item raises its flag, a pass that finds the solve finished or parked says so
 template <int NR, bool HPP_ONLY, bool PERKF = false>
-__device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int trial)
+__device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
 {
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long wst[5];
@@ -788,10 +737,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
     const int wg = (bid & 7) * (w.sched_per_xcd / kSchurWaves) + (bid >> 3);
     const SchedItem it = w.sched[wg * kSchurWaves + wv];    // this wave's slot: its share of an item one, two or four waves take
     const Ctrl *c = w.ctrl;
-    if (c->done) {
-        if (trial >= 0 && bid == 0 && threadIdx.x == 0) hx_st_u32(w.xs + kXsSkip, (unsigned)trial + 1u);
-        return;
-    }
+    if (c->done) return;
     const int sub = it.sub & 0xff, nsub = it.sub >> 8;
     __shared__ __attribute__((aligned(16))) double strips[kSchurWaves][54 * 16];
     __shared__ double wsum[kSchurWaves][64];
@@ -897,12 +843,11 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
     if (active && sub == 0) {
         double t = wsum[wv][lane];
         for (int q = 1; q < nsub; ++q) t += wsum[wv + q][lane];
-        // (write-through stores: the item's partial may be taken by a solve that is already resident on another stream)
         if (is_diag) {
             if (lane < 54) {
-                hx_st_f64(out + kDiagMap[lane], t);
+                *(out + kDiagMap[lane]) = t;
                 // the lane holding upper element (a,b) also fills its mirror (b,a) of the 6x6 block
-                if (lane < 21 && kDiagMirror[lane] >= 0) hx_st_f64(out + kDiagMirror[lane], t);
+                if (lane < 21 && kDiagMirror[lane] >= 0) *(out + kDiagMirror[lane]) = t;
             }
             // ... and once more as the on-chip PCG's setup reads it (DevWindow::rec_d): per row a of the keyframe's block the six
             // values of Hpp - sum B Dinv B^T, then (sum B Dinv b_l)_a and (b_p)_a.  The 54 sums sit one per lane ([0,21) upper
@@ -915,22 +860,15 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
                 double *rec = w.rec_d + (size_t)it.dst_a * 48;        // (diagonal items: dst_a = keyframe * rec_slots + the item's place in its pair)
                 if (lane < 36) {
                     const int a = lane / 6, q = lane - a * 6, u = a <= q ? ut6(a, q) : ut6(q, a);
-                    hx_st_f64(rec + a * 8 + q, wsum[wv][27 + u] - wsum[wv][u]);
-                } else if (lane < 42) hx_st_f64(rec + (lane - 36) * 8 + 6, wsum[wv][21 + (lane - 36)]);
-                else hx_st_f64(rec + (lane - 42) * 8 + 7, wsum[wv][48 + (lane - 42)]);
+                    *(rec + a * 8 + q) = wsum[wv][27 + u] - wsum[wv][u];
+                } else if (lane < 42) *(rec + (lane - 36) * 8 + 6) = wsum[wv][21 + (lane - 36)];
+                else *(rec + (lane - 42) * 8 + 7) = wsum[wv][48 + (lane - 42)];
             }
         } else if (lane < 36) {
-            hx_st_f64(out + lane, t);
+            *(out + lane) = t;
             // ... and where the lanes of the on-chip PCG that hold the block read it (DevWindow::img_b), as stored and transposed
-            if (it.dst_a >= 0) hx_st_f64(w.img_b + it.dst_a + (size_t)lane * kPcgRowsThreads, t);
-            if (it.dst_b >= 0) hx_st_f64(w.img_b + it.dst_b + (size_t)((lane % 6) * 6 + lane / 6) * kPcgRowsThreads, t);
-        }
-        if (trial >= 0) {           // ONE wave stored the item: its drain, then its first lane raises the item's flag
-            hx_drain();
-            if (lane == 0) hx_st_u32(w.xs + kXsItem0 + item, (unsigned)trial + 1u);
-#ifdef MOVBA_CLOCK_STAMP
-            if (lane == 0) atomicMax(&w.ctrl->dbg_xs[0], (unsigned long long)__builtin_amdgcn_s_memrealtime());
-#endif
+            if (it.dst_a >= 0) *(w.img_b + it.dst_a + (size_t)lane * kPcgRowsThreads) = t;
+            if (it.dst_b >= 0) *(w.img_b + it.dst_b + (size_t)((lane % 6) * 6 + lane / 6) * kPcgRowsThreads) = t;
         }
     }
 #ifdef MOVBA_CLOCK_STAMP
@@ -949,17 +887,17 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid, int tria
 #define MOVBA_SCHUR_MINWAVES 1
 #endif
 template <int NR, bool HPP_ONLY>
-__global__ __launch_bounds__(kSchurWaves * 64, MOVBA_SCHUR_MINWAVES) void k_schur(DevWindow w, int trial) { schur_body<NR, HPP_ONLY>(w, blockIdx.x, trial); }
+__global__ __launch_bounds__(kSchurWaves * 64, MOVBA_SCHUR_MINWAVES) void k_schur(DevWindow w) { schur_body<NR, HPP_ONLY>(w, blockIdx.x); }
 
 // (a window with intrinsics by keyframe: solved on its own, never in a batch - api.cpp)
 template <int NR, bool HPP_ONLY>
-__global__ __launch_bounds__(kSchurWaves * 64) void k_schur_kf(DevWindow w, int trial) { schur_body<NR, HPP_ONLY, true>(w, blockIdx.x, trial); }
+__global__ __launch_bounds__(kSchurWaves * 64) void k_schur_kf(DevWindow w) { schur_body<NR, HPP_ONLY, true>(w, blockIdx.x); }
 
 template <int NR, bool HPP_ONLY>
 __global__ __launch_bounds__(kSchurWaves * 64) void k_schur_b(BatchDev b)
 {
     const int wi = batch_window(b.blk_schur, b.n, blockIdx.x);
-    schur_body<NR, HPP_ONLY>(b.wins[wi], blockIdx.x - b.blk_schur[wi], -1);
+    schur_body<NR, HPP_ONLY>(b.wins[wi], blockIdx.x - b.blk_schur[wi]);
 }
 
 // --------------------------------------------------------------------------------
@@ -1132,14 +1070,6 @@ size_t point_lds_need(int NP, int nfree)
     return (24 * (size_t)NP + 6 * (size_t)nfree + 8) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
-// (first launch on a new stream: its hardware queue is set up here, not in front of a kernel other kernels wait for)
-__global__ void k_stream_warmup() {}
-hipError_t launch_stream_warmup(hipStream_t s)
-{
-    hipLaunchKernelGGL(k_stream_warmup, dim3(1), dim3(64), 0, s);
-    return hipGetLastError();
-}
-
 hipError_t launch_init(const DevWindow &w, hipStream_t s)
 {
     const int work = w.NP > (3 * w.P) / 2 ? w.NP : (3 * w.P) / 2;
@@ -1152,34 +1082,33 @@ hipError_t launch_init(const DevWindow &w, hipStream_t s)
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s)
 {
     if (w.kcam) {
-        if (w.stereo) hipLaunchKernelGGL((k_point_kf<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w, 0u);
-        else hipLaunchKernelGGL((k_point_kf<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w, 0u);
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w);
+        else hipLaunchKernelGGL((k_point_kf<false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes_for(w, false, false), s, w);
     } else if (!w.lds_poses) {
-        if (w.stereo) hipLaunchKernelGGL((k_point<false, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
-        else hipLaunchKernelGGL((k_point<false, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
-    } else if (w.stereo) hipLaunchKernelGGL((k_point<false, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
-    else hipLaunchKernelGGL((k_point<false, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w, 0u);
+        if (w.stereo) hipLaunchKernelGGL((k_point<false, true, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+        else hipLaunchKernelGGL((k_point<false, false, false>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<false, true, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
+    else hipLaunchKernelGGL((k_point<false, false, true>), dim3(w.n_pt_blocks), dim3(kPointBlock), point_lds_bytes(w, false), s, w);
     return hipGetLastError();
 }
 
-hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s)
+hipError_t launch_schur(const DevWindow &w, int mode, hipStream_t s)
 {
     const int nblk = 8 * (w.sched_per_xcd / kSchurWaves);     // four wave slots per workgroup; multiple of 8: a contiguous run of slots per XCD
-    if (mode == 1) trial = -1;          // (the pass that seeds lambda hands nothing over)
     if (w.kcam) {
         if (mode == 1) {
-            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
-            else hipLaunchKernelGGL((k_schur_kf<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+            else hipLaunchKernelGGL((k_schur_kf<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
         } else {
-            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
-            else hipLaunchKernelGGL((k_schur_kf<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+            if (w.stereo) hipLaunchKernelGGL((k_schur_kf<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+            else hipLaunchKernelGGL((k_schur_kf<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
         }
     } else if (mode == 1) {
-        if (w.stereo) hipLaunchKernelGGL((k_schur<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
-        else hipLaunchKernelGGL((k_schur<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+        if (w.stereo) hipLaunchKernelGGL((k_schur<3, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        else hipLaunchKernelGGL((k_schur<2, true>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
     } else {
-        if (w.stereo) hipLaunchKernelGGL((k_schur<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
-        else hipLaunchKernelGGL((k_schur<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w, trial);
+        if (w.stereo) hipLaunchKernelGGL((k_schur<3, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
+        else hipLaunchKernelGGL((k_schur<2, false>), dim3(nblk), dim3(kSchurWaves * 64), 0, s, w);
     }
     return hipGetLastError();
 }
@@ -1190,17 +1119,17 @@ hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_backsub(const DevWindow &w, unsigned wait_epoch, hipStream_t s)
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s)
 {
     // (one workgroup more than the points need: its first wave takes the LM decision, decide_body)
     if (w.kcam) {
-        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w, wait_epoch);
-        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w, wait_epoch);
+        if (w.stereo) hipLaunchKernelGGL((k_point_kf<true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
+        else hipLaunchKernelGGL((k_point_kf<true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes_for(w, true, false), s, w);
     } else if (!w.lds_poses) {
-        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
-        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
-    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
-    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w, wait_epoch);
+        if (w.stereo) hipLaunchKernelGGL((k_point<true, true, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+        else hipLaunchKernelGGL((k_point<true, false, false>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    } else if (w.stereo) hipLaunchKernelGGL((k_point<true, true, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
+    else hipLaunchKernelGGL((k_point<true, false, true>), dim3(w.n_pt_blocks + 1), dim3(kPointBlock), point_lds_bytes(w, true), s, w);
     return hipGetLastError();
 }
 

@@ -70,85 +70,24 @@ __device__ __forceinline__ double sum_fixed(const double *red)
 // OVERFLOW: some wave's gather list does not fit its 64 VGPR-resident pairs; the tail is multiplied from an L2 copy of S
 // (a separate instantiation: its extra live values must not cost the common case registers)
 // role 0: the solving workgroup, role 1: the coarse-level builder of the same launch
-// The workgroup waits until every work item of the trial's schur pass has raised its flag (the pass runs on another stream and
-// may still be at work when this launch becomes resident): 0 = all there, 1 = the pass was a no-op (the solve is finished or
-// parked: leave), 2 = gave up after 20 ms.  Workgroup-uniform; `scratch`: 8 ints of LDS.
-template <int kThreads>
-__device__ __forceinline__ int xs_wait_items(const DevWindow &w, unsigned epoch, int *scratch)
-{
-    const int tid = threadIdx.x;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-        bool ok = true;
-        for (int i = tid; i < w.nitems; i += kThreads) ok &= hx_ld_u32(w.xs + kXsItem0 + i) == epoch;
-        const bool skip = hx_ld_u32(w.xs + kXsSkip) >= epoch;        // (epochs only grow within a run: a later no-op pass may have overwritten this one's)
-        const bool late = __builtin_amdgcn_s_memrealtime() - t0 > w.wait_ticks;
-        const int bits = (__any(!ok) ? 1 : 0) | (__any(skip) ? 2 : 0) | (__any(late) ? 4 : 0);
-        if ((tid & 63) == 0) scratch[tid >> 6] = bits;
-        __syncthreads();
-        int all = 0;
-#pragma unroll
-        for (int k = 0; k < kThreads / 64; ++k) all |= scratch[k];
-        __syncthreads();
-        if (all & 2) return 1;
-        if (!(all & 1)) return 0;
-        if (all & 4) return 2;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-
-// one wave waits for the first sign of life of the trial's schur pass (the flag of work item 0: the pass found the solve
-// running, so the LM state this trial starts from is final) or for the pass's no-op word: 0 / 1 / 2 as xs_wait_items
-template <int kThreads>
-__device__ __forceinline__ int xs_wait_live(const DevWindow &w, unsigned epoch, int *scratch)
-{
-    const int tid = threadIdx.x;
-    if (tid == 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int st = 0;
-        for (;;) {
-            if (hx_ld_u32(w.xs + kXsItem0) == epoch) break;
-            if (hx_ld_u32(w.xs + kXsSkip) >= epoch) { st = 1; break; }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > w.wait_ticks) { st = 2; break; }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        scratch[0] = st;
-    }
-    __syncthreads();
-    const int st = scratch[0];
-    __syncthreads();
-    return st;
-}
-
-// XS: the launch sits on a stream of its own beside the schur pass of its trial (api.cpp, lm_loop).  Nothing the other stream's
-// kernels write is read before the pass's flags say so: the workgroup waits for the whole pass, makes ONE agent-scope acquire
-// (cdna_hip_programming.md Guideline 16's recipe) and reads what the pass left with plain loads.  Results leave
-// write-through, behind them the word the back-substitution pass waits for.  The arithmetic does not depend on XS.
-// (A solver that took the partials item by item, each lane as soon as its items were flagged, was measured 10 us per trial
-//  SLOWER than the one-stream launch: every look at a flag and every dependent load is a 1.5 - 2 us device-scope round trip,
-//  and a lane made six of them per turn of its polling loop - DESIGN.md, round 4.)
 // PADDED (PcgParams::padded: no block row with more than kOwnBatch entry pairs, nothing overflows - cfg3 and everything smaller):
 // the pair sums of the mat-vec are parked by ROW, each row with kOwnBatch slots of which the unused ones hold zeros for the
 // whole solve, and the residual exchange of a wave goes through a strip of its own whose unowned places hold zeros: the owner
 // sums and the restriction read their ten values without the forty v_cndmask per iteration that masked the over-read of the
 // packed layout.  Same values added in the same order: the two layouts give the same bits (batched runs may mix them).
-template <bool OVERFLOW, bool XS, bool PADDED>
+template <bool OVERFLOW, bool PADDED>
 __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParams &pp, int trial, int role)
 {
-    static_assert(!(OVERFLOW && XS), "windows whose lists overflow the registers stay on one stream");
     static_assert(!(OVERFLOW && PADDED), "the padded layout holds the register-resident pairs only");
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
     const int tid = threadIdx.x, ln = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: row ranges and their predicates live in SGPRs
-    const unsigned epoch = (unsigned)trial + 1u;
     // use_coarse == 2 (windows with at most one keyframe per wave: the coarse space is the whole space): the coarse level
     // is built FIRST, by this workgroup, from THIS trial's matrix, and the solve below converges in a couple of iterations
     const bool fresh = pp.use_coarse == 2;
-    // two streams: the solver proper first loads what does not depend on the pass (its plans, the coarse inverse), then waits
-    const bool late_wait = XS && role == 0 && !fresh;
     // ---- the solver proper: everything whose address follows from the kernel's arguments alone is REQUESTED first - its plans,
-    // the rows of the gather lists, the previous trial's coarse inverse, on one stream also the blocks the schur pass left for
+    // the rows of the gather lists, the previous trial's coarse inverse, the blocks the schur pass left for
     // this thread - before anything is waited for: the setup used to be a chain of five dependent round trips behind the
     // launch boundary (Ctrl -> plans -> item ranges -> partials), ~1 us each from a cold L2 ----
     const bool solver = role == 0 && !fresh;
@@ -167,30 +106,19 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     const double *part = w.part;
     if (!solver) {
         // the coarse-level workgroup, and a solver that builds its coarse level first, read every partial of the schur pass
-        if (!XS) { if (c->done) return; }
-        else {
-            const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(sm));
-            if (wt == 1) return;
-            if (wt == 2) {              // never seen: the back-substitution pass ends the solve and the host runs it again on one stream
-                if (role == 0 && tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24));
-                return;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        // (the LM state of this trial was written by the previous trial's decision: on the two-stream path a kernel of the other
-        //  stream, finished by the time the schur pass shows its flags)
-        cur = XS ? hx_ld_i32(&c->cur) : c->cur; lambda = XS ? hx_ld_f64(&c->lambda) : c->lambda;
+        if (c->done) return;
+        cur = c->cur; lambda = c->lambda;
         if (role == 1) {            // second workgroup: coarse level of THIS trial's matrix, for the next trial
-            coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true, true);
+            coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, true);
             return;
         }
-        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false, false);
+        coarse_build<kT, kNC, kPA>(w, pp, trial, lambda, sm, false);
         __syncthreads();
     }
     // ---- the requests, in the order their answers are needed (vector loads return in order).  One plan load per thread says
     // everything it needs of the window's structure (api.cpp, lay_out_rest); the rest follows from the kernel's arguments. ----
     int done_w = 0;
-    if (solver && !XS) { done_w = c->done; cur = c->cur; lambda = c->lambda; }
+    if (solver) { done_w = c->done; cur = c->cur; lambda = c->lambda; }
     const int4 *plan = reinterpret_cast<const int4 *>(w.lane_plan) + (size_t)tid * 3;
     const int4 pl0 = plan[0], pl1 = plan[1], plo = plan[2];
     const int oi0 = plo.x, oi1 = plo.y;                   // owner lanes: items of the diagonal pair (bi, bi): they carry b_p and B Dinv b_l
@@ -199,22 +127,20 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     constexpr int kRecFly = 4;
     double2 rv[kRecFly][4];
     const double2 *rec0 = reinterpret_cast<const double2 *>(w.rec_d + (size_t)bi * w.rec_slots * 48 + ba * 8);
-    if (!late_wait) {
 #pragma unroll
-        for (int u = 0; u < kRecFly; ++u) {
-            const double2 *src = rec0 + (size_t)min(u, w.rec_slots - 1) * 24;
+    for (int u = 0; u < kRecFly; ++u) {
+        const double2 *src = rec0 + (size_t)min(u, w.rec_slots - 1) * 24;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rv[u][q] = src[q];
-        }
+        for (int q = 0; q < 4; ++q) rv[u][q] = src[q];
     }
     double Bo[2][36];
-    if (!OVERFLOW && !late_wait) {
+    if (!OVERFLOW) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int q = 0; q < 36; ++q) Bo[k][q] = w.img_b[(size_t)(36 * k + q) * kT + tid];
     }
-    if (solver && !XS && done_w) return;
+    if (solver && done_w) return;
     SETUP_STAMP(6);
     const int npad = (n + 1) & ~1;
     const int nrowent_all = rp_nf;
@@ -309,20 +235,6 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // ---- diagonal blocks and right-hand side, cooperatively: owner lane (bi, ba) sums ROW ba of S_ii = Hpp + lambda I -
     // sum B Dinv B^T, b_p and B Dinv b_l over the work items of pair (bi, bi), four items in flight: the cost does not
     // grow with the number of items a long diagonal pair is cut into ----
-    // ---- two streams: everything above came from this stream's own kernels and from the upload; from here on the schur pass ----
-    if (late_wait) {
-        const int wt = xs_wait_items<kT>(w, epoch, reinterpret_cast<int *>(red0));
-        if (wt == 1) return;
-        if (wt == 2) { if (tid == 0) hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsFailed << 24)); return; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        cur = hx_ld_i32(&c->cur); lambda = hx_ld_f64(&c->lambda);
-#pragma unroll
-        for (int u = 0; u < kRecFly; ++u) {
-            const double2 *src = rec0 + (size_t)min(u, w.rec_slots - 1) * 24;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rv[u][q] = src[q];
-        }
-    }
     // ---- diagonal blocks and right-hand side: owner lane (bi, ba) sums ROW ba of S_ii = Hpp - sum B Dinv B^T (+ lambda), of
     // B Dinv b_l and of b_p over the work items of pair (bi, bi).  The schur pass leaves every diagonal item once more in the
     // layout THIS loop reads (DevWindow::rec_d: per item and row 8 contiguous doubles = the row of Hpp - B Dinv B^T, then
@@ -437,9 +349,6 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     SETUP_STAMP(0);
     // (a keyframe's diagonal block is read by a lane of the wave that owns its rows: no workgroup barrier between the two)
     wave_lds_sync0();
-#ifdef MOVBA_CLOCK_STAMP
-    const unsigned long long xs_t1 = __builtin_amdgcn_s_memrealtime();
-#endif
 
     // ---- this lane's pair of oriented blocks.  Off-diagonal ones: the schur pass leaves the block of a pair that is ONE work
     // item (almost all are) in both orientations where this kernel's lanes read it - DevWindow::img_b, element q of the block
@@ -454,13 +363,8 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         if (valid) colo[k] = pl.y & 0x3fffffff;
         const bool diag = valid && pl.x < nf, from_img = !OVERFLOW && valid && pl.x >= nf && pl.w - pl.z == 1;
         if (!OVERFLOW) {
-            // (every lane reads its image slot - the loads are coalesced whatever the lanes need; a slot nothing wrote is not used;
-            //  on one stream they were requested at the top of the kernel)
-            if (late_wait) {
-                const double *src = w.img_b + (size_t)(36 * k) * kT + tid;
-#pragma unroll
-                for (int q = 0; q < 36; ++q) Bo[k][q] = src[(size_t)q * kT];
-            }
+            // (every lane read its image slot at the top of the kernel - the loads are coalesced whatever the lanes need; a slot
+            //  nothing wrote is not used)
 #pragma unroll
             for (int q = 0; q < 36; ++q) Bo[k][q] = from_img ? -Bo[k][q] : 0.0;
         } else {
@@ -594,7 +498,6 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
 
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, seg_last = __builtin_amdgcn_s_memtime();
-    const unsigned long long xs_t2 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (!fail) {
         for (iters = 1; iters <= pp.max_iters; ++iters) {
@@ -746,35 +649,26 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         h0 = w.hidx[tid];
     }
     __syncthreads();
-#ifdef MOVBA_CLOCK_STAMP
-    const unsigned long long xs_t3 = __builtin_amdgcn_s_memrealtime();
-#endif
     // ---- no answer from the PCG (a diagonal block was not positive definite, the recurrence broke down, or the cap was
     // reached before the tolerance: a weakly constrained window, where an iterative solve departs from the exact step
     // anyway): park the solve (Ctrl::done = 2 turns every kernel queued behind into a no-op) and tell the host, which
     // queues the direct solver (dense_solve.hip) for this trial and for every later one.  fail / capped are workgroup-uniform.
     if (fail || capped) {
         if (tid == 0) {
-            // (write-through: the back-substitution pass of this trial may already be resident on the other stream, and the
-            //  passes queued behind it must find the solve parked)
             const int np = c->n_pause + 1;
-            hx_st_i32(&c->pcg_last_iters, iters);
-            hx_st_i32(&c->pcg_total_iters, c->pcg_total_iters + iters);
-            hx_st_i32(&c->solver_mode, 1); hx_st_i32(&c->direct_from, XS ? hx_ld_i32(&c->n_solves) : c->n_solves);
-            hx_st_i32(&c->n_pause, np);
-            hx_st_i32(&c->done, 2);
-            if (XS) { hx_drain(); hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsParked << 24)); }
+            c->pcg_last_iters = iters;
+            c->pcg_total_iters += iters;
+            c->solver_mode = 1; c->direct_from = c->n_solves;
+            c->n_pause = np;
+            c->done = 2;
             __hip_atomic_store(&w.hstat->pause_seq, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
 
     // ---- outputs: increment, pose part of computeScale(), trial poses (VertexSE3Expmap::oplusImpl) ----
-    // (two streams: everything the back-substitution pass reads leaves write-through, handoff.h: the pass may be resident already)
-    auto stq = [&](double *p, double v) { if (XS) hx_st_f64(p, v); else *p = v; };
-    auto sti = [&](int *p, int v) { if (XS) hx_st_i32(p, v); else *p = v; };
     const double xv = owner ? x_r : 0.0;
-    if (owner) { stq(w.xp + row, xv); p_lds[row] = xv; }
+    if (owner) { w.xp[row] = xv; p_lds[row] = xv; }
     {
         const double ps = wave_sum_dpp(owner ? xv * (lambda * xv + w.bp[row]) : 0.0);
         if (ln == 0) red0[wv] = ps;
@@ -800,19 +694,19 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         double R[9];
         quat_to_R(Tn, R);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) stq(S1.pose + 7 * i + k, Tn[k]);
+        for (int k = 0; k < 7; ++k) S1.pose[7 * i + k] = Tn[k];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) stq(S1.Rt + 12 * i + k, R[k]);
-        stq(S1.Rt + 12 * i + 9, Tn[4]); stq(S1.Rt + 12 * i + 10, Tn[5]); stq(S1.Rt + 12 * i + 11, Tn[6]);
+        for (int k = 0; k < 9; ++k) S1.Rt[12 * i + k] = R[k];
+        S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
     }
 #ifdef MOVBA_CLOCK_STAMP
     if (ln == 0) for (int k = 0; k < 8; ++k) c->dbg_wseg[wv][k] += seg[k];
 #endif
     if (tid == 0) {
-        stq(w.scale_part + w.n_pt_blocks, scs);
-        sti(&c->pcg_fail, 0);
-        sti(&c->pcg_last_iters, iters);
-        sti(&c->pcg_total_iters, c->pcg_total_iters + iters);
+        w.scale_part[w.n_pt_blocks] = scs;
+        c->pcg_fail = 0;
+        c->pcg_last_iters = iters;
+        c->pcg_total_iters += iters;
 #ifdef MOVBA_CLOCK_STAMP
         c->dbg_cycles += __builtin_amdgcn_s_memtime() - stamp_c0;
         c->dbg_ticks += __builtin_amdgcn_s_memrealtime() - stamp_t0;
@@ -820,29 +714,10 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         (void)setup_last;
 #endif
     }
-    // every storing wave drains, the workgroup meets, ONE lane raises the word the back-substitution pass waits for - once the
-    // coarse-level workgroup has read this trial's partials (long ago: the next schur pass, which overwrites them, starts
-    // behind that pass)
-    if (!XS) return;
-    hx_drain();
-    __syncthreads();
-    if (tid == 0) {
-        if (pp.use_coarse == 1) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (hx_ld_u32(w.xs + kXsCoarseRead) != epoch && __builtin_amdgcn_s_memrealtime() - t0 <= w.wait_ticks) __builtin_amdgcn_s_sleep(4);
-        }
-        hx_st_u32(w.xs + kXsPcgDone, epoch | (kXsOk << 24));
-#ifdef MOVBA_CLOCK_STAMP
-        if (XS) {
-            const unsigned long long xs_t4 = __builtin_amdgcn_s_memrealtime(), last = hx_ld_u32(w.xs) * 0ull + __hip_atomic_load(&c->dbg_xs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            c->dbg_xs[1] += xs_t1 - last; c->dbg_xs[2] += xs_t2 - last; c->dbg_xs[3] += xs_t3 - last; c->dbg_xs[4] += xs_t4 - last; c->dbg_xs[5] += 1;
-        }
-#endif
-    }
 }
 
-template <bool OVERFLOW, bool XS, bool PADDED>
-__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW, XS, PADDED>(w, pp, trial, blockIdx.x); }
+template <bool OVERFLOW, bool PADDED>
+__global__ __launch_bounds__(kT) void k_pcg_rows(DevWindow w, PcgParams pp, int trial) { pcg_rows_body<OVERFLOW, PADDED>(w, pp, trial, blockIdx.x); }
 
 // batched: workgroups 2 i and 2 i + 1 are the solver and the coarse builder of window i (a window in fresh-coarse mode
 // has no builder: its second workgroup returns at once)
@@ -853,24 +728,19 @@ __global__ __launch_bounds__(kT) void k_pcg_rows_b(BatchDev b, int trial)
     const PcgParams &pp = b.pps[wi];
     if (b.band_bw && b.band_bw[wi] >= 0) return;           // (this window's reduced solve is k_band_b's)
     if (role == 1 && pp.use_coarse != 1) return;
-    pcg_rows_body<OVERFLOW, false, PADDED>(b.wins[wi], pp, trial, role);
+    pcg_rows_body<OVERFLOW, PADDED>(b.wins[wi], pp, trial, role);
 }
 
 static_assert(kNW == kPcgPlanWaves && kNC == kCoarseDim && kOwnBatch == kPcgPlanOwnBatch, "pcg_plan.cpp sizes the LDS carve of this kernel");
 
-hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, bool xs, hipStream_t s)
+hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s)
 {
     const dim3 g(pp.use_coarse == 1 ? 2 : 1), t(kT);
     const bool padded = pp.padded && !pp.overflow;
     const size_t lds = pcg_rows_lds_bytes(w.nfree, nrowent, padded);
-    if (pp.overflow) {
-        if (xs) return hipErrorInvalidValue;        // (api.cpp keeps such windows on one stream)
-        hipLaunchKernelGGL((k_pcg_rows<true, false, false>), g, t, lds, s, w, pp, trial);
-    } else if (xs) {
-        if (padded) hipLaunchKernelGGL((k_pcg_rows<false, true, true>), g, t, lds, s, w, pp, trial);
-        else hipLaunchKernelGGL((k_pcg_rows<false, true, false>), g, t, lds, s, w, pp, trial);
-    } else if (padded) hipLaunchKernelGGL((k_pcg_rows<false, false, true>), g, t, lds, s, w, pp, trial);
-    else hipLaunchKernelGGL((k_pcg_rows<false, false, false>), g, t, lds, s, w, pp, trial);
+    if (pp.overflow) hipLaunchKernelGGL((k_pcg_rows<true, false>), g, t, lds, s, w, pp, trial);
+    else if (padded) hipLaunchKernelGGL((k_pcg_rows<false, true>), g, t, lds, s, w, pp, trial);
+    else hipLaunchKernelGGL((k_pcg_rows<false, false>), g, t, lds, s, w, pp, trial);
     return hipGetLastError();
 }
 
@@ -885,9 +755,8 @@ hipError_t launch_pcg_rows_batch(const BatchDev &b, bool overflow, bool padded, 
 
 hipError_t configure_pcg_rows()
 {
-    const void *fs[8] = { reinterpret_cast<const void *>(k_pcg_rows<false, false, false>), reinterpret_cast<const void *>(k_pcg_rows<false, false, true>),
-                          reinterpret_cast<const void *>(k_pcg_rows<true, false, false>),
-                          reinterpret_cast<const void *>(k_pcg_rows<false, true, false>), reinterpret_cast<const void *>(k_pcg_rows<false, true, true>),
+    const void *fs[6] = { reinterpret_cast<const void *>(k_pcg_rows<false, false>), reinterpret_cast<const void *>(k_pcg_rows<false, true>),
+                          reinterpret_cast<const void *>(k_pcg_rows<true, false>),
                           reinterpret_cast<const void *>(k_pcg_rows_b<false, false>), reinterpret_cast<const void *>(k_pcg_rows_b<false, true>),
                           reinterpret_cast<const void *>(k_pcg_rows_b<true, false>) };
     for (const void *f : fs) {

@@ -14,6 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MOVBA_LIB selects another build of the same library (diagnostic builds, e.g. -DMOVBA_CLOCK_STAMP)
 LIB_PATH = os.environ.get("MOVBA_LIB") or os.path.join(os.path.dirname(_HERE), "libmovba.so")
+# the TEST build of the same sources (-DMOVBA_TEST_HOOKS: per-handle switches through movba_test_hook; tests only)
+HOOKS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmovba_hooks.so")
 
 MAX_TRACE = 128
 NKERNELS = 6
@@ -54,7 +56,7 @@ class LbaResult(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("pcg_rel_tol", C.c_double), ("pcg_max_iters", C.c_int32), ("run_ahead", C.c_int32),
-                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32), ("reorder", C.c_int32), ("two_streams", C.c_int32)]
+                ("profile", C.c_int32), ("pcg_coarse", C.c_int32), ("host_wait", C.c_int32), ("pcg_spill", C.c_int32), ("solver", C.c_int32), ("reorder", C.c_int32), ("pad_o", C.c_int32)]
 
 
 class Profile(C.Structure):
@@ -90,7 +92,7 @@ EXPORTS = ["movba_version", "movba_status_string", "movba_create", "movba_destro
            "movba_structure_probe", "movba_pose_opt", "movba_set_profile_mask", "movba_lba_run_batch", "movba_pose_ransac_samples",
            "movba_host_alloc", "movba_host_free", "movba_dense_plan_probe"]
 
-_lib = None
+_libs = {False: None, True: None}
 
 
 def _one_hip_runtime():
@@ -111,15 +113,17 @@ def _one_hip_runtime():
             C.CDLL(p, mode=C.RTLD_GLOBAL)
 
 
-def lib():
-    """Load libmovba.so; raise loudly when the HIP extension has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise MovbaError(f"{LIB_PATH} not found: build it with `make -C mov-slam_amd/csrc` "
+def lib(hooks: bool = False):
+    """Load libmovba.so (hooks: the test build, libmovba_hooks.so); raise loudly when the HIP extension has not been built."""
+    if _libs[hooks] is None:
+        path = HOOKS_LIB_PATH if hooks else LIB_PATH
+        if not os.path.exists(path):
+            raise MovbaError(f"{path} not found: build it with `make -C mov-slam_amd/csrc` "
                              "(or __graft_entry__.build()); there is no CPU fallback")
         _one_hip_runtime()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
+        if hooks:
+            L.movba_test_hook.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
         L.movba_status_string.restype = C.c_char_p
         L.movba_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(Options)]
         L.movba_destroy.argtypes = [C.c_void_p]
@@ -144,8 +148,8 @@ def lib():
         L.movba_dense_plan_probe.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i, _i, C.c_int32, _i, C.c_int32]
         L.movba_host_free.argtypes = [C.c_void_p]
         L.movba_host_free.restype = None
-        _lib = L
-    return _lib
+        _libs[hooks] = L
+    return _libs[hooks]
 
 
 def status_string(s: int) -> str:
@@ -229,7 +233,7 @@ def ransac_samples(n: int, n_hyp: int, seed: int) -> np.ndarray:
 def run_batch(solvers) -> int:
     """movba_lba_run_batch over the resident windows of `solvers` (created on one stream); download each as usual."""
     arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
-    rc = lib().movba_lba_run_batch(arr, len(solvers))
+    rc = solvers[0]._L.movba_lba_run_batch(arr, len(solvers))
     if rc < 0:
         raise MovbaError(f"movba_lba_run_batch: {status_string(rc)}")
     return rc
@@ -240,24 +244,35 @@ class Solver:
 
     def __init__(self, device: int = 0, stream: int | None = None, pcg_rel_tol: float = 0.0,
                  pcg_max_iters: int = 0, run_ahead: int = 0, profile=False, pcg_coarse: bool = True, host_wait: int = 0,
-                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True, two_streams: bool = False, solver: int | None = None):
+                 pcg_spill: bool = False, direct: bool = False, reorder: bool = True, solver: int | None = None, hooks: bool = False):
         self._h = C.c_void_p()
+        self._L = lib(hooks)                # (hooks: the test build, whose handles take movba_test_hook)
+        self._hooks = hooks
         self._pinned_blocks = []
-        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, (int(solver) if solver is not None else (1 if direct else 0)), 0 if reorder else -1, 1 if two_streams else 0)
-        rc = lib().movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
+        opt = Options(pcg_rel_tol, pcg_max_iters, run_ahead, (0x3f if profile is True else int(profile)), 0 if pcg_coarse else -1, host_wait, 1 if pcg_spill else 0, (int(solver) if solver is not None else (1 if direct else 0)), 0 if reorder else -1, 0)
+        rc = self._L.movba_create(C.byref(self._h), device, C.c_void_p(stream) if stream else None, C.byref(opt))
         if rc != OK:
             self._h = C.c_void_p()
             raise MovbaError(f"movba_create failed: {status_string(rc)} (no CPU fallback)")
         self._keep = None
 
+    def hook(self, name: str, value: int):
+        """movba_test_hook (test build only: Solver(hooks=True)): host_structure, entries_unpacked, no_sorted_structure,
+        pcg_packed, helper_delay_us, wait_ticks, band_park_trial, device_cus"""
+        if not self._hooks:
+            raise MovbaError("test hooks exist in libmovba_hooks.so only: Solver(hooks=True)")
+        rc = self._L.movba_test_hook(self._h, name.encode(), int(value))
+        if rc != OK:
+            raise MovbaError(f"movba_test_hook({name}): {status_string(rc)}")
+
     def close(self):
         if self._h:
-            lib().movba_destroy(self._h)
+            self._L.movba_destroy(self._h)
             self._h = C.c_void_p()
         if getattr(self, "_pinned_blocks", None):
             self._prep = None
             for p in self._pinned_blocks:
-                lib().movba_host_free(p)
+                self._L.movba_host_free(p)
             self._pinned_blocks = []
 
     def __del__(self):
@@ -270,7 +285,7 @@ class Solver:
     def _pinned(self, shape):
         """float64 array in movba_host_alloc memory (released by close())"""
         n = int(np.prod(shape))
-        p = lib().movba_host_alloc(max(8 * n, 8))
+        p = self._L.movba_host_alloc(max(8 * n, 8))
         if not p:
             raise MovbaError("movba_host_alloc failed")
         self._pinned_blocks.append(p)
@@ -304,7 +319,7 @@ class Solver:
     def solve(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0) -> dict:
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
         r, out = self._alloc_result(d)
-        rc = lib().movba_lba_solve(self._h, C.byref(d), C.byref(r))
+        rc = self._L.movba_lba_solve(self._h, C.byref(d), C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_lba_solve: {status_string(rc)}")
         self._keep = (d, keep)             # (download() may be called again on the solved window)
@@ -323,7 +338,7 @@ class Solver:
     def solve_prepared(self, pack=True):
         """movba_lba_solve on the prepared buffers; pack=False returns only the status (results stay in the buffers)."""
         d, keep, r, out = self._prep
-        rc = lib().movba_lba_solve(self._h, C.byref(d), C.byref(r))
+        rc = self._L.movba_lba_solve(self._h, C.byref(d), C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_lba_solve: {status_string(rc)}")
         if not pack:
@@ -334,14 +349,14 @@ class Solver:
 
     def upload(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
-        rc = lib().movba_lba_upload(self._h, C.byref(d))
+        rc = self._L.movba_lba_upload(self._h, C.byref(d))
         if rc < 0:
             raise MovbaError(f"movba_lba_upload: {status_string(rc)}")
         self._keep = (d, keep)
         return rc
 
     def run(self) -> int:
-        rc = lib().movba_lba_run(self._h)
+        rc = self._L.movba_lba_run(self._h)
         if rc < 0:
             raise MovbaError(f"movba_lba_run: {status_string(rc)}")
         return rc
@@ -349,7 +364,7 @@ class Solver:
     def download(self) -> dict:
         d, keep = self._keep
         r, out = self._alloc_result(d)
-        rc = lib().movba_lba_download(self._h, C.byref(r))
+        rc = self._L.movba_lba_download(self._h, C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_lba_download: {status_string(rc)}")
         if rc != OK:
@@ -357,27 +372,27 @@ class Solver:
         return self._pack(r, out, rc)
 
     def export_poses_device(self, dst_ptr: int, nbytes: int):
-        rc = lib().movba_lba_export_poses_device(self._h, C.c_void_p(dst_ptr), nbytes)
+        rc = self._L.movba_lba_export_poses_device(self._h, C.c_void_p(dst_ptr), nbytes)
         if rc != OK:
             raise MovbaError(f"movba_lba_export_poses_device: {status_string(rc)}")
 
     def set_pose_export(self, dst_ptr: int, nbytes: int):
         """Register a device buffer that every later run() leaves the optimised poses in (0 unregisters)."""
-        rc = lib().movba_lba_set_pose_export(self._h, C.c_void_p(dst_ptr) if dst_ptr else None, nbytes)
+        rc = self._L.movba_lba_set_pose_export(self._h, C.c_void_p(dst_ptr) if dst_ptr else None, nbytes)
         if rc != OK:
             raise MovbaError(f"movba_lba_set_pose_export: {status_string(rc)}")
 
     def profile(self) -> dict:
         p = Profile()
-        lib().movba_get_profile(self._h, C.byref(p))
+        self._L.movba_get_profile(self._h, C.byref(p))
         return dict(kernels={p.name[k].decode(): dict(ms=p.ms[k], launches=p.launches[k]) for k in range(NKERNELS)},
                     upload_ms=p.upload_ms, structure_ms=p.structure_ms, download_ms=p.download_ms)
 
     def reset_profile(self):
-        lib().movba_reset_profile(self._h)
+        self._L.movba_reset_profile(self._h)
 
     def set_profile_mask(self, mask: int):
-        lib().movba_set_profile_mask(self._h, mask)
+        self._L.movba_set_profile_mask(self._h, mask)
 
     def pose_opt(self, Xw, obs, pose0, cam, huber_delta, chi2_gate, rounds=4, its=10, inv_sigma2=None, ransac_iters=0, ransac_seed=1,
                  confidence=0.0, lo_iters=0) -> dict:
@@ -395,7 +410,7 @@ class Solver:
         d.confidence, d.lo_iters = confidence, lo_iters
         outl = np.zeros(n, np.uint8); chi2 = np.zeros(n)
         r = PoseResult(); r.outlier = _p(outl, _u); r.chi2 = _p(chi2, _d)
-        rc = lib().movba_pose_opt(self._h, C.byref(d), C.byref(r))
+        rc = self._L.movba_pose_opt(self._h, C.byref(d), C.byref(r))
         if rc < 0:
             raise MovbaError(f"movba_pose_opt: {status_string(rc)}")
         return dict(status=rc, n_inliers=r.n_inliers, pose=np.array(r.pose[:]), outlier=outl, chi2=chi2,

@@ -151,13 +151,8 @@ hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t
 
 // ---- the LM controller's protocol ----
 namespace {
-// (Ctrl::done is the one word both streams of a two-stream solve may touch at the same moment - the solve parks itself while
-//  the back-substitution pass of its trial is starting - as on the device, where the pass then learns it from the solve's word)
 int rd_done(const Ctrl *c) { return __atomic_load_n(&c->done, __ATOMIC_ACQUIRE); }
 void wr_done(Ctrl *c, int v) { __atomic_store_n(&c->done, v, __ATOMIC_RELEASE); }
-// the hand-off words of the two streams (DevWindow::xs), as the kernels use them
-unsigned xs_rd(const DevWindow &w, int k) { return __atomic_load_n(w.xs + k, __ATOMIC_ACQUIRE); }
-void xs_wr(const DevWindow &w, int k, unsigned v) { __atomic_store_n(w.xs + k, v, __ATOMIC_RELEASE); }
 
 void fake_init(const DevWindow &w)
 {
@@ -170,7 +165,6 @@ void fake_init(const DevWindow &w)
     std::memcpy(w.st[0].pose, w.pose0, 56 * (size_t)w.NP);
     std::memcpy(w.st[0].point, w.point0, 24 * (size_t)w.P);
     std::memset(w.dec_rec, 0, sizeof(unsigned) * 8 * (size_t)w.n_pt_blocks);
-    for (int k = 0; k < kXsItem0 + w.nitems; ++k) xs_wr(w, k, 0u);
     Ctrl *c = w.ctrl;
     std::memset(c, 0, sizeof(Ctrl));
     c->nu = 2.0; wr_done(c, (w.max_iters <= 0) ? 1 : 0); c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
@@ -187,47 +181,36 @@ void fake_decide(const DevWindow &w)
     if (fin) __atomic_store_n(&c->done, 1, __ATOMIC_RELEASE);
     __atomic_store_n(&w.hstat->progress, HostStatus::pack(c->n_solves, c->it, fin), __ATOMIC_RELEASE);
 }
-void fake_schur(const DevWindow &w, int trial)
+void fake_schur(const DevWindow &w)
 {
     g_sink += (w.ent64 ? (long)w.ent64[0] : (long)w.ent_i[0]) + w.slot_point[0];
-    if (rd_done(w.ctrl)) { if (trial >= 0) xs_wr(w, kXsSkip, (unsigned)trial + 1u); return; }
-    if (trial >= 0) for (int i = 0; i < w.nitems; ++i) xs_wr(w, kXsItem0 + i, (unsigned)trial + 1u);
 }
 
-void fake_pcg(const DevWindow &w, int trial, bool xs)
+// a reduced solve that hands the solve over in the trial the driver asked for: the PCG that gives up, the banded factorisation
+// that meets a non-positive pivot
+bool fake_park(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
-    const unsigned epoch = (unsigned)trial + 1u;
-    if (!xs) { if (rd_done(c)) return; }
-    else {
-        for (;;) {              // every item of the trial's schur pass, or the pass's no-op word
-            if (xs_rd(w, kXsSkip) >= epoch) return;
-            bool ok = true;
-            for (int i = 0; i < w.nitems && ok; ++i) ok = xs_rd(w, kXsItem0 + i) == epoch;
-            if (ok) break;
-            std::this_thread::yield();
-        }
-    }
     if (g_park_trial.load() >= 0 && c->n_solves >= g_park_trial.load() && c->solver_mode == 0) {
         c->solver_mode = 1; c->direct_from = c->n_solves; c->n_pause += 1; wr_done(c, 2);
-        xs_wr(w, kXsPcgDone, epoch | (kXsParked << 24));
         __atomic_store_n(&w.hstat->pause_seq, c->n_pause, __ATOMIC_RELEASE);
-        return;
+        return true;
     }
+    return false;
+}
+void fake_pcg(const DevWindow &w)
+{
+    Ctrl *c = w.ctrl;
+    if (rd_done(c)) return;
+    if (fake_park(w)) return;
     c->pcg_last_iters = 7; c->pcg_total_iters += 7;
-    xs_wr(w, kXsPcgDone, epoch | (kXsOk << 24));
 }
 
-// the back-substitution pass and, in its last workgroup, the LM decision; wait_epoch: the solve of that epoch runs on another stream
-void fake_backsub(const DevWindow &w, unsigned wait_epoch)
+// the back-substitution pass and, in its last workgroup, the LM decision
+void fake_backsub(const DevWindow &w)
 {
     if (rd_done(w.ctrl)) return;
     g_sink += w.dec_rec[0];
-    if (wait_epoch) {
-        unsigned v;
-        while (((v = xs_rd(w, kXsPcgDone)) & kXsEpochMask) != wait_epoch) std::this_thread::yield();
-        if ((v >> 24) != kXsOk) return;
-    }
     fake_decide(w);
 }
 // What the one-launch direct solver (dense_persist.hip) indexes with values the HOST built - the item-range table prange read
@@ -296,13 +279,12 @@ void fake_finalize(const DevWindow &w)
 }
 }  // namespace
 
-hipError_t launch_stream_warmup(hipStream_t) { return hipSuccess; }
 hipError_t launch_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_init(w); }); return hipSuccess; }
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += rd_done(w.ctrl); }); return hipSuccess; }
-hipError_t launch_schur(const DevWindow &w, int mode, int trial, hipStream_t s) { fake_enqueue(s, [w, mode, trial] { fake_schur(w, mode == 1 ? -1 : trial); }); return hipSuccess; }
+hipError_t launch_schur(const DevWindow &w, int, hipStream_t s) { fake_enqueue(s, [w] { fake_schur(w); }); return hipSuccess; }
 hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->lambda = 1e-3; }); return hipSuccess; }
 // (the back-substitution pass takes the LM decision in its last workgroup: one launch)
-hipError_t launch_backsub(const DevWindow &w, unsigned wait_epoch, hipStream_t s) { fake_enqueue(s, [w, wait_epoch] { fake_backsub(w, wait_epoch); }); return hipSuccess; }
+hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_backsub(w); }); return hipSuccess; }
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_finalize(w); }); return hipSuccess; }
 hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
 {
@@ -314,7 +296,7 @@ hipError_t launch_export(const DevWindow &w, const ExportDst &d, hipStream_t s)
     });
     return hipSuccess;
 }
-hipError_t launch_pcg_rows(const DevWindow &w, int, const PcgParams &, int trial, bool xs, hipStream_t s) { fake_enqueue(s, [w, trial, xs] { fake_pcg(w, trial, xs); }); return hipSuccess; }
+hipError_t launch_pcg_rows(const DevWindow &w, int, const PcgParams &, int, hipStream_t s) { fake_enqueue(s, [w] { fake_pcg(w); }); return hipSuccess; }
 hipError_t launch_dense_solve(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_direct(w); }); return hipSuccess; }
 hipError_t launch_dense_persist(const DevWindow &w, unsigned, hipStream_t s) { fake_enqueue(s, [w] { fake_direct(w); }); return hipSuccess; }
 
@@ -322,18 +304,18 @@ hipError_t launch_dense_persist(const DevWindow &w, unsigned, hipStream_t s) { f
 hipError_t launch_init_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_init(b.wins[i]); }); return hipSuccess; }
 hipError_t launch_point_batch(const BatchDev &b, int, bool backsub, bool, bool, size_t, hipStream_t s)
 {
-    fake_enqueue(s, [b, backsub] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_point[i]; if (backsub) fake_backsub(b.wins[i], 0u); } });
+    fake_enqueue(s, [b, backsub] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_point[i]; if (backsub) fake_backsub(b.wins[i]); } });
     return hipSuccess;
 }
-hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_schur[i]; fake_schur(b.wins[i], -1); } }); return hipSuccess; }
+hipError_t launch_schur_batch(const BatchDev &b, int, int, bool, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { g_sink += b.blk_schur[i]; fake_schur(b.wins[i]); } }); return hipSuccess; }
 hipError_t launch_lambda_init_batch(const BatchDev &b, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) b.wins[i].ctrl->lambda = 1e-3; }); return hipSuccess; }
 hipError_t launch_finalize_batch(const BatchDev &b, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) fake_finalize(b.wins[i]); }); return hipSuccess; }
 // the banded factorisation: an exact solve in one launch - nothing parks, nothing waits
-static void fake_band(const DevWindow &w) { Ctrl *c = w.ctrl; if (rd_done(c)) return; c->pcg_last_iters = -2; c->n_band += 1; }
+static void fake_band(const DevWindow &w) { Ctrl *c = w.ctrl; if (rd_done(c)) return; if (fake_park(w)) return; c->pcg_last_iters = -2; c->n_band += 1; }
 hipError_t launch_band(const DevWindow &w, int, hipStream_t s) { fake_enqueue(s, [w] { fake_band(w); }); return hipSuccess; }
 hipError_t launch_band_batch(const BatchDev &b, size_t, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) if (b.band_bw[i] >= 0) fake_band(b.wins[i]); }); return hipSuccess; }
 hipError_t configure_band() { return hipSuccess; }
-hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { if (b.band_bw && b.band_bw[i] >= 0) continue; g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i], 0, false); } }); return hipSuccess; }
+hipError_t launch_pcg_rows_batch(const BatchDev &b, bool, bool, size_t, int, hipStream_t s) { fake_enqueue(s, [b] { for (int i = 0; i < b.n; ++i) { if (b.band_bw && b.band_bw[i] >= 0) continue; g_sink += b.pps[i].max_iters; fake_pcg(b.wins[i]); } }); return hipSuccess; }
 
 // ---- pose-only optimisation: echoes the start pose, every match an inlier ----
 hipError_t launch_pose_hyp(const PoseDev &p, hipStream_t s) { fake_enqueue(s, [p] { g_sink += sum_bytes(p.Xw, 24 * (size_t)p.n) + sum_bytes(p.samples, 12 * (size_t)p.n_hyp); }); return hipSuccess; }

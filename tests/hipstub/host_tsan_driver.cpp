@@ -195,30 +195,24 @@ int main()
         std::thread a(worker, 300u), b(worker, 700u);
         a.join(); b.join();
     }
-    // ---- 7. the two-stream LM loop (movba_options::two_streams): the PCG launches on a stream of the handle's own, the passes of
-    //         a trial handing over through the words of DevWindow::xs; a park in trial 3 (the solve's word says so, the passes
-    //         queued behind leave through their schur pass's no-op word), the stop flag, two runs of one upload ----
+    // ---- 7. a banded factorisation that meets a non-positive pivot in trial 3: the solve parks, the host queues the dense direct
+    //         solver for that trial and stays with it; the next window is solved by k_band again ----
     {
         movba_options opt{};
-        opt.two_streams = 1;
+        opt.solver = 2;
         movba_handle *h = nullptr;
         EXPECT(movba_create(&h, 0, nullptr, &opt) == MOVBA_OK);
         Win w;
-        for (int it = 0; it < 6; ++it) {
-            make(w, 10 + 4 * it, 2, 500 + 300 * it, 500 + it, false, it % 2 == 1);
-            check_solved(w, movba_lba_solve(h, &w.d, &w.r));
-            EXPECT(w.r.n_direct == 0 && w.r.n_sync_timeouts == 0);
-        }
+        make(w, 14, 2, 900, 77, false, false);
+        fake_set_mode(3, -1);
+        check_solved(w, movba_lba_solve(h, &w.d, &w.r));
+        EXPECT(w.r.n_pcg_giveups == 1 && w.r.direct_from == 3 && w.r.n_direct == 7 && w.r.n_band == 3);
+        fake_set_mode(-1, -1);
+        check_solved(w, movba_lba_solve(h, &w.d, &w.r));
+        EXPECT(w.r.n_pcg_giveups == 0 && w.r.n_direct == 0 && w.r.n_band == w.r.n_solves);
         EXPECT(movba_lba_upload(h, &w.d) == MOVBA_OK);
         EXPECT(movba_lba_run(h) == MOVBA_OK && movba_lba_run(h) == MOVBA_OK);
         check_solved(w, movba_lba_download(h, &w.r));
-        fake_set_mode(3, -1);
-        make(w, 14, 2, 900, 77, false, false);
-        check_solved(w, movba_lba_solve(h, &w.d, &w.r));
-        EXPECT(w.r.n_pcg_giveups == 1 && w.r.direct_from == 3 && w.r.n_direct == 7);
-        fake_set_mode(-1, -1);
-        check_solved(w, movba_lba_solve(h, &w.d, &w.r));
-        EXPECT(w.r.n_pcg_giveups == 0 && w.r.n_direct == 0);
         movba_destroy(h);
     }
     // ---- 8. the banded factorisation in one workgroup (small windows by default, any window whose band fits on request): one

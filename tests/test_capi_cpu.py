@@ -18,8 +18,27 @@ def test_library_exports_every_symbol_declared_in_header(built_lib):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(built_lib.EXPORTS) == declared
-    assert lib.movba_version() == 4
+    assert lib.movba_version() == 5
+    # the product library has no test hooks; the test build of the same sources has the same C-ABI plus movba_test_hook
+    assert not hasattr(lib, "movba_test_hook")
+    hooks = built_lib.lib(hooks=True)
+    for name in declared:
+        assert hasattr(hooks, name), name
+    assert hasattr(hooks, "movba_test_hook") and hooks.movba_version() == 5
     assert built_lib.status_string(0) == "ok" and built_lib.status_string(-2) == "HIP runtime error"
+
+
+def test_product_library_reads_only_its_documented_process_switches(built_lib):
+    """Every environment variable the product library knows is one of the diagnostic switches api.cpp documents, read once per
+    process; nothing a test switches lives in it (those are hooks of libmovba_hooks.so)."""
+    blob = open(built_lib.LIB_PATH, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"MOVBA_[A-Z_0-9]{3,}", blob))
+    allowed = {"MOVBA_WATCHDOG_MS", "MOVBA_TIME_UPLOAD", "MOVBA_TIME_SOLVE", "MOVBA_DENSE_STAMPS", "MOVBA_DENSE_MULTILAUNCH", "MOVBA_BAND", "MOVBA_BATCH_GROUPS"}
+    assert names <= allowed, names - allowed
+    for hook in (b"band_park_trial", b"helper_delay_us", b"host_structure", b"movba_test_hook"):
+        assert hook not in blob and hook in open(built_lib.HOOKS_LIB_PATH, "rb").read()
+    src = open(os.path.join(ROOT, "mov-slam_amd", "csrc", "api.cpp")).read()
+    assert src.count("std::getenv(") == len(allowed)          # all of them inside process_switches()
 
 
 def test_ctypes_struct_sizes_match_header_layout(built_lib):

@@ -281,11 +281,10 @@ def test_stereo_edges(solver, oracle_mod, frac):
 
 
 @pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged", "150kf", "descending-150kf", "400kf"])
-def test_device_structure_pass_equals_host_structure_pass(solver, name):
+def test_device_structure_pass_equals_host_structure_pass(solver, built_lib, name):
     """The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip up to 80 free keyframes, the sort-based
-    pass of struct_sort.hip beyond: "150kf", "400kf"); MOVBA_HOST_STRUCTURE=1 forces the host builder.  Same lists in the
-    same order => bit-identical solves."""
-    import os
+    pass of struct_sort.hip beyond: "150kf", "400kf"); the test build's hook `host_structure` forces the host builder.  Same
+    lists in the same order => bit-identical solves (the product library against the test build of the same sources)."""
     if name in ("150kf", "descending-150kf", "400kf"):
         w = synth.make_window(400, 8, 12000, 9, run_lo=2, run_hi=12) if name == "400kf" else synth.make_window(150, 6, 6000, 9, run_lo=2, run_hi=10)
         w.max_iters = 3
@@ -302,11 +301,12 @@ def test_device_structure_pass_equals_host_structure_pass(solver, name):
     else:
         w = synth.cfg(name)
     a = solver.solve(w)
-    os.environ["MOVBA_HOST_STRUCTURE"] = "1"
+    hs = built_lib.Solver(hooks=True)
     try:
-        b = solver.solve(w)
+        hs.hook("host_structure", 1)
+        b = hs.solve(w)
     finally:
-        del os.environ["MOVBA_HOST_STRUCTURE"]
+        hs.close()
     for k in ("poses", "points", "chi2", "outlier"):
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(a["trace"]["pcg"], b["trace"]["pcg"])
@@ -878,11 +878,11 @@ def test_two_threads_two_handles_like_local_mapping_and_tracking(built_lib):
 
 
 @pytest.mark.parametrize("case", ["stereo", "mono", "regrow", "ungrouped"])
-def test_a_late_helper_thread_changes_nothing(built_lib, case, monkeypatch):
+def test_a_late_helper_thread_changes_nothing(built_lib, case):
     """The upload's helper thread (staging copies of the caller's arrays and their transfer) started 3 ms late: everything the
     calling thread takes from it must be behind a wait — a stereo window (layout depends on the stereo flag), an upload
     that reallocates the arena, edges that are permuted after the helper's straight copies."""
-    s = built_lib.Solver()
+    s = built_lib.Solver(hooks=True)
     try:
         if case == "stereo":
             w = synth.make_window(12, 3, 1500, seed=262210, run_lo=4, run_hi=9, stereo_frac=0.5)
@@ -897,7 +897,7 @@ def test_a_late_helper_thread_changes_nothing(built_lib, case, monkeypatch):
         ref_solver = built_lib.Solver()
         ref = ref_solver.solve(w)
         ref_solver.close()
-        monkeypatch.setenv("MOVBA_HELPER_DELAY_US", "3000")
+        s.hook("helper_delay_us", 3000)
         r = s.solve(w)
         for k in ("poses", "points", "chi2", "outlier"):
             np.testing.assert_array_equal(r[k], ref[k])
@@ -926,16 +926,15 @@ def test_results_the_caller_does_not_ask_for_are_not_transferred(built_lib):
 
 
 @pytest.mark.parametrize("host_structure", [False, True])
-def test_packed_and_unpacked_schur_entries_give_the_same_bits(built_lib, monkeypatch, host_structure):
+def test_packed_and_unpacked_schur_entries_give_the_same_bits(built_lib, host_structure):
     """Off-diagonal schur entries travel as one 64-bit word (22 + 22 bits of slots, 20 of map point) when the window allows,
     else as three int32 arrays: same results either way, from the device's structure pass and from the host's."""
     w = synth.cfg("cfg2")
-    if host_structure:
-        monkeypatch.setenv("MOVBA_HOST_STRUCTURE", "1")
-    s = built_lib.Solver()
+    s = built_lib.Solver(hooks=True)
     try:
+        if host_structure: s.hook("host_structure", 1)
         a = s.solve(w)
-        monkeypatch.setenv("MOVBA_ENTRIES_UNPACKED", "1")
+        s.hook("entries_unpacked", 1)
         b = s.solve(w)
         for k in ("poses", "points", "chi2", "outlier"):
             np.testing.assert_array_equal(a[k], b[k])
@@ -1024,35 +1023,23 @@ def test_two_handles_on_the_one_launch_direct_solver_at_once(built_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cus", [64, 20, 4])
-def test_one_launch_direct_solver_planned_for_a_device_with_fewer_compute_units(built_lib, oracle_mod, tmp_path, cus):
+def test_one_launch_direct_solver_planned_for_a_device_with_fewer_compute_units(built_lib, oracle_mod, cus):
     """Every workgroup of the one-launch direct solver must be resident while it runs, so its schedule is built for the
-    compute units the device reports (a CPX partition of an MI355X shows 32): MOVBA_TEST_DEVICE_CUS makes a handle plan for
-    fewer than the box has.  Where the tiles of a window still fit the fewer workgroups' LDS slots (cfg3's 28 tiles on 62 or 19
-    workgroups) the solve stays one launch; where they do not (a 150-keyframe window's 190 tiles on 19 workgroups) or the device
-    is too small (4 compute units) the library goes launch by launch (dense_solve.hip).  Either way the oracle's result.
-    Child process: the variable is read when a handle is made."""
-    import subprocess, sys, os
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "from movba import capi, synth\n"
-        "s = capi.Solver(direct=True)\n"
-        "out = {}\n"
-        "for name, w in (('cfg3', synth.cfg('cfg3')), ('kf150', synth.make_window(150, 6, 3000, 77, run_lo=2, run_hi=9))):\n"
-        "    r = s.solve(w)\n"
-        "    out[name + '_poses'] = r['poses']; out[name + '_points'] = r['points']; out[name + '_nd'] = np.array([r['n_direct'], r['n_sync_timeouts'], r['status']])\n"
-        "np.savez(sys.argv[1], **out)\n" % os.path.join(ROOT, "mov-slam_amd"))
-    dump = str(tmp_path / "fewcus.npz")
-    p = subprocess.run([sys.executable, "-c", code, dump], env=dict(os.environ, MOVBA_TEST_DEVICE_CUS=str(cus)), capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stderr[-2000:]
-    got = np.load(dump)
-    for name, w in (("cfg3", synth.cfg("cfg3")), ("kf150", synth.make_window(150, 6, 3000, 77, run_lo=2, run_hi=9))):
-        o = oracle_mod.solve(w)
-        nd = got[name + "_nd"]
-        assert nd[0] > 0 and nd[1] == 0 and nd[2] == 0, nd
-        assert quat_angle(got[name + "_poses"][:, :4], o["poses"][:, :4]).max() < 1e-8
-        assert np.abs(got[name + "_poses"][:, 4:] - o["poses"][:, 4:]).max() < 1e-8
-        assert np.abs(got[name + "_points"] - o["points"]).max() < 1e-6
+    compute units the device reports (a CPX partition of an MI355X shows 32): the test build's hook `device_cus` makes a handle
+    plan for fewer than the box has.  Where the tiles of a window still fit the fewer workgroups' LDS slots (cfg3's 28 tiles on
+    62 or 19 workgroups) the solve stays one launch; where they do not (a 150-keyframe window's 190 tiles on 19 workgroups) or
+    the device is too small (4 compute units) the library goes launch by launch (dense_solve.hip).  Either way the oracle's result."""
+    s = built_lib.Solver(direct=True, hooks=True)
+    try:
+        s.hook("device_cus", cus)
+        for w in (synth.cfg("cfg3"), synth.make_window(150, 6, 3000, 77, run_lo=2, run_hi=9)):
+            r, o = s.solve(w), oracle_mod.solve(w)
+            assert r["n_direct"] > 0 and r["n_sync_timeouts"] == 0 and r["status"] == 0
+            assert quat_angle(r["poses"][:, :4], o["poses"][:, :4]).max() < 1e-8
+            assert np.abs(r["poses"][:, 4:] - o["poses"][:, 4:]).max() < 1e-8
+            assert np.abs(r["points"] - o["points"]).max() < 1e-6
+    finally:
+        s.close()
 
 
 @pytest.mark.gpu
@@ -1130,87 +1117,90 @@ def test_banded_factorisation_on_the_windows_the_sweep_found(built_lib, solver, 
 
 
 @pytest.mark.gpu
-def test_padded_and_packed_pair_sums_of_the_pcg_give_the_same_bits(built_lib, solver, tmp_path):
+def test_padded_and_packed_pair_sums_of_the_pcg_give_the_same_bits(built_lib):
     """k_pcg_rows keeps the mat-vec's pair sums by row in zero-padded slots when no block row has more than ten entry pairs
     (PcgParams::padded: cfg3 and everything smaller), packed pair by pair otherwise; a batch runs the packed layout unless all
     its windows are padded.  Same values, same order of additions: the bits must not depend on the layout.  The packed layout
-    is forced in a child process (MOVBA_PCG_PACKED is read once per process)."""
-    import subprocess, sys, os
-    from conftest import ROOT
-    code = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "from movba import capi, synth\n"
-        "s = capi.Solver()\n"
-        "out = {}\n"
-        "for name in ('small', 'cfg2', 'cfg3'):\n"
-        "    r = s.solve(synth.cfg(name))\n"
-        "    out[name + '_poses'] = r['poses']; out[name + '_points'] = r['points']; out[name + '_chi2'] = r['chi2']; out[name + '_pcg'] = r['trace']['pcg']\n"
-        "np.savez(sys.argv[1], **out)\n" % os.path.join(ROOT, "mov-slam_amd"))
-    dump = str(tmp_path / "packed.npz")
-    p = subprocess.run([sys.executable, "-c", code, dump], env=dict(os.environ, MOVBA_PCG_PACKED="1", MOVBA_BAND="0"), capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0, p.stderr[-2000:]
-    packed = np.load(dump)
+    is forced through the test build's hook `pcg_packed`."""
+    packed = built_lib.Solver(solver=3, hooks=True)
     pcg = built_lib.Solver(solver=3)
-    for name in ("small", "cfg2", "cfg3"):
-        r = pcg.solve(synth.cfg(name))
-        assert r["n_direct"] == 0 and r["n_band"] == 0
-        for k in ("poses", "points", "chi2"):
-            assert np.array_equal(r[k], packed[name + "_" + k]), (name, k)
-        assert np.array_equal(r["trace"]["pcg"], packed[name + "_pcg"])
-    pcg.close()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "revisit"])
-def test_two_stream_lm_loop_gives_the_bits_of_the_one_stream_loop(built_lib, solver, oracle_mod, name):
-    """movba_options::two_streams: the PCG launches of a solve on a stream of the handle's own, resident beside the schur pass of
-    their trial, the passes handing over through flags in device memory (DevWindow::xs).  Same kernels' arithmetic, so the same
-    bits as the one-stream loop, run after run; held to the oracle like every other path."""
-    if name == "stereo":
-        w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5)
-    else:
-        w = synth.cfg(name) if name != "revisit" else synth.pattern_cfg(name)
-    two = built_lib.Solver(two_streams=True)
-    one = built_lib.Solver(solver=3)                 # (the one-stream loop on the same reduced solver: the PCG)
     try:
-        r1 = one.solve(w)
-        r2 = two.solve(w)
-        assert r2["status"] == 0 and r2["n_sync_timeouts"] == 0 and r2["n_direct"] == r1["n_direct"]
-        for k in ("poses", "points", "chi2", "outlier"):
-            assert np.array_equal(r1[k], r2[k]), k
-        assert np.array_equal(r1["trace"]["pcg"], r2["trace"]["pcg"])
-        r3 = two.solve(w)
-        assert np.array_equal(r2["poses"], r3["poses"]) and np.array_equal(r2["chi2"], r3["chi2"])
-        check_against(r2, oracle_mod.solve(w), w, noise_guard=True)
+        packed.hook("pcg_packed", 1)
+        for name in ("small", "cfg2", "cfg3"):
+            w = synth.cfg(name)
+            r, q = pcg.solve(w), packed.solve(w)
+            assert r["n_direct"] == 0 and r["n_band"] == 0 and q["n_direct"] == 0 and q["n_band"] == 0
+            for k in ("poses", "points", "chi2"):
+                assert np.array_equal(r[k], q[k]), (name, k)
+            assert np.array_equal(r["trace"]["pcg"], q["trace"]["pcg"])
     finally:
-        two.close(); one.close()
+        pcg.close(); packed.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["two_streams", "direct"])
-def test_a_given_up_wait_inside_a_launch_reruns_the_solve_on_the_paths_without_waits(built_lib, solver, oracle_mod, mode, monkeypatch):
-    """Kernels that wait for other workgroups inside a launch (the two-stream loop's passes, the one-launch direct solver) bound
-    every wait; a solve in which one was given up is run again from the uploaded state on one stream, the direct solver launch
-    by launch, and the caller gets the result with movba_lba_result::n_sync_timeouts saying that it happened - not an error and
-    no skipped local BA (the reference never skips a solve for such a reason, src/Optimizer.cc:535).  MOVBA_TEST_WAIT_TICKS=0
-    makes the first attempt's waits give up at their first unsuccessful look."""
+def test_a_given_up_wait_inside_a_launch_reruns_the_solve_on_the_path_without_waits(built_lib, oracle_mod):
+    """The one-launch direct solver's workgroups wait for one another inside the launch and bound every wait; a solve in which
+    one was given up is run again from the uploaded state with the direct solver launch by launch, and the caller gets the
+    result with movba_lba_result::n_sync_timeouts saying that it happened - not an error and no skipped local BA (the reference
+    never skips a solve for such a reason, src/Optimizer.cc:535).  The test build's hook wait_ticks = 0 makes the first
+    attempt's waits give up at their first unsuccessful look."""
     w = synth.cfg("cfg2")
-    s = built_lib.Solver(two_streams=True) if mode == "two_streams" else built_lib.Solver(direct=True)
+    s = built_lib.Solver(direct=True, hooks=True)
     try:
         ref = s.solve(w)
         assert ref["status"] == 0 and ref["n_sync_timeouts"] == 0
-        monkeypatch.setenv("MOVBA_TEST_WAIT_TICKS", "0")
+        s.hook("wait_ticks", 0)
         r = s.solve(w)
-        monkeypatch.delenv("MOVBA_TEST_WAIT_TICKS")
+        s.hook("wait_ticks", -1)
         assert r["status"] == 0 and r["n_sync_timeouts"] > 0
         o = oracle_mod.solve(w)
         check_against(r, o, w, noise_guard=True)
-        if mode == "direct":
-            assert r["n_direct"] == r["n_solves"]
+        assert r["n_direct"] == r["n_solves"]
         again = s.solve(w)
         assert again["n_sync_timeouts"] == 0 and np.array_equal(again["poses"], ref["poses"])
     finally:
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trial", [0, 3])
+def test_banded_factorisation_that_meets_a_non_positive_pivot_hands_the_solve_to_the_dense_solver(built_lib, oracle_mod, trial):
+    """S is positive definite in exact arithmetic, so a finite non-positive pivot in k_band is rounding in a window that is
+    singular but for the LM damping: the factorisation parks the solve - as a PCG that gives up does - and the dense direct
+    solver answers that trial and every later one (it decides whether the trial fails as a failed Cholesky does in g2o).  No
+    window of the randomised sweep gets there any more, so the test build's hook `band_park_trial` makes the factorisation of
+    one trial behave as if it had: solo, and in a batch beside windows that stay on k_band and on the PCG, where the parked window
+    leaves the batch and is finished on its own - same bits as its solo run."""
+    w = synth.cfg("cfg2")
+    o = oracle_mod.solve(w)
+    s = built_lib.Solver(hooks=True)
+    try:
+        s.hook("band_park_trial", trial)
+        r = s.solve(w)
+        assert r["status"] == 0 and r["n_pcg_giveups"] == 1 and r["n_band"] == trial and r["n_direct"] == r["n_solves"] - trial
+        assert r["direct_from"] == trial and (r["trace"]["pcg"][:trial] == -2).all() and (r["trace"]["pcg"][trial:] == -1).all()
+        check_against(r, o, w, noise_guard=True)
+        r2 = s.solve(w)
+        assert np.array_equal(r["poses"], r2["poses"]) and np.array_equal(r["points"], r2["points"])
+    finally:
+        s.close()
+    # in a batch: the parked window, a window that stays on k_band, a window of the PCG
+    st, stream = _shared_stream_solvers(built_lib, 3, hooks=True)
+    ws = [w, synth.cfg("small"), synth.cfg("cfg3")]
+    try:
+        stream[0].hook("band_park_trial", trial)
+        solo = [sv.solve(x) for sv, x in zip(stream, ws)]
+        for sv, x in zip(stream, ws): sv.upload(x)
+        built_lib.run_batch(stream)
+        got = [sv.download() for sv in stream]
+        assert got[0]["n_pcg_giveups"] == 1 and got[0]["n_direct"] > 0 and got[0]["n_band"] == trial
+        assert got[1]["n_band"] == got[1]["n_solves"] and got[2]["n_band"] == 0 and got[2]["n_direct"] == 0
+        for g, q in zip(got, solo):
+            for k in ("poses", "points", "chi2", "outlier"):
+                assert np.array_equal(g[k], q[k]), k
+        assert np.array_equal(got[0]["poses"], r["poses"])
+    finally:
+        for sv in stream: sv.close()
 
 
 def _two_pose_frame(seed=5):
