@@ -15,6 +15,10 @@ extern "C" void movba_adapter_last_timing(double out[3]);
 extern "C" int movba_adapter_last_status(void);
 extern "C" long movba_adapter_error_count(void);
 
+// KeyFrame's keypoints, right coordinates and baseline are const members in the reference (KeyFrame.h:315-324), filled by its
+// constructors and, when a keyframe is deserialised, through const_cast (KeyFrame.h:68-88): the test map is filled the same way
+template <typename T> static T &fill(const T &x) { return const_cast<T &>(x); }
+
 template <typename T> static std::vector<T> rd(FILE *f, size_t n)
 {
     std::vector<T> v(n);
@@ -58,7 +62,7 @@ static int run_lba(const char *in, const char *out, bool global)
     std::vector<MapPoint> mps(P);
     for (int i = 0; i < NP; ++i) {
         KeyFrame &k = kfs[i];
-        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = cams.empty() ? &cam : &cams[i]; k.mbf = (float)(bf_kf.empty() ? bf : bf_kf[i]);
+        k.mnId = 100 + i; k.mpMap = &map; k.mpCamera = cams.empty() ? &cam : &cams[i]; fill(k.mbf) = (float)(bf_kf.empty() ? bf : bf_kf[i]);
         k.mTcw = Sophus::SE3f(Eigen::Quaternionf((float)poses[7 * i + 3], (float)poses[7 * i], (float)poses[7 * i + 1], (float)poses[7 * i + 2]),
                               Eigen::Vector3f((float)poses[7 * i + 4], (float)poses[7 * i + 5], (float)poses[7 * i + 6]));
         map.mvKFs.push_back(&k);
@@ -73,7 +77,7 @@ static int run_lba(const char *in, const char *out, bool global)
         KeyFrame &k = kfs[ep[e]];
         cv::KeyPoint kp; kp.pt.x = (float)obs[2 * e]; kp.pt.y = (float)obs[2 * e + 1]; kp.octave = 0;
         const int idx = (int)k.mvKeysUn.size();
-        k.mvKeysUn.push_back(kp); k.mvuRight.push_back(obs_right.empty() ? -1.f : (float)obs_right[e]); k.mvpMapPoints.push_back(&mps[el[e]]);
+        fill(k.mvKeysUn).push_back(kp); fill(k.mvuRight).push_back(obs_right.empty() ? -1.f : (float)obs_right[e]); k.mvpMapPoints.push_back(&mps[el[e]]);
         mps[el[e]].AddObservation(&k, idx);               // (nObs as MapPoint.cc:139-169 counts it: a stereo observation twice)
         if (!mps[el[e]].mpRefKF) mps[el[e]].mpRefKF = &k;           // the keyframe that created the point
     }

@@ -28,7 +28,7 @@ public:
     const int NLeft = -1, NRight = -1;                       // KeyFrame.h:452 (no fisheye rig in this fork)
     const int mnScaleLevels = 8;                             // KeyFrame.h:335
     const std::vector<float> mvScaleFactors = std::vector<float>{1.f, 1.2f, 1.44f, 1.728f, 2.0736f, 2.48832f, 2.985984f, 3.5831808f};
-    std::vector<cv::KeyPoint> mvKeys, mvKeysRight;
+    const std::vector<cv::KeyPoint> mvKeys, mvKeysRight;     // KeyFrame.h:322, :450 (const: the test plumbing fills them as the reference's deserialiser does, through const_cast)
     int nCenterReads = 0;
     std::vector<KeyFrame *> GetVectorCovisibleKeyFrames() { std::unique_lock<std::mutex> lock(mMutexConnections); return mvCovisible; }
     std::vector<MapPoint *> GetMapPointMatches() { std::unique_lock<std::mutex> lock(mMutexFeatures); return mvpMapPoints; }
@@ -44,10 +44,10 @@ public:
     Map *GetMap() { std::unique_lock<std::mutex> lock(mMutexMap); return mpMap; }
     long unsigned int mnId = 0, mnBALocalForKF = ~0ul, mnBAFixedForKF = ~0ul, mnBAGlobalForKF = 0;
     Sophus::SE3f mTcwGBA;
-    std::vector<cv::KeyPoint> mvKeysUn;
-    std::vector<float> mvuRight;
-    float mbf = 0.f;
-    std::vector<float> mvInvLevelSigma2 = std::vector<float>(8, 1.0f);
+    const std::vector<cv::KeyPoint> mvKeysUn;
+    const std::vector<float> mvuRight;
+    const float mbf = 0.f;
+    const std::vector<float> mvInvLevelSigma2 = std::vector<float>(8, 1.0f);
     GeometricCamera *mpCamera = nullptr, *mpCamera2 = nullptr;
     std::mutex mMutexPose, mMutexConnections, mMutexFeatures, mMutexMap;
     // test plumbing
