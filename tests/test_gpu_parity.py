@@ -27,13 +27,13 @@ def noise_floor_trial(o):
     return int(k[0]) if len(k) else len(f0)
 
 
-def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_guard=False):
+def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_guard=False, lam_rtol=1e-7):
     assert r["status"] == o["status"] == 0
     k0 = noise_floor_trial(o) if noise_guard else len(o["trace"]["accept"])
     if k0 == len(o["trace"]["accept"]):
         assert r["n_solves"] == o["n_solves"] and r["iters_done"] == o["iters_done"]
     assert np.array_equal(r["trace"]["accept"][:k0], o["trace"]["accept"][:k0])
-    np.testing.assert_allclose(r["trace"]["lam"][:k0], o["trace"]["lam"][:k0], rtol=1e-7)
+    np.testing.assert_allclose(r["trace"]["lam"][:k0], o["trace"]["lam"][:k0], rtol=lam_rtol)
     np.testing.assert_allclose(r["trace"]["f1"][:k0], o["trace"]["f1"][:k0], rtol=1e-6 if noise_guard else 1e-8)
     assert quat_angle(r["poses"][:, :4], o["poses"][:, :4]).max() < rot
     assert np.abs(r["poses"][:, 4:] - o["poses"][:, 4:]).max() < trans
@@ -1105,7 +1105,9 @@ def test_banded_factorisation_on_the_windows_the_sweep_found(built_lib, solver, 
     try:
         r, o = s.solve(w), oracle_mod.solve(w)
         tol, usual, noise = _sweep_tolerances(w, oracle_mod)
-        check_against(r, o, w, noise_guard=True, **tol)
+        # (lambda follows rho = (F0 - F1) / scale: where the oracle's own poses move by more than the usual tolerance from one edge
+        #  order to the next, so does its lambda trace - 1.0e-7 relative was seen against the usual 1e-7)
+        check_against(r, o, w, noise_guard=True, lam_rtol=1e-7 if 3 * noise[1] <= usual["trans"] else 1e-5, **tol)
         if which == "banded" and r["n_band"] > 0:
             assert r["n_pcg_giveups"] == 0 and r["n_direct"] == 0 and r["n_band"] == r["n_solves"]
         # a window the oracle reproduces to the usual tolerance is held to it
