@@ -139,6 +139,7 @@ static const ProcessSwitches &process_switches()
 
 struct TestHooks {
     int host_structure = 0;         // structure pass on the host even where the device would build it
+    int host_grouping = 0;          // grouping pass (build_basic) on the calling thread even where the device would run it
     int entries_unpacked = 0;       // 12-byte schur entries where the 8-byte packed form would do
     int no_sorted_structure = 0;    // beyond the pair-bin masks: host structure pass instead of the sort-based device pass
     int pcg_packed = 0;             // packed layout of the PCG's pair sums where the padded one would do
@@ -165,6 +166,8 @@ struct movba_handle {
 #ifdef MOVBA_TEST_HOOKS
     TestHooks hooks;                    // (test build only: movba_test_hook)
 #endif
+    bool early_setup = false;           // the upload has queued k_init_pose and the first linearisation itself (behind the edge data, in
+                                        // the shadow of its own pair layout): the next run starts with the Hpp pass
     int sync_retries = 0;               // > 0: this run's first attempt gave up that many in-launch waits and was repeated on the paths without any
     hipEvent_t edgeb_event = nullptr;   // the derived edge arrays sent early on the copy stream have arrived
     uint64_t count_seq = 0;             // uploads that went through the device structure pass (what the host polls for in the counts buffer)
@@ -416,6 +419,7 @@ int movba_test_hook(movba_handle *h, const char *name, long long value)
     if (!h || !name) return MOVBA_ERR_ARG;
     const std::string n(name);
     if (n == "host_structure") h->hooks.host_structure = (int)value;
+    else if (n == "host_grouping") h->hooks.host_grouping = (int)value;
     else if (n == "entries_unpacked") h->hooks.entries_unpacked = (int)value;
     else if (n == "no_sorted_structure") h->hooks.no_sorted_structure = (int)value;
     else if (n == "pcg_packed") h->hooks.pcg_packed = (int)value;
@@ -669,6 +673,16 @@ struct Upload {
     uint64_t arena_gen_at_edge_copy = 0;
     bool edge_b_early = false, edge_b_stale = false, edge_b_queued = false;
     double upload_host_ms = 0.0;
+    // --- grouping pass on the device (group_on_device) ---
+    int nf_expect = 0;                  // non-fixed keyframes: the free keyframes of the window unless one of them has no edge
+    bool raw_synced = false;
+    bool direct_raw = false;            // the caller's big arrays lie in movba_host_alloc memory: they cross the bus from where they are
+    const int32_t *view_pose = nullptr, *view_point = nullptr;     // device views of the caller's index arrays when those are pinned
+    bool dev_first = false;             // validation, point ranges, hessian indices and slots are the device's work: no pass over the edges here
+    BasicDev bd{};
+    size_t so_cnt = 0, so_err = 0, so_ent0 = 0, so_cntw = 0, so_pe = 0, so_info = 0, so_H = 0;
+    volatile int32_t *misc_seq = nullptr;
+    int32_t seq = 0;
     // --- structure ---
     StructDev sd{};
     bool dev_structure = false, ent_packed = false, filled_early = false;
@@ -695,7 +709,8 @@ struct Upload {
 
     Upload(movba_handle *h_, const movba_lba_desc *d_) : h(h_), d(d_), NP(d_->n_poses), P(d_->n_points), E(d_->n_edges) {}
     // (every way out waits for the helper first: it reads the caller's arrays and writes to this object)
-    ~Upload() { h->packer.wait(); }
+    // (... and in direct mode the copy engine reads the caller's own arrays: through with them before the caller has them back)
+    ~Upload() { h->packer.wait(); if (direct_raw && !raw_synced) (void)hipStreamSynchronize(h->copy_stream); }
 
     const Structure &s() const { return h->st; }
     void lap(const char *what)
@@ -714,11 +729,18 @@ struct Upload {
         return MOVBA_OK;
     }
 
-    int run();
+    int run(bool allow_dev_first);
     // phases, in the order run() takes them
     int begin();                        // arguments, edge layout, buffers, streams drained
     void post_helper();                 // the caller's arrays: staging buffer + copy stream, on the helper thread
     int group();                        // build_basic (grouping / validation); the early ways out
+    bool dev_first_eligible() const;
+    int group_on_device();              // ... the same on the device, behind the index arrays' way into the staging buffer
+    void carve_state();                 // device-only arrays whose size follows from the caller's counts alone
+    bool state_carved = false;
+    int carve_scratch(bool basic);
+    int launch_counts();
+    int after_counts();
     int pack_derived();                 // derived edge arrays into the staging buffer
     int send_edge_a();                  // what the device structure pass reads -> stream; the rest early -> copy stream
     int structure_on_host();
@@ -743,7 +765,7 @@ struct Upload {
 int Upload::begin()
 {
     HIP_TRY(hipSetDevice(h->device));
-    h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK;
+    h->uploaded = false; h->ran = false; h->early_status = MOVBA_OK; h->early_setup = false;
     t0 = lap_t = now_ms();
     lap_on = process_switches().time_upload;
     // ---- edge region of the arena, laid out from the caller's counts alone so that the helper thread can start copying the
@@ -770,7 +792,7 @@ int Upload::begin()
     L.max_end = c.off;
     // (the device structure passes hand the pair counts back through the tail of the staging buffer: up to kSortedMaxPoses keyframes)
     const size_t nf_dev = (size_t)(NP <= kSortedMaxPoses ? NP : 80);
-    misc_bytes = (nf_dev * nf_dev + 8) * sizeof(int32_t) * 2 + 4096;
+    misc_bytes = (nf_dev * nf_dev + 8) * sizeof(int32_t) * 2 + 4096 + sizeof(int32_t) * ((size_t)std::min(NP, 1024) + kBasicInfo + 8);
     int rc = ensure_stage(h, L.max_end + misc_bytes); if (rc) return rc;
     // first sizing of the arena: room for the states and pair lists too, so that it is not reallocated a moment later
     if (L.max_end > h->arena_cap) { rc = ensure_arena(h, 10 * L.max_end); if (rc) return rc; }
@@ -799,12 +821,41 @@ void Upload::post_helper()
     const movba_lba_desc *const dd = d;
     const int np = NP, p = P, e = E;
     HelperHandOff *const out = &ho;
+    const bool idx_direct = view_pose && view_point, raw_direct = direct_raw;
     h->packer.post([=]() {
         if (helper_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(helper_delay_us));
-        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_a otherwise)
-        std::memcpy(stage + lay.gpose, dd->edge_pose, sizeof(int32_t) * (size_t)e);
-        std::memcpy(stage + lay.gpoint, dd->edge_point, sizeof(int32_t) * (size_t)e);
+        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_a otherwise; not needed
+        //  at all when the device reads the caller's own pinned arrays)
+        if (!idx_direct) {
+            std::memcpy(stage + lay.gpose, dd->edge_pose, sizeof(int32_t) * (size_t)e);
+            std::memcpy(stage + lay.gpoint, dd->edge_point, sizeof(int32_t) * (size_t)e);
+        }
         out->idx_ready.store(1, std::memory_order_release);
+        if (raw_direct) {
+            // the caller's arrays are pinned: DMA straight out of them, nothing staged (the call does not return before the
+            // copies have left them: send_pairs)
+            hipError_t err = hipSetDevice(hh->device);
+            auto dma = [&](size_t to, const void *from, size_t bytes) {
+                if (err == hipSuccess && bytes) err = hipMemcpyAsync(out->arena + to, from, bytes, hipMemcpyHostToDevice, hh->copy_stream);
+            };
+            dma(lay.obs, dd->obs, sizeof(double) * 2 * (size_t)e);
+            dma(lay.isig, dd->inv_sigma2, sizeof(double) * (size_t)e);
+            if (dd->obs_right) dma(lay.obsr, dd->obs_right, sizeof(double) * (size_t)e);
+            dma(lay.pose0, dd->poses, sizeof(double) * 7 * (size_t)np);
+            dma(lay.point0, dd->points, sizeof(double) * 3 * (size_t)p);
+            if (lay.has_kcam) {
+                double *kc = reinterpret_cast<double *>(stage + lay.kcam);
+                for (int i = 0; i < np; ++i) {
+                    const double *ck = dd->cam_kf ? dd->cam_kf + 4 * (size_t)i : &dd->fx;
+                    kc[8 * i] = ck[0]; kc[8 * i + 1] = ck[1]; kc[8 * i + 2] = ck[2]; kc[8 * i + 3] = ck[3];
+                    kc[8 * i + 4] = dd->bf_kf ? dd->bf_kf[i] : dd->bf; kc[8 * i + 5] = kc[8 * i + 6] = kc[8 * i + 7] = 0.0;
+                }
+                dma(lay.kcam, stage + lay.kcam, sizeof(double) * 8 * (size_t)np);
+            }
+            if (err == hipSuccess) err = hipEventRecord(hh->copy_event, hh->copy_stream);
+            out->copy_err = err;
+            return;
+        }
         // ... each part straight on to the device on the copy stream while the next one is being staged: most of the upload
         // is across the bus before the calling thread has finished its pass over the edges (the solve's first kernels wait
         // for copy_event, nothing else does)
@@ -860,6 +911,105 @@ int Upload::group()
     nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
     edge_bytes = s().already_grouped ? L.grouped_end : L.max_end;
     nbins = nf * nf;
+    return MOVBA_OK;
+}
+
+// States, per-edge records, cost partials, controller, results: sizes from NP, P, E (and the free keyframes' number) alone, so
+// that a device grouping pass can carve them BEFORE the pair structure exists and start the solve's first kernels on them.
+// (pose-major arrays are sized for E edges of free keyframes, their upper bound)
+void Upload::carve_state()
+{
+    for (int b = 0; b < 2; ++b) {
+        o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
+        o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
+        o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);       // erecA
+        o_st[b][6] = 0;  o_st[b][7] = 0;
+        o_st[b][8] = c.take<double>(nb);
+        o_st[b][9] = 0;
+        o_st[b][10] = 0;
+    }
+    o_obspm = c.take<double>(2 * (size_t)E + 2); o_obsrpm = c.take<double>(stereo ? (size_t)E + 1 : 1);
+    o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
+    o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
+    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(8 * (size_t)nb + 8);
+    o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
+    state_carved = true;
+}
+
+// The grouping pass on the device: wanted where the device also builds the pair structure through its pair-bin masks (up to 80
+// free keyframes: every window MoV-SLAM's local mapping produces) and where the host can tell from the keyframes' flags
+// alone how many free keyframes there are.
+bool Upload::dev_first_eligible() const
+{
+    if (HOOK(h, host_structure) || HOOK(h, host_grouping)) return false;
+    if (E <= 0 || P <= 0 || NP <= 0 || NP > 1024) return false;
+    int nfix = 0;
+    for (int i = 0; i < NP; ++i) nfix += d->pose_fixed[i] != 0;
+    const int nfm = NP - nfix;
+    return nfix > 0 && nfm > 0 && nfm <= 80 && struct_lds_fits(nfm, NP);
+}
+
+// What build_basic derives in one pass over the caller's edges on this thread (0.11 ms at cfg3, a tenth of the whole call, with
+// the device idle but for the copies) is the device's work here: it validates the index arrays, finds the points' ranges,
+// counts the edges per keyframe, numbers the free keyframes and ranks every edge among its keyframe's edges (k_basic_hist,
+// k_basic_index), then counts the pair bins as before; this thread waits ONCE, for the pair counts and the edges per keyframe
+// together, and rebuilds its own small tables (hessian indices, free poses, first slots) from the latter.  A window the pass
+// cannot take as it is - edges not grouped by point, a free keyframe nobody observes - is handed back to the host pass.
+constexpr int kRetryClassic = 1 << 20;
+int Upload::group_on_device()
+{
+    Structure &st = h->st;
+    reset_structure(st, NP, P, E);
+    st.no_reorder = h->opt.reorder == -1;
+    for (nf_expect = 0, nf = 0; nf < NP; ++nf) nf_expect += d->pose_fixed[nf] == 0;
+    nf = nf_expect; nbins = nf * nf;
+    nb = (P + kPointsPerBlock - 1) / kPointsPerBlock;
+    edge_bytes = L.grouped_end;
+    carve_state();
+    int rc = carve_scratch(true); if (rc) return rc;
+    char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;
+    // The device reads the caller's index arrays and the keyframes' flags out of HOST memory (the staging buffer is mapped,
+    // movba_host_alloc blocks are): no copy commands, k_basic_hist leaves the index arrays in the arena as it reads them.
+    // (the flags travel through the place of the hessian indices, which the device makes itself here)
+    std::memcpy(sg + L.hidx, d->pose_fixed, (size_t)NP);
+    HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_info + sizeof(int32_t) * kBasicInfo - so_cnt, h->stream));    // bin totals, error word, edges per keyframe, info words
+    bd = BasicDev{};
+    bd.E = E; bd.P = P; bd.NP = NP; bd.nblk = (E + kBasicBlock - 1) / kBasicBlock;
+    if (view_pose && view_point) { bd.src_pose = view_pose; bd.src_point = view_point; }
+    else {
+        // (the helper thread's copy of them in the staging buffer: its first piece of work)
+        while (ho.idx_ready.load(std::memory_order_acquire) == 0) host_relax(h->opt.host_wait);
+        bd.src_pose = reinterpret_cast<const int32_t *>(h->stage_dev + L.gpose); bd.src_point = reinterpret_cast<const int32_t *>(h->stage_dev + L.gpoint);
+    }
+    arena_gen_at_edge_copy = ho.arena_gen;
+    bd.edge_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); bd.edge_point = reinterpret_cast<int32_t *>(h->arena + L.gpoint);
+    bd.pose_fixed = reinterpret_cast<const uint8_t *>(h->stage_dev + L.hidx);
+    bd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart); bd.rank = reinterpret_cast<int32_t *>(h->arena + L.slot);
+    bd.H = reinterpret_cast<int32_t *>(sa + so_H); bd.pose_edges = reinterpret_cast<int32_t *>(sa + so_pe);
+    bd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx); bd.base = reinterpret_cast<int32_t *>(h->arena + L.base);
+    bd.free_pose = reinterpret_cast<int32_t *>(h->arena + L.free_pose); bd.info = reinterpret_cast<int32_t *>(sa + so_info);
+    HIP_TRY(launch_basic(bd, h->stream));
+    rc = launch_counts(); if (rc) return rc;
+    HIP_TRY(launch_basic_scan(bd, h->stream));      // (what the slots need: behind the counts the host waits for)
+    lap("index H2D + grouping + count launches");
+    {
+        const double t_wait = now_ms();
+        while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
+            host_relax(h->opt.host_wait);
+            if (now_ms() - t_wait > 10000.0) { HIP_TRY(hipStreamSynchronize(h->stream)); if (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) return MOVBA_ERR_HIP; }
+        }
+    }
+    const int32_t *info = reinterpret_cast<const int32_t *>(misc) + nbins + 2, *pe = info + kBasicInfo;
+    if (info[0]) { (void)join_helper(); (void)hipStreamSynchronize(h->copy_stream); return MOVBA_ERR_ARG; }      // an index out of range
+    if (info[1] || info[2] != nf_expect) return kRetryClassic;
+    st.pose_edges.assign(pe, pe + NP); st.pose_edges.push_back(0);
+    index_poses(d->pose_fixed, st);
+    if (st.nfree != nf_expect || st.E_free != info[3]) return MOVBA_ERR_HIP;      // (the device and this thread number the same keyframes)
+    st.already_grouped = true; st.perm.clear(); st.gp = d->edge_pose; st.gl = d->edge_point;
+    st.pt_start.clear();        // (the points' ranges exist on the device only)
+    rank_mode = true;
+    h->stop = d->stop;
+    lap("wait for the grouping pass and the pair counts");
     return MOVBA_OK;
 }
 
@@ -936,6 +1086,7 @@ int Upload::send_edge_a()
 
 int Upload::queue_edge_b()
 {
+    if (dev_first) { edge_b_queued = true; return MOVBA_OK; }       // (point ids, ranks, first slots: all made on the device)
     if (edge_b_early) HIP_TRY(hipStreamWaitEvent(h->stream, h->edgeb_event, 0));
     if (!edge_b_early || edge_b_stale) {
         // (not sent yet, or packed again since: host-built slots instead of ranks)
@@ -978,7 +1129,8 @@ int Upload::launch_slotpt()
 {
     HIP_TRY(launch_slot_point(reinterpret_cast<int32_t *>(h->arena + L.slot), reinterpret_cast<const int32_t *>(h->arena + L.gpose),
                               rank_mode ? reinterpret_cast<const int32_t *>(h->arena + L.base) : nullptr,
-                              reinterpret_cast<const int32_t *>(h->arena + L.gpoint), reinterpret_cast<int32_t *>(h->arena + o_slotpt), E, h->stream));
+                              reinterpret_cast<const int32_t *>(h->arena + L.gpoint), reinterpret_cast<int32_t *>(h->arena + o_slotpt), E,
+                              dev_first ? reinterpret_cast<const int32_t *>(h->scratch + so_H) : nullptr, NP, h->stream));
     return MOVBA_OK;
 }
 
@@ -994,40 +1146,64 @@ int Upload::structure_on_host()
     return MOVBA_OK;
 }
 
-// ... counted and filled on the GPU (struct_kernels.hip): the reference's own edge order, up to 80 free keyframes
-int Upload::structure_on_device()
+// scratch of the device structure pass (and of the device grouping pass in front of it)
+int Upload::carve_scratch(bool basic)
 {
-    const int nchunks = (s().P + 63) / 64;
+    const int nchunks = (P + 63) / 64;
     Carver sc;
-    const size_t so_cnt = sc.take<int32_t>(nbins), so_err = sc.take<int32_t>(4);
-    const size_t so_ent0 = sc.take<int32_t>(nbins);
-    const size_t so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
+    so_cnt = sc.take<int32_t>(nbins); so_err = sc.take<int32_t>(4);
+    so_pe = sc.take<int32_t>(basic ? NP : 0); so_info = sc.take<int32_t>(basic ? kBasicInfo : 0);     // (zeroed together with the two above)
+    so_ent0 = sc.take<int32_t>(nbins);
+    so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
+    so_H = sc.take<int32_t>(basic ? (size_t)((E + kBasicBlock - 1) / kBasicBlock) * NP : 0);
     if (sc.off > h->scratch_cap) {
         if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
         const size_t cap = align_up(sc.off + sc.off / 4, 1 << 20);
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->scratch), cap));
         h->scratch_cap = cap;
     }
+    return MOVBA_OK;
+}
+
+// count launches of the device structure pass; the bins' totals (and, after a device grouping pass, its results) come back
+// through the tail of the staging buffer, behind a sequence number
+int Upload::launch_counts()
+{
+    const int nchunks = (P + 63) / 64;
     char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;    // tail of the staging buffer: the pair region is packed in front of it
-    HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));        // bin totals and the error word
-    sd.P = s().P; sd.nfree = nf; sd.nchunks = nchunks; sd.NP = NP;
-    // grouped edges, point ranges and hessian indices are read where the edge copy just put them
+    sd.P = P; sd.nfree = nf; sd.nchunks = nchunks; sd.NP = NP;
+    // grouped edges, point ranges and hessian indices are read where the edge copy (or the device grouping pass) put them
     sd.g_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart);
     sd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx);
     sd.cntw = reinterpret_cast<int32_t *>(sa + so_cntw); sd.cnt = reinterpret_cast<int32_t *>(sa + so_cnt);
     sd.error = reinterpret_cast<int32_t *>(sa + so_err);
     sd.ent0 = reinterpret_cast<int32_t *>(sa + so_ent0);
+    sd.abort = dev_first ? reinterpret_cast<const int32_t *>(sa + so_info) : nullptr;
     HIP_TRY(launch_struct_count(sd, h->stream));
-    // cnt and the error word are adjacent in the scratch carve: one D2H copy; the host waits for exactly that copy, the
-    // stream goes on to the entry offsets of the fill kernel
-    // (misc: nbins totals, the error word, the sequence number of this upload)
-    volatile int32_t *misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
-    const int32_t seq = (int32_t)(++h->count_seq & 0x7fffffff);
+    // (misc: nbins totals, the error word, the sequence number of this upload[, kBasicInfo words, NP edges per keyframe])
+    misc_seq = reinterpret_cast<volatile int32_t *>(misc) + nbins + 1;
+    seq = (int32_t)(++h->count_seq & 0x7fffffff);
     __atomic_store_n(misc_seq, seq - 1, __ATOMIC_RELAXED);
-    HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream));
+    HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream,
+                                     dev_first ? reinterpret_cast<const int32_t *>(sa + so_pe) : nullptr, dev_first ? reinterpret_cast<const int32_t *>(sa + so_info) : nullptr));
     HIP_TRY(launch_struct_scan(sd, h->stream));
+    return MOVBA_OK;
+}
+
+// ... counted and filled on the GPU (struct_kernels.hip): the reference's own edge order, up to 80 free keyframes
+int Upload::structure_on_device()
+{
+    int rc = carve_scratch(false); if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(h->scratch + so_cnt, 0, so_err + 16 - so_cnt, h->stream));        // bin totals and the error word
+    rc = launch_counts(); if (rc) return rc;
     lap("edge H2D + count launches");
-    {
+    return after_counts();
+}
+
+int Upload::after_counts()
+{
+    char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;
+    if (!dev_first) {
         const double t_wait = now_ms();
         while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
             host_relax(h->opt.host_wait);
@@ -1048,7 +1224,11 @@ int Upload::structure_on_device()
             std::memcpy(sg + L.base, s().pose_slot0.data(), sizeof(int32_t) * NP);
             std::memcpy(sg + L.free_pose, s().free_pose.data(), sizeof(int32_t) * nf);
             HIP_TRY(hipMemcpyAsync(h->arena + L.hidx, sg + L.hidx, sizeof(int32_t) * NP, hipMemcpyHostToDevice, h->stream));
-            edge_b_stale = true;
+            if (dev_first) {
+                // (the device made these itself in the caller's numbering: only the three renumbered tables travel)
+                HIP_TRY(hipMemcpyAsync(h->arena + L.base, sg + L.base, sizeof(int32_t) * NP, hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(hipMemcpyAsync(h->arena + L.free_pose, sg + L.free_pose, sizeof(int32_t) * nf, hipMemcpyHostToDevice, h->stream));
+            } else edge_b_stale = true;
             HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_err + 16 - so_cnt, h->stream));
             HIP_TRY(launch_struct_count(sd, h->stream));
             HIP_TRY(launch_struct_counts_out(sd, nullptr, 0, h->stream));
@@ -1072,6 +1252,22 @@ int Upload::structure_on_device()
         int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
         rq = launch_fill(); if (rq) return rq;
         filled_early = true; fill_gen = h->arena_gen;
+        // The solve's first two kernels - state 0 from the uploaded estimates, the first linearisation - need the edge data, the
+        // slots and the state arrays, none of which depends on the pair structure this thread is about to lay out: queued
+        // here, they run in the shadow of finish_pairs / the solver choice / the pair region's packing, and movba_lba_run starts
+        // with the Hpp pass.  (Where the caller's arrays are still being staged by the helper thread, waiting for its event
+        // here would stall this thread: the run queues them as before.)
+        if (dev_first && direct_raw) {
+            rq = join_helper(); if (rq) return rq;
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
+            device_view();
+            {
+                ScopedEvents ev(h, KC_SETUP);
+                HIP_TRY(launch_init(h->win, h->stream));
+                HIP_TRY(launch_linearize(h->win, h->stream));
+            }
+            h->early_setup = true;
+        }
     }
     lap("edge B H2D + fill kernel (queued)");
     const int rc = finish_pairs(h->st, reinterpret_cast<const int32_t *>(misc));
@@ -1276,25 +1472,13 @@ int Upload::lay_out_rest()
     o_prange = c.take<int32_t>(dense_one ? 2 * (size_t)nf * nf : 1);
     if (!dev_structure) o_ent = c.take<int32_t>(ent_words());       // host-built entry lists (off-diagonal; the diagonal ones are their slot) travel with the pair region
     h2d = c.off;
-    // ---- device-only region ----
-    for (int b = 0; b < 2; ++b) {
-        o_st[b][0] = c.take<double>(7 * (size_t)NP); o_st[b][1] = c.take<double>(12 * (size_t)NP);
-        o_st[b][2] = c.take<double>(3 * (size_t)P);  o_st[b][3] = c.take<double>(6 * (size_t)P);
-        o_st[b][4] = c.take<double>(3 * (size_t)P);  o_st[b][5] = c.take<double>(4 * (size_t)E);       // erecA
-        o_st[b][6] = 0;  o_st[b][7] = 0;
-        o_st[b][8] = c.take<double>(nb);
-        o_st[b][9] = 0;
-        o_st[b][10] = 0;
-    }
-    o_obspm = c.take<double>(2 * (size_t)s().E_free + 2); o_obsrpm = c.take<double>(stereo ? (size_t)s().E_free + 1 : 1);
+    // ---- device-only region (what does not depend on the pair structure: carve_state) ----
+    if (!state_carved) carve_state();
     const size_t part_stride = ((size_t)s().nitems * kPartStride + 31) / 32 * 32;
     o_part = c.take<double>(part_stride + 1); o_blocks = c.take<double>((size_t)s().npairs * 36 + 1);
     o_recd = c.take<double>((size_t)nf * rec_slots * 48 + 2); o_imgb = c.take<double>((size_t)72 * kPcgRowsThreads);
     o_blocks_ov = c.take<double>(h->rows_kernel && h->pp.overflow ? s().row_ent.size() * 36 + 2 : 2);
-    o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1); o_aci = c.take<double>(3 * kCoarseDim * kCoarseDim + 2); o_acitag = c.take<int32_t>(2);
-    o_bp = c.take<double>(6 * (size_t)nf + 1); o_xp = c.take<double>(6 * (size_t)nf + 1);
-    o_scale = c.take<double>(nb + 1); o_hmax = c.take<double>(nb); o_tick = c.take<uint32_t>(8 * (size_t)nb + 8);
-    o_ctrl = c.take<Ctrl>(1); o_chi2 = c.take<double>(E); o_outl = c.take<uint8_t>(E);
+    o_blocks_c = c.take<double>((size_t)s().npairs * 36 + 1);
     // direct solver (dense_solve.hip): tiles of the lower block triangle + right-hand side row, diagonal factors, failure flag
     o_dtiles = c.take<double>(dense_tiles_doubles(nf)); o_ddiag = c.take<double>((size_t)ntile * kDenseNB * kDenseNB + 1); o_dfail = c.take<int32_t>(4);
     o_dx = c.take<double>((size_t)ntile * kDenseNB + 1);
@@ -1308,6 +1492,7 @@ int Upload::lay_out_rest()
     //  the caller's arrays into the staging buffer and sends them to the arena it was given at the start)
     if (total > h->arena_cap || h2d - hole + misc_bytes > h->stage_cap) { const int rw = join_helper(); if (rw) return rw; }
     int rc = ensure_arena(h, total); if (rc) return rc;
+    if (dev_first && (h->arena_gen != arena_gen_at_edge_copy || h2d - hole + misc_bytes > h->stage_cap)) return kRetryClassic;   // (tables the device made are gone with the old arena)
     if (h->arena_gen != arena_gen_at_edge_copy) {
         // the arena was reallocated (told by its generation: the new allocation may sit at the old address): queue the
         // edge region again (the staging copy is intact); the fill below then runs on the new arena
@@ -1373,6 +1558,8 @@ int Upload::send_pairs()
     // the solve's kernels start behind the caller's arrays on the copy stream (the structure pass above did not need them)
     { const int rw = join_helper(); if (rw) return rw; }          // (the helper has recorded copy_event by now)
     HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
+    // (arrays the copy engine reads out of the caller's own memory: through before the caller has them back)
+    if (direct_raw) { HIP_TRY(hipEventSynchronize(h->copy_event)); raw_synced = true; }
     // no synchronise: the solve's kernels queue on the same stream behind these transfers, and the caller's buffers were
     // copied to the staging buffer already (the next upload synchronises before it refills it)
     lap("pair H2D (queued)");
@@ -1445,13 +1632,34 @@ void Upload::device_view()
     w.direct_only = h->rows_kernel ? 0 : 1;
     w.wait_ticks = 2000000ull;
     w.lds_poses = point_lds_need(NP, nf) <= kPointLdsLimit ? 1 : 0;
-    h->uploaded = true;
 }
 
-int Upload::run()
+int Upload::run(bool allow_dev_first)
 {
     int rc = begin(); if (rc) return rc;
+    dev_first = allow_dev_first && dev_first_eligible();
+    if (dev_first) {
+        // arrays of the caller that lie in movba_host_alloc memory (pinned, mapped) are read by the device where they are
+        view_pose = reinterpret_cast<const int32_t *>(host_block_view(d->edge_pose, sizeof(int32_t) * (size_t)E));
+        view_point = reinterpret_cast<const int32_t *>(host_block_view(d->edge_point, sizeof(int32_t) * (size_t)E));
+        direct_raw = host_block_view(d->obs, sizeof(double) * 2 * (size_t)E) && host_block_view(d->inv_sigma2, sizeof(double) * (size_t)E) &&
+                     host_block_view(d->poses, sizeof(double) * 7 * (size_t)NP) && host_block_view(d->points, sizeof(double) * 3 * (size_t)P) &&
+                     (!d->obs_right || host_block_view(d->obs_right, sizeof(double) * (size_t)E));
+    }
     post_helper();
+    if (dev_first) {
+        rc = group_on_device(); if (rc) return rc;
+        ent_packed = s().E_free < kEntPackSlots && P < kEntPackPoints && !HOOK(h, entries_unpacked);
+        dev_structure = true;
+        rc = after_counts(); if (rc) return rc;
+        choose_solver();
+        rc = lay_out_rest(); if (rc) return rc;
+        pack_pairs();
+        rc = send_pairs(); if (rc) return rc;
+        device_view();
+        h->uploaded = true;
+        return MOVBA_OK;
+    }
     rc = group(); if (rc || done) return rc;
     rc = pack_derived(); if (rc) return rc;
     rc = send_edge_a(); if (rc) return rc;
@@ -1474,6 +1682,7 @@ int Upload::run()
     pack_pairs();
     rc = send_pairs(); if (rc) return rc;
     device_view();
+    h->uploaded = true;
     return MOVBA_OK;
 }
 
@@ -1482,8 +1691,15 @@ int Upload::run()
 int movba_lba_upload(movba_handle *h, const movba_lba_desc *d)
 {
     if (!h || !d) return MOVBA_ERR_ARG;
+    {
+        Upload u(h, d);
+        const int rc = u.run(true);
+        if (rc != kRetryClassic) return rc;
+    }
+    // (edges not grouped by point, a free keyframe without an edge, an arena that had to grow under the device's own tables:
+    //  once more with the grouping pass on this thread)
     Upload u(h, d);
-    return u.run();
+    return u.run(false);
 }
 
 int movba_lba_reset(movba_handle *h)
@@ -1710,8 +1926,11 @@ int movba_lba_run(movba_handle *h)
         __atomic_store_n(&h->hstat->progress, (uint64_t)0, __ATOMIC_RELAXED); wr_stop(h->hstat, 0);
         {   // state 0 from the uploaded estimates, first linearisation, lambda_0 and F0
             ScopedEvents ev(h, KC_SETUP);
-            HIP_TRY(launch_init(w, s));
-            HIP_TRY(launch_linearize(w, s));
+            if (!h->early_setup) {          // (else: queued by the upload already, behind the edge data)
+                HIP_TRY(launch_init(w, s));
+                HIP_TRY(launch_linearize(w, s));
+            }
+            h->early_setup = false;
             if (w.nitems > 0) HIP_TRY(launch_schur(w, 1, s));
             HIP_TRY(launch_lambda_init(w, s));
         }
@@ -1767,7 +1986,7 @@ int movba_lba_run_batch(movba_handle *const *hs, int32_t n)
     std::vector<movba_handle *> act, solo;
     for (int i = 0; i < n; ++i) {
         movba_handle *h = hs[i];
-        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false;
+        h->ran = false; h->run_status = MOVBA_OK; h->export_in_run = false; h->early_setup = false;      // (the batch queues every window's setup itself)
         if (h->early_status != MOVBA_OK) { h->ran = true; continue; }
         if (caller_stop(h->stop)) { h->run_status = MOVBA_STOPPED; h->ran = true; continue; }
         if (!h->rows_kernel || h->win.kcam) { solo.push_back(h); continue; }      // (direct-solver windows and windows with intrinsics by keyframe run on their own)

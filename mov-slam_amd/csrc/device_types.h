@@ -202,8 +202,31 @@ struct StructDev {
     const int32_t *slot;        // E: pose-major slot of a grouped edge (fill)
     int32_t *ent_i, *ent_j, *ent_l;     // off-diagonal entry lists (fill), or ...
     unsigned long long *ent64;          // ... the packed form (non-null: used instead)
-    int32_t pad5, pad6;
+    const int32_t *abort;               // non-null: two words of the device grouping pass (BasicDev::info[0], [1]); either one set = the
+                                        // points' ranges are not to be trusted (an index out of range, edges not grouped): the pass leaves at once
 };
+
+// The grouping pass on the device (struct_kernels.hip: k_basic_hist, k_basic_index, k_basic_scan): what structure.cpp's
+// build_basic derives on the host in one pass over the caller's edges - validation, the points' edge ranges, edges per
+// keyframe, hessian indices, first pose-major slots, every edge's rank among its keyframe's edges - from the caller's index
+// arrays where the upload's first copy put them.
+constexpr int kBasicBlock = 256;        // edges per workgroup of k_basic_hist (and of k_slot_point, which completes the slots)
+struct BasicDev {
+    int32_t E, P, NP, nblk;
+    // the caller's index arrays where the device can read them - its own pinned arrays (movba_host_alloc) or the staging
+    // buffer's copy, both host memory read across the bus - and their place in the arena, which k_basic_hist fills on the way
+    const int32_t *src_pose, *src_point;
+    int32_t *edge_pose, *edge_point;
+    const uint8_t *pose_fixed;                  // (host memory too)
+    int32_t *pt_start;          // P + 1
+    int32_t *rank;              // E: the edge's rank among the edges of its keyframe INSIDE its workgroup's 256 edges
+    int32_t *H;                 // nblk x NP: edges of keyframe k in workgroup b, then (k_basic_scan) in the workgroups before b
+    int32_t *pose_edges;        // NP (zeroed): edges per keyframe
+    int32_t *hidx, *base, *free_pose;           // NP, NP + 1, <= NP
+    int32_t *info;              // kBasicInfo words (zeroed): [0] an index out of range, [1] edges not grouped by point,
+                                // [2] free keyframes with edges, [3] their edges, [4] fixed keyframes
+};
+constexpr int kBasicInfo = 8;
 
 struct PcgParams {
     double rel_tol;

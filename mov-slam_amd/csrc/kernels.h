@@ -15,7 +15,10 @@ hipError_t configure_pcg_rows();
 hipError_t configure_struct_kernels();
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s);
-hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s);
+hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s, const int32_t *basic_pe = nullptr, const int32_t *basic_info = nullptr);
+// the grouping pass on the device (BasicDev): k_basic_hist + k_basic_index; the scan of its per-workgroup counts (what the slots need)
+hipError_t launch_basic(const BasicDev &bd, hipStream_t s);
+hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s);
 bool struct_lds_fits(int nfree, int NP);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
 // structure pass beyond k_struct_pairs' reach (struct_sort.hip): counts by atomics, fill by a stable sort of the couples
@@ -23,7 +26,7 @@ hipError_t launch_couple_count(const StructDev &sd, int32_t *cnt_pt, hipStream_t
 size_t sorted_fill_temp_bytes(int P, long long noff, int nfree);
 hipError_t launch_sorted_fill(const StructDev &sd, const int32_t *cnt_pt, int32_t *off, unsigned *keys_in, unsigned *keys_out,
                               unsigned long long *vals_in, void *tmp, size_t tmp_bytes, long long noff, hipStream_t s);
-hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s);
+hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, const int32_t *hx, int NP, hipStream_t s);
 bool pcg_rows_supported(int nfree, const int32_t *row_ptr, PcgParams *pp);
 hipError_t launch_pcg_rows(const DevWindow &w, int nrowent, const PcgParams &pp, int trial, hipStream_t s);
 

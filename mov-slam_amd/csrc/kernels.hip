@@ -49,8 +49,8 @@ __device__ __forceinline__ void init_pose_body(const DevWindow &w, int bid, int 
         c->it = 0; c->qmax = 0; c->cur = 0; c->done = (w.max_iters <= 0) ? 1 : 0;
         c->n_solves = 0; c->last_rejected = 0; c->iters_done = 0; c->n_trace = 0;
         c->pcg_fail = 0; c->pcg_last_iters = 0; c->pcg_total_iters = 0; c->n_outliers = 0;
-        c->solver_mode = w.direct_only ? 1 : 0; c->n_pause = 0; c->n_direct = 0; c->n_chol_fail = 0; c->n_band = 0;
-        c->direct_from = w.direct_only ? 0 : -1; c->n_sync_timeouts = 0;
+        // (solver_mode / direct_from: k_lambda_init - this kernel may run before the upload has chosen the reduced solver)
+        c->n_pause = 0; c->n_direct = 0; c->n_chol_fail = 0; c->n_band = 0; c->n_sync_timeouts = 0;
         w.aci_tag[0] = -1; w.aci_tag[1] = -1;
         w.ac_prev[kCoarseDim * kCoarseDim + 1] = -1.0;
         c->dbg_cycles = 0; c->dbg_ticks = 0;
@@ -907,8 +907,10 @@ __global__ __launch_bounds__(kSchurWaves * 64) void k_schur_b(BatchDev b)
 __device__ __forceinline__ void lambda_init_body(const DevWindow &w)
 {
     Ctrl *c = w.ctrl;
-    if (c->done) return;
     const int lane = threadIdx.x;
+    // which reduced solver the window starts on (no on-chip PCG: the direct solver from the first trial)
+    if (lane == 0) { c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1; }
+    if (c->done) return;
     double m = 0.0, F = 0.0;
     // fixed-order cost sum: lane-strided partials (loads 8 deep), then a fixed butterfly
     for (int k0 = lane; k0 < w.n_pt_blocks; k0 += 64 * 8) {

@@ -52,6 +52,9 @@ __global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd
     int *htab = hcache_all + 64 * kDegCap * (FILL ? 2 : 1);                 // NP
     int *cnt_row = htab + sd.NP, *ent0_row = cnt_row + nbins;               // (fill only)
     const int l = chunk * 64 + lane;
+    // (behind a grouping pass of the device that found the caller's edges unusable as they are: the points' ranges were never
+    //  written - whatever the arena held before stands there - and the host is about to do the pass itself)
+    if (sd.abort && (sd.abort[0] | sd.abort[1])) return;
     int begin = 0, end = 0;
     if (l < sd.P) { begin = sd.pt_start[l]; end = sd.pt_start[l + 1]; }
     for (int b = threadIdx.x; b < nbins; b += NT) masks[b] = 0ull;
@@ -160,15 +163,14 @@ __global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd
 // exclusive scan over the chunks of every bin's counts (in place).  A workgroup takes 64 bins (one per
 // lane: coalesced across bins) and cuts the chunks into 16 segments, one per wave: segment sums, a 16-step prefix through
 // LDS, then the running prefixes written back; 8 loads in flight per lane in both passes.
-__global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
+__device__ __forceinline__ void scan_columns(int32_t *tab, int nbins, int nrows)
 {
     __shared__ int seg_tot[16][64];
-    const int nbins = sd.nfree * sd.nfree;
     const int tx = threadIdx.x & 63, sy = threadIdx.x >> 6;
     const int bin = blockIdx.x * 64 + tx;
     const bool live = bin < nbins;
-    const int L = (sd.nchunks + 15) / 16, c_beg = sy * L, c_end = min(sd.nchunks, c_beg + L);
-    int32_t *col = sd.cntw + (live ? bin : 0);
+    const int L = (nrows + 15) / 16, c_beg = sy * L, c_end = min(nrows, c_beg + L);
+    int32_t *col = tab + (live ? bin : 0);
     int sum = 0;
     for (int c0 = c_beg; c0 < c_end && live; c0 += 8) {
         int v[8];
@@ -193,24 +195,133 @@ __global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd)
     }
 }
 
+__global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd) { scan_columns(sd.cntw, sd.nfree * sd.nfree, sd.nchunks); }
+// ... and of the grouping pass's edges per (workgroup, keyframe): H becomes "edges of the keyframe in the workgroups before"
+__global__ __launch_bounds__(1024) void k_basic_scan(BasicDev bd) { scan_columns(bd.H, bd.NP, bd.nblk); }
+
+hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_basic_scan, dim3((bd.NP + 63) / 64), dim3(1024), 0, s, bd);
+    return hipGetLastError();
+}
+
+// ---- the grouping pass on the device (BasicDev, device_types.h) ----
+// One thread per edge, 256 edges per workgroup.  Validation and the grouped-order test are per edge; a point's range starts at
+// the first edge whose predecessor belongs to another point; the rank of an edge among its keyframe's edges is assembled from
+// three exclusive counts - the workgroups before (H, scanned by k_basic_scan), the waves before inside the workgroup, the
+// lanes before inside the wave (one ballot per distinct keyframe of the wave: 64 consecutive edges belong to ~10 neighbouring
+// points, hence to a dozen keyframes) - so that it is the host builder's rank whatever the scheduling.
+__global__ __launch_bounds__(kBasicBlock) void k_basic_hist(BasicDev bd)
+{
+    extern __shared__ int whist[];                      // (kBasicBlock / 64) x NP
+    constexpr int NW = kBasicBlock / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * kBasicBlock + threadIdx.x;
+    for (int k = threadIdx.x; k < NW * bd.NP; k += kBasicBlock) whist[k] = 0;
+    const bool live = e < bd.E;
+    // (the caller's arrays are read ONCE, across the bus, and left in the arena for every later kernel; a lane's predecessor is
+    //  its neighbour's value, the first lane of a wave reads one more word)
+    int kf = live ? bd.src_pose[e] : -1, l = live ? bd.src_point[e] : 0;
+    int lp = __shfl_up(l, 1);
+    if (lane == 0) lp = (live && e > 0) ? bd.src_point[e - 1] : -1;
+    if (live) { bd.edge_pose[e] = kf; bd.edge_point[e] = l; }
+    bool bad = false;
+    if (live) {
+        if ((unsigned)kf >= (unsigned)bd.NP || (unsigned)l >= (unsigned)bd.P) { bad = true; kf = -1; }
+        else {
+            if (l < lp) bd.info[1] = 1;                 // not in ascending point order: the host groups such a window itself
+            else for (int q = max(lp, -1) + 1; q <= l; ++q) bd.pt_start[q] = e;       // (points nobody observes start where the next one does)
+            if (e == bd.E - 1) for (int q = l + 1; q <= bd.P; ++q) bd.pt_start[q] = bd.E;
+        }
+    }
+    if (bad) bd.info[0] = 1;
+    __syncthreads();
+    int r = 0;
+    unsigned long long todo = __ballot(kf >= 0);
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int k = __builtin_amdgcn_readlane(kf, lead);
+        const unsigned long long m = __ballot(kf == k);
+        if (kf == k) r = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == lead) whist[wv * bd.NP + k] = __popcll(m);
+        todo &= ~m;
+    }
+    __syncthreads();
+    if (kf >= 0) {
+        for (int q = 0; q < wv; ++q) r += whist[q * bd.NP + kf];
+        bd.rank[e] = r;
+    } else if (live) bd.rank[e] = 0;
+    for (int k = threadIdx.x; k < bd.NP; k += kBasicBlock) {
+        int t = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += whist[q * bd.NP + k];
+        bd.H[(size_t)blockIdx.x * bd.NP + k] = t;
+        if (t) atomicAdd(&bd.pose_edges[k], t);        // (integer totals: order-independent)
+    }
+}
+
+// hessian indices, first pose-major slots and the free-pose list from the edges per keyframe, as build_basic numbers them:
+// free keyframes with at least one edge, in caller order.  One workgroup; keyframes in rounds of 1024.
+__global__ __launch_bounds__(1024) void k_basic_index(BasicDev bd)
+{
+    __shared__ int sc_a[1024], sc_e[1024];
+    __shared__ int carry[3];
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; carry[2] = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < bd.NP; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < bd.NP;
+        const int pe = in ? bd.pose_edges[i] : 0;
+        const bool fixed = in && bd.pose_fixed[i] != 0;
+        const bool act = in && !fixed && pe > 0;
+        sc_a[threadIdx.x] = act ? 1 : 0; sc_e[threadIdx.x] = act ? pe : 0;
+        const int nfix = __syncthreads_count(fixed);
+        for (int d = 1; d < 1024; d <<= 1) {            // Hillis-Steele, inclusive
+            const int va = threadIdx.x >= d ? sc_a[threadIdx.x - d] : 0, ve = threadIdx.x >= d ? sc_e[threadIdx.x - d] : 0;
+            __syncthreads();
+            sc_a[threadIdx.x] += va; sc_e[threadIdx.x] += ve;
+            __syncthreads();
+        }
+        const int h = carry[0] + sc_a[threadIdx.x] - (act ? 1 : 0), b = carry[1] + sc_e[threadIdx.x] - (act ? pe : 0);
+        if (in) { bd.hidx[i] = act ? h : -1; bd.base[i] = act ? b : -1; if (act) bd.free_pose[h] = i; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry[0] += sc_a[1023]; carry[1] += sc_e[1023]; }
+        if (threadIdx.x == 0) carry[2] += nfix;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bd.base[bd.NP] = -1; bd.info[2] = carry[0]; bd.info[3] = carry[1]; bd.info[4] = carry[2]; }
+}
+
 // map point of every pose-major slot (what a diagonal schur entry needs besides its slot).  With `base` the slot array
 // arrives holding each edge's rank among its keyframe's edges (structure.h, build_basic): the slots are completed here.
-__global__ __launch_bounds__(256) void k_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E)
+// (hx: the grouping pass ran on the device, the rank counts inside the edge's workgroup of kBasicBlock edges only: the
+//  workgroups before contribute hx[workgroup x NP + keyframe])
+__global__ __launch_bounds__(kBasicBlock) void k_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E,
+                                                              const int32_t *hx, int NP)
 {
-    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.x * kBasicBlock + threadIdx.x;
     if (g >= E) return;
     int sl = slot[g];
     if (base) {
-        const int b = base[g_pose[g]];
+        const int kf = g_pose[g];
+        const int b = base[kf];
+        if (hx && b >= 0) sl += hx[(size_t)blockIdx.x * NP + kf];
         sl = b >= 0 ? b + sl : -1;
         slot[g] = sl;
     }
     if (sl >= 0) slot_point[sl] = g_point[g];
 }
 
-hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s)
+hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, const int32_t *hx, int NP, hipStream_t s)
 {
-    if (E > 0) hipLaunchKernelGGL(k_slot_point, dim3((E + 255) / 256), dim3(256), 0, s, slot, g_pose, base, g_point, slot_point, E);
+    if (E > 0) hipLaunchKernelGGL(k_slot_point, dim3((E + kBasicBlock - 1) / kBasicBlock), dim3(kBasicBlock), 0, s, slot, g_pose, base, g_point, slot_point, E, hx, NP);
+    return hipGetLastError();
+}
+
+hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_basic_hist, dim3(bd.nblk), dim3(kBasicBlock), sizeof(int) * (kBasicBlock / 64) * (size_t)bd.NP, s, bd);
+    hipLaunchKernelGGL(k_basic_index, dim3(1), dim3(1024), 0, s, bd);
     return hipGetLastError();
 }
 
@@ -228,13 +339,19 @@ hipError_t launch_struct_count(const StructDev &sd, hipStream_t s)
 //     entries in row-major order (structure.cpp, finish_pairs), and the off-diagonal entry lists follow that order, so
 //     ent0[bin] is the exclusive prefix sum of cnt over the bins (i, j), i < j, taken row-major: every thread sums a run of
 //     consecutive bins, the run totals are scanned through LDS.  The fill kernel therefore needs nothing from the host.
-__global__ __launch_bounds__(1024) void k_struct_counts_out(StructDev sd, int32_t *host_cnt, int seq)
+// (basic_pe / basic_info: the grouping pass ran on the device too - its edges per keyframe and its info words travel behind the
+//  sequence number's place: host_cnt[nbins + 2 ...] = kBasicInfo words, then NP counts)
+__global__ __launch_bounds__(1024) void k_struct_counts_out(StructDev sd, int32_t *host_cnt, int seq, const int32_t *basic_pe, const int32_t *basic_info)
 {
     __shared__ int tot[1024];
     const int nf = sd.nfree, nbins = nf * nf;
     if (host_cnt) {         // (null on the second pass of a renumbered window: the host has permuted its copy itself)
         for (int b = threadIdx.x; b < nbins; b += 1024) host_cnt[b] = sd.cnt[b];
         if (threadIdx.x == 0) host_cnt[nbins] = *sd.error;
+        if (basic_pe) {
+            if (threadIdx.x < kBasicInfo) host_cnt[nbins + 2 + threadIdx.x] = basic_info[threadIdx.x];
+            for (int k = threadIdx.x; k < sd.NP; k += 1024) host_cnt[nbins + 2 + kBasicInfo + k] = basic_pe[k];
+        }
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -258,9 +375,9 @@ __global__ __launch_bounds__(1024) void k_struct_counts_out(StructDev sd, int32_
     }
 }
 
-hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s)
+hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s, const int32_t *basic_pe, const int32_t *basic_info)
 {
-    hipLaunchKernelGGL(k_struct_counts_out, dim3(1), dim3(1024), 0, s, sd, host_cnt_dev, seq);
+    hipLaunchKernelGGL(k_struct_counts_out, dim3(1), dim3(1024), 0, s, sd, host_cnt_dev, seq, basic_pe, basic_info);
     return hipGetLastError();
 }
 

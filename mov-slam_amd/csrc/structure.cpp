@@ -6,18 +6,41 @@
 
 namespace movba {
 
-int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out)
+void reset_structure(Structure& s, int NP, int P, int E)
 {
-    const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
-    if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
-    if ((NP && (!d.poses || !d.pose_fixed)) || (P && !d.points)) return MOVBA_ERR_ARG;
-    if (E && (!d.edge_pose || !d.edge_point || !d.obs || !d.inv_sigma2)) return MOVBA_ERR_ARG;
     // keep the vectors' capacity across calls (a handle solves window after window: fresh multi-MB allocations
     // would be paid in page faults every time)
     s.nfree = 0; s.npairs = 0; s.nitems = 0; s.max_degree = 0; s.nentries = 0; s.already_grouped = true; s.n_fixed = 0; s.n_agg = 0; s.reordered = false;
     s.free_pose.clear(); s.pair_i.clear(); s.pair_j.clear(); s.items.clear(); s.sched.clear(); s.sched_per_xcd = 0; s.row_ent.clear();
     s.cblk_g.clear(); s.cblk_h.clear(); s.cblk_ptr.clear(); s.cblk_ent.clear(); s.ent_i.clear(); s.ent_j.clear(); s.ent_l.clear(); s.E_free = 0;
     s.NP = NP; s.P = P; s.E = E;
+}
+
+// hessian indices, free-pose list and first pose-major slots from the edges per keyframe: free keyframes with at least one
+// edge, in caller order (the tail of build_basic; the upload path runs it alone when the device has counted the edges)
+void index_poses(const uint8_t* pose_fixed, Structure& s)
+{
+    const int NP = s.NP;
+    s.hidx.assign(NP, -1);
+    // pose-major slots: the edges of free pose h occupy [pstart[h], pstart[h+1]) in ascending map-point order, so the
+    // schur pass reads the per-edge records of one keyframe as (nearly) contiguous memory
+    std::vector<int32_t>& pstart = s.pose_slot0;
+    pstart.assign(NP + 1, -1);
+    int run = 0;
+    for (int i = 0; i < NP; ++i) {
+        if (pose_fixed[i]) { s.n_fixed++; continue; }
+        if (s.pose_edges[i] > 0) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); pstart[i] = run; run += s.pose_edges[i]; }
+    }
+    s.E_free = run;
+}
+
+int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out)
+{
+    const int NP = d.n_poses, P = d.n_points, E = d.n_edges;
+    if (NP < 0 || P < 0 || E < 0) return MOVBA_ERR_ARG;
+    if ((NP && (!d.poses || !d.pose_fixed)) || (P && !d.points)) return MOVBA_ERR_ARG;
+    if (E && (!d.edge_pose || !d.edge_point || !d.obs || !d.inv_sigma2)) return MOVBA_ERR_ARG;
+    reset_structure(s, NP, P, E);
 
     // active vertices = those with >= 1 edge (SparseOptimizer::initializeOptimization).  ONE pass over the caller's
     // edges: validation, edges per pose, edges per point, and whether the edges already come grouped by map point.
@@ -74,17 +97,7 @@ int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out)
         }
         s.gp = s.g_pose.data(); s.gl = s.g_point.data();
     }
-    s.hidx.assign(NP, -1);
-    // pose-major slots: the edges of free pose h occupy [pstart[h], pstart[h+1]) in ascending map-point order, so the
-    // schur pass reads the per-edge records of one keyframe as (nearly) contiguous memory
-    std::vector<int32_t>& pstart = s.pose_slot0;
-    pstart.assign(NP + 1, -1);
-    int run = 0;
-    for (int i = 0; i < NP; ++i) {
-        if (d.pose_fixed[i]) { s.n_fixed++; continue; }
-        if (s.pose_edges[i] > 0) { s.hidx[i] = s.nfree++; s.free_pose.push_back(i); pstart[i] = run; run += s.pose_edges[i]; }
-    }
-    s.E_free = run;
+    index_poses(d.pose_fixed, s);
     if (!rank_out) build_slots(s);
     if (E == 0) return MOVBA_EMPTY;
     return MOVBA_OK;

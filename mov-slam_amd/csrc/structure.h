@@ -98,6 +98,8 @@ int build_structure(const movba_lba_desc& d, Structure& s);
 // of every free keyframe (-1: fixed or unobserved) — for edges already grouped by point, slot = pose_slot0[pose] + rank, which
 // the upload path leaves to the device; build_slots(s) completes the job on the host otherwise.
 int build_basic(const movba_lba_desc& d, Structure& s, int32_t* rank_out = nullptr);
+void reset_structure(Structure& s, int NP, int P, int E);       // what build_basic starts with ...
+void index_poses(const uint8_t* pose_fixed, Structure& s);      // ... and ends with (from s.pose_edges), for a grouping pass that ran on the device
 void build_slots(Structure& s);                               // (s.gp must still be valid: the caller's arrays, or s.g_pose)
 int finish_pairs(Structure& s, const int32_t* cnt);           // cnt[i*nfree+j] (i <= j) -> pairs, items, gather lists
 

@@ -282,16 +282,30 @@ class Solver:
             pass
 
     # -- results ---------------------------------------------------------------
-    def _pinned(self, shape):
-        """float64 array in movba_host_alloc memory (released by close())"""
+    def _pinned(self, shape, dtype=np.float64):
+        """array in movba_host_alloc memory (released by close()); float64 unless said otherwise"""
         n = int(np.prod(shape))
-        p = self._L.movba_host_alloc(max(8 * n, 8))
+        item = np.dtype(dtype).itemsize
+        p = self._L.movba_host_alloc(max(item * n, 8))
         if not p:
             raise MovbaError("movba_host_alloc failed")
         self._pinned_blocks.append(p)
-        a = np.ctypeslib.as_array((C.c_double * max(n, 1)).from_address(p))[:n].reshape(shape)
-        a[...] = 0.0
+        a = np.frombuffer((C.c_uint8 * max(item * n, 8)).from_address(p), dtype=dtype, count=n).reshape(shape)
+        a[...] = 0
         return a
+
+    def _pin_inputs(self, d, keep):
+        """The descriptor's input arrays moved into movba_host_alloc memory (what a C++ caller that flattens its window into
+        buffers of the library's allocator hands over: the adapter's): the device reads the index arrays where they lie and the
+        copy engine takes the observations and estimates straight out of them, nothing is staged."""
+        for key, field, ptr in (("poses", "poses", _d), ("fixed", "pose_fixed", _u), ("points", "points", _d), ("ep", "edge_pose", _i),
+                                ("el", "edge_point", _i), ("obs", "obs", _d), ("isg", "inv_sigma2", _d), ("obs_right", "obs_right", _d)):
+            if key not in keep:
+                continue
+            a = self._pinned(keep[key].shape, keep[key].dtype)
+            a[...] = keep[key]
+            keep[key] = a
+            setattr(d, field, _p(a, ptr))
 
     def _alloc_result(self, d, pinned=False, chi2=True):
         mk = self._pinned if pinned else np.zeros
@@ -331,6 +345,8 @@ class Solver:
         """Descriptor and result buffers built once for repeated solve_prepared() calls: what a C++ caller that keeps its
         flattened arrays and result buffers does (nothing is allocated or converted per call)."""
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
+        if pinned:
+            self._pin_inputs(d, keep)                     # ... and input arrays the device reads where they lie
         r, out = self._alloc_result(d, pinned, chi2)      # pinned: result arrays the solve's last kernel writes into directly
         self._keep = (d, keep)
         self._prep = (d, keep, r, out)

@@ -109,13 +109,17 @@ hipError_t launch_sorted_fill(const StructDev &sd, const int32_t *cnt_pt, int32_
     return hipSuccess;
 }
 
-hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt, int seq, hipStream_t s)
+hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt, int seq, hipStream_t s, const int32_t *basic_pe, const int32_t *basic_info)
 {
-    fake_enqueue(s, [sd, host_cnt, seq] {
+    fake_enqueue(s, [sd, host_cnt, seq, basic_pe, basic_info] {
         const int nbins = sd.nfree * sd.nfree;
         if (host_cnt) {
             for (int b = 0; b < nbins; ++b) host_cnt[b] = sd.cnt[b];
             host_cnt[nbins] = *sd.error;
+            if (basic_pe) {
+                for (int k = 0; k < kBasicInfo; ++k) host_cnt[nbins + 2 + k] = basic_info[k];
+                for (int k = 0; k < sd.NP; ++k) host_cnt[nbins + 2 + kBasicInfo + k] = basic_pe[k];
+            }
             __atomic_store_n(host_cnt + nbins + 1, seq, __ATOMIC_RELEASE);
         }
         int run = 0;
@@ -137,14 +141,52 @@ hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s)
     });
     return hipSuccess;
 }
-hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, hipStream_t s)
+hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t *base, const int32_t *g_point, int32_t *slot_point, int E, const int32_t *hx, int NP, hipStream_t s)
 {
     fake_enqueue(s, [=] {
         for (int g = 0; g < E; ++g) {
             int sl = slot[g];
-            if (base) { const int b = base[g_pose[g]]; sl = b >= 0 ? b + sl : -1; slot[g] = sl; }
+            if (base) {
+                const int b = base[g_pose[g]];
+                if (hx && b >= 0) sl += hx[(size_t)(g / kBasicBlock) * NP + g_pose[g]];
+                sl = b >= 0 ? b + sl : -1; slot[g] = sl;
+            }
             if (sl >= 0) slot_point[sl] = g_point[g];
         }
+    });
+    return hipSuccess;
+}
+// the grouping pass of the device (k_basic_hist, k_basic_index), word for word what the kernels leave behind
+hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
+{
+    fake_enqueue(s, [bd] {
+        std::vector<int> seen((size_t)bd.NP);
+        for (int b = 0; b < bd.nblk; ++b) {
+            std::fill(seen.begin(), seen.end(), 0);
+            for (int e = b * kBasicBlock; e < std::min(bd.E, (b + 1) * kBasicBlock); ++e) {
+                const int kf = bd.src_pose[e], l = bd.src_point[e], lp = e > 0 ? bd.src_point[e - 1] : -1;
+                bd.edge_pose[e] = kf; bd.edge_point[e] = l;
+                if ((unsigned)kf >= (unsigned)bd.NP || (unsigned)l >= (unsigned)bd.P) { bd.info[0] = 1; bd.rank[e] = 0; continue; }
+                if (l < lp) bd.info[1] = 1; else for (int q = std::max(lp, -1) + 1; q <= l; ++q) bd.pt_start[q] = e;
+                if (e == bd.E - 1) for (int q = l + 1; q <= bd.P; ++q) bd.pt_start[q] = bd.E;
+                bd.rank[e] = seen[kf]++;
+            }
+            for (int k = 0; k < bd.NP; ++k) { bd.H[(size_t)b * bd.NP + k] = seen[k]; bd.pose_edges[k] += seen[k]; }
+        }
+        int nf = 0, run = 0, nfix = 0;
+        for (int i = 0; i < bd.NP; ++i) {
+            bd.hidx[i] = -1; bd.base[i] = -1;
+            if (bd.pose_fixed[i]) { ++nfix; continue; }
+            if (bd.pose_edges[i] > 0) { bd.hidx[i] = nf; bd.free_pose[nf++] = i; bd.base[i] = run; run += bd.pose_edges[i]; }
+        }
+        bd.base[bd.NP] = -1; bd.info[2] = nf; bd.info[3] = run; bd.info[4] = nfix;
+    });
+    return hipSuccess;
+}
+hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s)
+{
+    fake_enqueue(s, [bd] {
+        for (int k = 0; k < bd.NP; ++k) { int run = 0; for (int b = 0; b < bd.nblk; ++b) { const int v = bd.H[(size_t)b * bd.NP + k]; bd.H[(size_t)b * bd.NP + k] = run; run += v; } }
     });
     return hipSuccess;
 }
@@ -167,7 +209,7 @@ void fake_init(const DevWindow &w)
     std::memset(w.dec_rec, 0, sizeof(unsigned) * 8 * (size_t)w.n_pt_blocks);
     Ctrl *c = w.ctrl;
     std::memset(c, 0, sizeof(Ctrl));
-    c->nu = 2.0; wr_done(c, (w.max_iters <= 0) ? 1 : 0); c->solver_mode = w.direct_only ? 1 : 0; c->direct_from = w.direct_only ? 0 : -1;
+    c->nu = 2.0; wr_done(c, (w.max_iters <= 0) ? 1 : 0);
 }
 void fake_decide(const DevWindow &w)
 {
@@ -282,7 +324,7 @@ void fake_finalize(const DevWindow &w)
 hipError_t launch_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_init(w); }); return hipSuccess; }
 hipError_t launch_linearize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { g_sink += rd_done(w.ctrl); }); return hipSuccess; }
 hipError_t launch_schur(const DevWindow &w, int, hipStream_t s) { fake_enqueue(s, [w] { fake_schur(w); }); return hipSuccess; }
-hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->lambda = 1e-3; }); return hipSuccess; }
+hipError_t launch_lambda_init(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { w.ctrl->solver_mode = w.direct_only ? 1 : 0; w.ctrl->direct_from = w.direct_only ? 0 : -1; w.ctrl->lambda = 1e-3; }); return hipSuccess; }
 // (the back-substitution pass takes the LM decision in its last workgroup: one launch)
 hipError_t launch_backsub(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_backsub(w); }); return hipSuccess; }
 hipError_t launch_finalize(const DevWindow &w, hipStream_t s) { fake_enqueue(s, [w] { fake_finalize(w); }); return hipSuccess; }

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <random>
 #include <thread>
@@ -245,6 +246,42 @@ int main()
             movba_destroy(hs[i]);
         }
         (void)hipStreamDestroy(st);
+    }
+    // ---- 9. a caller whose flattened window lies in movba_host_alloc memory (the adapter): the device reads the index arrays where
+    //         they are, the copy engine the rest, nothing is staged, and the upload itself queues the solve's first two kernels;
+    //         window after window on one handle, two such threads at once, then the same windows from ordinary memory again ----
+    {
+        auto worker = [&](unsigned seed0) {
+            movba_handle *h = nullptr;
+            EXPECT(movba_create(&h, 0, nullptr, nullptr) == MOVBA_OK);
+            Win w;
+            for (int it = 0; it < 6; ++it) {
+                make(w, 9 + 7 * it, 2, 600 + 250 * it, seed0 + it, false, it % 3 == 2);
+                const size_t E = w.ep.size();
+                struct Pin { void *p; } pins[7];
+                auto pin = [&](const void *src, size_t bytes, int k) { pins[k].p = movba_host_alloc(bytes); EXPECT(pins[k].p != nullptr); std::memcpy(pins[k].p, src, bytes); return pins[k].p; };
+                w.d.poses = static_cast<double *>(pin(w.poses.data(), 8 * w.poses.size(), 0)); w.d.points = static_cast<double *>(pin(w.points.data(), 8 * w.points.size(), 1));
+                w.d.edge_pose = static_cast<int32_t *>(pin(w.ep.data(), 4 * E, 2)); w.d.edge_point = static_cast<int32_t *>(pin(w.el.data(), 4 * E, 3));
+                w.d.obs = static_cast<double *>(pin(w.obs.data(), 16 * E, 4)); w.d.inv_sigma2 = static_cast<double *>(pin(w.isig.data(), 8 * E, 5));
+                pins[6].p = nullptr;
+                if (w.d.obs_right) w.d.obs_right = static_cast<double *>(pin(w.obs_right.data(), 8 * E, 6));
+                check_solved(w, movba_lba_solve(h, &w.d, &w.r));
+                // the arrays are the caller's again: scribbled over, then the phased calls on a fresh copy
+                std::memset(const_cast<double *>(w.d.obs), 0x7f, 16 * E); std::memset(const_cast<int32_t *>(w.d.edge_pose), 0x7f, 4 * E);
+                std::memcpy(const_cast<double *>(w.d.obs), w.obs.data(), 16 * E); std::memcpy(const_cast<int32_t *>(w.d.edge_pose), w.ep.data(), 4 * E);
+                EXPECT(movba_lba_upload(h, &w.d) == MOVBA_OK);
+                EXPECT(movba_lba_run(h) == MOVBA_OK && movba_lba_run(h) == MOVBA_OK);
+                check_solved(w, movba_lba_download(h, &w.r));
+                for (Pin &q : pins) if (q.p) movba_host_free(q.p);
+                // ... and from the caller's ordinary vectors
+                w.d.poses = w.poses.data(); w.d.points = w.points.data(); w.d.edge_pose = w.ep.data(); w.d.edge_point = w.el.data();
+                w.d.obs = w.obs.data(); w.d.inv_sigma2 = w.isig.data(); if (w.d.obs_right) w.d.obs_right = w.obs_right.data();
+                check_solved(w, movba_lba_solve(h, &w.d, &w.r));
+            }
+            movba_destroy(h);
+        };
+        std::thread a(worker, 1300u), b(worker, 1700u);
+        a.join(); b.join();
     }
     if (fails) { std::fprintf(stderr, "HOST-TSAN FAILED: %d expectation(s)\n", fails); return 1; }
     std::printf("HOST-TSAN OK\n");

@@ -27,7 +27,7 @@ def noise_floor_trial(o):
     return int(k[0]) if len(k) else len(f0)
 
 
-def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_guard=False, lam_rtol=1e-7):
+def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_guard=False, lam_rtol=1e-7, chi2_tol=(1e-6, 1e-7)):
     assert r["status"] == o["status"] == 0
     k0 = noise_floor_trial(o) if noise_guard else len(o["trace"]["accept"])
     if k0 == len(o["trace"]["accept"]):
@@ -38,7 +38,7 @@ def check_against(r, o, w, rot=ROT_TOL, trans=TRANS_TOL, point=POINT_TOL, noise_
     assert quat_angle(r["poses"][:, :4], o["poses"][:, :4]).max() < rot
     assert np.abs(r["poses"][:, 4:] - o["poses"][:, 4:]).max() < trans
     assert np.abs(r["points"] - o["points"]).max() < point
-    np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(r["chi2"], o["chi2"], rtol=chi2_tol[0], atol=chi2_tol[1])
     mism = r["outlier"] != o["outlier"]
     assert (np.abs(o["chi2"][mism] - w.chi2_gate) <= GUARD).all(), "outlier flags differ outside the guard band"
     assert r["n_outliers"] == int(r["outlier"].sum())
@@ -310,6 +310,72 @@ def test_device_structure_pass_equals_host_structure_pass(solver, built_lib, nam
     for k in ("poses", "points", "chi2", "outlier"):
         assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(a["trace"]["pcg"], b["trace"]["pcg"])
+
+
+@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged", "shuffled", "free-keyframe-without-edges", "ungrouped", "points-nobody-observes"])
+def test_device_grouping_pass_equals_host_grouping_pass(solver, built_lib, name):
+    """Validation, the points' edge ranges, edges per keyframe, hessian indices and pose-major slots - structure.cpp's build_basic,
+    one pass over the caller's edges on the calling thread - are made on the GPU for the windows whose pair structure the device
+    builds too (k_basic_hist / k_basic_index / k_basic_scan, struct_kernels.hip); the test build's hook `host_grouping` keeps the
+    host pass.  Same tables => bit-identical solves.  A window the device pass hands back (a free keyframe nobody observes, edges
+    not grouped by point) is solved by the host pass as before."""
+    if name == "stereo":
+        w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5)
+    elif name == "ragged":
+        w = synth.make_window(5, 2, 150, seed=77, run_lo=1, run_hi=7, min_obs=1)
+        order = np.lexsort((-w.edge_pose, w.edge_point))
+        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[order], w.edge_point[order], w.obs[order], w.inv_sigma2[order]
+    elif name == "shuffled":
+        w = synth.pattern_cfg("shuffled")
+    elif name == "free-keyframe-without-edges":
+        w = synth.cfg("cfg2")
+        keep = w.edge_pose != 5                                        # keyframe 5 (free) loses all its observations
+        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[keep], w.edge_point[keep], w.obs[keep], w.inv_sigma2[keep]
+    elif name == "ungrouped":
+        w = synth.cfg("cfg2")
+        pm = np.random.default_rng(5).permutation(w.n_edges)
+        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[pm], w.edge_point[pm], w.obs[pm], w.inv_sigma2[pm]
+    elif name == "points-nobody-observes":
+        w = synth.cfg("cfg2")
+        keep = ~np.isin(w.edge_point, [0, 7, 8, 9, w.n_points - 1])
+        w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[keep], w.edge_point[keep], w.obs[keep], w.inv_sigma2[keep]
+    else:
+        w = synth.cfg(name)
+    a = solver.solve(w)
+    hs = built_lib.Solver(hooks=True)
+    try:
+        hs.hook("host_grouping", 1)
+        b = hs.solve(w)
+    finally:
+        hs.close()
+    assert a["status"] == b["status"] == 0
+    for k in ("poses", "points", "chi2", "outlier"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["trace"]["pcg"], b["trace"]["pcg"]) and np.array_equal(a["trace"]["f1"], b["trace"]["f1"])
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "stereo"])
+def test_input_arrays_in_the_librarys_pinned_memory_are_read_where_they_lie(built_lib, solver, name):
+    """A caller that flattens its window into movba_host_alloc memory (the adapter does): the device reads the index arrays out
+    of it and the copy engine takes observations and estimates straight from it - nothing is staged.  Same bits as the same
+    window handed over in ordinary memory, call after call, and the caller's arrays are its own again when the call returns
+    (overwritten with garbage between calls here)."""
+    w = synth.make_window(12, 3, 1500, seed=57, run_lo=2, run_hi=7, stereo_frac=0.5) if name == "stereo" else synth.cfg(name)
+    ref = solver.solve(w)
+    s = built_lib.Solver()
+    try:
+        s.prepare(w, pinned=True)
+        d, keep, r, out = s._prep
+        for _ in range(3):
+            got = s.solve_prepared()
+            for k in ("poses", "points", "chi2", "outlier"):
+                assert np.array_equal(got[k], ref[k]), k
+            saved = {k: keep[k].copy() for k in ("obs", "isg", "poses", "points", "ep", "el")}
+            for k in saved: keep[k][...] = 0            # the call has returned: nothing of it may still be reading these
+            import time; time.sleep(0.002)
+            for k in saved: keep[k][...] = saved[k]
+    finally:
+        s.close()
 
 
 def test_runs_are_bitwise_reproducible(solver):
@@ -1107,7 +1173,9 @@ def test_banded_factorisation_on_the_windows_the_sweep_found(built_lib, solver, 
         tol, usual, noise = _sweep_tolerances(w, oracle_mod)
         # (lambda follows rho = (F0 - F1) / scale: where the oracle's own poses move by more than the usual tolerance from one edge
         #  order to the next, so does its lambda trace - 1.0e-7 relative was seen against the usual 1e-7)
-        check_against(r, o, w, noise_guard=True, lam_rtol=1e-7 if 3 * noise[1] <= usual["trans"] else 1e-5, **tol)
+        noisy = 3 * noise[1] > usual["trans"]
+        # (... and the per-edge chi2 follows the poses: 1e-6 m of pose at 320 px focal length and a few metres of depth is 1e-4 px)
+        check_against(r, o, w, noise_guard=True, lam_rtol=1e-5 if noisy else 1e-7, chi2_tol=(1e-3, 1e-4) if noisy else (1e-6, 1e-7), **tol)
         if which == "banded" and r["n_band"] > 0:
             assert r["n_pcg_giveups"] == 0 and r["n_direct"] == 0 and r["n_band"] == r["n_solves"]
         # a window the oracle reproduces to the usual tolerance is held to it
