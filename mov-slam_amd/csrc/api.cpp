@@ -166,10 +166,13 @@ struct movba_handle {
 #ifdef MOVBA_TEST_HOOKS
     TestHooks hooks;                    // (test build only: movba_test_hook)
 #endif
+    unsigned *ingest_counter = nullptr; // device word: workgroups of k_ingest that are through (IngestArgs::counter), never reset
+    unsigned ingest_expect = 0;         // its value once every launch queued so far is through
     bool early_setup = false;           // the upload has queued k_init_pose and the first linearisation itself (behind the edge data, in
                                         // the shadow of its own pair layout): the next run starts with the Hpp pass
     int sync_retries = 0;               // > 0: this run's first attempt gave up that many in-launch waits and was repeated on the paths without any
-    hipEvent_t edgeb_event = nullptr;   // the derived edge arrays sent early on the copy stream have arrived
+    hipEvent_t edgeb_event = nullptr;   // the derived edge arrays sent early on the copy stream have arrived; device grouping pass: the
+                                        // index arrays have been read out of host memory (the big arrays' DMA starts behind it)
     uint64_t count_seq = 0;             // uploads that went through the device structure pass (what the host polls for in the counts buffer)
     movba_options opt{};
     // device arena
@@ -485,6 +488,7 @@ int movba_create(movba_handle **out, int device, void *stream, const movba_optio
     if ((h->copy_stream = shared_copy_stream(device)) == nullptr ||
         hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->edgeb_event, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&h->ingest_counter), 256) != hipSuccess || hipMemset(h->ingest_counter, 0, 256) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->hstat), sizeof(HostStatus), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(reinterpret_cast<void **>(&h->hstat_dev), h->hstat, 0) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&h->ctrl_host), sizeof(Ctrl), hipHostMallocMapped) != hipSuccess ||
@@ -508,6 +512,7 @@ void movba_destroy(movba_handle *h)
     if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);        // shared: stays
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
     if (h->edgeb_event) (void)hipEventDestroy(h->edgeb_event);
+    if (h->ingest_counter) (void)hipFree(h->ingest_counter);
     harvest_events(h);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->arena) (void)hipFree(h->arena);
@@ -647,6 +652,7 @@ struct HelperHandOff {
     std::atomic<int> idx_ready{0};      // the caller's index arrays are in the staging buffer (release / acquire): what the
                                         // structure pass on the device waits for
     hipError_t copy_err = hipSuccess;   // read by the caller only after Worker::wait()
+    hipError_t idx_err = hipSuccess;    // ... this one behind idx_ready (release / acquire)
     // fixed before the helper is posted, read by both
     char *arena = nullptr;              // the arena the helper sends to ...
     uint64_t arena_gen = 0;             // ... and its generation: a reallocation later on is told by it
@@ -677,15 +683,15 @@ struct Upload {
     int nf_expect = 0;                  // non-fixed keyframes: the free keyframes of the window unless one of them has no edge
     bool raw_synced = false;
     bool direct_raw = false;            // the caller's big arrays lie in movba_host_alloc memory: they cross the bus from where they are
-    const int32_t *view_pose = nullptr, *view_point = nullptr;     // device views of the caller's index arrays when those are pinned
     bool dev_first = false;             // validation, point ranges, hessian indices and slots are the device's work: no pass over the edges here
     BasicDev bd{};
-    size_t so_cnt = 0, so_err = 0, so_ent0 = 0, so_cntw = 0, so_pe = 0, so_info = 0, so_H = 0;
+    size_t so_cnt = 0, so_err = 0, so_ent0 = 0, so_cntw = 0, so_pe = 0, so_info = 0, so_fixed = 0, so_H = 0;
     volatile int32_t *misc_seq = nullptr;
     int32_t seq = 0;
     // --- structure ---
     StructDev sd{};
     bool dev_structure = false, ent_packed = false, filled_early = false;
+    bool scan_pending = false;          // k_struct_scan of this upload is still to be launched (in front of the fill)
     bool sorted_structure = false;      // the device pass of struct_sort.hip (beyond k_struct_pairs' 80 free keyframes)
     size_t s2_off = 0, s2_keys_in = 0, s2_keys_out = 0, s2_vals_in = 0, s2_tmp = 0, s2_tmp_bytes = 0, so_cntpt = 0;
     uint64_t fill_gen = 0;
@@ -811,6 +817,44 @@ void Upload::post_helper()
 {
     ho.arena = h->arena;
     ho.arena_gen = h->arena_gen;
+    if (direct_raw) {
+        // Direct mode: every array of the caller lies in movba_host_alloc memory (pinned, mapped): nothing is staged.  The index
+        // arrays, which the pair structure waits for, are read across the bus by a kernel on the handle's stream (k_ingest,
+        // group_on_device: no copy command, no event between it and the grouping kernel); estimates, observations and
+        // information go through the copy engine, queued here by the helper thread at once.  (A second k_ingest launch on the
+        // copy stream was tried for them: the two streams share a hardware queue, and every kernel of the structure chain
+        // queued behind it waited for its 60 us; the copy engine's commands cost ~8 us of latency each but run beside anything.)
+        movba_handle *const hh = h;
+        const movba_lba_desc *const dd = d;
+        const EdgeLayout lay = L;
+        char *const stage = sg;
+        const int np = NP, p = P, e = E;
+        HelperHandOff *const out = &ho;
+        h->packer.post([=]() {
+            hipError_t err = hipSetDevice(hh->device);
+            auto dma = [&](size_t to, const void *from, size_t bytes) {
+                if (err == hipSuccess && bytes) err = hipMemcpyAsync(out->arena + to, from, bytes, hipMemcpyHostToDevice, hh->copy_stream);
+            };
+            dma(lay.obs, dd->obs, sizeof(double) * 2 * (size_t)e);
+            dma(lay.isig, dd->inv_sigma2, sizeof(double) * (size_t)e);
+            if (dd->obs_right) dma(lay.obsr, dd->obs_right, sizeof(double) * (size_t)e);
+            dma(lay.point0, dd->points, sizeof(double) * 3 * (size_t)p);
+            dma(lay.pose0, dd->poses, sizeof(double) * 7 * (size_t)np);
+            if (lay.has_kcam) {
+                double *kc = reinterpret_cast<double *>(stage + lay.kcam);
+                for (int i = 0; i < np; ++i) {
+                    const double *ck = dd->cam_kf ? dd->cam_kf + 4 * (size_t)i : &dd->fx;      // (fx, fy, cx, cy are contiguous in the descriptor)
+                    kc[8 * i] = ck[0]; kc[8 * i + 1] = ck[1]; kc[8 * i + 2] = ck[2]; kc[8 * i + 3] = ck[3];
+                    kc[8 * i + 4] = dd->bf_kf ? dd->bf_kf[i] : dd->bf; kc[8 * i + 5] = kc[8 * i + 6] = kc[8 * i + 7] = 0.0;
+                }
+                dma(lay.kcam, stage + lay.kcam, sizeof(double) * 8 * (size_t)np);
+            }
+            if (err == hipSuccess) err = hipEventRecord(hh->copy_event, hh->copy_stream);
+            out->copy_err = err;
+        });
+        ho.idx_ready.store(1, std::memory_order_release);
+        return;
+    }
     // (test hook helper_delay_us: the helper starts that much later: whatever this thread takes from the helper
     //  without waiting for it shows up as a wrong result instead of hiding behind the usual timing)
     const int helper_delay_us = HOOK(h, helper_delay_us);
@@ -821,41 +865,20 @@ void Upload::post_helper()
     const movba_lba_desc *const dd = d;
     const int np = NP, p = P, e = E;
     HelperHandOff *const out = &ho;
-    const bool idx_direct = view_pose && view_point, raw_direct = direct_raw;
+    const bool send_idx = dev_first;        // (device grouping pass: the index arrays cross first, on the copy stream, behind edgeb_event)
     h->packer.post([=]() {
         if (helper_delay_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(helper_delay_us));
-        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_a otherwise; not needed
-        //  at all when the device reads the caller's own pinned arrays)
-        if (!idx_direct) {
-            std::memcpy(stage + lay.gpose, dd->edge_pose, sizeof(int32_t) * (size_t)e);
-            std::memcpy(stage + lay.gpoint, dd->edge_point, sizeof(int32_t) * (size_t)e);
+        // (the index arrays as they are: right when the edges come grouped by point, overwritten by pack_a otherwise)
+        std::memcpy(stage + lay.gpose, dd->edge_pose, sizeof(int32_t) * (size_t)e);
+        std::memcpy(stage + lay.gpoint, dd->edge_point, sizeof(int32_t) * (size_t)e);
+        if (send_idx) {
+            hipError_t e0 = hipSetDevice(hh->device);
+            if (e0 == hipSuccess) e0 = hipMemcpyAsync(out->arena + lay.gpose, stage + lay.gpose, sizeof(int32_t) * (size_t)e, hipMemcpyHostToDevice, hh->copy_stream);
+            if (e0 == hipSuccess) e0 = hipMemcpyAsync(out->arena + lay.gpoint, stage + lay.gpoint, sizeof(int32_t) * (size_t)e, hipMemcpyHostToDevice, hh->copy_stream);
+            if (e0 == hipSuccess) e0 = hipEventRecord(hh->edgeb_event, hh->copy_stream);
+            out->idx_err = e0;
         }
         out->idx_ready.store(1, std::memory_order_release);
-        if (raw_direct) {
-            // the caller's arrays are pinned: DMA straight out of them, nothing staged (the call does not return before the
-            // copies have left them: send_pairs)
-            hipError_t err = hipSetDevice(hh->device);
-            auto dma = [&](size_t to, const void *from, size_t bytes) {
-                if (err == hipSuccess && bytes) err = hipMemcpyAsync(out->arena + to, from, bytes, hipMemcpyHostToDevice, hh->copy_stream);
-            };
-            dma(lay.obs, dd->obs, sizeof(double) * 2 * (size_t)e);
-            dma(lay.isig, dd->inv_sigma2, sizeof(double) * (size_t)e);
-            if (dd->obs_right) dma(lay.obsr, dd->obs_right, sizeof(double) * (size_t)e);
-            dma(lay.pose0, dd->poses, sizeof(double) * 7 * (size_t)np);
-            dma(lay.point0, dd->points, sizeof(double) * 3 * (size_t)p);
-            if (lay.has_kcam) {
-                double *kc = reinterpret_cast<double *>(stage + lay.kcam);
-                for (int i = 0; i < np; ++i) {
-                    const double *ck = dd->cam_kf ? dd->cam_kf + 4 * (size_t)i : &dd->fx;
-                    kc[8 * i] = ck[0]; kc[8 * i + 1] = ck[1]; kc[8 * i + 2] = ck[2]; kc[8 * i + 3] = ck[3];
-                    kc[8 * i + 4] = dd->bf_kf ? dd->bf_kf[i] : dd->bf; kc[8 * i + 5] = kc[8 * i + 6] = kc[8 * i + 7] = 0.0;
-                }
-                dma(lay.kcam, stage + lay.kcam, sizeof(double) * 8 * (size_t)np);
-            }
-            if (err == hipSuccess) err = hipEventRecord(hh->copy_event, hh->copy_stream);
-            out->copy_err = err;
-            return;
-        }
         // ... each part straight on to the device on the copy stream while the next one is being staged: most of the upload
         // is across the bus before the calling thread has finished its pass over the edges (the solve's first kernels wait
         // for copy_event, nothing else does)
@@ -968,30 +991,41 @@ int Upload::group_on_device()
     carve_state();
     int rc = carve_scratch(true); if (rc) return rc;
     char *sa = h->scratch, *misc = sg + h->stage_cap - misc_bytes;
-    // The device reads the caller's index arrays and the keyframes' flags out of HOST memory (the staging buffer is mapped,
-    // movba_host_alloc blocks are): no copy commands, k_basic_hist leaves the index arrays in the arena as it reads them.
-    // (the flags travel through the place of the hessian indices, which the device makes itself here)
+    // (the keyframes' flags are read out of host memory - the staging buffer is mapped -, through the place of the hessian
+    //  indices, which the device makes itself here)
     std::memcpy(sg + L.hidx, d->pose_fixed, (size_t)NP);
     HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_info + sizeof(int32_t) * kBasicInfo - so_cnt, h->stream));    // bin totals, error word, edges per keyframe, info words
     bd = BasicDev{};
     bd.E = E; bd.P = P; bd.NP = NP; bd.nblk = (E + kBasicBlock - 1) / kBasicBlock;
-    if (view_pose && view_point) { bd.src_pose = view_pose; bd.src_point = view_point; }
-    else {
-        // (the helper thread's copy of them in the staging buffer: its first piece of work)
+    if (direct_raw) {
+        // The caller's index arrays out of its own pinned memory, by kernel (struct_kernels.hip: k_ingest), on this stream, in
+        // front of the grouping kernel that reads them.
+        auto view = [](const void *p, size_t bytes) { return static_cast<const void *>(host_block_view(p, bytes)); };
+        IngestArgs ia{};
+        ia.seg[0] = IngestSeg{ view(d->edge_pose, sizeof(int32_t) * (size_t)E), h->arena + L.gpose, sizeof(int32_t) * (size_t)E };
+        ia.seg[1] = IngestSeg{ view(d->edge_point, sizeof(int32_t) * (size_t)E), h->arena + L.gpoint, sizeof(int32_t) * (size_t)E };
+        // (the keyframes' flags with them: four bytes at a time out of the staging buffer's copy, which is padded)
+        ia.seg[2] = IngestSeg{ h->stage_dev + L.hidx, sa + so_fixed, ((size_t)NP + 3) & ~(size_t)3 };
+        ia.nseg = 3; ia.counter = h->ingest_counter; ia.wait_for = 0;
+        HIP_TRY(launch_ingest(ia, h->stream));
+        h->ingest_expect += (unsigned)ingest_workgroups();
+    } else {
+        // the index arrays are on their way on the copy stream (post_helper): the grouping kernel starts behind their event
         while (ho.idx_ready.load(std::memory_order_acquire) == 0) host_relax(h->opt.host_wait);
-        bd.src_pose = reinterpret_cast<const int32_t *>(h->stage_dev + L.gpose); bd.src_point = reinterpret_cast<const int32_t *>(h->stage_dev + L.gpoint);
+        if (ho.idx_err != hipSuccess) { std::fprintf(stderr, "libmovba: upload copy failed: %s\n", hipGetErrorString(ho.idx_err)); return MOVBA_ERR_HIP; }
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->edgeb_event, 0));
     }
     arena_gen_at_edge_copy = ho.arena_gen;
-    bd.edge_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); bd.edge_point = reinterpret_cast<int32_t *>(h->arena + L.gpoint);
-    bd.pose_fixed = reinterpret_cast<const uint8_t *>(h->stage_dev + L.hidx);
+    bd.edge_pose = reinterpret_cast<const int32_t *>(h->arena + L.gpose); bd.edge_point = reinterpret_cast<const int32_t *>(h->arena + L.gpoint);
+    // (staged mode: the flags are read out of the mapped staging buffer; direct mode: k_ingest has brought them along)
+    bd.pose_fixed = direct_raw ? reinterpret_cast<const uint8_t *>(sa + so_fixed) : reinterpret_cast<const uint8_t *>(h->stage_dev + L.hidx);
     bd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart); bd.rank = reinterpret_cast<int32_t *>(h->arena + L.slot);
     bd.H = reinterpret_cast<int32_t *>(sa + so_H); bd.pose_edges = reinterpret_cast<int32_t *>(sa + so_pe);
     bd.hidx = reinterpret_cast<int32_t *>(h->arena + L.hidx); bd.base = reinterpret_cast<int32_t *>(h->arena + L.base);
     bd.free_pose = reinterpret_cast<int32_t *>(h->arena + L.free_pose); bd.info = reinterpret_cast<int32_t *>(sa + so_info);
     HIP_TRY(launch_basic(bd, h->stream));
     rc = launch_counts(); if (rc) return rc;
-    HIP_TRY(launch_basic_scan(bd, h->stream));      // (what the slots need: behind the counts the host waits for)
-    lap("index H2D + grouping + count launches");
+    lap("grouping + count launches");
     {
         const double t_wait = now_ms();
         while (__atomic_load_n(misc_seq, __ATOMIC_ACQUIRE) != seq) {
@@ -1104,6 +1138,8 @@ int Upload::queue_edge_b()
 
 int Upload::launch_fill()
 {
+    // (the scan of the per-chunk counts the fill reads, where launch_counts left it to whoever launches the fill)
+    if (scan_pending) { HIP_TRY(launch_struct_scan(sd, h->stream)); scan_pending = false; }
     if (sorted_structure) {
         sd.ent64 = reinterpret_cast<unsigned long long *>(h->arena + o_ent);
         sd.g_pose = reinterpret_cast<int32_t *>(h->arena + L.gpose); sd.pt_start = reinterpret_cast<int32_t *>(h->arena + L.ptstart);
@@ -1155,6 +1191,7 @@ int Upload::carve_scratch(bool basic)
     so_pe = sc.take<int32_t>(basic ? NP : 0); so_info = sc.take<int32_t>(basic ? kBasicInfo : 0);     // (zeroed together with the two above)
     so_ent0 = sc.take<int32_t>(nbins);
     so_cntw = sc.take<int32_t>((size_t)nbins * nchunks);
+    so_fixed = sc.take<uint8_t>(basic ? (size_t)NP + 4 : 0);
     so_H = sc.take<int32_t>(basic ? (size_t)((E + kBasicBlock - 1) / kBasicBlock) * NP : 0);
     if (sc.off > h->scratch_cap) {
         if (h->scratch) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->scratch)); h->scratch = nullptr; h->scratch_cap = 0; }
@@ -1186,7 +1223,9 @@ int Upload::launch_counts()
     __atomic_store_n(misc_seq, seq - 1, __ATOMIC_RELAXED);
     HIP_TRY(launch_struct_counts_out(sd, reinterpret_cast<int32_t *>(h->stage_dev + (misc - sg)), seq, h->stream,
                                      dev_first ? reinterpret_cast<const int32_t *>(sa + so_pe) : nullptr, dev_first ? reinterpret_cast<const int32_t *>(sa + so_info) : nullptr));
-    HIP_TRY(launch_struct_scan(sd, h->stream));
+    // (the scan over the chunks is what the FILL needs, not the host: in direct mode the helper thread launches it with the fill)
+    scan_pending = dev_first && direct_raw && h->opt.profile == 0;
+    if (!scan_pending) HIP_TRY(launch_struct_scan(sd, h->stream));
     return MOVBA_OK;
 }
 
@@ -1233,6 +1272,7 @@ int Upload::after_counts()
             HIP_TRY(launch_struct_count(sd, h->stream));
             HIP_TRY(launch_struct_counts_out(sd, nullptr, 0, h->stream));
             HIP_TRY(launch_struct_scan(sd, h->stream));
+            scan_pending = false;
             lap("covisibility reorder + recount");
         }
     }
@@ -1249,24 +1289,36 @@ int Upload::after_counts()
     o_ent = c.take<int32_t>(ent_words());
     o_slotpt = c.take<int32_t>((size_t)s().E_free + 1);
     if (c.off <= h->arena_cap && h->arena_gen == ho.arena_gen) {
-        int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
-        rq = launch_fill(); if (rq) return rq;
         filled_early = true; fill_gen = h->arena_gen;
-        // The solve's first two kernels - state 0 from the uploaded estimates, the first linearisation - need the edge data, the
-        // slots and the state arrays, none of which depends on the pair structure this thread is about to lay out: queued
-        // here, they run in the shadow of finish_pairs / the solver choice / the pair region's packing, and movba_lba_run starts
-        // with the Hpp pass.  (Where the caller's arrays are still being staged by the helper thread, waiting for its event
-        // here would stall this thread: the run queues them as before.)
-        if (dev_first && direct_raw) {
-            rq = join_helper(); if (rq) return rq;
-            HIP_TRY(hipStreamWaitEvent(h->stream, h->copy_event, 0));
+        if (dev_first && direct_raw && h->opt.profile == 0) {
+            // The slots' completion, the fill of the entry lists and the solve's first two kernels - state 0 from the uploaded
+            // estimates, the first linearisation: they need the edge data, the slots and the state arrays, none of which depends
+            // on the pair structure - are queued by the HELPER thread (idle in direct mode) while this thread lays out the pairs:
+            // four launches and an event wait are ~25 us of API calls that would otherwise stand in front of finish_pairs, and
+            // the kernels run in the shadow of the pair layout; movba_lba_run then starts with the Hpp pass.  Whatever order the
+            // two threads' commands reach the stream in, each of this thread's (the pair region's copy) is independent of the
+            // helper's; send_pairs joins the helper before the run can queue anything behind them.
+            { const int rw = join_helper(); if (rw) return rw; }      // (its DMA commands are queued: ~30 us into the call)
             device_view();
-            {
-                ScopedEvents ev(h, KC_SETUP);
-                HIP_TRY(launch_init(h->win, h->stream));
-                HIP_TRY(launch_linearize(h->win, h->stream));
-            }
+            const DevWindow wv = h->win;
+            movba_handle *const hh = h;
+            Upload *const self = this;
+            HelperHandOff *const out = &ho;
+            h->packer.post([=]() {
+                hipError_t err = hipSetDevice(hh->device);
+                int rq = MOVBA_OK;
+                if (err == hipSuccess) rq = self->launch_slotpt();
+                if (err == hipSuccess && rq == MOVBA_OK) rq = self->launch_fill();
+                if (err == hipSuccess && rq == MOVBA_OK) err = hipStreamWaitEvent(hh->stream, hh->copy_event, 0);
+                if (err == hipSuccess && rq == MOVBA_OK) err = launch_init(wv, hh->stream);
+                if (err == hipSuccess && rq == MOVBA_OK) err = launch_linearize(wv, hh->stream);
+                out->copy_err = (err == hipSuccess && rq != MOVBA_OK) ? hipErrorUnknown : err;
+            });
+            ho.joined = false;                              // (send_pairs waits for it)
             h->early_setup = true;
+        } else {
+            int rq = launch_slotpt(); if (rq) return rq;         // (completes the slots the fill reads)
+            rq = launch_fill(); if (rq) return rq;
         }
     }
     lap("edge B H2D + fill kernel (queued)");
@@ -1552,7 +1604,16 @@ int Upload::send_pairs()
 {
     const double t2 = now_ms();
     h->prof.structure_ms += (t2 - t0) - upload_host_ms;
-    HIP_TRY(hipMemcpyAsync(h->arena + pair_begin, sg + L.max_end, h2d - pair_begin, hipMemcpyHostToDevice, h->stream));
+    // The pair region (~100 KB at cfg3) stands between the last structure kernel and the solve's first pass over the pairs: a
+    // copy command costs it ~10 us to start and ~9 us to be seen finished by the kernel behind it; read out of the (mapped)
+    // staging buffer by k_ingest it is one more kernel in the chain.  Large regions (host-built entry lists) take the copy engine.
+    if (h2d - pair_begin <= (size_t)1 << 20) {
+        IngestArgs ia{};
+        ia.seg[0] = IngestSeg{ h->stage_dev + L.max_end, h->arena + pair_begin, ((h2d - pair_begin) + 3) & ~(size_t)3 };
+        ia.nseg = 1; ia.counter = nullptr; ia.wait_for = 0;
+        HIP_TRY(launch_ingest(ia, h->stream));
+    } else
+        HIP_TRY(hipMemcpyAsync(h->arena + pair_begin, sg + L.max_end, h2d - pair_begin, hipMemcpyHostToDevice, h->stream));
     if (!(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_slotpt(); if (rq) return rq; }
     if (dev_structure && !(filled_early && fill_gen == h->arena_gen)) { const int rq = launch_fill(); if (rq) return rq; }
     // the solve's kernels start behind the caller's arrays on the copy stream (the structure pass above did not need them)
@@ -1640,9 +1701,7 @@ int Upload::run(bool allow_dev_first)
     dev_first = allow_dev_first && dev_first_eligible();
     if (dev_first) {
         // arrays of the caller that lie in movba_host_alloc memory (pinned, mapped) are read by the device where they are
-        view_pose = reinterpret_cast<const int32_t *>(host_block_view(d->edge_pose, sizeof(int32_t) * (size_t)E));
-        view_point = reinterpret_cast<const int32_t *>(host_block_view(d->edge_point, sizeof(int32_t) * (size_t)E));
-        direct_raw = host_block_view(d->obs, sizeof(double) * 2 * (size_t)E) && host_block_view(d->inv_sigma2, sizeof(double) * (size_t)E) &&
+        direct_raw = host_block_view(d->edge_pose, sizeof(int32_t) * (size_t)E) && host_block_view(d->edge_point, sizeof(int32_t) * (size_t)E) && host_block_view(d->obs, sizeof(double) * 2 * (size_t)E) && host_block_view(d->inv_sigma2, sizeof(double) * (size_t)E) &&
                      host_block_view(d->poses, sizeof(double) * 7 * (size_t)NP) && host_block_view(d->points, sizeof(double) * 3 * (size_t)P) &&
                      (!d->obs_right || host_block_view(d->obs_right, sizeof(double) * (size_t)E));
     }

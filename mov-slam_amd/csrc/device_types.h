@@ -213,20 +213,24 @@ struct StructDev {
 constexpr int kBasicBlock = 256;        // edges per workgroup of k_basic_hist (and of k_slot_point, which completes the slots)
 struct BasicDev {
     int32_t E, P, NP, nblk;
-    // the caller's index arrays where the device can read them - its own pinned arrays (movba_host_alloc) or the staging
-    // buffer's copy, both host memory read across the bus - and their place in the arena, which k_basic_hist fills on the way
-    const int32_t *src_pose, *src_point;
-    int32_t *edge_pose, *edge_point;
-    const uint8_t *pose_fixed;                  // (host memory too)
+    const int32_t *edge_pose, *edge_point;      // the caller's index arrays in the arena (the upload's first copies)
+    const uint8_t *pose_fixed;                  // (host memory: the staging buffer is mapped)
     int32_t *pt_start;          // P + 1
     int32_t *rank;              // E: the edge's rank among the edges of its keyframe INSIDE its workgroup's 256 edges
     int32_t *H;                 // nblk x NP: edges of keyframe k in workgroup b, then (k_basic_scan) in the workgroups before b
     int32_t *pose_edges;        // NP (zeroed): edges per keyframe
     int32_t *hidx, *base, *free_pose;           // NP, NP + 1, <= NP
     int32_t *info;              // kBasicInfo words (zeroed): [0] an index out of range, [1] edges not grouped by point,
-                                // [2] free keyframes with edges, [3] their edges, [4] fixed keyframes
+                                // [2] free keyframes with edges, [3] their edges, [4] fixed keyframes, [5] workgroups of k_basic_hist done
 };
 constexpr int kBasicInfo = 8;
+
+// k_ingest (struct_kernels.hip): arrays of the caller that lie in mapped host memory, read across the bus by the kernel itself
+// and left in the arena.  Up to eight pieces per launch, in order; `counter` is raised once by every workgroup when it is
+// through, and a launch may hold its reads back until the counter has reached `wait_for` (the launch in front of it is through:
+// the bus is the bottleneck, and whoever the pair structure waits for gets it first).
+struct IngestSeg { const void *src; void *dst; unsigned long long bytes; };
+struct IngestArgs { IngestSeg seg[8]; int32_t nseg, pad_i; unsigned *counter; unsigned wait_for; unsigned pad_w; };
 
 struct PcgParams {
     double rel_tol;

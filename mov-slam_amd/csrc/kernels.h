@@ -16,9 +16,11 @@ hipError_t configure_struct_kernels();
 hipError_t launch_struct_count(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_scan(const StructDev &sd, hipStream_t s);
 hipError_t launch_struct_counts_out(const StructDev &sd, int32_t *host_cnt_dev, int seq, hipStream_t s, const int32_t *basic_pe = nullptr, const int32_t *basic_info = nullptr);
-// the grouping pass on the device (BasicDev): k_basic_hist + k_basic_index; the scan of its per-workgroup counts (what the slots need)
+// arrays in mapped host memory -> arena, read by the kernel itself (IngestArgs); every workgroup raises a.counter once
+hipError_t launch_ingest(const IngestArgs &a, hipStream_t s);
+int ingest_workgroups();
+// the grouping pass on the device (BasicDev): k_basic_hist, then k_basic_scan (whose last workgroup numbers the keyframes)
 hipError_t launch_basic(const BasicDev &bd, hipStream_t s);
-hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s);
 bool struct_lds_fits(int nfree, int NP);
 hipError_t launch_struct_fill(const StructDev &sd, hipStream_t s);
 // structure pass beyond k_struct_pairs' reach (struct_sort.hip): counts by atomics, fill by a stable sort of the couples

@@ -14,6 +14,8 @@
 // order (pair, then point) is exactly the host builder's and does not depend on scheduling.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "device_types.h"
 #include "kernels.h"
 
@@ -163,11 +165,11 @@ __global__ __launch_bounds__(64 * kStructWaves) void k_struct_pairs(StructDev sd
 // exclusive scan over the chunks of every bin's counts (in place).  A workgroup takes 64 bins (one per
 // lane: coalesced across bins) and cuts the chunks into 16 segments, one per wave: segment sums, a 16-step prefix through
 // LDS, then the running prefixes written back; 8 loads in flight per lane in both passes.
-__device__ __forceinline__ void scan_columns(int32_t *tab, int nbins, int nrows)
+__device__ __forceinline__ int scan_columns(int32_t *tab, int nbins, int nrows, int blk)
 {
     __shared__ int seg_tot[16][64];
     const int tx = threadIdx.x & 63, sy = threadIdx.x >> 6;
-    const int bin = blockIdx.x * 64 + tx;
+    const int bin = blk * 64 + tx;
     const bool live = bin < nbins;
     const int L = (nrows + 15) / 16, c_beg = sy * L, c_end = min(nrows, c_beg + L);
     int32_t *col = tab + (live ? bin : 0);
@@ -193,17 +195,57 @@ __device__ __forceinline__ void scan_columns(int32_t *tab, int nbins, int nrows)
             carry += v[u];
         }
     }
+    return carry;       // (the last segment's threads: the column's total)
 }
 
-__global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd) { scan_columns(sd.cntw, sd.nfree * sd.nfree, sd.nchunks); }
-// ... and of the grouping pass's edges per (workgroup, keyframe): H becomes "edges of the keyframe in the workgroups before"
-__global__ __launch_bounds__(1024) void k_basic_scan(BasicDev bd) { scan_columns(bd.H, bd.NP, bd.nblk); }
+__global__ __launch_bounds__(1024) void k_struct_scan(StructDev sd) { scan_columns(sd.cntw, sd.nfree * sd.nfree, sd.nchunks, blockIdx.x); }
 
-hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s)
+// ---- the caller's arrays out of mapped host memory into the arena (IngestArgs, device_types.h) ----
+// Measured on an MI355X box (scripts/probes/pcie_probe.hip): 64 workgroups with four 16-byte loads per lane in flight take in
+// 48 GB/s, what one large copy-engine command gets (51 GB/s) - but the upload's six arrays as six copy commands take 125 us for
+// 4 MB (each command costs ~8 us of latency the next one waits behind), two launches of this kernel ~95 us.
+constexpr int kIngestGrid = 64, kIngestBlock = 256, kIngestFly = 4;
+__global__ __launch_bounds__(kIngestBlock) void k_ingest(IngestArgs a)
 {
-    hipLaunchKernelGGL(k_basic_scan, dim3((bd.NP + 63) / 64), dim3(1024), 0, s, bd);
+    if (a.wait_for) {
+        // a hint, not a dependency: after ~200 us the launch goes ahead whatever the counter says
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((int)(__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.wait_for) < 0 &&
+               __builtin_amdgcn_s_memrealtime() - t0 < 20000ull) __builtin_amdgcn_s_sleep(8);
+    }
+    const size_t stride = (size_t)gridDim.x * kIngestBlock;
+    for (int q = 0; q < a.nseg; ++q) {
+        const IngestSeg sg = a.seg[q];
+        const bool wide = ((reinterpret_cast<size_t>(sg.src) | reinterpret_cast<size_t>(sg.dst)) & 15) == 0;
+        const size_t n16 = wide ? sg.bytes / 16 : 0;
+        // (non-temporal stores: 3.5 MB of dirty lines in the L2s would be written back by the release at the END of every kernel
+        //  that finishes on another stream meanwhile - the grouping and count kernels took 3 - 4 times their time beside a
+        //  write-back ingest)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i *src = static_cast<const v4i *>(sg.src);
+        v4i *dst = static_cast<v4i *>(sg.dst);
+        for (size_t i0 = (size_t)blockIdx.x * kIngestBlock + threadIdx.x; i0 < n16; i0 += stride * kIngestFly) {
+            v4i v[kIngestFly];
+#pragma unroll
+            for (int u = 0; u < kIngestFly; ++u) { const size_t i = i0 + u * stride; if (i < n16) v[u] = src[i]; }
+#pragma unroll
+            for (int u = 0; u < kIngestFly; ++u) { const size_t i = i0 + u * stride; if (i < n16) __builtin_nontemporal_store(v[u], dst + i); }
+        }
+        // the tail (and a piece that is not 16-byte aligned as a whole): 4 bytes at a time
+        const unsigned *s4 = static_cast<const unsigned *>(sg.src);
+        unsigned *d4 = static_cast<unsigned *>(sg.dst);
+        for (size_t i = n16 * 4 + (size_t)blockIdx.x * kIngestBlock + threadIdx.x; i < sg.bytes / 4; i += stride) d4[i] = s4[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && a.counter) atomicAdd(a.counter, 1u);
+}
+
+hipError_t launch_ingest(const IngestArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ingest, dim3(kIngestGrid), dim3(kIngestBlock), 0, s, a);
     return hipGetLastError();
 }
+int ingest_workgroups() { return kIngestGrid; }
 
 // ---- the grouping pass on the device (BasicDev, device_types.h) ----
 // One thread per edge, 256 edges per workgroup.  Validation and the grouped-order test are per edge; a point's range starts at
@@ -211,31 +253,86 @@ hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s)
 // three exclusive counts - the workgroups before (H, scanned by k_basic_scan), the waves before inside the workgroup, the
 // lanes before inside the wave (one ballot per distinct keyframe of the wave: 64 consecutive edges belong to ~10 neighbouring
 // points, hence to a dozen keyframes) - so that it is the host builder's rank whatever the scheduling.
+// hessian indices, first pose-major slots and the free-pose list from the edges per keyframe, as build_basic numbers them:
+// free keyframes with at least one edge, in caller order.  One workgroup (the LAST one of k_basic_scan to finish); keyframes
+// in rounds of its threads.
+template <int NT>
+__device__ __forceinline__ void basic_index(const BasicDev &bd, const int *pe_lds /* NP */, int *sc /* 2 x (NT / 64) + 4 ints of LDS */)
+{
+    constexpr int NWV = NT / 64;
+    int *wa = sc, *we = sc + NWV, *carry = we + NWV;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; carry[2] = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < bd.NP; i0 += NT) {
+        const int i = i0 + threadIdx.x;
+        const bool in = i < bd.NP;
+        const int pe = in ? pe_lds[i] : 0;
+        const bool fixed = in && bd.pose_fixed[i] != 0;
+        const bool act = in && !fixed && pe > 0;
+        // inclusive scans over the workgroup: inside a wave by shuffles, the waves' totals through LDS
+        int ia = act ? 1 : 0, ie = act ? pe : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ta = __shfl_up(ia, d), te = __shfl_up(ie, d);
+            if (lane >= d) { ia += ta; ie += te; }
+        }
+        if (lane == 63) { wa[wv] = ia; we[wv] = ie; }
+        const int nfix = __syncthreads_count(fixed);
+        int oa = 0, oe = 0, ta = 0, te = 0;
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) { const int a = wa[q], e = we[q]; if (q < wv) { oa += a; oe += e; } ta += a; te += e; }
+        const int h = carry[0] + oa + ia - (act ? 1 : 0), b = carry[1] + oe + ie - (act ? pe : 0);
+        if (in) { bd.hidx[i] = act ? h : -1; bd.base[i] = act ? b : -1; if (act) bd.free_pose[h] = i; }
+        __syncthreads();
+        if (threadIdx.x == 0) { carry[0] += ta; carry[1] += te; carry[2] += nfix; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { bd.base[bd.NP] = -1; bd.info[2] = carry[0]; bd.info[3] = carry[1]; bd.info[4] = carry[2]; }
+}
+
+// H becomes "edges of the keyframe in the workgroups before" (what the slots need), the columns' totals are the edges per
+// keyframe, and the keyframes are numbered from them: ONE workgroup for all of it (64 columns per turn), so that nothing has to
+// travel between workgroups - a ticket counter with its two device-scope fences cost this kernel 10 of its 17 us (a release
+// fence writes back the whole L2 of its XCD on this chip).
+__global__ __launch_bounds__(1024) void k_basic_scan(BasicDev bd)
+{
+    __shared__ int sc[2 * 16 + 4];
+    __shared__ int pe_lds[1024];
+    for (int g = 0; g * 64 < bd.NP; ++g) {
+        const int total = scan_columns(bd.H, bd.NP, bd.nblk, g);
+        const int col = g * 64 + (threadIdx.x & 63);
+        if ((threadIdx.x >> 6) == 15 && col < bd.NP) { pe_lds[col] = total; bd.pose_edges[col] = total; }
+        __syncthreads();                                // (seg_tot of scan_columns is reused by the next turn)
+    }
+    basic_index<1024>(bd, pe_lds, sc);
+}
+
 __global__ __launch_bounds__(kBasicBlock) void k_basic_hist(BasicDev bd)
 {
-    extern __shared__ int whist[];                      // (kBasicBlock / 64) x NP
+    extern __shared__ int whist[];                      // (kBasicBlock / 64) x NP ints
+    __shared__ int slice[kBasicBlock];
+    __shared__ int lp_first;
     constexpr int NW = kBasicBlock / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int e = blockIdx.x * kBasicBlock + threadIdx.x;
+    const int e0 = blockIdx.x * kBasicBlock, e = e0 + threadIdx.x;
     for (int k = threadIdx.x; k < NW * bd.NP; k += kBasicBlock) whist[k] = 0;
+    // (the index arrays are in the arena: the upload's first copies, which this launch waits for)
+    if (threadIdx.x == 0) lp_first = e0 > 0 && e0 < bd.E ? bd.edge_point[e0 - 1] : -1;
     const bool live = e < bd.E;
-    // (the caller's arrays are read ONCE, across the bus, and left in the arena for every later kernel; a lane's predecessor is
-    //  its neighbour's value, the first lane of a wave reads one more word)
-    int kf = live ? bd.src_pose[e] : -1, l = live ? bd.src_point[e] : 0;
-    int lp = __shfl_up(l, 1);
-    if (lane == 0) lp = (live && e > 0) ? bd.src_point[e - 1] : -1;
-    if (live) { bd.edge_pose[e] = kf; bd.edge_point[e] = l; }
-    bool bad = false;
-    if (live) {
-        if ((unsigned)kf >= (unsigned)bd.NP || (unsigned)l >= (unsigned)bd.P) { bad = true; kf = -1; }
-        else {
-            if (l < lp) bd.info[1] = 1;                 // not in ascending point order: the host groups such a window itself
-            else for (int q = max(lp, -1) + 1; q <= l; ++q) bd.pt_start[q] = e;       // (points nobody observes start where the next one does)
-            if (e == bd.E - 1) for (int q = l + 1; q <= bd.P; ++q) bd.pt_start[q] = bd.E;
-        }
-    }
-    if (bad) bd.info[0] = 1;
+    int kf = live ? bd.edge_pose[e] : -1;
+    const int l = live ? bd.edge_point[e] : 0;
+    slice[threadIdx.x] = l;
     __syncthreads();
+    bool bad = false;
+    if (live && ((unsigned)kf >= (unsigned)bd.NP || (unsigned)l >= (unsigned)bd.P)) { bad = true; kf = -1; }
+    if (bad) bd.info[0] = 1;
+    if (live && !bad) {
+        const int lp = threadIdx.x > 0 ? slice[threadIdx.x - 1] : lp_first;
+        if (l < lp) bd.info[1] = 1;                     // not in ascending point order: the host groups such a window itself
+        else for (int q = max(lp, -1) + 1; q <= l; ++q) bd.pt_start[q] = e;       // (points nobody observes start where the next one does)
+        if (e == bd.E - 1) for (int q = l + 1; q <= bd.P; ++q) bd.pt_start[q] = bd.E;
+    }
     int r = 0;
     unsigned long long todo = __ballot(kf >= 0);
     while (todo) {
@@ -255,41 +352,9 @@ __global__ __launch_bounds__(kBasicBlock) void k_basic_hist(BasicDev bd)
         int t = 0;
 #pragma unroll
         for (int q = 0; q < NW; ++q) t += whist[q * bd.NP + k];
+        // (the keyframes' totals are the scan's by-product: 432 workgroups adding into 60 words by device-scope atomics took 35 us)
         bd.H[(size_t)blockIdx.x * bd.NP + k] = t;
-        if (t) atomicAdd(&bd.pose_edges[k], t);        // (integer totals: order-independent)
     }
-}
-
-// hessian indices, first pose-major slots and the free-pose list from the edges per keyframe, as build_basic numbers them:
-// free keyframes with at least one edge, in caller order.  One workgroup; keyframes in rounds of 1024.
-__global__ __launch_bounds__(1024) void k_basic_index(BasicDev bd)
-{
-    __shared__ int sc_a[1024], sc_e[1024];
-    __shared__ int carry[3];
-    if (threadIdx.x == 0) { carry[0] = 0; carry[1] = 0; carry[2] = 0; }
-    __syncthreads();
-    for (int i0 = 0; i0 < bd.NP; i0 += 1024) {
-        const int i = i0 + threadIdx.x;
-        const bool in = i < bd.NP;
-        const int pe = in ? bd.pose_edges[i] : 0;
-        const bool fixed = in && bd.pose_fixed[i] != 0;
-        const bool act = in && !fixed && pe > 0;
-        sc_a[threadIdx.x] = act ? 1 : 0; sc_e[threadIdx.x] = act ? pe : 0;
-        const int nfix = __syncthreads_count(fixed);
-        for (int d = 1; d < 1024; d <<= 1) {            // Hillis-Steele, inclusive
-            const int va = threadIdx.x >= d ? sc_a[threadIdx.x - d] : 0, ve = threadIdx.x >= d ? sc_e[threadIdx.x - d] : 0;
-            __syncthreads();
-            sc_a[threadIdx.x] += va; sc_e[threadIdx.x] += ve;
-            __syncthreads();
-        }
-        const int h = carry[0] + sc_a[threadIdx.x] - (act ? 1 : 0), b = carry[1] + sc_e[threadIdx.x] - (act ? pe : 0);
-        if (in) { bd.hidx[i] = act ? h : -1; bd.base[i] = act ? b : -1; if (act) bd.free_pose[h] = i; }
-        __syncthreads();
-        if (threadIdx.x == 1023) { carry[0] += sc_a[1023]; carry[1] += sc_e[1023]; }
-        if (threadIdx.x == 0) carry[2] += nfix;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { bd.base[bd.NP] = -1; bd.info[2] = carry[0]; bd.info[3] = carry[1]; bd.info[4] = carry[2]; }
 }
 
 // map point of every pose-major slot (what a diagonal schur entry needs besides its slot).  With `base` the slot array
@@ -321,7 +386,7 @@ hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t
 hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
 {
     hipLaunchKernelGGL(k_basic_hist, dim3(bd.nblk), dim3(kBasicBlock), sizeof(int) * (kBasicBlock / 64) * (size_t)bd.NP, s, bd);
-    hipLaunchKernelGGL(k_basic_index, dim3(1), dim3(1024), 0, s, bd);
+    hipLaunchKernelGGL(k_basic_scan, dim3(1), dim3(1024), 0, s, bd);
     return hipGetLastError();
 }
 

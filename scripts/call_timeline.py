@@ -15,9 +15,9 @@ if mc:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY %s %s B" % (r.get("Direction", "?"), r.get("Bytes", r.get("Size", "?")))))
 ev.sort()
 last = max(i for i, e in enumerate(ev) if "k_init_pose" in e[2])
-# the call's first activity: walk back from k_init_pose while the gaps stay below 300 us
+# the call's first activity: walk back from k_init_pose to the end of the previous call (its k_export)
 i0 = last
-while i0 > 0 and ev[i0][0] - ev[i0 - 1][1] < 300000: i0 -= 1
+while i0 > 0 and "k_export" not in ev[i0 - 1][2]: i0 -= 1
 t0 = ev[i0][0]
 end = max(e[1] for e in ev[i0:])
 print("call span on the GPU: %.1f us" % ((end - t0) / 1e3))

@@ -156,6 +156,15 @@ hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t
     });
     return hipSuccess;
 }
+hipError_t launch_ingest(const IngestArgs &a, hipStream_t s)
+{
+    fake_enqueue(s, [a] {
+        for (int q = 0; q < a.nseg; ++q) std::memcpy(a.seg[q].dst, a.seg[q].src, a.seg[q].bytes);
+        if (a.counter) __atomic_fetch_add(a.counter, (unsigned)ingest_workgroups(), __ATOMIC_RELAXED);
+    });
+    return hipSuccess;
+}
+int ingest_workgroups() { return 64; }
 // the grouping pass of the device (k_basic_hist, k_basic_index), word for word what the kernels leave behind
 hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
 {
@@ -164,8 +173,7 @@ hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
         for (int b = 0; b < bd.nblk; ++b) {
             std::fill(seen.begin(), seen.end(), 0);
             for (int e = b * kBasicBlock; e < std::min(bd.E, (b + 1) * kBasicBlock); ++e) {
-                const int kf = bd.src_pose[e], l = bd.src_point[e], lp = e > 0 ? bd.src_point[e - 1] : -1;
-                bd.edge_pose[e] = kf; bd.edge_point[e] = l;
+                const int kf = bd.edge_pose[e], l = bd.edge_point[e], lp = e > 0 ? bd.edge_point[e - 1] : -1;
                 if ((unsigned)kf >= (unsigned)bd.NP || (unsigned)l >= (unsigned)bd.P) { bd.info[0] = 1; bd.rank[e] = 0; continue; }
                 if (l < lp) bd.info[1] = 1; else for (int q = std::max(lp, -1) + 1; q <= l; ++q) bd.pt_start[q] = e;
                 if (e == bd.E - 1) for (int q = l + 1; q <= bd.P; ++q) bd.pt_start[q] = bd.E;
@@ -173,6 +181,7 @@ hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
             }
             for (int k = 0; k < bd.NP; ++k) { bd.H[(size_t)b * bd.NP + k] = seen[k]; bd.pose_edges[k] += seen[k]; }
         }
+        for (int k = 0; k < bd.NP; ++k) { int run = 0; for (int b = 0; b < bd.nblk; ++b) { const int v = bd.H[(size_t)b * bd.NP + k]; bd.H[(size_t)b * bd.NP + k] = run; run += v; } }
         int nf = 0, run = 0, nfix = 0;
         for (int i = 0; i < bd.NP; ++i) {
             bd.hidx[i] = -1; bd.base[i] = -1;
@@ -180,13 +189,6 @@ hipError_t launch_basic(const BasicDev &bd, hipStream_t s)
             if (bd.pose_edges[i] > 0) { bd.hidx[i] = nf; bd.free_pose[nf++] = i; bd.base[i] = run; run += bd.pose_edges[i]; }
         }
         bd.base[bd.NP] = -1; bd.info[2] = nf; bd.info[3] = run; bd.info[4] = nfix;
-    });
-    return hipSuccess;
-}
-hipError_t launch_basic_scan(const BasicDev &bd, hipStream_t s)
-{
-    fake_enqueue(s, [bd] {
-        for (int k = 0; k < bd.NP; ++k) { int run = 0; for (int b = 0; b < bd.nblk; ++b) { const int v = bd.H[(size_t)b * bd.NP + k]; bd.H[(size_t)b * bd.NP + k] = run; run += v; } }
     });
     return hipSuccess;
 }

@@ -104,6 +104,7 @@ hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKin
     fake_enqueue(s, [=] { std::memcpy(dst, src, bytes); });
     return hipSuccess;
 }
+hipError_t hipMemset(void *dst, int value, size_t bytes) { std::memset(dst, value, bytes); return hipSuccess; }
 hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t s)
 {
     fake_enqueue(s, [=] { std::memset(dst, value, bytes); });

@@ -44,6 +44,7 @@ hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned flags);
 hipError_t hipMemcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemsetAsync(void *dst, int value, size_t bytes, hipStream_t s);
+hipError_t hipMemset(void *dst, int value, size_t bytes);
 
 // the fake device's side of a stream: queue a closure behind everything queued so far (fake_device.cpp)
 #include <functional>
