@@ -65,6 +65,102 @@ def algorithmic_bytes(K, F, P, E):
     return per
 
 
+def main_windows(args):
+    """--windows W: the W windows of BASELINE cfg5 (cfg3 shape, seeds 2000 ...) whatever the number of ranks; rank r takes windows
+    r, r + N, ... and solves them in ONE batched run per step (movba_lba_upload each, movba_lba_run_batch, movba_lba_download
+    each: host arrays in -> host arrays out for all of them), then the poses of all W windows are all-gathered (RCCL).  Strong
+    scaling: the job is the same at every N.  value = LM iterations of all W windows per second of the slowest rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from movba import capi, shard, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the local-BA path has no CPU fallback")
+    if args.windows % world:
+        raise SystemExit("--windows must be a multiple of the number of ranks (equal blocks for the all-gather)")
+    rehearsal = os.environ.get("MOVBA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world, **({} if rehearsal else {"device_id": dev}))
+    shape = (50, 10, 20000, 2, 10)
+    mine = shard.windows_for_rank(args.windows, rank, world)
+    ws = [synth.make_window(shape[0], shape[1], shape[2], shard.window_seed(i), run_lo=shape[3], run_hi=shape[4]) for i in mine]
+    NP = ws[0].n_poses
+    stream = torch.cuda.Stream(device=dev)                  # the handles of a batch share one (non-default) stream
+    pose_buf = torch.empty((len(ws), NP, 7), dtype=torch.float64, device=dev)
+    solvers = []
+    for k, w in enumerate(ws):
+        sv = capi.Solver(device=local_rank, stream=stream.cuda_stream)
+        sv.set_pose_export(pose_buf[k].data_ptr(), NP * 7 * 8)
+        sv.prepare(w, pinned=True)
+        solvers.append(sv)
+
+    def step():
+        for sv in solvers:
+            sv.upload_prepared()
+        capi.run_batch(solvers)
+        for sv in solvers:
+            sv.download_prepared()
+        if world > 1:
+            stream.synchronize()
+            return shard.gather_poses(pose_buf.cpu()) if rehearsal else shard.gather_poses(pose_buf)
+        return pose_buf.unsqueeze(0)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    res = [sv.download_prepared(pack=True) for sv in solvers]
+    solves_local = sum(r["n_solves"] for r in res) * args.steps
+    red_dev = torch.device("cpu") if rehearsal else dev
+    tt = torch.tensor([dt], dtype=torch.float64, device=red_dev); ss = torch.tensor([float(solves_local)], dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(ss, op=dist.ReduceOp.SUM)
+    dt_max, solves_total = float(tt.item()), float(ss.item())
+    if rank == 0 and os.environ.get("MOVBA_BENCH_DUMP_POSES"):
+        np.save(os.environ["MOVBA_BENCH_DUMP_POSES"], gathered.detach().cpu().numpy())
+    if rank == 0:
+        K, F, P = ws[0].n_free, ws[0].n_poses - ws[0].n_free, ws[0].n_points
+        E_all = [w.n_edges for w in ws]
+        b_iter = sum(algorithmic_bytes(K, F, P, e)["B_iter"] for e in E_all) / len(E_all)
+        chain = b_iter * solves_total / dt_max / 1e9
+        out = {"metric": "local-BA iterations/sec (50 KF x 20k MapPoint window)", "value": solves_total / dt_max, "unit": "LM iterations/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{args.windows} LocalBundleAdjustment windows of 50 KF + 10 fixed x 20 000 MapPoints (BASELINE cfg5: seeds 2000-{2000 + args.windows - 1}), "
+                                      f"{len(ws)} per GPU in one batched run (movba_lba_run_batch), Huber on, 10 LM iterations",
+                          "windows_per_rank": len(ws), "window_solves_per_s": args.windows * args.steps / dt_max,
+                          "parallelism": f"{world} rank(s) x {len(ws)} window(s); " + ("gloo pose all-gather, all ranks on ONE GPU (rehearsal)" if rehearsal else "RCCL pose all-gather of all windows") if world > 1 else f"1 rank x {len(ws)} windows, no collective",
+                          "timed_region": "per window movba_lba_upload (host arrays in) -> one movba_lba_run_batch -> movba_lba_download (results in host memory), then the pose all-gather",
+                          "note": "opt-in mode (--windows): the default bench line (one window per rank, weak scaling) is the one SCALE compares across N; "
+                                  "no 2/4/8-GPU curve of either mode has been measured by this repository (one-GPU boxes)"},
+               "roofline": {"bound": "hbm", "kernel": "whole batched LM iteration (all kernels + launch gaps)", "achieved": chain, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": chain / HBM_PEAK_GBS, "traffic": None, "B_iter_bytes": b_iter}}
+        print(json.dumps(out), flush=True)
+    for sv in solvers:
+        sv.close()
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,7 +170,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the informational extras (resident / batched / adapter runs): profiling passes")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="opt-in: BASELINE cfg5 as SURVEY 8(e) words it - ALWAYS this many windows (8: seeds 2000-2007), dealt round-robin "
+                         "to the ranks and solved by each rank in one batched run (strong scaling); default 0 = one window per rank")
     args = ap.parse_args()
+    if args.windows > 0:
+        return main_windows(args)
 
     import numpy as np
     import torch

@@ -376,7 +376,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
 #pragma unroll
         for (int k = 0; k < 7; ++k) Tq[k] = S0.pose[7 * i + k];
         const int h = w.hidx[i];
-        if (h >= 0) {
+        if (h >= 0 && !fail) {          // (a failed factorisation moves nothing: g2o returns from solve() before its update)
             double u[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) u[k] = aux[6 * h + k];

@@ -924,7 +924,7 @@ __global__ __launch_bounds__(kPT) void k_dense_persist(DevWindow w, unsigned epo
 #pragma unroll
         for (int q = 0; q < 7; ++q) T[q] = S0.pose[7 * i + q];
         const int h = w.hidx[i];
-        if (h >= 0) {
+        if (h >= 0 && !fail) {          // (a failed factorisation moves nothing: g2o returns from solve() before its update)
             double u[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) u[q] = x[6 * h + q];

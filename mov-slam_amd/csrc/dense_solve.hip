@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kBackThreads) void k_dense_backsolve(DevWindow w)
 #pragma unroll
         for (int k = 0; k < 7; ++k) T[k] = S0.pose[7 * i + k];
         const int h = w.hidx[i];
-        if (h >= 0) {
+        if (h >= 0 && !fail) {          // (a failed factorisation moves nothing: g2o returns from solve() before its update)
             double u[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) u[k] = x[6 * h + k];

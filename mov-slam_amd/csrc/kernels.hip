@@ -154,6 +154,11 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
     scale = wave_sum(scale);
     if (lane != 0) return;
     scale += scale_pose;
+    // g2o on a failed solve: tempChi = DBL_MAX (std::numeric_limits<double>::max(): FINITE), scale = 1e-3, nothing updated.  With a
+    // finite current cost rho is hugely negative and the trial is rejected; with an infinite one (a point on a keyframe's z = 0
+    // plane) rho = +inf and the trial counts as ACCEPTED - of a state that has not moved, whose cost the next iteration's
+    // computeActiveErrors() finds again: F1_eval, what this pass has just summed over the unmoved trial state.
+    const double F1_eval = F1;
     if (pcg_fail) { F1 = DBL_MAX; scale = 0.0; }
     scale += 1e-3;
     const double rho = (F0 - F1) / scale;
@@ -169,7 +174,7 @@ __device__ __forceinline__ void decide_body(const DevWindow &w, int cur)
         alpha = fmin(alpha, 2.0 / 3.0);
         c->lambda = lambda0 * fmax(1.0 / 3.0, alpha);
         c->nu = 2.0;
-        c->F0 = F1;
+        c->F0 = pcg_fail ? F1_eval : F1;
         c->cur = cur ^ 1;                    // discardTop(): the trial state becomes current
         c->last_rejected = 0;
         accepted = 1;
@@ -408,8 +413,15 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const double x0 = D[0] * c0 + D[1] * c1 + D[2] * c2;
             const double x1 = D[1] * c0 + D[3] * c1 + D[4] * c2;
             const double x2 = D[2] * c0 + D[4] * c1 + D[5] * c2;
-            X[0] += x0; X[1] += x1; X[2] += x2;
-            if (sub == 0) scale = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+            // A reduced solve that failed (Ctrl::pcg_fail: a Cholesky factorisation that met a non-positive pivot, NaN in the
+            // normal equations) moves NOTHING: g2o's solver returns false before any vertex is updated
+            // (OptimizationAlgorithmLevenberg::solve: `ok2 = _solver->solve(); if (ok2) update`), so the trial state is the current
+            // state, evaluated once more below - which is what the next iteration's fresh cost is taken from when the decision
+            // counts such a trial as accepted (decide_body).
+            if (!c->pcg_fail) {
+                X[0] += x0; X[1] += x1; X[2] += x2;
+                if (sub == 0) scale = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+            }
         }
     }
 
@@ -435,7 +447,9 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
         }
         double rho0 = chi2, rho1 = 1.0;
         if (w.huber_delta > 0.0 && !(chi2 <= dsqr)) {
-            const double rs = rsqrt(chi2), sq = chi2 * rs;
+            // (sqrt(chi2) = chi2 / sqrt(chi2): for chi2 = inf - a point on the keyframe's z = 0 plane - the product is inf * 0;
+            //  g2o's RobustKernelHuber takes sqrt(inf) = inf there, an infinite cost, not NaN)
+            const double rs = rsqrt(chi2), sq = chi2 > DBL_MAX ? chi2 : chi2 * rs;
             rho0 = 2.0 * sq * w.huber_delta - dsqr;
             rho1 = w.huber_delta * rs;
         }

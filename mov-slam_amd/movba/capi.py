@@ -363,6 +363,23 @@ class Solver:
             out["poses"][:] = keep["poses"]; out["points"][:] = keep["points"]
         return self._pack(r, dict(out), rc)
 
+    def upload_prepared(self):
+        """movba_lba_upload of the prepared descriptor (phased calls on buffers built once: batched runs)"""
+        d, keep, r, out = self._prep
+        rc = self._L.movba_lba_upload(self._h, C.byref(d))
+        if rc < 0:
+            raise MovbaError(f"movba_lba_upload: {status_string(rc)}")
+        self._keep = (d, keep)
+        return rc
+
+    def download_prepared(self, pack=False):
+        """movba_lba_download into the prepared result buffers"""
+        d, keep, r, out = self._prep
+        rc = self._L.movba_lba_download(self._h, C.byref(r))
+        if rc < 0:
+            raise MovbaError(f"movba_lba_download: {status_string(rc)}")
+        return self._pack(r, dict(out), rc) if pack else rc
+
     def upload(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0):
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
         rc = self._L.movba_lba_upload(self._h, C.byref(d))

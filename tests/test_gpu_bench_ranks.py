@@ -70,3 +70,38 @@ def test_bench_sends_the_poses_through_rccl_in_a_one_rank_group(built_lib, tmp_p
     finally:
         sv.close()
     assert g.shape[0] == 1 and np.array_equal(g[0].reshape(-1, 7), r["poses"])
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_windows_mode_solves_the_eight_cfg5_windows_whatever_the_rank_count(built_lib, tmp_path, ranks):
+    """bench.py --windows 8 (cfg5's eight windows, 8 / N per rank through movba_lba_run_batch, all of their poses
+    gathered): with one rank (all eight in one batch, no collective) and with two (rehearsal mode: both ranks on device 0, gloo),
+    the gathered poses are the solo solves of seeds 2000 ... 2007 in rank-major order, and the line says strong scaling."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dump = str(tmp_path / "poses8.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MOVBA_BENCH_DUMP_POSES=dump)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--windows", "8", "--steps", "2", "--warmup", "1"]
+    if ranks == 1:
+        cmd = [sys.executable] + tail
+    else:
+        env["MOVBA_BENCH_REHEARSAL"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["config"]["windows_per_rank"] == 8 // ranks and out["value"] > 0
+    g = np.load(dump)
+    assert g.shape[:2] == (ranks, 8 // ranks) and g.shape[-1] == 7
+    sv = built_lib.Solver()
+    solves = 0
+    try:
+        for r in range(ranks):
+            for k, wid in enumerate(shard.windows_for_rank(8, r, ranks)):
+                res = sv.solve(synth.make_window(50, 10, 20000, shard.window_seed(wid), run_lo=2, run_hi=10))
+                assert np.array_equal(g[r, k], res["poses"]), (r, k)
+                solves += res["n_solves"]
+    finally:
+        sv.close()
+    assert abs(out["value"] - solves * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]

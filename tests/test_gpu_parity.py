@@ -243,9 +243,11 @@ def test_point_on_the_z0_plane_of_an_observing_keyframe(solver, oracle_mod):
     Pinhole.cpp:36-43).  The reference's gate (Optimizer.cc:769) has two tests, chi2 > 5.0 and !isDepthPositive(): the edge comes
     out flagged through the depth test whatever its chi2 is (inf, like the IEEE division gives: the product's Newton-refined
     reciprocal is made zero-safe where depths are inverted).  The robust cost is inf from the start, the normal equations hold
-    NaN, every factorisation fails (F1 = DBL_MAX) and no trial moves the state: the estimates come back as they went in, in
-    the oracle and on the GPU alike.  (Whether g2o counts such a trial as accepted — DBL_MAX against inf over a scale term that
-    holds NaN — and what it leaves in the edges' errors is pinned by nothing the reference holds: not compared.)"""
+    NaN, every factorisation fails and no trial moves the state: the estimates come back as they went in, in the oracle and on
+    the GPU alike.  g2o's own bookkeeping of such a trial is followed too: tempChi = DBL_MAX is finite, the scale is 1e-3, so
+    rho = (inf - DBL_MAX) / 1e-3 = +inf and the trial counts as ACCEPTED (of a state that did not move - the solver returned
+    before its update), lambda falls to a third, and the next iteration finds the cost infinite again: accept trace, lambda
+    trace and the F0 / F1 of every trial equal the oracle's."""
     w = synth.cfg("small")
     assert np.array_equal(w.poses[0], [0, 0, 0, 1, 0, 0, 0]) and w.pose_fixed[0] == 1         # keyframe 0: identity pose, Xc == Xw
     e0 = int(np.flatnonzero(w.edge_pose == 0)[0]); l0 = int(w.edge_point[e0])
@@ -256,6 +258,12 @@ def test_point_on_the_z0_plane_of_an_observing_keyframe(solver, oracle_mod):
         assert r["outlier"][e0] == 1 and o["outlier"][e0] == 1 and not np.isfinite(o["chi2"][e0]) and not np.isfinite(r["chi2"][e0])
         assert np.array_equal(r["points"], w.points) and np.array_equal(o["points"], w.points)
         assert np.isfinite(r["poses"]).all() and np.abs(r["poses"] - o["poses"]).max() < 1e-15
+        assert r["n_solves"] == o["n_solves"] == iters and r["iters_done"] == o["iters_done"]
+        assert np.array_equal(r["trace"]["accept"], o["trace"]["accept"]) and (o["trace"]["accept"] == 1).all()
+        np.testing.assert_allclose(r["trace"]["lam"], o["trace"]["lam"], rtol=1e-7)
+        assert np.array_equal(r["trace"]["f1"], o["trace"]["f1"]) and (o["trace"]["f1"] == np.finfo(float).max).all()
+        assert np.isinf(r["trace"]["f0"]).all() and np.isinf(o["trace"]["f0"]).all()
+        assert r["n_chol_fail"] == iters
     # and the window is solved as usual once the point is off the plane again
     w.points[l0, 2] = 1e-3
     assert solver.solve(w)["status"] == 0
