@@ -63,13 +63,13 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-    // LDS carve (pcg_plan.cpp: band_lds_bytes): the band, the right-hand side (then y), a second vector (b_p's partner, then x),
-    // the reciprocals of the factor's diagonal, a strip for the reductions, the enumeration of the trailing blocks, two failure words
+    // LDS carve (pcg_plan.cpp: band_lds_bytes): the band, the right-hand side (then z), a second vector (b_p's partner, then x),
+    // the step's panel times D, a strip for the reductions, the enumeration of the trailing blocks, two failure words
     double *Lb = sm;                                  // nf x (bw + 1) x 36: block (i, j), i - bw <= j <= i, at band_off(i, j)
     double *rhs = Lb + (size_t)nf * B1 * 36;          // n
     double *aux = rhs + npad;                         // n
-    double *idg = aux + npad;                         // n: 1 / L_aa of every pivot block (what the backward sweep divides by)
-    double *gs = idg + npad;                          // 12
+    double *T = aux + npad;                           // bw x 36 + 6 (+ 2): the step's rows below the pivot and its right-hand side, times D
+    double *gs = T + bw * 36 + 8;                     // 12
     int *tri = reinterpret_cast<int *>(gs + 12);      // bw (bw + 1) / 2 pairs (irel << 8 | jrel)
     int *failw = tri + ((bw * (bw + 1) / 2 + 1) & ~1);     // [0] a pivot was NaN / inf, [1] a pivot was not positive
 
@@ -143,44 +143,54 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     __syncthreads();
 
     BAND_STAMP(0);
-    // ---- factorisation S = L L^T, the right-hand side carried along as one more row (y = L^-1 b) ----
+    // ---- factorisation S = L D L^T (L unit lower, D diagonal: Cholesky without its square roots), the right-hand side carried
+    //      along as one more row (z = D^-1 L^-1 b) ----
     // Step k is ONE sweep over the stacked rows [ D_k ; A_(k+1)k ; ... ; A_(k+m)k ; b_k^T ], one row of six per lane: column by
-    // column, pivot p = the diagonal element as updated so far, every row's entry scaled by 1 / sqrt(p) and taken out of the
-    // row's later entries with the pivot block's own scaled entries (broadcast from lanes 0 - 5 through v_readlane).  Lanes
-    // 0 - 5 come out holding L_kk, every other lane its row of L_ik = A_ik L_kk^-T - a triangular solve - or y_k: in place,
-    // no inverse of a pivot block anywhere (backward stable like the reference's own Cholesky, src/Optimizer.cc:535).
+    // column, pivot d = the diagonal element as updated so far (broadcast from its lane through v_readlane, like the pivot block's
+    // other entries of the column), every row's entry divided by d - hardware reciprocal and ONE cubic step, 2^-22 -> 2^-66 - and
+    // taken out of the row's later entries.  A lane keeps both forms of its row: divided (L: in place in the band) and as it
+    // stood when its column came up (L D: into the panel T), because the trailing update A_ij -= L_ik D_k L_jk^T multiplies one by
+    // the other.  No square root, no inverse of a pivot block: the dependent chain per pivot is reciprocal, three fused
+    // multiply-adds and the update of the next pivot (1 610 cycles per block at cfg3's band against the 1 780 of a Cholesky sweep
+    // with 1 / sqrt(d) by two Newton steps: a dependent fp64 operation of a wave that runs alone costs ~35 cycles here, and the
+    // sweep is a chain of ~40 of them), and the factorisation is backward stable like the reference's Cholesky
+    // (src/Optimizer.cc:535): the only thing that can go wrong is a pivot that is not positive.
     // What a thread touches in a step does not depend on the step but for a common offset (k (bw + 1) 36 doubles into the band,
     // 6 k into the right-hand side): decoded once.
     const int step_stride = B1 * 36;
     // the sweep: lanes 0 - 5 of every sweeping wave hold D_k's rows (identical arithmetic in every wave), lane 6 of wave 0 the
     // right-hand side, the other lanes the rows below, 58 per wave
-    int s_off, s_irel;                                 // s_irel: -1 = row of D_k, -2 = right-hand side, >= 0: panel block
-    if (ln < 6) { s_off = bw * 36 + ln * 6; s_irel = -1; }
+    int s_off, s_irel, s_toff;                         // s_irel: -1 = row of D_k, -2 = right-hand side, >= 0: panel block; s_toff: the row's place in T
+    if (ln < 6) { s_off = bw * 36 + ln * 6; s_irel = -1; s_toff = 0; }
     else {
         const int rr = kSweepRows * wv + ln - 6;
-        if (rr == 0) { s_off = 0; s_irel = -2; }
-        else { const int irel = (rr - 1) / 6, a = (rr - 1) - irel * 6; s_irel = irel; s_off = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6; }
+        if (rr == 0) { s_off = 0; s_irel = -2; s_toff = bw * 36; }
+        else { const int irel = (rr - 1) / 6, a = (rr - 1) - irel * 6; s_irel = irel; s_off = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6; s_toff = (rr - 1) * 6; }
     }
     const int sw_first_irel = wv == 0 ? -1 : (kSweepRows * wv - 1) / 6;      // the first panel block a wave beyond the first has rows of
-    // Trailing phase: up to four elements per thread - (a, b) of block (irel, jrel) below the pivot, enumerated by irel so that
-    // a short last band (irel >= m) just drops out - or, behind them, component a of the right-hand side of block irel.
-    constexpr int kTr = 4;
-    const int ntr_full = bw * (bw + 1) / 2 * 36;
-    const bool fast_tr = ntr_full + bw * 6 <= kTr * kBT;
-    int t_irel[kTr], t_T[kTr], t_A[kTr], t_dst[kTr];      // t_A / t_dst < 0: into the right-hand side (offset -1 - x)
+    // Trailing phase: a thread takes a 3 x 3 piece of a block below the pivot - three rows of L_ik, three rows of (L D)_jk, nine
+    // dot products of six - or three components of a block of the right-hand side; up to three such pieces per thread.  (A third of
+    // the LDS bytes of the element-by-element form, which re-read two 48-byte rows per element - and the same ~1 430 cycles per
+    // step: the phase is two barriers and a load -> dot -> store chain, not bandwidth; 3 x 2 pieces over all eight waves: 1 690.)
+    // Pieces are enumerated by the block row below the pivot (irel), so that a short last band (irel >= m) just drops out.
+    constexpr int kTr = 3;
+    const int npair = bw * (bw + 1) / 2, nblk_items = npair * 4, nitems_full = nblk_items + bw * 2;
+    const bool fast_tr = nitems_full <= kTr * kBT;
+    int t_irel[kTr], t_A[kTr], t_B[kTr], t_dst[kTr];     // t_B < 0: the right-hand side (three components at t_dst)
 #pragma unroll
     for (int u = 0; u < kTr; ++u) {
         const int idx = tid + u * kBT;
-        t_irel[u] = 1 << 20; t_T[u] = 0; t_A[u] = 0; t_dst[u] = 0;
-        if (idx < ntr_full) {
-            const int pr = idx / 36, q = idx - pr * 36, a = q / 6, b = q - a * 6;
+        t_irel[u] = 1 << 20; t_A[u] = 0; t_B[u] = 0; t_dst[u] = 0;
+        if (idx < nblk_items) {
+            const int pr = idx >> 2, a3 = (idx >> 1) & 1, b3 = idx & 1;
             const int ij = tri[pr], irel = ij >> 8, jrel = ij & 0xff;
-            t_irel[u] = irel; t_T[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6;
-            t_A[u] = ((1 + jrel) * B1 + (bw - 1 - jrel)) * 36 + b * 6;
-            t_dst[u] = ((1 + irel) * B1 + (jrel - irel + bw)) * 36 + q;
-        } else if (idx < ntr_full + bw * 6) {
-            const int r = idx - ntr_full, irel = r / 6, a = r - irel * 6;
-            t_irel[u] = irel; t_T[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a * 6; t_A[u] = -1; t_dst[u] = -1 - (6 * (1 + irel) + a);
+            t_irel[u] = irel;
+            t_A[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a3 * 18;          // rows 3 a3 ... of L_ik (relative to the step's base)
+            t_B[u] = jrel * 36 + b3 * 18;                                         // rows 3 b3 ... of (L D)_jk in T
+            t_dst[u] = ((1 + irel) * B1 + (jrel - irel + bw)) * 36 + a3 * 18 + b3 * 3;
+        } else if (idx < nitems_full) {
+            const int r = idx - nblk_items, irel = r >> 1, a3 = r & 1;
+            t_irel[u] = irel; t_A[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a3 * 18; t_B[u] = -1; t_dst[u] = 6 * (1 + irel) + a3 * 3;
         }
     }
     for (int k = 0; k < nf; ++k) {
@@ -194,31 +204,31 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
             { const double2 *rp = reinterpret_cast<const double2 *>(row);
               const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
               v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y; v[4] = r2.x; v[5] = r2.y; }
+            double wu[6];                                   // the row as it stood when its column came up: (L D)
             bool nonfinite = false, nonpos = false;
-            double ri_own = 0.0;
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) {
-                const double p = readlane_f64(v[kk], kk);
-                if (!isfinite(p)) nonfinite = true;
-                if (!(p > 0.0)) nonpos = true;
-                // 1 / sqrt(p): v_rsq_f64 and two Newton steps y <- y (1.5 - (p / 2) y^2)
-                const double hp = 0.5 * p;
-                double y = __builtin_amdgcn_rsq(p);
-                y = y * (1.5 - (hp * y) * y);
-                y = y * (1.5 - (hp * y) * y);
-                ri_own = ln == kk ? y : ri_own;
-                v[kk] *= y;
+                const double d = readlane_f64(v[kk], kk);
+                double cq[6];
 #pragma unroll
-                for (int q = kk + 1; q < 6; ++q) v[q] -= v[kk] * readlane_f64(v[kk], q);
+                for (int q = kk + 1; q < 6; ++q) cq[q] = readlane_f64(v[kk], q);      // d l_qk of the pivot block's rows below
+                if (!isfinite(d)) nonfinite = true;
+                if (!(d > 0.0)) nonpos = true;
+                const double r0 = __builtin_amdgcn_rcp(d);
+                const double e = __builtin_fma(-d, r0, 1.0), t = __builtin_fma(e, e, e);
+                const double g = v[kk] * r0;
+                wu[kk] = v[kk];
+                v[kk] = __builtin_fma(g, t, g);
+#pragma unroll
+                for (int q = kk + 1; q < 6; ++q) v[q] = __builtin_fma(-v[kk], cq[q], v[q]);
             }
             if (act && ln >= 6) {
                 double2 *wp = reinterpret_cast<double2 *>(row);
                 wp[0] = make_double2(v[0], v[1]); wp[1] = make_double2(v[2], v[3]); wp[2] = make_double2(v[4], v[5]);
+                double2 *tp = reinterpret_cast<double2 *>(T + s_toff);
+                tp[0] = make_double2(wu[0], wu[1]); tp[1] = make_double2(wu[2], wu[3]); tp[2] = make_double2(wu[4], wu[5]);
             }
-            if (wv == 0) {
-                if (ln < 6) idg[6 * k + ln] = ri_own;
-                if (ln == 0) { if (nonfinite) failw[0] = 1; if (nonpos) failw[1] = 1; }
-            }
+            if (wv == 0 && ln == 0) { if (nonfinite) failw[0] = 1; if (nonpos) failw[1] = 1; }
         }
         // L_kk goes over D_k only when every sweeping wave has read D_k (the trailing phase does not touch block (k, k))
         if (m > 0) __syncthreads();
@@ -228,56 +238,59 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
         }
         if (m == 0) break;                                  // (the last step has nothing below it)
         BAND_STAMP(1);
-        // trailing blocks A_ij -= L_ik L_jk^T (i >= j below k in the band) and right-hand side b_i -= L_ik y_k
-        const int ntr = m * (m + 1) / 2 * 36;
-        if (fast_tr) {
-            double2 t0[kTr], t1[kTr], t2[kTr], u0[kTr], u1[kTr], u2[kTr];
-            double old[kTr];
-            double *dst[kTr];
+        // trailing blocks A_ij -= L_ik (L D)_jk^T (i >= j below k in the band) and right-hand side b_i -= L_ik (D z)_k
+        auto piece = [&](const double *A, const double *Bq, double *dst, bool is_rhs, bool live) {
+            double2 ar[3][3];
 #pragma unroll
-            for (int u = 0; u < kTr; ++u) {
-                const bool act = t_irel[u] < m;
-                const double2 *tp = reinterpret_cast<const double2 *>(Lk + (act ? t_T[u] : 0));
-                const double2 *ap = reinterpret_cast<const double2 *>(t_A[u] < 0 ? rhs + 6 * k : Lk + (act ? t_A[u] : 0));
-                dst[u] = t_dst[u] < 0 ? rhs + 6 * k + (-1 - t_dst[u]) : Lk + t_dst[u];
-                if (!act) dst[u] = gs;                      // (a place nobody reads here)
-                t0[u] = tp[0]; t1[u] = tp[1]; t2[u] = tp[2]; u0[u] = ap[0]; u1[u] = ap[1]; u2[u] = ap[2];
-                old[u] = *dst[u];
-            }
+            for (int ra = 0; ra < 3; ++ra) { const double2 *ap = reinterpret_cast<const double2 *>(A + 6 * ra); ar[ra][0] = ap[0]; ar[ra][1] = ap[1]; ar[ra][2] = ap[2]; }
+            if (is_rhs) {
+                const double2 *yp = reinterpret_cast<const double2 *>(Bq);
+                const double2 y0 = yp[0], y1 = yp[1], y2 = yp[2];
+                double old[3];
 #pragma unroll
-            for (int u = 0; u < kTr; ++u) {
-                const double sdot = ((t0[u].x * u0[u].x + t0[u].y * u0[u].y) + (t1[u].x * u1[u].x + t1[u].y * u1[u].y)) + (t2[u].x * u2[u].x + t2[u].y * u2[u].y);
-                if (t_irel[u] < m) *dst[u] = old[u] - sdot;
-            }
-        } else for (int i0 = tid; i0 < ntr + m * 6; i0 += kBT * kTr) {
-            double2 t0[kTr], t1[kTr], t2[kTr], u0[kTr], u1[kTr], u2[kTr];
-            double old[kTr];
-            double *dst[kTr];
+                for (int ra = 0; ra < 3; ++ra) old[ra] = dst[ra];
 #pragma unroll
-            for (int u = 0; u < kTr; ++u) {
-                const int idx = min(i0 + u * kBT, ntr + m * 6 - 1);
-                const double *Ti, *Aj;
-                if (idx < ntr) {
-                    const int pr = idx / 36, q = idx - pr * 36, a = q / 6, b = q - a * 6;
-                    const int ij = tri[pr], irel = ij >> 8, jrel = ij & 0xff;
-                    Ti = Lb + band_off(k + 1 + irel, k, bw) + a * 6;
-                    Aj = Lb + band_off(k + 1 + jrel, k, bw) + b * 6;
-                    dst[u] = Lb + band_off(k + 1 + irel, k + 1 + jrel, bw) + q;
-                } else {
-                    const int r = idx - ntr, irel = r / 6, a = r - irel * 6;
-                    Ti = Lb + band_off(k + 1 + irel, k, bw) + a * 6;
-                    Aj = rhs + 6 * k;
-                    dst[u] = rhs + 6 * (k + 1 + irel) + a;
+                for (int ra = 0; ra < 3; ++ra) {
+                    const double sdot = ((ar[ra][0].x * y0.x + ar[ra][0].y * y0.y) + (ar[ra][1].x * y1.x + ar[ra][1].y * y1.y)) + (ar[ra][2].x * y2.x + ar[ra][2].y * y2.y);
+                    if (live) dst[ra] = old[ra] - sdot;
                 }
-                const double2 *tp = reinterpret_cast<const double2 *>(Ti), *ap = reinterpret_cast<const double2 *>(Aj);
-                t0[u] = tp[0]; t1[u] = tp[1]; t2[u] = tp[2]; u0[u] = ap[0]; u1[u] = ap[1]; u2[u] = ap[2];
-                old[u] = *dst[u];
+            } else {
+                double2 br[3][3];
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) { const double2 *bp = reinterpret_cast<const double2 *>(Bq + 6 * rb); br[rb][0] = bp[0]; br[rb][1] = bp[1]; br[rb][2] = bp[2]; }
+                double old[3][3];
+#pragma unroll
+                for (int ra = 0; ra < 3; ++ra)
+#pragma unroll
+                    for (int rb = 0; rb < 3; ++rb) old[ra][rb] = dst[6 * ra + rb];
+#pragma unroll
+                for (int ra = 0; ra < 3; ++ra)
+#pragma unroll
+                    for (int rb = 0; rb < 3; ++rb) {
+                        const double sdot = ((ar[ra][0].x * br[rb][0].x + ar[ra][0].y * br[rb][0].y) + (ar[ra][1].x * br[rb][1].x + ar[ra][1].y * br[rb][1].y)) +
+                                            (ar[ra][2].x * br[rb][2].x + ar[ra][2].y * br[rb][2].y);
+                        if (live) dst[6 * ra + rb] = old[ra][rb] - sdot;
+                    }
             }
+        };
+        if (fast_tr) {
 #pragma unroll
             for (int u = 0; u < kTr; ++u) {
-                const double sdot = ((t0[u].x * u0[u].x + t0[u].y * u0[u].y) + (t1[u].x * u1[u].x + t1[u].y * u1[u].y)) + (t2[u].x * u2[u].x + t2[u].y * u2[u].y);
-                if (i0 + u * kBT < ntr + m * 6) *dst[u] = old[u] - sdot;
+                if (__ballot(t_irel[u] < m) == 0ull) continue;          // (nothing for this wave in this round)
+                const bool live = t_irel[u] < m, is_rhs = t_B[u] < 0;
+                const double *A = Lk + (live ? t_A[u] : 0);
+                const double *Bq = is_rhs ? T + bw * 36 : T + (live ? t_B[u] : 0);
+                double *dst = live ? (is_rhs ? rhs + 6 * k + t_dst[u] : Lk + t_dst[u]) : gs;
+                if (is_rhs) piece(A, Bq, dst, true, live); else piece(A, Bq, dst, false, live);
             }
+        } else for (int i0 = tid; i0 < nitems_full; i0 += kBT) {
+            int irel, a3, b3 = 0, jrel = 0; bool is_rhs = false;
+            if (i0 < nblk_items) { const int ij = tri[i0 >> 2]; irel = ij >> 8; jrel = ij & 0xff; a3 = (i0 >> 1) & 1; b3 = i0 & 1; }
+            else { const int r = i0 - nblk_items; irel = r >> 1; a3 = r & 1; is_rhs = true; }
+            if (irel >= m) continue;
+            const double *A = Lb + band_off(k + 1 + irel, k, bw) + a3 * 18;
+            if (is_rhs) piece(A, T + bw * 36, rhs + 6 * (k + 1 + irel) + a3 * 3, true, true);
+            else piece(A, T + jrel * 36 + b3 * 18, Lb + band_off(k + 1 + irel, k + 1 + jrel, bw) + a3 * 18 + b3 * 3, false, true);
         }
         __syncthreads();
         BAND_STAMP(2);
@@ -303,50 +316,65 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
         }
         return;
     }
-    // ---- backward sweep L^T x = y by one wave: x_k = L_kk^-T s_k by a triangular solve in lanes 0 - 5 (the partial sums of
-    //      the later unknowns broadcast through v_readlane), then s_j -= L_kj^T x_k for the band above ----
+    // ---- backward sweep L^T x = z (L unit lower) by one wave.  Block k's unknowns in lanes 0 - 5: what the blocks from k + 2 on
+    //      contribute is in the right-hand side already (lanes 6 ... of earlier steps, through LDS, two steps and more ahead of its
+    //      use); block k + 1's contribution is added HERE, from its x in scalar registers, and the six unknowns follow by
+    //      back-substitution through v_readlane - the chain of a step holds no LDS round trip and no division.  (~970 cycles per
+    //      step all the same, as with the contributions passed through LDS: the chain is ~25 dependent operations) ----
     if (wv == 0) {
         const int a6 = min(ln, 5);
-        for (int k = nf - 1; k >= 0; --k) {
+        double xs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };    // x of block k + 1 (wave-uniform)
+        // what a step reads of the factor does not depend on any x: requested ONE STEP AHEAD, in the shadow of the step's chain
+        const int li = ln - 6, q0 = 2 + li / 6, qa = li - (li / 6) * 6;
+        double lc[6], ln1[6], lq[6], s_cur;
+        auto fetch = [&](int k, double (&c_)[6], double (&n_)[6], double (&q_)[6], double &s_) {
             const int mk = min(bw, k);
             const double *D = Lb + band_off(k, k, bw);
-            // (everything that does not depend on x_k is requested ahead of the chain)
-            double lc[6];
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) lc[cc] = D[cc * 6 + a6];                    // column a6 of L_kk
-            const double idv = idg[6 * k + a6];
-            double s = rhs[6 * k + a6];
-            const int jrel0 = ln / 6, a0 = ln - jrel0 * 6;
-            const bool up0 = ln < mk * 6;
-            const double *L0 = Lb + band_off(k, up0 ? k - 1 - jrel0 : k, bw) + a0;
-            double l0[6];
+            for (int cc = 0; cc < 6; ++cc) c_[cc] = D[cc * 6 + a6];                    // column a6 of L_kk (entries below the diagonal are used)
+            const bool below = k + 1 < nf;
+            const double *L1 = Lb + band_off(below ? k + 1 : k, k, bw) + a6;           // column a6 of L_(k+1)k
 #pragma unroll
-            for (int cc = 0; cc < 6; ++cc) l0[cc] = L0[cc * 6];
-            double *y0 = rhs + 6 * (up0 ? k - 1 - jrel0 : k) + a0;
-            const double y0v = *y0;
-            double x[6], x_own = 0.0;
+            for (int cc = 0; cc < 6; ++cc) n_[cc] = below ? L1[cc * 6] : 0.0;
+            const bool up = ln >= 6 && q0 <= mk;
+            const double *Lq = Lb + band_off(k, up ? k - q0 : k, bw) + (up ? qa : 0);  // column qa of L_k(k-q0)
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) q_[cc] = Lq[cc * 6];
+            s_ = rhs[6 * k + a6];      // (complete but for block k + 1's contribution, which the step adds from registers)
+        };
+        fetch(nf - 1, lc, ln1, lq, s_cur);
+        for (int k = nf - 1; k >= 0; --k) {
+            const int mk = min(bw, k);
+            double lc2[6], ln2[6], lq2[6], s_nxt = 0.0;
+            if (k > 0) fetch(k - 1, lc2, ln2, lq2, s_nxt);
+            // block k + 1's contribution, then the block's own back-substitution
+            double s = s_cur - (((ln1[0] * xs[0] + ln1[1] * xs[1]) + (ln1[2] * xs[2] + ln1[3] * xs[3])) + (ln1[4] * xs[4] + ln1[5] * xs[5]));
+            double x_own = 0.0;
 #pragma unroll
             for (int cc = 5; cc >= 0; --cc) {
-                const double t = s * idv;
-                x[cc] = readlane_f64(t, cc);
-                x_own = ln == cc ? x[cc] : x_own;
-                s -= lc[cc] * x[cc];
+                xs[cc] = readlane_f64(s, cc);
+                x_own = ln == cc ? xs[cc] : x_own;
+                s = __builtin_fma(-lc[cc], xs[cc], s);
             }
             if (ln < 6) aux[6 * k + ln] = x_own;
-            if (up0) {
-                double acc = l0[0] * x[0];
-#pragma unroll
-                for (int cc = 1; cc < 6; ++cc) acc += l0[cc] * x[cc];
-                *y0 = y0v - acc;
+            // lanes 6 ...: what x_k contributes to the blocks k - 2 ... k - mk, ADDED in LDS (ds_add_f64: nothing read back; a block
+            // receives one addition per step, in step order); block k - 1 is served in registers by the next step
+            if (ln >= 6 && q0 <= mk) {
+                const double acc = ((lq[0] * xs[0] + lq[1] * xs[1]) + (lq[2] * xs[2] + lq[3] * xs[3])) + (lq[4] * xs[4] + lq[5] * xs[5]);
+                atomicAdd(rhs + 6 * (k - q0) + qa, -acc);
             }
-            for (int l = ln + 64; l < mk * 6; l += 64) {
-                const int jrel = l / 6, a = l - jrel * 6, j = k - 1 - jrel;
-                const double *L = Lb + band_off(k, j, bw) + a;
-                double acc = L[0] * x[0];
+            for (int l = li + 58; 2 + l / 6 <= mk; l += 58) {        // (bands wider than ten blocks)
+                if (ln < 6) break;
+                const int q = 2 + l / 6, a = l - (l / 6) * 6;
+                const double *L = Lb + band_off(k, k - q, bw) + a;
+                double acc = L[0] * xs[0];
 #pragma unroll
-                for (int cc = 1; cc < 6; ++cc) acc += L[cc * 6] * x[cc];
-                rhs[6 * j + a] -= acc;
+                for (int cc = 1; cc < 6; ++cc) acc += L[cc * 6] * xs[cc];
+                atomicAdd(rhs + 6 * (k - q) + a, -acc);
             }
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) { lc[cc] = lc2[cc]; ln1[cc] = ln2[cc]; lq[cc] = lq2[cc]; }
+            s_cur = s_nxt;
             band_wave_sync();
         }
     }

@@ -244,7 +244,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
 #endif
         if (BACKSUB && bid == w.n_pt_blocks && threadIdx.x < 64) decide_body(w, cur);
 #ifdef MOVBA_CLOCK_STAMP
-        if (BACKSUB && threadIdx.x == 0 && ns0 == 3) {
+        if (BACKSUB && threadIdx.x == 0 && ns0 == 3 && 20000 + 8 * ((size_t)bid + 1) <= (size_t)w.E) {      // (stamps live in the chi2 array: windows large enough only)
             unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 20000 + 8 * (size_t)bid;
             dbg[0] = pst[0]; dbg[1] = __builtin_amdgcn_s_memrealtime(); dbg[7] = 2;
         }
@@ -515,7 +515,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
             const __amdgpu_buffer_rsrc_t rr = hx_rsrc(w.dec_rec, 32u * (unsigned)w.n_pt_blocks);
             hx_st_tagged(rr, 2u * (unsigned)bid, Fsum, tag); hx_st_tagged(rr, 2u * (unsigned)bid + 1u, ssum, tag);
 #ifdef MOVBA_CLOCK_STAMP
-            if (c->n_solves == 3) {
+            if (c->n_solves == 3 && 20000 + 8 * ((size_t)bid + 1) <= (size_t)w.E) {
                 PSTAMP(5);
                 unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 20000 + 8 * (size_t)bid;
                 for (int k = 0; k < 6; ++k) dbg[k] = pst[k];
@@ -887,7 +887,7 @@ __device__ __forceinline__ void schur_body(const DevWindow &w, int bid)
     }
 #ifdef MOVBA_CLOCK_STAMP
     WSTAMP(4);
-    if (!HPP_ONLY && lane == 0 && c->n_solves == 3) {        // one launch: per-wave stamps (100 MHz ticks), read back through out_chi2
+    if (!HPP_ONLY && lane == 0 && c->n_solves == 3 && 8 * ((size_t)(bid * kSchurWaves + wv) + 1) <= (size_t)w.E) {        // one launch: per-wave stamps (100 MHz ticks), read back through out_chi2
         unsigned long long *dbg = reinterpret_cast<unsigned long long *>(w.out_chi2) + 8 * (size_t)(bid * kSchurWaves + wv);
         for (int k = 0; k < 5; ++k) dbg[k] = wst[k];
         dbg[5] = (unsigned long long)(wend - wbeg);

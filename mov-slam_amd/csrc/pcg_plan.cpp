@@ -18,12 +18,12 @@ size_t pcg_rows_lds_bytes(int nfree, int nrowent, bool padded)
     return solve > coarse ? solve : coarse;
 }
 
-// k_band's LDS carve (band_kernel.hip): band, three vectors, a strip, the enumeration of the trailing blocks, two words
+// k_band's LDS carve (band_kernel.hip): band, two vectors, the step's panel, a strip, the enumeration of the trailing blocks, two words
 size_t band_lds_bytes(int nfree, int bw)
 {
     const size_t n = 6 * (size_t)nfree, npad = (n + 1) & ~(size_t)1;
     const size_t ntri = ((size_t)bw * (bw + 1) / 2 + 1) & ~(size_t)1;
-    return ((size_t)nfree * (bw + 1) * 36 + 3 * npad + 12) * sizeof(double) + (ntri + 4) * sizeof(int32_t);
+    return ((size_t)nfree * (bw + 1) * 36 + 2 * npad + (size_t)bw * 36 + 8 + 12) * sizeof(double) + (ntri + 4) * sizeof(int32_t);
 }
 
 // (8 waves x 58 rows of the sweep: 6 bw + 1 <= 464)

@@ -129,6 +129,35 @@ namespace MOV_SLAM
             void reset() { cam_set = false; any_stereo = false; bf = 0.0; cam_mixed = false; }
         };
 
+        // The arrays the window is flattened INTO live in movba_host_alloc memory (pinned, device-visible) wherever the library
+        // can provide it: the device then reads the index arrays where they lie and the copy engine takes observations, information
+        // and estimates straight out of them - nothing is staged in between (movba.h, movba_lba_desc).  Allocations happen when a
+        // vector grows, i.e. during the first windows of a session; ordinary memory when the library has none to give.
+        template <class T> struct PinnedAlloc
+        {
+            typedef T value_type;
+            PinnedAlloc() = default;
+            template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+            T *allocate(size_t n)
+            {
+                // (a small header in front of the block says which allocator it came from)
+                const size_t bytes = n * sizeof(T) + 16;
+                char *p = static_cast<char *>(movba_host_alloc(bytes));
+                const bool pinned = p != nullptr;
+                if (!p) p = static_cast<char *>(::operator new(bytes));
+                *reinterpret_cast<uint64_t *>(p) = pinned ? 1u : 0u;
+                return reinterpret_cast<T *>(p + 16);
+            }
+            void deallocate(T *q, size_t)
+            {
+                char *p = reinterpret_cast<char *>(q) - 16;
+                if (*reinterpret_cast<uint64_t *>(p)) movba_host_free(p); else ::operator delete(p);
+            }
+            template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+            template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+        };
+        template <class T> using pinned_vector = std::vector<T, PinnedAlloc<T>>;
+
         // Flattened window in the layout of movba_lba_desc, plus the bookkeeping to write results back.
         // One instance per calling thread, reused from call to call (the vectors keep their capacity).
         struct Flat : CamState
@@ -150,15 +179,15 @@ namespace MOV_SLAM
                 edge_kf.resize(n); edge_mp.resize(n); obs_right.resize(n);
             }
             std::vector<KeyFrame *> kfs;            // vertex order: ascending mnId (g2o's hessian order)
-            std::vector<uint8_t> fixed;
-            std::vector<double> poses;
+            pinned_vector<uint8_t> fixed;
+            pinned_vector<double> poses;
             std::vector<MapPoint *> mps;
-            std::vector<double> points;
-            std::vector<int32_t> edge_pose, edge_point;
-            std::vector<double> obs, inv_sigma2;
+            pinned_vector<double> points;
+            pinned_vector<int32_t> edge_pose, edge_point;
+            pinned_vector<double> obs, inv_sigma2;
             std::vector<KeyFrame *> edge_kf;        // vpEdgeKFMono
             std::vector<MapPoint *> edge_mp;        // vpMapPointEdgeMono
-            std::vector<double> obs_right;          // mvuRight of stereo observations, -1 for monocular ones
+            pinned_vector<double> obs_right;        // mvuRight of stereo observations, -1 for monocular ones
         };
 
         void push_pose(Flat &f, KeyFrame *pKF, bool isFixed)
@@ -179,13 +208,15 @@ namespace MOV_SLAM
             std::vector<size_t> order(f.kfs.size());
             for (size_t i = 0; i < order.size(); ++i) order[i] = i;
             std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return f.kfs[a]->mnId < f.kfs[b]->mnId; });
-            Flat g;
+            // (permuted through ordinary temporaries and written back: the window's own arrays keep their pinned storage)
+            std::vector<KeyFrame *> kfs; std::vector<uint8_t> fixed; std::vector<double> poses;
             for (size_t k : order)
             {
-                g.kfs.push_back(f.kfs[k]); g.fixed.push_back(f.fixed[k]);
-                for (int q = 0; q < 7; ++q) g.poses.push_back(f.poses[7 * k + q]);
+                kfs.push_back(f.kfs[k]); fixed.push_back(f.fixed[k]);
+                for (int q = 0; q < 7; ++q) poses.push_back(f.poses[7 * k + q]);
             }
-            f.kfs.swap(g.kfs); f.fixed.swap(g.fixed); f.poses.swap(g.poses);
+            f.kfs.swap(kfs);
+            std::copy(fixed.begin(), fixed.end(), f.fixed.begin()); std::copy(poses.begin(), poses.end(), f.poses.begin());
         }
 
         // The edges of one MapPoint vertex (Optimizer.cc:623-705 / :142-190) from the point's observation list, written to
