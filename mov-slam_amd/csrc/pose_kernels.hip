@@ -515,7 +515,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
                 const double chi2 = e0 * (om * e0) + e1 * (om * e1);
                 double rho0 = chi2, rho1 = 1.0;
                 if (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) {
-                    const double rs = rsqrt(chi2), sq = chi2 * rs;
+                    const double rs = rsqrt(chi2), sq = chi2 > DBL_MAX ? chi2 : chi2 * rs;       // (sqrt(inf) = inf, not inf * 0)
                     rho0 = 2.0 * sq * p.huber_delta - dsqr; rho1 = p.huber_delta * rs;
                 }
                 const double wg = rho1 * om, r0 = -wg * e0, r1 = -wg * e1;
