@@ -35,6 +35,7 @@ constexpr int kPointGroup = 8;      // lanes cooperating on one map point
 #endif
 constexpr int kPointBlock = MOVBA_POINT_BLOCK;    // threads per block of the point kernels
 constexpr int kPointsPerBlock = kPointBlock / kPointGroup;
+constexpr int kPointRed = 2 * (kPointBlock / 64) > 8 ? 2 * (kPointBlock / 64) : 8;     // doubles of the point kernels' reduction strip
 constexpr int kMaxTrace = MOVBA_MAX_TRACE;
 
 struct DevState {

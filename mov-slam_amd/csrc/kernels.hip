@@ -260,8 +260,8 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     double *sRt = sm;                               // NP x 12 at dst
     double *sR0 = sm + (LDSP ? 12 * w.NP : 0);      // NP x 12 at cur  (BACKSUB)
     double *sxp = sR0 + ((BACKSUB && LDSP) ? 12 * w.NP : 0);  // nfree x 6       (BACKSUB)
-    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// 8
-    int *shidx = reinterpret_cast<int *>(red + 8);  // NP              (BACKSUB)
+    double *red = sxp + ((BACKSUB && LDSP) ? 6 * w.nfree : 0);// kPointRed
+    int *shidx = reinterpret_cast<int *>(red + kPointRed);  // NP              (BACKSUB)
     // where the pose data is read from: the LDS images, or the state buffers themselves
     const double *pRt = LDSP ? sRt : S1.Rt;
     const double *pR0 = LDSP ? sR0 : S0.Rt;
@@ -501,7 +501,7 @@ __device__ __forceinline__ void point_body(const DevWindow &w, int bid)
     if (BACKSUB) {
         // cost and scale partials of the workgroup behind ONE barrier (the sums in block_reduce's order)
         constexpr int NWV = kPointBlock / 64;
-        static_assert(2 * NWV <= 8, "red holds eight doubles (point_lds_bytes)");
+        static_assert(2 * NWV <= kPointRed, "red holds kPointRed doubles (point_lds_bytes)");
         F = wave_sum(F); scale = wave_sum(scale);
         if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = F; red[NWV + (threadIdx.x >> 6)] = scale; }
         __syncthreads();
@@ -1075,15 +1075,15 @@ __global__ __launch_bounds__(256) void k_export(DevWindow w, ExportDst d)
 // --------------------------------------------------------------------------------
 static inline size_t point_lds_bytes(const DevWindow &w, bool backsub)
 {
-    if (!w.lds_poses) return 8 * sizeof(double) + 16;
-    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + 8;
+    if (!w.lds_poses) return kPointRed * sizeof(double) + 16;
+    size_t d = 12 * (size_t)w.NP + (backsub ? 12 * (size_t)w.NP + 6 * (size_t)w.nfree : 0) + kPointRed;
     return d * sizeof(double) + (backsub ? sizeof(int) * (size_t)w.NP : 0) + 16;
 }
 
 // the largest LDS image the point kernels would stage for this window (decides DevWindow::lds_poses)
 size_t point_lds_need(int NP, int nfree)
 {
-    return (24 * (size_t)NP + 6 * (size_t)nfree + 8) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
+    return (24 * (size_t)NP + 6 * (size_t)nfree + kPointRed) * sizeof(double) + sizeof(int) * (size_t)NP + 16;
 }
 
 hipError_t launch_init(const DevWindow &w, hipStream_t s)

@@ -47,6 +47,13 @@ namespace movba {
 #define SETUP_STAMP(k) do { } while (0)
 #endif
 
+// wave-uniform scalars of the CG recurrences: moved to scalar registers (two VGPRs less per value) or left where they are
+#ifdef MOVBA_PCG_NO_UNIFORM
+#define PCG_UNI(x) (x)
+#else
+#define PCG_UNI(x) uniform_f64(x)
+#endif
+
 namespace {
 
 constexpr int kT = kPcgRowsThreads;     // 512 = 8 waves, 2 per SIMD -> 256 VGPRs per lane
@@ -608,25 +615,25 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
                 a += dpp_mov0<0xb1>(a); b += dpp_mov0<0xb1>(b);
                 a += dpp_mov0<0x4e>(a); b += dpp_mov0<0x4e>(b);
                 a += dpp_mov0<0x141>(a); b += dpp_mov0<0x141>(b);       // row_half_mirror: lanes 0 - 3 meet lanes 7 - 4
-                g = uniform_f64(a); delta = uniform_f64(b);
+                g = PCG_UNI(a); delta = PCG_UNI(b);
             }
             // the dense coarse product of this iteration (independent of the scalar recurrences)
             const double yc = coarse ? coarse_rows() : 0.0;
             if (!isfinite(g) || !isfinite(delta)) { fail = true; break; }
             if (first) {
-                thresh = uniform_f64(pp.rel_tol * pp.rel_tol * g);
+                thresh = PCG_UNI(pp.rel_tol * pp.rel_tol * g);
                 if (!(g >= 0.0)) { fail = true; break; }
                 if (g == 0.0) { iters = 0; break; }
             }
             if (!first && g <= thresh) break;
-            const double beta = uniform_f64(first ? 0.0 : g * inv_gamma);
+            const double beta = PCG_UNI(first ? 0.0 : g * inv_gamma);
             const double den = delta - beta * g * inv_alpha;          // = p.Ap of the new search direction
             if (!(den > 0.0)) { fail = true; break; }
             // (reciprocals by v_rcp_f64 + two Newton steps: the IEEE division sequence is ~25 dependent instructions, on the
             //  critical path of every iteration; the two are independent of each other and overlap)
-            inv_gamma = uniform_f64(fast_rcp(g));
-            alpha = uniform_f64(g * fast_rcp(den));
-            inv_alpha = uniform_f64(den * inv_gamma);
+            inv_gamma = PCG_UNI(fast_rcp(g));
+            alpha = PCG_UNI(g * fast_rcp(den));
+            inv_alpha = PCG_UNI(den * inv_gamma);
             first = false;
             p_r = z_r + beta * p_r;
             s_r = w_r + beta * s_r;

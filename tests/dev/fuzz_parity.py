@@ -70,6 +70,8 @@ for it in range(n):
             noisy += 1
             print(f"[{it}] ORDER-NOISE K={K} F={F} P={P} run {lo}-{hi} stereo {stereo} seed {seed}: dq {dq:.2e} dt {dt:.2e} pt {pt:.2e} against the oracle's own spread {nq:.2e} {nt:.2e} {npt:.2e} (band trials {rg['n_band']}, direct {rg['n_direct']})", flush=True)
             continue
+    if it % 50 == 49:
+        print(f"[{it}] ... {it + 1} windows, {bad} mismatches, {noisy} inside the oracle's edge-order spread so far", flush=True)
     if not ok:
         bad += 1
         print(f"[{it}] weak={weak} direct_from={rg['direct_from']} n_direct={rg['n_direct']} chol_fail={rg['n_chol_fail']}", flush=True)
