@@ -45,8 +45,13 @@ __device__ __forceinline__ void band_wave_sync()
 
 #ifdef MOVBA_CLOCK_STAMP
 #define BAND_STAMP(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); if (tid == 0) c->dbg_seg2[k] += _t - stamp_last; stamp_last = _t; } while (0)
+// fine stamps of ONE block step (k == 10), kept in registers and written once at the end; `dep`: a value of the chain the stamp
+// has to stand behind (stamps are scalar instructions, the chain is vector ones)
+#define BAND_FINE(i, dep) do { if (k == 10) { const int d_ = __builtin_amdgcn_readfirstlane(__double2loint(dep)); unsigned long long t_; \
+    asm volatile("s_nop 7\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "s"(d_) : "memory"); fine[i] = t_; } } while (0)
 #else
 #define BAND_STAMP(k) do { } while (0)
+#define BAND_FINE(i, dep) do { } while (0)
 #endif
 
 __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
@@ -62,6 +67,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     const int nf = w.nfree, n = 6 * nf, npad = (n + 1) & ~1, B1 = bw + 1;
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    unsigned long long fine[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     // LDS carve (pcg_plan.cpp: band_lds_bytes): the band, the right-hand side (then z), a second vector (b_p's partner, then x),
     // the step's panel times D, a strip for the reductions, the enumeration of the trailing blocks, two failure words
@@ -150,11 +156,14 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     // other entries of the column), every row's entry divided by d - hardware reciprocal and ONE cubic step, 2^-22 -> 2^-66 - and
     // taken out of the row's later entries.  A lane keeps both forms of its row: divided (L: in place in the band) and as it
     // stood when its column came up (L D: into the panel T), because the trailing update A_ij -= L_ik D_k L_jk^T multiplies one by
-    // the other.  No square root, no inverse of a pivot block: the dependent chain per pivot is reciprocal, three fused
-    // multiply-adds and the update of the next pivot (1 610 cycles per block at cfg3's band against the 1 780 of a Cholesky sweep
-    // with 1 / sqrt(d) by two Newton steps: a dependent fp64 operation of a wave that runs alone costs ~35 cycles here, and the
-    // sweep is a chain of ~40 of them), and the factorisation is backward stable like the reference's Cholesky
-    // (src/Optimizer.cc:535): the only thing that can go wrong is a pivot that is not positive.
+    // the other.  No square root, no inverse of a pivot block: the dependent chain per pivot is a v_readlane hop, the
+    // reciprocal, three fused multiply-adds and the update of the next pivot (~80 cycles: a dependent v_fma_f64 costs 4, a
+    // v_readlane or v_rcp_f64 link ~20 more, profiles/r05_chain_probe.log), and the factorisation is backward stable like the
+    // reference's Cholesky (src/Optimizer.cc:535): the only thing that can go wrong is a pivot that is not positive.
+    // Where a block step's ~2 600 cycles go at cfg3's band of nine (stamps inside one step, profiles/r05_band_stamps_cfg3.log):
+    // the sweeping wave's three 16-byte LDS loads ~210, the six columns ~480, its six 16-byte stores ~320 (a lone wave gets half
+    // the LDS store rate and drains before the barrier), the trailing phase ~1 500 (18 wide loads, 9 + 9 eight-byte loads and
+    // stores, 54 fp64 operations per thread on one wave per SIMD), the two barriers ~100 together.
     // What a thread touches in a step does not depend on the step but for a common offset (k (bw + 1) 36 doubles into the band,
     // 6 k into the right-hand side): decoded once.
     const int step_stride = B1 * 36;
@@ -171,7 +180,8 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     // Trailing phase: a thread takes a 3 x 3 piece of a block below the pivot - three rows of L_ik, three rows of (L D)_jk, nine
     // dot products of six - or three components of a block of the right-hand side; up to three such pieces per thread.  (A third of
     // the LDS bytes of the element-by-element form, which re-read two 48-byte rows per element - and the same ~1 430 cycles per
-    // step: the phase is two barriers and a load -> dot -> store chain, not bandwidth; 3 x 2 pieces over all eight waves: 1 690.)
+    // step: 36 LDS instructions per thread at a wave per SIMD, each wave waiting out its own loads; 3 x 2 pieces over all eight
+    // waves: 1 690.)
     // Pieces are enumerated by the block row below the pivot (irel), so that a short last band (irel >= m) just drops out.
     constexpr int kTr = 3;
     const int npair = bw * (bw + 1) / 2, nblk_items = npair * 4, nitems_full = nblk_items + bw * 2;
@@ -193,10 +203,23 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
             t_irel[u] = irel; t_A[u] = ((1 + irel) * B1 + (bw - 1 - irel)) * 36 + a3 * 18; t_B[u] = -1; t_dst[u] = 6 * (1 + irel) + a3 * 3;
         }
     }
+    // (conditions a scalar branch waits for are kept out of the step loop: a vector compare feeding a branch costs ~60 cycles,
+    //  profiles/r05_chain_probe.log - the pivots' verdicts are collected in scalar masks and stored once, behind the loop; which
+    //  rounds of pieces a wave has anything to do in is known per wave before the loop)
+    int t_first[kTr];                                   // the smallest irel among the wave's pieces of round u
+#pragma unroll
+    for (int u = 0; u < kTr; ++u) {
+        int mn = t_irel[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+        t_first[u] = __builtin_amdgcn_readfirstlane(mn);
+    }
+    bool nonfinite = false, nonpos = false;
     for (int k = 0; k < nf; ++k) {
         const int m = min(bw, nf - 1 - k);
         double *Lk = Lb + (size_t)k * step_stride;        // what the decoded offsets are relative to
         double v[6];
+        BAND_FINE(0, lambda);
         if (sw_first_irel < m) {
             const bool act = s_irel < m;
             double *row = s_irel == -2 ? rhs + 6 * k : Lk + s_off;
@@ -204,16 +227,16 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
             { const double2 *rp = reinterpret_cast<const double2 *>(row);
               const double2 r0 = rp[0], r1 = rp[1], r2 = rp[2];
               v[0] = r0.x; v[1] = r0.y; v[2] = r1.x; v[3] = r1.y; v[4] = r2.x; v[5] = r2.y; }
+            BAND_FINE(1, v[5]);
             double wu[6];                                   // the row as it stood when its column came up: (L D)
-            bool nonfinite = false, nonpos = false;
 #pragma unroll
             for (int kk = 0; kk < 6; ++kk) {
                 const double d = readlane_f64(v[kk], kk);
                 double cq[6];
 #pragma unroll
                 for (int q = kk + 1; q < 6; ++q) cq[q] = readlane_f64(v[kk], q);      // d l_qk of the pivot block's rows below
-                if (!isfinite(d)) nonfinite = true;
-                if (!(d > 0.0)) nonpos = true;
+                nonfinite |= !isfinite(d);
+                nonpos |= !(d > 0.0);
                 const double r0 = __builtin_amdgcn_rcp(d);
                 const double e = __builtin_fma(-d, r0, 1.0), t = __builtin_fma(e, e, e);
                 const double g = v[kk] * r0;
@@ -222,16 +245,18 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
 #pragma unroll
                 for (int q = kk + 1; q < 6; ++q) v[q] = __builtin_fma(-v[kk], cq[q], v[q]);
             }
+            BAND_FINE(2, v[5]);
             if (act && ln >= 6) {
                 double2 *wp = reinterpret_cast<double2 *>(row);
                 wp[0] = make_double2(v[0], v[1]); wp[1] = make_double2(v[2], v[3]); wp[2] = make_double2(v[4], v[5]);
                 double2 *tp = reinterpret_cast<double2 *>(T + s_toff);
                 tp[0] = make_double2(wu[0], wu[1]); tp[1] = make_double2(wu[2], wu[3]); tp[2] = make_double2(wu[4], wu[5]);
             }
-            if (wv == 0 && ln == 0) { if (nonfinite) failw[0] = 1; if (nonpos) failw[1] = 1; }
         }
+        BAND_FINE(3, lambda);
         // L_kk goes over D_k only when every sweeping wave has read D_k (the trailing phase does not touch block (k, k))
         if (m > 0) __syncthreads();
+        BAND_FINE(4, lambda);
         if (wv == 0 && ln < 6) {
             double2 *wp = reinterpret_cast<double2 *>(Lk + s_off);
             wp[0] = make_double2(v[0], v[1]); wp[1] = make_double2(v[2], v[3]); wp[2] = make_double2(v[4], v[5]);
@@ -276,7 +301,7 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
         if (fast_tr) {
 #pragma unroll
             for (int u = 0; u < kTr; ++u) {
-                if (__ballot(t_irel[u] < m) == 0ull) continue;          // (nothing for this wave in this round)
+                if (t_first[u] >= m) continue;                          // (nothing for this wave in this round)
                 const bool live = t_irel[u] < m, is_rhs = t_B[u] < 0;
                 const double *A = Lk + (live ? t_A[u] : 0);
                 const double *Bq = is_rhs ? T + bw * 36 : T + (live ? t_B[u] : 0);
@@ -292,9 +317,12 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
             if (is_rhs) piece(A, T + bw * 36, rhs + 6 * (k + 1 + irel) + a3 * 3, true, true);
             else piece(A, T + jrel * 36 + b3 * 18, Lb + band_off(k + 1 + irel, k + 1 + jrel, bw) + a3 * 18 + b3 * 3, false, true);
         }
+        BAND_FINE(5, lambda);
         __syncthreads();
+        BAND_FINE(6, lambda);
         BAND_STAMP(2);
     }
+    if (tid == 0) { failw[0] = nonfinite; failw[1] = nonpos; }      // (wave 0 sweeps in every step)
     __syncthreads();
     const bool fail = failw[0] != 0;
     bool park = failw[1] != 0 && !fail;
@@ -320,7 +348,8 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     //      contribute is in the right-hand side already (lanes 6 ... of earlier steps, through LDS, two steps and more ahead of its
     //      use); block k + 1's contribution is added HERE, from its x in scalar registers, and the six unknowns follow by
     //      back-substitution through v_readlane - the chain of a step holds no LDS round trip and no division.  (~970 cycles per
-    //      step all the same, as with the contributions passed through LDS: the chain is ~25 dependent operations) ----
+    //      step all the same, as with the contributions passed through LDS: six v_readlane hops with the multiply-adds between
+    //      them are ~150 cycles; the rest is this one wave's eighteen LDS loads of the step ahead and its stores) ----
     if (wv == 0) {
         const int a6 = min(ln, 5);
         double xs[6] = { 0.0, 0.0, 0.0, 0.0, 0.0, 0.0 };    // x of block k + 1 (wave-uniform)
@@ -422,6 +451,9 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
         S1.Rt[12 * i + 9] = Tn[4]; S1.Rt[12 * i + 10] = Tn[5]; S1.Rt[12 * i + 11] = Tn[6];
     }
     BAND_STAMP(5);
+#ifdef MOVBA_CLOCK_STAMP
+    if (tid == 0) for (int i = 0; i < 7; ++i) c->dbg_wseg[0][i] += i ? fine[i] - fine[i - 1] : 0;
+#endif
     if (tid == 0) {
         w.scale_part[w.n_pt_blocks] = scs;
         c->pcg_fail = fail ? 1 : 0;

@@ -502,12 +502,18 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     bool fail = anybad != 0;
     bool first = true;
     int iters = 0;
+    // How an iteration's checks came out (0 go on, 1 broken down, 2 converged, 3 zero right-hand side): DECIDED where the
+    // reduction's sums arrive, TESTED at the top of the next iteration, before anything of it is applied - same iterates, same
+    // iteration counts.  A vector compare that a scalar branch waits for costs ~60 cycles (profiles/r05_chain_probe.log), and
+    // there were four of them in a row on the chain of every iteration; this way the branch finds its condition long computed.
+    int stop = 0;
 
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long seg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, seg_last = __builtin_amdgcn_s_memtime();
 #endif
     if (!fail) {
         for (iters = 1; iters <= pp.max_iters; ++iters) {
+            if (stop) break;
             SEG_STAMP(7);
             // ---- x += alpha p, r -= alpha s, z = Minv r (wave-local) ----
             x_r += alpha * p_r;
@@ -619,16 +625,16 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             }
             // the dense coarse product of this iteration (independent of the scalar recurrences)
             const double yc = coarse ? coarse_rows() : 0.0;
-            if (!isfinite(g) || !isfinite(delta)) { fail = true; break; }
-            if (first) {
-                thresh = PCG_UNI(pp.rel_tol * pp.rel_tol * g);
-                if (!(g >= 0.0)) { fail = true; break; }
-                if (g == 0.0) { iters = 0; break; }
-            }
-            if (!first && g <= thresh) break;
+            if (first) thresh = PCG_UNI(pp.rel_tol * pp.rel_tol * g);
             const double beta = PCG_UNI(first ? 0.0 : g * inv_gamma);
             const double den = delta - beta * g * inv_alpha;          // = p.Ap of the new search direction
-            if (!(den > 0.0)) { fail = true; break; }
+            {
+                // (in the order the checks have always had: not finite, the first residual's sign, a zero right-hand side,
+                //  converged, p.Ap not positive)
+                const bool nonfin = !(isfinite(g) && isfinite(delta));
+                const bool neg = first && !(g >= 0.0), zero = first && g == 0.0, conv = !first && g <= thresh, noden = !(den > 0.0);
+                stop = (nonfin || neg) ? 1 : zero ? 3 : conv ? 2 : noden ? 1 : 0;
+            }
             // (reciprocals by v_rcp_f64 + two Newton steps: the IEEE division sequence is ~25 dependent instructions, on the
             //  critical path of every iteration; the two are independent of each other and overlap)
             inv_gamma = PCG_UNI(fast_rcp(g));
@@ -644,6 +650,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             SEG_STAMP(6);
         }
     }
+    if (stop) { iters = stop == 3 ? 0 : iters - 1; fail = stop == 1; }      // (the loop counted one more before it looked)
     const bool capped = iters > pp.max_iters;
     if (capped) iters = pp.max_iters;
     // (the current pose of this thread's keyframe, for the update at the very end: requested here, a cold round trip that runs
