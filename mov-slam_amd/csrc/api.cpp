@@ -2485,6 +2485,10 @@ extern "C" int movba_pose_opt(movba_handle *h, const movba_pose_desc *d, movba_p
     res->n_inliers = (int32_t)po[7];
     res->ransac_inliers = n_hyp > 0 ? (int32_t)po[8] : 0;
     res->lm_iters = (int32_t)po[16];
+#ifdef MOVBA_CLOCK_STAMP
+    std::fprintf(stderr, "libmovba[stamp]: k_pose_opt, cycles per LM iteration (%d): system pass %.0f, reduction of 28 %.0f, solve + update %.0f, cost pass + reduction %.0f\n",
+                 res->lm_iters, po[20] / res->lm_iters, po[21] / res->lm_iters, po[22] / res->lm_iters, po[23] / res->lm_iters);
+#endif
     res->ransac_samples_used = n_hyp > 0 ? (int32_t)po[17] : 0; res->lo_accepted = n_hyp > 0 ? (int32_t)po[18] : 0; res->lo_inliers = n_hyp > 0 ? (int32_t)po[19] : 0;
     for (int k = 0; k < 7; ++k) res->ransac_pose[k] = n_hyp > 0 ? po[9 + k] : d->pose0[k];
     if (res->outlier) std::memcpy(res->outlier, sg + o_lvl, (size_t)n);

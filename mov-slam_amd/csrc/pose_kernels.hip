@@ -39,41 +39,62 @@ __device__ __forceinline__ void q2R(const double q[7], double R[12])
 __device__ __forceinline__ void qnorm(double q[4]) { quat_normalize(q); }
 __device__ __forceinline__ void oplus(const double u[6], const double T[7], double out[7]) { se3_oplus(u, T, out); }
 
-// fixed-order reduction of NV values per thread; result in every thread.  Inside a wave: two DPP steps sum each quad, the
-// 16 quad sums of every value cross a wave-private LDS strip and lane k adds those of value k up in order (a butterfly of
-// 64-bit shuffles per value costs ~500 cycles each: 28 of them were three quarters of an LM iteration); then the waves'
-// sums are combined in wave order.
+// fixed-order reduction of NV values per thread; result in every thread (wave-uniform: scalar registers).  Inside a wave: two
+// DPP steps sum each quad, the 16 quad sums of every value cross a wave-private LDS strip and lane k adds those of value k up in
+// order (a butterfly of 64-bit shuffles per value costs ~500 cycles each: 28 of them were three quarters of an LM iteration);
+// one or two values take the whole-wave DPP tree instead.  Then ONE workgroup barrier: lane k of EVERY wave adds the waves' sums
+// of value k in wave order and the values go round by v_readlane - until round 5 every thread read all kW x NV sums back from
+// LDS itself behind a second barrier (112 eight-byte loads of a lone wave per SIMD: 1 400 of the reduction's 3 600 cycles).
+// The waves' sums alternate between two places (`flip`), so a wave that runs ahead into the next reduction cannot overwrite
+// what a slower one still reads: it stops at that reduction's barrier first.
+constexpr int kRedMax = 28;
+constexpr int kRedLds = 2 * kW * kRedMax + kW * kRedMax * 16;
 template <int NV>
-__device__ __forceinline__ void reduce_all(double (&v)[NV], double *lds /* kW * NV + kW * NV * 16 */)
+__device__ __forceinline__ void reduce_all(double (&v)[NV], double *lds /* kRedLds */, int &flip)
 {
+    static_assert(NV <= kRedMax, "reduce_all: LDS strips sized for 28 values");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *strip = lds + kW * NV + wave * (NV * 16);
+    double *cross = lds + flip * (kW * kRedMax);
+    flip ^= 1;
+    if (NV <= 2) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double t = v[k];
-        t += dpp_mov0<0xb1>(t);
-        t += dpp_mov0<0x4e>(t);
-        if ((lane & 3) == 0) strip[k * 16 + (lane >> 2)] = t;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < NV) {
-        const double2 *src = reinterpret_cast<const double2 *>(strip + lane * 16);
-        double s = 0.0;
+        for (int k = 0; k < NV; ++k) {
+            const double t = wave_sum_dpp(v[k]);
+            if (lane == 0) cross[wave * NV + k] = t;
+        }
+    } else {
+        double *strip = lds + 2 * kW * kRedMax + wave * (NV * 16);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { const double2 t = src[q]; s += t.x; s += t.y; }
-        lds[wave * NV + lane] = s;
+        for (int k = 0; k < NV; ++k) {
+            double t = v[k];
+            t += dpp_mov0<0xb1>(t);
+            t += dpp_mov0<0x4e>(t);
+            if ((lane & 3) == 0) strip[k * 16 + (lane >> 2)] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < NV) {
+            const double2 *src = reinterpret_cast<const double2 *>(strip + lane * 16);
+            double2 t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = src[q];
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { s += t[q].x; s += t[q].y; }
+            cross[wave * NV + lane] = s;
+        }
     }
     __syncthreads();
+    const int kk = lane < NV ? lane : NV - 1;
+    double w[kW];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double s = lds[k];
+    for (int q = 0; q < kW; ++q) w[q] = cross[q * NV + kk];
+    double tot = w[0];
 #pragma unroll
-        for (int q = 1; q < kW; ++q) s += lds[q * NV + k];
-        v[k] = s;
-    }
-    __syncthreads();
+    for (int q = 1; q < kW; ++q) tot += w[q];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = readlane_f64(tot, k);
 }
 
 // dense 6x6 LL^T solve, every thread redundantly (H upper-triangle packed 21)
@@ -388,7 +409,8 @@ __global__ __launch_bounds__(kT) void k_pose_hyp(PoseDev p)
 template <bool STAGED>
 __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
 {
-    __shared__ __attribute__((aligned(16))) double lds[kW * 28 + kW * 28 * 16];      // reduce_all: the waves' sums, then a strip per wave
+    __shared__ __attribute__((aligned(16))) double lds[kRedLds];      // reduce_all: the waves' sums (two places), then a strip per wave
+    int flip = 0;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     const int tid = threadIdx.x;
     const double *Xw = p.Xw, *obs = p.obs, *isig = p.isig;
@@ -466,52 +488,102 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
     double *wls = STAGED ? dyn + 6 * (size_t)p.n : p.chi2;       // (not staged: the chi2 output array, rewritten by every round below)
     const double *wuse = nullptr;                               // weights of the LM passes (the local-optimisation step), or none
     // robust cost of the active matches at a pose
+    // The passes over the matches take a thread's matches kFly at a time: every load of the batch is requested before the first
+    // is used, and a match that is switched off (level1) is not branched round but run with a harmless point and weight zero -
+    // it adds exact zeros.  (One match at a time behind `if (level1[i]) continue`, every match paid its own LDS round trip and
+    // a vector-compare-to-branch hop: ~1 050 cycles per match in the system pass for ~600 of arithmetic, profiles/r05_pose_stamps.log.)
+    constexpr int kFly = 4;
+    struct Batch { double X[kFly][3], o[kFly][2], om[kFly]; bool in[kFly]; };
+    auto fetch = [&](int i0, Batch &b) {
+        // (no branch and no wait between the loads: `iu < n && level1[i] == 0` written with && put a wait-and-branch
+        //  in front of every match's loads)
+        uint8_t lv[kFly];
+        double wq[kFly];
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) {
+            const int i = min(i0 + u * kT, p.n - 1);
+            lv[u] = level1[i];
+            b.X[u][0] = Xw[3 * i]; b.X[u][1] = Xw[3 * i + 1]; b.X[u][2] = Xw[3 * i + 2];
+            b.o[u][0] = obs[2 * i]; b.o[u][1] = obs[2 * i + 1];
+            b.om[u] = isig[i];
+        }
+        if (wuse) {
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) wq[u] = wuse[min(i0 + u * kT, p.n - 1)];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) b.om[u] *= wq[u];
+        }
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) b.in[u] = (i0 + u * kT < p.n) & (lv[u] == 0);
+    };
     auto cost = [&](const double T[7], bool robust) {
         double R[12];
         q2R(T, R);
         double F[1] = { 0.0 };
-        for (int i = tid; i < p.n; i += kT) {
-            if (level1[i]) continue;
-            const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
-            const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
-            const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
-            const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-            const double om = wuse ? isig[i] * wuse[i] : isig[i];
-            const double iz = fast_rcp(z);
-            const double e0 = obs[2 * i] - (p.fx * x * iz + p.cx), e1 = obs[2 * i + 1] - (p.fy * y * iz + p.cy);
-            const double chi2 = e0 * (om * e0) + e1 * (om * e1);
-            F[0] += (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) ? 2.0 * sqrt(chi2) * p.huber_delta - dsqr : chi2;
+        for (int i0 = tid; i0 < p.n; i0 += kFly * kT) {
+            Batch b;
+            fetch(i0, b);
+            const int w0 = __builtin_amdgcn_readfirstlane(i0);          // (the wave's lowest index: places wholly past the end are skipped)
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) {
+                if (w0 + u * kT >= p.n) break;
+                const double X0 = b.X[u][0], X1 = b.X[u][1], X2 = b.X[u][2];
+                const bool in = b.in[u];
+                const double x = in ? R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9] : 0.0;
+                const double y = in ? R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10] : 0.0;
+                const double z = in ? R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11] : 1.0;
+                const double om = in ? b.om[u] : 0.0;
+                const double iz = fast_rcp(z);
+                const double e0 = b.o[u][0] - (p.fx * x * iz + p.cx), e1 = b.o[u][1] - (p.fy * y * iz + p.cy);
+                const double chi2 = e0 * (om * e0) + e1 * (om * e1);
+                F[0] += (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) ? 2.0 * sqrt(chi2) * p.huber_delta - dsqr : chi2;
+            }
         }
-        reduce_all<1>(F, lds);
+        reduce_all<1>(F, lds, flip);
         return F[0];
     };
 
     int n_bad = 0, n_lm = 0;
+#ifdef MOVBA_CLOCK_STAMP
+    unsigned long long pseg[4] = { 0, 0, 0, 0 }, plast = 0;
+#define POSE_STAMP0() do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(plast) :: "memory"); } while (0)
+#define POSE_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pseg[k] += t_ - plast; plast = t_; } while (0)
+#else
+#define POSE_STAMP0() do { } while (0)
+#define POSE_STAMP(k) do { } while (0)
+#endif
     // the LM iterations of one round over the active matches (level1 == 0), from and into `pose`
     auto lm_round = [&](bool robust, int its) {
         double cnt[1] = { 0.0 };
         for (int i = tid; i < p.n; i += kT) cnt[0] += level1[i] ? 0.0 : 1.0;
-        reduce_all<1>(cnt, lds);
+        reduce_all<1>(cnt, lds, flip);
         bool ok = cnt[0] > 0.0;
         double lambda = 0.0, ni = 2.0;
         for (int it = 0; it < its && ok; ++it) {
             ++n_lm;
+            POSE_STAMP0();
             // computeActiveErrors + buildSystem in one pass
             double R[12];
             q2R(pose, R);
             double acc[28];
 #pragma unroll
             for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-            for (int i = tid; i < p.n; i += kT) {
-                if (level1[i]) continue;
-                const double X0 = Xw[3 * i], X1 = Xw[3 * i + 1], X2 = Xw[3 * i + 2];
-                const double x = R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9];
-                const double y = R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10];
-                const double z = R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11];
-                const double om = wuse ? isig[i] * wuse[i] : isig[i];
+            for (int i0 = tid; i0 < p.n; i0 += kFly * kT) {
+              Batch b;
+              fetch(i0, b);
+              const int w0 = __builtin_amdgcn_readfirstlane(i0);
+#pragma unroll
+              for (int u = 0; u < kFly; ++u) {
+                if (w0 + u * kT >= p.n) break;
+                const double X0 = b.X[u][0], X1 = b.X[u][1], X2 = b.X[u][2];
+                const bool in = b.in[u];
+                const double x = in ? R[0] * X0 + R[1] * X1 + R[2] * X2 + R[9] : 0.0;
+                const double y = in ? R[3] * X0 + R[4] * X1 + R[5] * X2 + R[10] : 0.0;
+                const double z = in ? R[6] * X0 + R[7] * X1 + R[8] * X2 + R[11] : 1.0;
+                const double om = in ? b.om[u] : 0.0;
                 // (one reciprocal per match and pass instead of six divisions)
                 const double iz = fast_rcp(z), uu = p.fx * x * iz, vv = p.fy * y * iz;
-                const double e0 = obs[2 * i] - (uu + p.cx), e1 = obs[2 * i + 1] - (vv + p.cy);
+                const double e0 = b.o[u][0] - (uu + p.cx), e1 = b.o[u][1] - (vv + p.cy);
                 const double chi2 = e0 * (om * e0) + e1 * (om * e1);
                 double rho0 = chi2, rho1 = 1.0;
                 if (robust && p.huber_delta > 0.0 && !(chi2 <= dsqr)) {
@@ -522,16 +594,29 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
                 const double a00 = -(p.fx * iz), a02 = uu * iz, a11 = -(p.fy * iz), a12 = vv * iz;
                 const double C0[6] = { a02 * y, a00 * z - a02 * x, -a00 * y, a00, 0.0, a02 };
                 const double C1[6] = { -a11 * z + a12 * y, -a12 * x, a11 * x, 0.0, a11, a12 };
-                int u = 0;
+                // H += J^T (wg J), b += J^T r: the weight taken into one factor once (D = wg C), every entry two fused
+                // multiply-adds, and the terms of the structural zeros C0[4] = C1[3] = 0 left out (they add exact zeros):
+                // 50 operations per match where `acc += wg * (C0 C0 + C1 C1)` over all 21 + 6 entries took 75
+                double D0[6], D1[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { D0[a] = a == 4 ? 0.0 : wg * C0[a]; D1[a] = a == 3 ? 0.0 : wg * C1[a]; }
+                int ue = 0;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
-                    acc[21 + a] += C0[a] * r0 + C1[a] * r1;
+                    if (a != 4) acc[21 + a] = __builtin_fma(C0[a], r0, acc[21 + a]);
+                    if (a != 3) acc[21 + a] = __builtin_fma(C1[a], r1, acc[21 + a]);
 #pragma unroll
-                    for (int c = a; c < 6; ++c) acc[u++] += wg * (C0[a] * C0[c] + C1[a] * C1[c]);
+                    for (int c = a; c < 6; ++c, ++ue) {
+                        if (a != 4 && c != 4) acc[ue] = __builtin_fma(D0[a], C0[c], acc[ue]);
+                        if (a != 3 && c != 3) acc[ue] = __builtin_fma(D1[a], C1[c], acc[ue]);
+                    }
                 }
                 acc[27] += rho0;
+              }
             }
-            reduce_all<28>(acc, lds);
+            POSE_STAMP(0);
+            reduce_all<28>(acc, lds, flip);
+            POSE_STAMP(1);
             double F0 = acc[27];
             if (it == 0) {
                 double md = 0.0;
@@ -547,7 +632,9 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
                 for (int k = 0; k < 7; ++k) bk[k] = pose[k];
                 const bool ok2 = solve6(acc, lambda, acc + 21, x);
                 if (ok2) oplus(x, bk, pose);
+                POSE_STAMP(2);
                 double F1 = cost(pose, robust);
+                POSE_STAMP(3);
                 if (!ok2) F1 = DBL_MAX;
                 double scale = 1e-3;
                 if (ok2) {
@@ -594,7 +681,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             sc[0] += in ? 1.0 : 0.0; sc[1] += ls;
             if (mark) { level1[i] = in ? 0 : 1; wls[i] = wt; }
         }
-        reduce_all<2>(sc, lds);
+        reduce_all<2>(sc, lds, flip);
         cnt_o = sc[0]; cst_o = sc[1];
     };
     // ---- local optimisation of the winning hypothesis (USAC's LO step; MAGSAC++'s model polishing is iteratively reweighted least
@@ -646,7 +733,7 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
             level1[i] = (uint8_t)bad;
             nb[0] += bad;
         }
-        reduce_all<1>(nb, lds);
+        reduce_all<1>(nb, lds, flip);
         n_bad = (int)nb[0];
         if (p.n - n_bad < 10) break;
     }
@@ -659,6 +746,9 @@ __global__ __launch_bounds__(kT) void k_pose_opt(PoseDev p)
         for (int k = 0; k < 7; ++k) p.pose_out[k] = pose[k];
         p.pose_out[7] = (double)(p.n - n_bad);
         p.pose_out[16] = (double)n_lm;
+#ifdef MOVBA_CLOCK_STAMP
+        for (int k = 0; k < 4; ++k) p.pose_out[20 + k] = (double)pseg[k];
+#endif
     }
 }
 

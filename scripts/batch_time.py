@@ -1,16 +1,22 @@
-"""Window solves per second: n resident cfg3-shaped windows through movba_lba_run_batch against one after the other."""
+"""Window solves per second: n resident cfg3-shaped windows through movba_lba_run_batch against one after the other.
+--short: three batched runs and nothing else (the counter passes of scripts/profile_patterns.sh)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "mov-slam_amd"))
 import torch
 from movba import capi, synth, shard
 st = torch.cuda.Stream(device=0)
-for n in [int(v) for v in sys.argv[1:]] or (1, 2, 4, 8, 16):
+short = "--short" in sys.argv
+for n in [int(v) for v in sys.argv[1:] if v != "--short"] or (1, 2, 4, 8, 16):
     ws = [synth.make_window(50, 10, 20000, shard.window_seed(i), run_lo=2, run_hi=10) for i in range(n)]
     solvers = [capi.Solver(device=0, stream=st.cuda_stream) for _ in range(n)]
     for s, w in zip(solvers, ws):
         s.upload(w)
     capi.run_batch(solvers); capi.run_batch(solvers)
+    if short:
+        capi.run_batch(solvers)
+        for s in solvers: s.close()
+        continue
     reps = 10
     t0 = time.perf_counter()
     for _ in range(reps):

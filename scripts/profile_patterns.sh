@@ -25,3 +25,7 @@ OUT=$ROOT/gpurun_out/prof_${TAG}_batch8; mkdir -p $OUT
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/scripts/batch_time.py 8 > $OUT/stats.log 2>&1 || exit 1
 cp $(ls $OUT/stats/*/*kernel_stats.csv | head -1) $ROOT/gpurun_out/${TAG}_batch8_kernel_stats.csv || exit 1
 tail -2 $OUT/stats.log
+# HBM traffic of the batched kernels (one --pmc pass per counter, nothing else beside it):
+# scripts/summarise_profiles.py gpurun_out/prof_<tag>_batch8 <tag>_batch8 -> profiles/<tag>_batch8_pmc_traffic.json
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/scripts/batch_time.py 8 --short > $OUT/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/scripts/batch_time.py 8 --short > $OUT/pmc_write.log 2>&1 || exit 1
