@@ -156,7 +156,11 @@ namespace MOV_SLAM
             template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
             template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
         };
+#ifdef MOVBA_ADAPTER_PLAIN_VECTORS
+        template <class T> using pinned_vector = std::vector<T>;
+#else
         template <class T> using pinned_vector = std::vector<T, PinnedAlloc<T>>;
+#endif
 
         // Flattened window in the layout of movba_lba_desc, plus the bookkeeping to write results back.
         // One instance per calling thread, reused from call to call (the vectors keep their capacity).
