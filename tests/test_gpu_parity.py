@@ -422,6 +422,15 @@ def test_stop_flag_set_before_the_call(solver, built_lib):
     assert r["status"] == 0 and r["n_solves"] >= 10
 
 
+def test_cfg3_cg_iteration_counts_per_trial_are_those_of_round_4(solver):
+    """The PCG's exit checks moved (round 5: decided where the reduction's sums arrive, tested at the top of the next
+    iteration, before anything of it is applied): same iterates, so the same iteration count in every trial as
+    profiles/r04_pcg_stamps_cfg3.log recorded for the headline window."""
+    r = solver.solve(synth.cfg("cfg3"))
+    assert r["n_direct"] == 0 and r["n_pcg_giveups"] == 0
+    assert list(r["trace"]["pcg"]) == [17, 29, 21, 19, 19, 20, 21, 22, 23, 24] and r["pcg_iters"] == 215
+
+
 def test_stop_flag_raised_while_solving(solver):
     """Tracking raises mbAbortBA from another thread (LocalMapping.cc:162, 684); g2o polls it between LM trials.
     The solve must end early (or normally, if it was faster than the flag) with a consistent, finite state."""
