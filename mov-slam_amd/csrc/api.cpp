@@ -651,6 +651,7 @@ struct HelperHandOff {
     // helper -> caller
     std::atomic<int> idx_ready{0};      // the caller's index arrays are in the staging buffer (release / acquire): what the
                                         // structure pass on the device waits for
+
     hipError_t copy_err = hipSuccess;   // read by the caller only after Worker::wait()
     hipError_t idx_err = hipSuccess;    // ... this one behind idx_ready (release / acquire)
     // fixed before the helper is posted, read by both
@@ -832,6 +833,10 @@ void Upload::post_helper()
         HelperHandOff *const out = &ho;
         h->packer.post([=]() {
             hipError_t err = hipSetDevice(hh->device);
+            // (The bus is shared: beside these 3.5 MB the index arrays' k_ingest takes 27 us for its 0.9 MB instead of 19 - 22.
+            //  Holding the copy commands back behind that launch was tried: the last, small copy of the chain is a blit kernel,
+            //  which then queued up behind the structure kernels of the handle's stream, and the solve's first kernels - which
+            //  wait for it - started 25 us later: 1.107 ms per call against 1.09.)
             auto dma = [&](size_t to, const void *from, size_t bytes) {
                 if (err == hipSuccess && bytes) err = hipMemcpyAsync(out->arena + to, from, bytes, hipMemcpyHostToDevice, hh->copy_stream);
             };
@@ -994,7 +999,9 @@ int Upload::group_on_device()
     // (the keyframes' flags are read out of host memory - the staging buffer is mapped -, through the place of the hessian
     //  indices, which the device makes itself here)
     std::memcpy(sg + L.hidx, d->pose_fixed, (size_t)NP);
-    HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, so_info + sizeof(int32_t) * kBasicInfo - so_cnt, h->stream));    // bin totals, error word, edges per keyframe, info words
+    // bin totals, error word, edges per keyframe, info words: cleared by the ingest launch itself (direct mode)
+    const size_t zero_bytes = so_info + sizeof(int32_t) * kBasicInfo - so_cnt;
+    if (!direct_raw) HIP_TRY(hipMemsetAsync(sa + so_cnt, 0, zero_bytes, h->stream));
     bd = BasicDev{};
     bd.E = E; bd.P = P; bd.NP = NP; bd.nblk = (E + kBasicBlock - 1) / kBasicBlock;
     if (direct_raw) {
@@ -1007,8 +1014,10 @@ int Upload::group_on_device()
         // (the keyframes' flags with them: four bytes at a time out of the staging buffer's copy, which is padded)
         ia.seg[2] = IngestSeg{ h->stage_dev + L.hidx, sa + so_fixed, ((size_t)NP + 3) & ~(size_t)3 };
         ia.nseg = 3; ia.counter = h->ingest_counter; ia.wait_for = 0;
+        ia.zero = reinterpret_cast<unsigned *>(sa + so_cnt); ia.zero_words = (unsigned)(zero_bytes / 4);
         HIP_TRY(launch_ingest(ia, h->stream));
         h->ingest_expect += (unsigned)ingest_workgroups();
+
     } else {
         // the index arrays are on their way on the copy stream (post_helper): the grouping kernel starts behind their event
         while (ho.idx_ready.load(std::memory_order_acquire) == 0) host_relax(h->opt.host_wait);
@@ -1304,15 +1313,25 @@ int Upload::after_counts()
             movba_handle *const hh = h;
             Upload *const self = this;
             HelperHandOff *const out = &ho;
+            const bool laps = lap_on;
+            const double tz = t0;
             h->packer.post([=]() {
+                double tl[6]; tl[0] = now_ms();
                 hipError_t err = hipSetDevice(hh->device);
                 int rq = MOVBA_OK;
                 if (err == hipSuccess) rq = self->launch_slotpt();
+                tl[1] = now_ms();
                 if (err == hipSuccess && rq == MOVBA_OK) rq = self->launch_fill();
+                tl[2] = now_ms();
                 if (err == hipSuccess && rq == MOVBA_OK) err = hipStreamWaitEvent(hh->stream, hh->copy_event, 0);
+                tl[3] = now_ms();
                 if (err == hipSuccess && rq == MOVBA_OK) err = launch_init(wv, hh->stream);
+                tl[4] = now_ms();
                 if (err == hipSuccess && rq == MOVBA_OK) err = launch_linearize(wv, hh->stream);
+                tl[5] = now_ms();
                 out->copy_err = (err == hipSuccess && rq != MOVBA_OK) ? hipErrorUnknown : err;
+                if (laps) std::fprintf(stderr, "libmovba[upload]: helper's launches (ms into the call): start %.3f, slots %.3f, scan + fill %.3f, event wait %.3f, init %.3f, linearise %.3f\n",
+                                       tl[0] - tz, tl[1] - tz, tl[2] - tz, tl[3] - tz, tl[4] - tz, tl[5] - tz);
             });
             ho.joined = false;                              // (send_pairs waits for it)
             h->early_setup = true;

@@ -231,7 +231,9 @@ constexpr int kBasicInfo = 8;
 // through, and a launch may hold its reads back until the counter has reached `wait_for` (the launch in front of it is through:
 // the bus is the bottleneck, and whoever the pair structure waits for gets it first).
 struct IngestSeg { const void *src; void *dst; unsigned long long bytes; };
-struct IngestArgs { IngestSeg seg[8]; int32_t nseg, pad_i; unsigned *counter; unsigned wait_for; unsigned pad_w; };
+// `zero` / `zero_words`: a piece of device memory the launch clears first (the grouping pass's counters: a hipMemsetAsync in
+// front of the launch cost the stream ~6 us and the calling thread another launch call)
+struct IngestArgs { IngestSeg seg[8]; int32_t nseg, pad_i; unsigned *counter; unsigned wait_for; unsigned zero_words; unsigned *zero; };
 
 struct PcgParams {
     double rel_tol;

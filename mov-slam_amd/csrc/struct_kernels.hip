@@ -173,6 +173,35 @@ __device__ __forceinline__ int scan_columns(int32_t *tab, int nbins, int nrows, 
     const bool live = bin < nbins;
     const int L = (nrows + 15) / 16, c_beg = sy * L, c_end = min(nrows, c_beg + L);
     int32_t *col = tab + (live ? bin : 0);
+    // Segments of up to kKeep rows (cfg3: 27 of the grouping pass's table, 20 of the pair bins') stay in registers between the
+    // two passes, all their loads in flight at once: the table was written by the launch in front, by workgroups on every XCD,
+    // so each round of loads is a round trip past this XCD's L2 (~1 us) - eight at a time and read twice that was 8 of them.
+    constexpr int kKeep = 32;
+    if (L <= kKeep) {
+        int v[kKeep];
+        // (one running 32-bit offset from the table: kKeep separate 64-bit addresses spilled under the 128 registers of a
+        //  1 024-thread workgroup)
+        const unsigned step = (unsigned)nbins, first = (unsigned)c_beg * step + (unsigned)(live ? bin : 0);
+        const int nrow = live ? max(c_end - c_beg, 0) : 0;
+        unsigned o = first;
+#pragma unroll
+        for (int u = 0; u < kKeep; ++u) { v[u] = u < nrow ? tab[o] : 0; o += step; }
+        int sum = 0;
+#pragma unroll
+        for (int u = 0; u < kKeep; ++u) sum += v[u];
+        seg_tot[sy][tx] = sum;
+        __syncthreads();
+        int carry = 0;
+        for (int q = 0; q < sy; ++q) carry += seg_tot[q][tx];
+        o = first;
+#pragma unroll
+        for (int u = 0; u < kKeep; ++u) {
+            if (u < nrow) tab[o] = carry;
+            carry += v[u];
+            o += step;
+        }
+        return carry;
+    }
     int sum = 0;
     for (int c0 = c_beg; c0 < c_end && live; c0 += 8) {
         int v[8];
@@ -214,6 +243,7 @@ __global__ __launch_bounds__(kIngestBlock) void k_ingest(IngestArgs a)
                __builtin_amdgcn_s_memrealtime() - t0 < 20000ull) __builtin_amdgcn_s_sleep(8);
     }
     const size_t stride = (size_t)gridDim.x * kIngestBlock;
+    for (size_t i = (size_t)blockIdx.x * kIngestBlock + threadIdx.x; i < a.zero_words; i += stride) a.zero[i] = 0u;
     for (int q = 0; q < a.nseg; ++q) {
         const IngestSeg sg = a.seg[q];
         const bool wide = ((reinterpret_cast<size_t>(sg.src) | reinterpret_cast<size_t>(sg.dst)) & 15) == 0;

@@ -159,6 +159,7 @@ hipError_t launch_slot_point(int32_t *slot, const int32_t *g_pose, const int32_t
 hipError_t launch_ingest(const IngestArgs &a, hipStream_t s)
 {
     fake_enqueue(s, [a] {
+        if (a.zero_words) std::memset(a.zero, 0, 4 * (size_t)a.zero_words);
         for (int q = 0; q < a.nseg; ++q) std::memcpy(a.seg[q].dst, a.seg[q].src, a.seg[q].bytes);
         if (a.counter) __atomic_fetch_add(a.counter, (unsigned)ingest_workgroups(), __ATOMIC_RELAXED);
     });
