@@ -320,7 +320,8 @@ def test_device_structure_pass_equals_host_structure_pass(solver, built_lib, nam
     assert np.array_equal(a["trace"]["pcg"], b["trace"]["pcg"])
 
 
-@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged", "shuffled", "free-keyframe-without-edges", "ungrouped", "points-nobody-observes"])
+@pytest.mark.parametrize("name", ["small", "cfg2", "cfg3", "stereo", "ragged", "shuffled", "free-keyframe-without-edges", "ungrouped", "points-nobody-observes",
+                                  "beyond-the-scans-register-segments"])
 def test_device_grouping_pass_equals_host_grouping_pass(solver, built_lib, name):
     """Validation, the points' edge ranges, edges per keyframe, hessian indices and pose-major slots - structure.cpp's build_basic,
     one pass over the caller's edges on the calling thread - are made on the GPU for the windows whose pair structure the device
@@ -343,6 +344,11 @@ def test_device_grouping_pass_equals_host_grouping_pass(solver, built_lib, name)
         w = synth.cfg("cfg2")
         pm = np.random.default_rng(5).permutation(w.n_edges)
         w.edge_pose, w.edge_point, w.obs, w.inv_sigma2 = w.edge_pose[pm], w.edge_point[pm], w.obs[pm], w.inv_sigma2[pm]
+    elif name == "beyond-the-scans-register-segments":
+        # more than 512 blocks of 256 edges and more than 512 chunks of 64 points: the column scans (struct_kernels.hip,
+        # scan_columns) keep a segment of up to 32 rows in registers and walk longer ones eight rows at a time, twice
+        w = synth.make_window(40, 8, 36000, seed=4242, run_lo=3, run_hi=6)
+        assert w.n_edges > 512 * 256 and w.n_points > 512 * 64
     elif name == "points-nobody-observes":
         w = synth.cfg("cfg2")
         keep = ~np.isin(w.edge_point, [0, 7, 8, 9, w.n_points - 1])
