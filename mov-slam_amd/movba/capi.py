@@ -343,7 +343,10 @@ class Solver:
 
     def prepare(self, w, flags=FLAG_STALE_ERROR_QUIRK, stop=None, max_iters=None, max_trials=0, pinned=False, chi2=True):
         """Descriptor and result buffers built once for repeated solve_prepared() calls: what a C++ caller that keeps its
-        flattened arrays and result buffers does (nothing is allocated or converted per call)."""
+        flattened arrays and result buffers does (nothing is allocated or converted per call).  pinned=True: the buffers are
+        blocks of movba_host_alloc memory that live until close() (results handed out earlier stay valid): prepare a window
+        once and keep it - `self._prep` may be saved and put back to alternate between prepared windows - rather than
+        preparing it again for every call."""
         d, keep = make_desc(w, flags, stop, max_iters, max_trials)
         if pinned:
             self._pin_inputs(d, keep)                     # ... and input arrays the device reads where they lie
