@@ -647,6 +647,11 @@ struct EdgeLayout {
 
 constexpr int kSortedMaxPoses = 1024;   // windows the sort-based device structure pass takes (pair counts back: 4 NP^2 bytes of pinned memory)
 
+// (below this many edges the host builds grouping, pair counts and entry lists itself: its passes are a few microseconds then,
+//  less than the device's chain of launches and the two trips across the bus - 0.43 against 0.47 ms per call at 693 edges,
+//  0.54 against 0.52 at 7 102, scripts/small_paths.py)
+constexpr int kDeviceStructureMinEdges = 2048;
+
 struct HelperHandOff {
     // helper -> caller
     std::atomic<int> idx_ready{0};      // the caller's index arrays are in the staging buffer (release / acquire): what the
@@ -970,6 +975,7 @@ void Upload::carve_state()
 bool Upload::dev_first_eligible() const
 {
     if (HOOK(h, host_structure) || HOOK(h, host_grouping)) return false;
+    if (E < kDeviceStructureMinEdges) return false;
     if (E <= 0 || P <= 0 || NP <= 0 || NP > 1024) return false;
     int nfix = 0;
     for (int i = 0; i < NP; ++i) nfix += d->pose_fixed[i] != 0;
@@ -1118,7 +1124,9 @@ int Upload::send_edge_a()
     arena_gen_at_edge_copy = ho.arena_gen;
     // grouped edges: the rest of the derived arrays (point ids, ranks / slots, first slots) leaves at once on the copy
     // stream, beside the structure kernels of this stream; what needs it (slot completion, fill) waits for edgeb_event
-    if (s().already_grouped && h->arena_gen == ho.arena_gen) {
+    // (not where the host goes on to build the pair structure itself - windows below kDeviceStructureMinEdges -: it packs its
+    //  slots over the ranks in the staging buffer, which this copy would still be reading; that part then travels once, later)
+    if (s().already_grouped && h->arena_gen == ho.arena_gen && E >= kDeviceStructureMinEdges && !HOOK(h, host_structure)) {
         HIP_TRY(hipMemcpyAsync(h->arena + L.a_end, sg + L.a_end, L.raw_begin - L.a_end, hipMemcpyHostToDevice, h->copy_stream));
         HIP_TRY(hipEventRecord(h->edgeb_event, h->copy_stream));
         edge_b_early = true;
@@ -1744,7 +1752,7 @@ int Upload::run(bool allow_dev_first)
     // The per-pair entry lists are counted and filled on the GPU (struct_kernels.hip) when the caller's edges are
     // already grouped by map point (the reference's own order) and the pair-bin masks fit in LDS; otherwise on the host.
     // (on the device: up to 80 free keyframes, and as many keyframes in all as the kernels' LDS image has room for)
-    const bool on_device = s().already_grouped && s().nfree > 0 && !HOOK(h, host_structure);
+    const bool on_device = s().already_grouped && s().nfree > 0 && !HOOK(h, host_structure) && E >= kDeviceStructureMinEdges;
     const bool masks_fit = s().nfree <= 80 && struct_lds_fits(s().nfree, NP);
     // entry lists and slot -> point map: device-only, carved ahead of the pair region so that the fill kernel can be
     // launched before the pair region is laid out (host-built entry lists travel inside the pair region instead)
