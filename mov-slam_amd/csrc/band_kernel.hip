@@ -59,12 +59,40 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     const int bw = bw_arg & 0xffff;                     // (from bit 16: the test build's park hook, api.cpp band_arg)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     Ctrl *c = w.ctrl;
-    if (c->done) return;
     const int tid = threadIdx.x, ln = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cur = c->cur;
-    const double lambda = c->lambda;
     const int nf = w.nfree, n = 6 * nf, npad = (n + 1) & ~1, B1 = bw + 1;
+    // Everything whose address follows from the kernel's arguments alone is REQUESTED here, in front of the first wait: the
+    // controller's words, the first round of the diagonal records, the first round of the pairs' item ranges.  The assembly was
+    // four dependent round trips behind the launch boundary (controller -> pair tables -> partials -> records, ~1.5 us each from
+    // L2s that the schur pass filled on other XCDs): two now (these, then the partials).
+    const int done0 = c->done, cur = c->cur;
+    const double lambda = c->lambda;
+    constexpr int kDFly = 5, kItemsFly = 4, kFly = 16;
+    const int noff = w.npairs - nf;
+    int d_ni[kDFly];
+    double d_v[kDFly][kItemsFly];
+#pragma unroll
+    for (int u = 0; u < kDFly; ++u) {
+        const int e = min(tid + u * kBT, nf * 48 - 1);
+        const int h = e / 48, r = e - h * 48;
+        d_ni[u] = w.pair_item_start[h + 1] - w.pair_item_start[h];
+        const double *rec = w.rec_d + (size_t)h * w.rec_slots * 48 + r;
+#pragma unroll
+        for (int t = 0; t < kItemsFly; ++t) d_v[u][t] = rec[(size_t)min(t, w.rec_slots - 1) * 48];
+    }
+    // (the first kPre of a thread's sixteen elements: 113 off-diagonal pairs, every window of up to fifteen keyframes whole)
+    constexpr int kPre = 8;
+    int o_i[kPre], o_j[kPre], o_it0[kPre], o_it1[kPre];
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        const int e = max(min(tid + u * kBT, noff * 36 - 1), 0);
+        const int p = nf + e / 36;
+        const bool any = u * kBT < noff * 36;           // (workgroup-uniform: this round of elements exists)
+        o_i[u] = any ? w.pair_i[p] : 0; o_j[u] = any ? w.pair_j[p] : 0;
+        o_it0[u] = any ? w.pair_item_start[p] : 0; o_it1[u] = any ? w.pair_item_start[p + 1] : 0;
+    }
+    if (done0) return;
 #ifdef MOVBA_CLOCK_STAMP
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
     unsigned long long fine[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -88,42 +116,23 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
     }
     if (tid == 0) { failw[0] = 0; failw[1] = 0; }
     __syncthreads();
-    // off-diagonal pairs (i < j): the lower block (j, i) = - (sum over the pair's work items of the 6 x 6 partial)^T, items in order
-    // (sixteen elements per thread in flight through the two dependent load levels - pair -> its items' partials -: walked one
-    //  element at a time the loop was 32 x 2 cold round trips, 100 us of a 160 us launch at cfg3)
-    const int noff = w.npairs - nf;
-    constexpr int kFly = 16;
-    for (int e0 = tid; e0 < noff * 36; e0 += kBT * kFly) {
-        int dst[kFly], src[kFly], it0[kFly], it1[kFly];
-#pragma unroll
-        for (int u = 0; u < kFly; ++u) {
-            const int e = min(e0 + u * kBT, noff * 36 - 1);
-            const int pr = e / 36, q = e - pr * 36, a = q / 6, b = q - a * 6, p = nf + pr;
-            const int i = w.pair_i[p], j = w.pair_j[p];
-            it0[u] = w.pair_item_start[p]; it1[u] = w.pair_item_start[p + 1];
-            dst[u] = band_off(j, i, bw) + a * 6 + b;
-            src[u] = b * 6 + a;
-        }
-        double v[kFly];
-#pragma unroll
-        for (int u = 0; u < kFly; ++u) v[u] = it1[u] > it0[u] ? w.part[(size_t)it0[u] * kPartStride + src[u]] : 0.0;
-#pragma unroll
-        for (int u = 0; u < kFly; ++u) {
-            double s = 0.0 - v[u];
-            for (int it = it0[u] + 1; it < it1[u]; ++it) s -= w.part[(size_t)it * kPartStride + src[u]];      // (pairs cut into several items)
-            if (e0 + u * kBT < noff * 36) Lb[dst[u]] = s;
-        }
-    }
+    // (the diagonal first: its records are in flight since the top of the kernel and leave their registers here)
     // diagonal blocks and right-hand side from the diagonal items' records (DevWindow::rec_d: per item and row a: the row of
     // Hpp - sum B Dinv B^T, then (sum B Dinv b_l)_a and (b_p)_a), items in order, four items and five elements in flight
-    constexpr int kDFly = 5, kItemsFly = 4;
     for (int e0 = tid; e0 < nf * 48; e0 += kBT * kDFly) {
         int ni[kDFly];
         double v[kDFly][kItemsFly];
+        const bool first_round = e0 == tid;
 #pragma unroll
         for (int u = 0; u < kDFly; ++u) {
             const int e = min(e0 + u * kBT, nf * 48 - 1);
             const int h = e / 48, r = e - h * 48;
+            if (first_round) {
+                ni[u] = d_ni[u];
+#pragma unroll
+                for (int t = 0; t < kItemsFly; ++t) v[u][t] = d_v[u][t];
+                continue;
+            }
             ni[u] = w.pair_item_start[h + 1] - w.pair_item_start[h];
             const double *rec = w.rec_d + (size_t)h * w.rec_slots * 48 + r;
 #pragma unroll
@@ -142,6 +151,35 @@ __device__ __forceinline__ void band_body(const DevWindow &w, int bw_arg)
             if (q < 6) Lb[band_off(h, h, bw) + a * 6 + q] = s + (q == a ? lambda : 0.0);
             else if (q == 6) aux[6 * h + a] = s;
             else rhs[6 * h + a] = s;
+        }
+    }
+    // off-diagonal pairs (i < j): the lower block (j, i) = - (sum over the pair's work items of the 6 x 6 partial)^T, items in order
+    // (sixteen elements per thread in flight through the two dependent load levels - pair -> its items' partials -: walked one
+    //  element at a time the loop was 32 x 2 cold round trips, 100 us of a 160 us launch at cfg3)
+    for (int e0 = tid; e0 < noff * 36; e0 += kBT * kFly) {
+        int dst[kFly], src[kFly], it0[kFly], it1[kFly];
+        const bool first_round = e0 == tid;             // (its pair tables were requested at the top of the kernel)
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) {
+            const int e = min(e0 + u * kBT, noff * 36 - 1);
+            const int pr = e / 36, q = e - pr * 36, a = q / 6, b = q - a * 6, p = nf + pr;
+            int i = 0, j = 0;
+            it0[u] = 0; it1[u] = 0;
+            if (first_round && u < kPre) { i = o_i[u]; j = o_j[u]; it0[u] = o_it0[u]; it1[u] = o_it1[u]; }
+            else if (e0 - tid + u * kBT < noff * 36) {       // (workgroup-uniform; nothing is loaded for rounds past the end)
+                i = w.pair_i[p]; j = w.pair_j[p]; it0[u] = w.pair_item_start[p]; it1[u] = w.pair_item_start[p + 1];
+            }
+            dst[u] = band_off(j, i, bw) + a * 6 + b;
+            src[u] = b * 6 + a;
+        }
+        double v[kFly];
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) v[u] = it1[u] > it0[u] ? w.part[(size_t)it0[u] * kPartStride + src[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < kFly; ++u) {
+            double s = 0.0 - v[u];
+            for (int it = it0[u] + 1; it < it1[u]; ++it) s -= w.part[(size_t)it * kPartStride + src[u]];      // (pairs cut into several items)
+            if (e0 + u * kBT < noff * 36) Lb[dst[u]] = s;
         }
     }
     __syncthreads();
