@@ -841,7 +841,10 @@ void Upload::post_helper()
             // (The bus is shared: beside these 3.5 MB the index arrays' k_ingest takes 27 us for its 0.9 MB instead of 19 - 22.
             //  Holding the copy commands back behind that launch was tried: the last, small copy of the chain is a blit kernel,
             //  which then queued up behind the structure kernels of the handle's stream, and the solve's first kernels - which
-            //  wait for it - started 25 us later: 1.107 ms per call against 1.09.)
+            //  wait for it - started 25 us later: 1.107 ms per call against 1.09.  With that small copy sent first and only the
+            //  large commands held back: the copy engine's chain - three commands of ~8 us latency each and 78 us of transfer -
+            //  then ends ~25 us behind the structure kernels instead of ahead of them, and the solve's first kernels wait for IT:
+            //  1.09 - 1.10 ms.  The bus time of the upload, ~85 us for 4.4 MB, has to start at once.)
             auto dma = [&](size_t to, const void *from, size_t bytes) {
                 if (err == hipSuccess && bytes) err = hipMemcpyAsync(out->arena + to, from, bytes, hipMemcpyHostToDevice, hh->copy_stream);
             };
