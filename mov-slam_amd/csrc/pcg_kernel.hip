@@ -625,6 +625,19 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             }
             // the dense coarse product of this iteration (independent of the scalar recurrences)
             const double yc = coarse ? coarse_rows() : 0.0;
+#ifdef MOVBA_PCG_EARLY_CHECKS
+            // (the checks where they stood until round 5, four compare -> branch hops on the iteration's chain: A/B builds)
+            if (!isfinite(g) || !isfinite(delta)) { stop = 1; ++iters; break; }
+            if (first) {
+                thresh = PCG_UNI(pp.rel_tol * pp.rel_tol * g);
+                if (!(g >= 0.0)) { stop = 1; ++iters; break; }
+                if (g == 0.0) { stop = 3; ++iters; break; }
+            }
+            if (!first && g <= thresh) { stop = 2; ++iters; break; }
+            const double beta = PCG_UNI(first ? 0.0 : g * inv_gamma);
+            const double den = delta - beta * g * inv_alpha;          // = p.Ap of the new search direction
+            if (!(den > 0.0)) { stop = 1; ++iters; break; }
+#else
             if (first) thresh = PCG_UNI(pp.rel_tol * pp.rel_tol * g);
             const double beta = PCG_UNI(first ? 0.0 : g * inv_gamma);
             const double den = delta - beta * g * inv_alpha;          // = p.Ap of the new search direction
@@ -635,6 +648,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
                 const bool neg = first && !(g >= 0.0), zero = first && g == 0.0, conv = !first && g <= thresh, noden = !(den > 0.0);
                 stop = (nonfin || neg) ? 1 : zero ? 3 : conv ? 2 : noden ? 1 : 0;
             }
+#endif
             // (reciprocals by v_rcp_f64 + two Newton steps: the IEEE division sequence is ~25 dependent instructions, on the
             //  critical path of every iteration; the two are independent of each other and overlap)
             inv_gamma = PCG_UNI(fast_rcp(g));
