@@ -447,6 +447,29 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             rcg[wv * kPA + ln] = ln < 6 ? tc : (ti - agg_cc * tc) * agg_ih;
         }
     };
+    // The same in two halves for the iteration: the exchange and the ten loads by ALL lanes (the lanes that restrict nothing
+    // read a place of the wave's own strip), THEN the wave's dot-product reductions - seven DPP links that used to queue up
+    // behind the masked block's wait for its loads -, then the sums and the store by the twelve lanes that restrict.
+    const int ra = ln < kPA ? (ln < 6 ? ln : ln - 6) : 0;
+    auto restrict_issue = [&](double v_r, double (&v)[10]) {
+        if (PADDED) rsw[ln] = owner ? v_r : 0.0;
+        else if (owner) r_lds[row] = v_r;
+        wave_lds_sync();
+        const double *rb = PADDED ? rsw + ra : r_lds + b0 * 6 + ra;
+#pragma unroll
+        for (int u = 0; u < 10; ++u) v[u] = rb[6 * u];
+    };
+    auto restrict_finish = [&](double (&v)[10]) {
+        if (ln < kPA) {
+            if (!PADDED) {
+#pragma unroll
+                for (int u = 0; u < 10; ++u) v[u] = (u < nb) ? v[u] : 0.0;
+            }
+            const double tc = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (v[8] + v[9]);
+            const double ti = (((v[1] + 2.0 * v[2]) + (3.0 * v[3] + 4.0 * v[4])) + ((5.0 * v[5] + 6.0 * v[6]) + (7.0 * v[7] + 8.0 * v[8]))) + 9.0 * v[9];
+            rcg[wv * kPA + ln] = ln < 6 ? tc : (ti - agg_cc * tc) * agg_ih;
+        }
+    };
     // (A_c^-1 v_c)[own row crow], v_c = rcg (all aggregates, visible after a workgroup barrier): valid in lanes with cq == 0.
     // A_c^-1 sits in LDS rounded to fp32: as a preconditioner the inverse needs no more (same CG iteration counts), and
     // this product reads all 96 x 96 entries every iteration: in fp64 that was more LDS traffic than the rest of the
@@ -530,6 +553,8 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
                     __syncthreads();                          // rcg is rewritten before the next reduction barrier
                 } else if (ln < kPA) zstrip[ln] -= alpha * ustrip[ln];  // z_c -= alpha u_c; ordered before precond's reads by its wave-local sync
             }
+            // (the preconditioner's exchange and loads in FRONT of that masked read-modify-write were tried: 62.9 - 63.7 us per
+            //  launch against 62.2 - 62.7, same box)
             z_r = precond(r_r);
             if (owner) p_lds[row] = z_r;                      // the vector the mat-vec multiplies
             SEG_STAMP(0);
@@ -601,12 +626,14 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
                 }
             }
             SEG_STAMP(3);
-            if (coarse) restrict_own(w_r);                    // P^T w of this wave's aggregate, published with the dot-product partials
+            double rv10[10];
+            if (coarse) restrict_issue(w_r, rv10);            // P^T w of this wave's aggregate, published with the dot-product partials
             {
                 double g = owner ? r_r * z_r : 0.0, d = owner ? w_r * z_r : 0.0;
                 wave_sum_dpp2(g, d);
                 if (ln == 0) *reinterpret_cast<double2 *>(red0 + 2 * wv) = make_double2(g, d);      // (red0 / red1: one run of 2 kNW doubles)
             }
+            if (coarse) restrict_finish(rv10);
             SEG_STAMP(4);
             __syncthreads();                                  // (B) r.z, w.z and P^T w visible; all reads of z done
             SEG_STAMP(5);
