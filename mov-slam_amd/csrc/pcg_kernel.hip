@@ -162,6 +162,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     double *rcg = red1 + kNW + 2 + kNC * kNC / 2;         // kNC: restricted vector of every aggregate
     double *zstrip = rcg + kNC + 32 * wv;                 // 16 per wave: the wave's coarse correction z_c = A_c^-1 P^T r (kPA used)
     double *ustrip = zstrip + 16;                         // 16 per wave: A_c^-1 P^T s of the wave's aggregate
+    double z_reg = 0.0, u_reg = 0.0;                      // ... both in registers since round 5 (lane 4 r: coarse row r of the wave's aggregate)
     double *ypart = rcg + kNC + 32 * kNW;                 // 6 doubles per gather-list PAIR (+ one dummy strip); PADDED: kOwnBatch per row
     constexpr int kYDummy = 5 * kOwnBatch + 6;            // PADDED: where the lanes without a pair write (stride kOwnBatch like the others)
     const int ypart_len = PADDED ? n * kOwnBatch + kYDummy + kOwnBatch : 6 * ((nrowent_all >> 1) + 1 + kOwnBatch);
@@ -494,10 +495,10 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     };
     if (coarse) {
         restrict_own(r_r);
-        if (ln < 16) ustrip[ln] = 0.0;
+        u_reg = 0.0;
         __syncthreads();
         const double t = coarse_rows();
-        if (cq == 0 && ln < 4 * kPA) zstrip[ln >> 2] = t;
+        z_reg = t;                                            // (valid in the lanes with cq == 0, lane 4 r for coarse row r)
         __syncthreads();                                      // rcg is rewritten inside the loop
     } else __syncthreads();                                   // (the waves' block-inverse verdicts are in)
     int anybad = 0;
@@ -512,7 +513,12 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         double s = (m0.x * r0.x + m0.y * r0.y) + (m1.x * r1.x + m1.y * r1.y) + (m2.x * r2.x + m2.y * r2.y);
         // fresh mode: every aggregate is one keyframe, the coarse space is the whole space and A_c^-1 is S^-1 itself
         if (fresh && coarse) s = 0.0;
-        if (coarse && owner) s += zstrip[ba] + phi * zstrip[6 + ba];
+        if (coarse) {
+            // z_c of the wave's aggregate lives in registers (lane 4 r: row r, where the coarse product leaves it); an owner
+            // lane takes the two values of its pose component across the wave (ds_bpermute: the LDS crossbar, no memory)
+            const double zc0 = __shfl(z_reg, 4 * ba), zc1 = __shfl(z_reg, 24 + 4 * ba);
+            if (owner) s += zc0 + phi * zc1;
+        }
         return owner ? s : 0.0;
     };
     // ---- conjugate gradients, single-reduction form (Chronopoulos & Gear): with z = Minv r and w = A z,
@@ -549,9 +555,9 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
                     restrict_own(r_r);
                     __syncthreads();
                     const double zc = coarse_rows();
-                    if (cq == 0 && ln < 4 * kPA) zstrip[ln >> 2] = zc;
+                    z_reg = zc;
                     __syncthreads();                          // rcg is rewritten before the next reduction barrier
-                } else if (ln < kPA) zstrip[ln] -= alpha * ustrip[ln];  // z_c -= alpha u_c; ordered before precond's reads by its wave-local sync
+                } else z_reg -= alpha * u_reg;                // z_c -= alpha u_c, in the registers of the lanes that hold them
             }
             // (the preconditioner's exchange and loads in FRONT of that masked read-modify-write were tried: 62.9 - 63.7 us per
             //  launch against 62.2 - 62.7, same box)
@@ -685,7 +691,7 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
             p_r = z_r + beta * p_r;
             s_r = w_r + beta * s_r;
             if (coarse) {
-                if (cq == 0 && ln < 4 * kPA) ustrip[ln >> 2] = yc + beta * ustrip[ln >> 2];
+                u_reg = yc + beta * u_reg;
                 wave_lds_sync();                              // u_c is read by lanes 0-11 at the top of the next iteration
             }
             SEG_STAMP(6);
