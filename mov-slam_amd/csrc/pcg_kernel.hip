@@ -126,6 +126,27 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
     // everything it needs of the window's structure (api.cpp, lay_out_rest); the rest follows from the kernel's arguments. ----
     int done_w = 0;
     if (solver) { done_w = c->done; cur = c->cur; lambda = c->lambda; }
+    // The previous trial's coarse inverse (36 KB, fp32) goes from global memory STRAIGHT into its place in LDS
+    // (global_load_lds_dwordx4: no register in between - the kernel is at its 256 - and no second pass), requested here with
+    // everything else; whether it is valid (its tag) is looked at further down, the first read of it lies behind workgroup barriers.
+    // (It used to be requested ~3 us into the kernel, behind the diagonal sums, through 18 registers, and stored to LDS after the
+    //  block inverses.)
+    int aci_tag = -1;
+    if (pp.use_coarse) {
+        typedef __attribute__((address_space(1))) const void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const int npad0 = (6 * w.nfree + 1) & ~1;
+        float *acf0 = reinterpret_cast<float *>(sm + 2 * npad0 + 36 * w.nfree + 2 * kNW + 2);      // (= Acf of the carve below)
+        aci_tag = w.aci_tag[max(ctrial, 0) & 1];
+        const float *src = w.aci + (size_t)(max(ctrial, 0) & 1) * kNC * kNC;
+        static_assert((kNC * kNC) % 256 == 0, "whole waves of 16-byte pieces");
+#pragma unroll
+        for (int u = 0; u * kT * 4 < kNC * kNC; ++u) {
+            const int piece = tid + u * kT;                 // 16-byte piece; a wave's 64 pieces land behind one another
+            if ((piece & ~63) * 4 < kNC * kNC)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + 4 * piece), (lptr_t)(acf0 + 4 * (piece & ~63)), 16, 0, 0);
+        }
+    }
     const int4 *plan = reinterpret_cast<const int4 *>(w.lane_plan) + (size_t)tid * 3;
     const int4 pl0 = plan[0], pl1 = plan[1], plo = plan[2];
     const int oi0 = plo.x, oi1 = plo.y;                   // owner lanes: items of the diagonal pair (bi, bi): they carry b_p and B Dinv b_l
@@ -287,16 +308,8 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         for (int q = 0; q < 6; ++q) mi[q] = d6[q];
     }
     SETUP_STAMP(7);
-    // coarse level: usable when the previous trial's launch left a valid inverse (never for the first trial).  Requested here (36 KB, rounded to
-    // fp32 by its builder): its round trip runs beside the block inverses below.
-    int aci_tag = -1;
-    float2 av[kNC * kNC / 2 / kT];
-    if (pp.use_coarse) {
-        aci_tag = w.aci_tag[max(ctrial, 0) & 1];
-        const float2 *src = reinterpret_cast<const float2 *>(w.aci + (size_t)(max(ctrial, 0) & 1) * kNC * kNC);
-#pragma unroll
-        for (int u = 0; u < kNC * kNC / 2 / kT; ++u) av[u] = src[tid + u * kT];
-    }
+    // (coarse level: usable when the previous trial's launch left a valid inverse - never for the first trial; on its way into
+    //  LDS since the top of the kernel)
     // ---- block-Jacobi preconditioner: S_ii^-1 by the block's six owner lanes, each holding a row: in-place Gauss-Jordan, the
     // scaled pivot row handed round through a wave-private LDS strip (alternating between two: no wait before the next
     // pivot's write), then symmetrised.  (Until round 4 ONE thread per keyframe factored its block on its own - a 600-flop
@@ -349,11 +362,6 @@ __device__ __forceinline__ void pcg_rows_body(const DevWindow &w, const PcgParam
         if (ln == 0) reinterpret_cast<int *>(red1)[wv] = wbad;
     }
     const bool coarse = pp.use_coarse && ctrial >= 0 && aci_tag == ctrial;
-    if (coarse) {
-        float2 *dst = reinterpret_cast<float2 *>(Acf);
-#pragma unroll
-        for (int u = 0; u < kNC * kNC / 2 / kT; ++u) dst[tid + u * kT] = av[u];
-    }
     SETUP_STAMP(0);
     // (a keyframe's diagonal block is read by a lane of the wave that owns its rows: no workgroup barrier between the two)
     wave_lds_sync0();
