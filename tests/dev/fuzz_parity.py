@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity sweep over window shapes (run on a GPU box): free/fixed keyframe counts around every
 code-path boundary (one keyframe per wave, two rows per aggregate, VGPR overflow, generic PCG), track lengths, stereo,
 unobserved map points, edges that do not arrive grouped by map point, intrinsics by keyframe.
-    python tests/dev/fuzz_parity.py <seed> <windows> [direct|band]      ("direct": every window on the one-launch direct solver;
+    python tests/dev/fuzz_parity.py <seed> <windows> [direct|band|pcg]  ("direct": every window on the one-launch direct solver;
                                                                          "band": on the banded factorisation wherever its band fits one CU's LDS)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,8 @@ from conftest import oracle_order_noise
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 mode = sys.argv[3] if len(sys.argv) > 3 else "default"
-s = capi.Solver(direct=True) if mode == "direct" else capi.Solver(solver=2) if mode == "band" else capi.Solver()
+s = (capi.Solver(direct=True) if mode == "direct" else capi.Solver(solver=2) if mode == "band" else
+     capi.Solver(solver=3) if mode == "pcg" else capi.Solver())       # "pcg": never the banded factorisation (small windows reach the PCG's fresh coarse level)
 worst = dict(dq=0.0, dt=0.0, pt=0.0, outl=0)
 bad = 0
 noisy = 0       # windows beyond their tolerance but inside three times the oracle's own spread over the reference's edge orders
